@@ -1,0 +1,114 @@
+"""Deterministic synthetic weights and clips (no network, no checkpoints on the GPU box).
+
+Everything is generated from a counter-based integer hash (splitmix64) so that the
+build container (where the reference is imported to make golden vectors) and the GPU
+box (where only this package exists) produce bit-identical fp32 tensors.
+
+All-zero tensors of the reference's default init (every CFT conv ``keep_arch.py:459-463``,
+every CFA linear ``keep_arch.py:510-517``, ``position_emb`` ``keep_arch.py:928``, all
+biases) are given non-zero values here, otherwise parity tests would be vacuous for
+those modules ("hard parts").
+"""
+import hashlib
+import math
+
+import numpy as np
+import torch
+
+from .arch import DEFAULT_ARCH, state_dict_spec
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x):
+    """Vectorised splitmix64 finaliser on a uint64 array (wrap-around arithmetic)."""
+    with np.errstate(over='ignore'):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _name_key(name: str, seed: int) -> np.uint64:
+    h = hashlib.blake2b(f'{seed}:{name}'.encode(), digest_size=8).digest()
+    return np.uint64(int.from_bytes(h, 'little'))
+
+
+def uniform_pm1(name: str, n: int, seed: int = 0) -> np.ndarray:
+    """n float64 values in (-1, 1), a pure function of (name, seed, index)."""
+    key = _name_key(name, seed)
+    idx = np.arange(n, dtype=np.uint64)
+    with np.errstate(over='ignore'):
+        bits = _splitmix64(_splitmix64(idx ^ key) + key)
+    top = (bits >> np.uint64(40)).astype(np.float64)          # 24 random bits
+    return (top + 0.5) * (2.0 / 16777216.0) - 1.0
+
+
+def _sigma_for(name: str, shape):
+    """(mean, std) of the synthetic distribution for a non-normalisation tensor."""
+    if name == 'position_emb':
+        return 0.0, 0.3
+    if name == 'quantize.embedding.weight':
+        return 0.0, 0.7
+    if name == 'idx_pred_layer.1.weight':                 # peaked logits (top-1/top-2 margins ~ trained nets)
+        return 0.0, 4.0 / math.sqrt(shape[1])
+    if len(shape) == 4:                                   # conv weight
+        fan_in = shape[1] * shape[2] * shape[3]
+        return 0.0, 1.0 / math.sqrt(fan_in)
+    if len(shape) == 2:                                   # linear weight
+        return 0.0, 1.0 / math.sqrt(shape[1])
+    return 0.0, 0.05                                      # conv / linear bias
+
+
+def _is_norm_affine(name, spec):
+    """1-D 'weight' tensors are always normalisation scales (conv/linear weights are >=2-D);
+    a 1-D 'bias' is a norm shift iff its sibling 'weight' is 1-D."""
+    leaf = name.rsplit('.', 1)[-1]
+    if leaf == 'weight':
+        return len(spec[name]) == 1
+    if leaf == 'bias':
+        sib = name[:-4] + 'weight'
+        return sib in spec and len(spec[sib]) == 1
+    return False
+
+
+def synth_state_dict(cfg=None, seed: int = 0):
+    """name -> fp32 CPU tensor for every entry of ``state_dict_spec(cfg)``."""
+    spec = state_dict_spec(cfg)
+    out = {}
+    for name, shape in spec.items():
+        n = int(np.prod(shape))
+        u = uniform_pm1(name, n, seed)
+        leaf = name.rsplit('.', 1)[-1]
+        if len(shape) == 1 and _is_norm_affine(name, spec):
+            mean, std = (1.0, 0.1) if leaf == 'weight' else (0.0, 0.1)
+        else:
+            mean, std = _sigma_for(name, shape)
+        v = mean + u * (math.sqrt(3.0) * std)
+        out[name] = torch.from_numpy(v.astype(np.float32).reshape(shape))
+    return out
+
+
+def synth_clip(T: int = 20, B: int = 1, size: int = 512, seed: int = 1234, phase: float = 0.0):
+    """smooth moving pattern + 10 % hash noise, fp32 [B,T,3,S,S] in [-1,1].
+
+    x[t,c,y,x] = 0.6 sin(2pi(3x+2y)/S + 0.7c + 0.15t + phase) + 0.3 sin(2pi(5x-4y)/S + 0.05t) + 0.1 u
+    """
+    S = size
+    ys, xs = np.meshgrid(np.arange(S, dtype=np.float64), np.arange(S, dtype=np.float64), indexing='ij')
+    out = np.empty((B, T, 3, S, S), dtype=np.float32)
+    for b in range(B):
+        for t in range(T):
+            for c in range(3):
+                base = (0.6 * np.sin(2 * np.pi * (3 * xs + 2 * ys) / S + 0.7 * c + 0.15 * t + phase + 0.9 * b)
+                        + 0.3 * np.sin(2 * np.pi * (5 * xs - 4 * ys) / S + 0.05 * t))
+                u = uniform_pm1(f'clip:{b}:{t}:{c}', S * S, seed).reshape(S, S)
+                out[b, t, c] = (base + 0.1 * u).astype(np.float32)
+    return torch.from_numpy(out)
+
+
+def ramp_image(h: int = 512, w: int = 512):
+    """uint8 BGR ramp, pixel(y,x,c) = (37y + 91x + 53c) mod 256."""
+    y, x, c = np.meshgrid(np.arange(h), np.arange(w), np.arange(3), indexing='ij')
+    return ((37 * y + 91 * x + 53 * c) % 256).astype(np.uint8)

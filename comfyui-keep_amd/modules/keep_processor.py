@@ -1,0 +1,235 @@
+"""Frame / clip driver -- drop-in for reference ``modules/keep_processor.py:117-307``.
+
+Hot loop #1 of the path: crops of all frames are stacked frame-major
+(faces of one frame adjacent), cut into chunks of ``max_clip_length`` and every chunk is one
+independent ``keep_net`` clip (keep_processor.py:256-270).  Behaviour kept bug-compatible:
+  * multi-face sequences interleave faces inside a clip (P1);
+  * a chunk of length 1 is duplicated to T=2 and frame 0 kept (keep_processor.py:266-268, 173-175);
+  * with ``has_aligned_frames`` the restored faces are computed and then NOT used: the output
+    is the resized input (keep_processor.py:289-291) -- see ``last_restored_faces`` below;
+  * ComfyUI progress: N + N + N ticks, then one tick per frame that had faces (KP:200-304).
+Detection / tracking / alignment / paste-back stay with the reference's ``FaceRestoreHelper``
+(out of scope, unchanged); tracking + smoothing (KP:33-115, 216-231) are restated in
+``face_tracks.py`` because they live in the reference's own glue file.
+
+What this build adds: independent clips are handed to the engine in one call
+(``keep_net.run_clips``) so it can batch equal-length clips per GPU and shard them across
+GPUs; results are identical to the sequential loop because clips share no state.
+"""
+import numpy as np
+import torch
+from tqdm import tqdm
+
+from .utils import comfy_image_to_cv2, crops_to_net_input, cv2_to_comfy_image, net_output_to_bgr_u8
+from .face_tracks import smooth_center_face, smooth_tracked_faces
+
+try:  # ComfyUI runtime
+    from comfy.utils import ProgressBar, tiled_scale
+except ModuleNotFoundError:  # engine-only use outside ComfyUI
+    tiled_scale = None
+
+    class ProgressBar:  # minimal stand-in with the same calls
+        def __init__(self, total):
+            self.total, self.current = total, 0
+
+        def update(self, n):
+            self.current += n
+
+
+def _cv2():
+    import cv2
+    return cv2
+
+
+def _resize(img, w, h, interp_name):
+    if img.shape[0] == h and img.shape[1] == w:
+        return img
+    cv2 = _cv2()
+    return cv2.resize(img, (w, h), interpolation=getattr(cv2, interp_name))
+
+
+def _is_gray(img, threshold=10):
+    """wm_facelib/utils/misc.py:146-160: mean variance of channel differences <= threshold."""
+    if img.ndim == 2:
+        return True
+    c = img.astype(np.int16)
+    d = ((c[..., 0] - c[..., 1]).var() + (c[..., 1] - c[..., 2]).var() + (c[..., 2] - c[..., 0]).var()) / 3.0
+    return bool(d <= threshold)
+
+
+def split_clips(num_faces: int, max_clip_length: int):
+    """[(start, end)] chunk boundaries of the flat crop list (keep_processor.py:263-264)."""
+    return [(s, min(s + max_clip_length, num_faces)) for s in range(0, num_faces, max_clip_length)]
+
+
+class KEEPFaceProcessor:
+    def __init__(self, model_pack):
+        self.keep_net = model_pack.keep_net
+        self.face_helper = model_pack.face_helper
+        self.bg_upscale_model = model_pack.bg_upscale_model
+        self.face_upscale_model = model_pack.face_upscale_model
+        self.device = model_pack.device
+        self.model_type_str = model_pack.model_type_str
+        # restored 512x512 faces of the last call, uint8 BGR (the reference discards them on the
+        # aligned-sequence path; exposed so callers / tests can read what the net produced)
+        self.last_restored_faces = []
+
+    # ------------------------------------------------------------------ net invocation
+    def _restore_clips(self, crops_tensor, max_clip_length):
+        """crops_tensor [1,N,3,512,512] on device -> [N,3,512,512] restored (fp32, unclamped)."""
+        n = crops_tensor.shape[1]
+        clips = []
+        for s, e in split_clips(n, max_clip_length):
+            clip = crops_tensor[:, s:e]
+            if clip.shape[1] == 1:                       # net needs T>=2 in the reference
+                clip = torch.cat([clip, clip], dim=1)
+            clips.append(clip)
+        run_clips = getattr(self.keep_net, 'run_clips', None)
+        if run_clips is not None:                        # engine: batch / shard independent clips
+            outs = run_clips(clips, need_upscale=False)
+        else:
+            outs = [self.keep_net(c, need_upscale=False)
+                    for c in tqdm(clips, desc="Restoring faces with KEEP")]
+        kept = []
+        for (s, e), o in zip(split_clips(n, max_clip_length), outs):
+            kept.append(o[:, 0:1] if e - s == 1 else o)
+        return torch.cat(kept, dim=1).squeeze(0)
+
+    def _run_upscaler(self, model, cv2_image):
+        if model is None:
+            return cv2_image
+        t = cv2_to_comfy_image(cv2_image).to(self.device).movedim(-1, -3)
+        s = tiled_scale(t, lambda a: model.model(a), tile_x=512, tile_y=512, overlap=64,
+                        upscale_amount=model.scale)
+        return comfy_image_to_cv2(torch.clamp(s.movedim(-3, -1), min=0, max=1.0))
+
+    def _final_background(self, frame_bgr, factor):
+        up = self._run_upscaler(self.bg_upscale_model, frame_bgr)
+        h, w, _ = frame_bgr.shape
+        return _resize(up, int(w * factor), int(h * factor), 'INTER_LANCZOS4')
+
+    # ------------------------------------------------------------------ single image
+    @torch.no_grad()
+    def process_image(self, cv2_image_orig: np.ndarray, final_upscale_factor: float, has_aligned: bool,
+                      only_center_face: bool, draw_box: bool):
+        helper = self.face_helper
+        helper.upscale_factor = final_upscale_factor
+        bg_img_final = self._final_background(cv2_image_orig, final_upscale_factor)
+
+        if has_aligned:
+            face = _resize(cv2_image_orig, 512, 512, 'INTER_LINEAR')
+            helper.is_gray = _is_gray(face, threshold=10)
+            helper.cropped_faces = [face]
+            crops = [face]
+        else:
+            helper.clean_all()
+            helper.read_image(cv2_image_orig)
+            if helper.get_face_landmarks_5(only_center_face=only_center_face, resize=640,
+                                           eye_dist_threshold=5) == 0:
+                return bg_img_final
+            helper.align_warp_face()
+            crops = list(helper.cropped_faces)
+            if not crops:
+                return bg_img_final
+
+        x = crops_to_net_input(crops).unsqueeze(0).to(self.device)
+        # one face -> T=2 duplicate, keep frame 0; several faces -> one "clip" of T=#faces (KP:173-178)
+        restored = self._restore_clips(x, max_clip_length=max(x.shape[1], 1))
+        faces = [net_output_to_bgr_u8(f) for f in restored]
+        self.last_restored_faces = faces
+        helper.restored_faces = [f.astype('uint8') for f in faces]
+
+        if not has_aligned:
+            helper.get_inverse_affine(None)
+            out = helper.paste_faces_to_input_image(upsample_img=bg_img_final, draw_box=draw_box,
+                                                    face_upsampler=self.face_upscale_model)
+        else:
+            out = helper.restored_faces[0]
+            if self.face_upscale_model:
+                out = self._run_upscaler(self.face_upscale_model, out)
+            side = int(512 * final_upscale_factor)
+            out = _resize(out, side, side, 'INTER_LANCZOS4')
+        return out if out is not None else bg_img_final
+
+    # ------------------------------------------------------------------ sequence
+    def _detect_all(self, frames_bgr, only_center_face):
+        raw = []
+        helper = self.face_helper
+        for frame in tqdm(frames_bgr, desc="Detecting face landmarks"):
+            helper.clean_all()
+            helper.read_image(frame)
+            helper.get_face_landmarks_5(only_center_face=only_center_face, resize=640, eye_dist_threshold=5)
+            raw.append(list(helper.all_landmarks_5))
+        return raw
+
+    @torch.no_grad()
+    def process_image_sequence(self, image_sequence_tensor: torch.Tensor, final_upscale_factor: float,
+                               has_aligned_frames: bool, only_center_face: bool, draw_box: bool,
+                               max_clip_length: int = 20):
+        n_frames = image_sequence_tensor.shape[0]
+        if n_frames == 0:
+            return image_sequence_tensor
+        pbar = ProgressBar(n_frames * 4)
+        frames_bgr = [comfy_image_to_cv2(image_sequence_tensor[i].unsqueeze(0)) for i in range(n_frames)]
+        helper = self.face_helper
+
+        # -- 1. landmarks per frame -> temporally smoothed tracks
+        tracks = {}
+        if not has_aligned_frames:
+            raw = self._detect_all(frames_bgr, only_center_face)
+            pbar.update(n_frames)
+            tracks = smooth_center_face(raw) if only_center_face else smooth_tracked_faces(raw)
+            pbar.update(n_frames)
+        else:
+            pbar.update(n_frames * 2)
+
+        # -- 2. crops, flat and frame-major
+        crops, affines, faces_per_frame = [], [], []
+        for i in tqdm(range(n_frames), desc="Cropping and aligning faces"):
+            if has_aligned_frames:
+                frame_crops, frame_aff = [_resize(frames_bgr[i], 512, 512, 'INTER_LINEAR')], []
+            else:
+                frame_crops, frame_aff = [], []
+                active = [seq[i] for seq in tracks.values() if not np.isnan(seq[i]).any()]
+                if active:
+                    helper.clean_all()
+                    helper.read_image(frames_bgr[i])
+                    helper.all_landmarks_5 = active
+                    helper.align_warp_face()
+                    frame_crops = list(helper.cropped_faces)
+                    frame_aff = list(helper.affine_matrices)
+            faces_per_frame.append(len(frame_crops))
+            crops.extend(frame_crops)
+            affines.extend(frame_aff)
+
+        # -- 3. restore: the hot path
+        restored_faces = []
+        if crops:
+            x = crops_to_net_input(crops).unsqueeze(0).to(self.device)
+            restored = self._restore_clips(x, max_clip_length)
+            restored_faces = [net_output_to_bgr_u8(f) for f in restored]
+            del x, restored
+        self.last_restored_faces = restored_faces
+        pbar.update(n_frames)
+
+        # -- 4. paste back
+        out_frames = []
+        face_ptr = aff_ptr = 0
+        for i in tqdm(range(n_frames), desc="Pasting faces and finalizing frames"):
+            bg = self._final_background(frames_bgr[i], final_upscale_factor)
+            k = faces_per_frame[i]
+            if k == 0 or has_aligned_frames:            # aligned: restored faces unused (reference quirk P2)
+                out_frames.append(bg)
+                continue
+            helper.restored_faces = [f.astype('uint8') for f in restored_faces[face_ptr:face_ptr + k]]
+            helper.affine_matrices = affines[aff_ptr:aff_ptr + k]
+            helper.upscale_factor = final_upscale_factor
+            helper.get_inverse_affine(None)
+            out_frames.append(helper.paste_faces_to_input_image(
+                upsample_img=bg, draw_box=draw_box, face_upsampler=self.face_upscale_model))
+            face_ptr += k
+            aff_ptr += k
+            pbar.update(1)
+
+        tensors = [cv2_to_comfy_image(f) for f in out_frames]
+        return torch.cat(tensors, dim=0) if tensors else image_sequence_tensor

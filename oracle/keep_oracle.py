@@ -1,0 +1,540 @@
+"""TEST INFRASTRUCTURE ONLY -- the parity oracle for the KEEP hot path.
+
+A CPU restatement (PyTorch-CPU, fp32, eager, functional, explicit weight dict) of the
+reference algorithm ``KEEP.forward`` and everything it calls.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module,
+and only as the checker / reported CPU baseline -- never from the product path
+(``comfyui-keep_amd/``), which runs on hand-written gfx950 kernels and fails loudly when
+the HIP library is missing.
+
+Pinning: the reference holds no tests or golden vectors for this path,
+so this restatement is pinned against the *imported reference module itself* in the build
+container (``oracle/make_golden.py`` -> ``tests/golden/*.npz``; ``tests/test_oracle_vs_reference.py``
+re-checks live whenever /root/reference is present).  One piece is "parity unpinned":
+``diffusers.models.attention.FeedForward`` (GEGLU) is neither vendored nor pinned by the
+reference (keep_arch.py:21) -- its gate order / exact-erf GELU follow upstream diffusers.
+
+Every function cites the reference lines it follows.  Abbreviations:
+  KA = modules/deps/wm_basicsr/archs/keep_arch.py     VQ = .../archs/vqgan_arch.py
+  AU = .../archs/arch_util.py    GF = .../archs/gmflow_arch.py    GM = .../archs/gmflow/gmflow/
+"""
+import math
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+load_package()
+from comfyui_keep_amd.engine.arch import (  # noqa: E402
+    CHANNELS, DEFAULT_ARCH, FUSE_ENCODER_BLOCK, FUSE_GENERATOR_BLOCK, GMFLOW, encoder_blocks, generator_blocks)
+
+
+# ----------------------------------------------------------------------------- VQGAN pieces
+def group_norm(x, W, p):
+    """VQ:16-17 -- GroupNorm(32 groups, eps=1e-6, affine)."""
+    return F.group_norm(x, 32, W[f'{p}.weight'], W[f'{p}.bias'], eps=1e-6)
+
+
+def swish(x):
+    """VQ:20-22."""
+    return x * torch.sigmoid(x)
+
+
+def conv(x, W, p, stride=1, padding=1):
+    return F.conv2d(x, W[f'{p}.weight'], W.get(f'{p}.bias'), stride=stride, padding=padding)
+
+
+def resblock(x_in, W, p):
+    """VQ:170-181 -- GN,swish,conv3x3, GN,swish,conv3x3, + (conv1x1(x_in) if Cin!=Cout)."""
+    x = conv(swish(group_norm(x_in, W, f'{p}.norm1')), W, f'{p}.conv1')
+    x = conv(swish(group_norm(x, W, f'{p}.norm2')), W, f'{p}.conv2')
+    if f'{p}.conv_out.weight' in W:
+        x_in = conv(x_in, W, f'{p}.conv_out', padding=0)
+    return x + x_in
+
+
+def attnblock(x, W, p):
+    """VQ:219-243 -- single-head spatial self-attention over H*W tokens, scale C^-0.5 after bmm."""
+    h = group_norm(x, W, f'{p}.norm')
+    q = conv(h, W, f'{p}.q', padding=0)
+    k = conv(h, W, f'{p}.k', padding=0)
+    v = conv(h, W, f'{p}.v', padding=0)
+    b, c, hh, ww = q.shape
+    q = q.reshape(b, c, hh * ww).permute(0, 2, 1)
+    k = k.reshape(b, c, hh * ww)
+    w_ = torch.bmm(q, k) * (int(c) ** (-0.5))
+    w_ = F.softmax(w_, dim=2)
+    v = v.reshape(b, c, hh * ww)
+    h = torch.bmm(v, w_.permute(0, 2, 1)).reshape(b, c, hh, ww)
+    return x + conv(h, W, f'{p}.proj_out', padding=0)
+
+
+def downsample(x, W, p):
+    """VQ:135-139 -- zero-pad right/bottom by one, conv3x3 stride 2 pad 0."""
+    return conv(F.pad(x, (0, 1, 0, 1), mode='constant', value=0), W, f'{p}.conv', stride=2, padding=0)
+
+
+def upsample(x, W, p):
+    """VQ:148-152 -- nearest x2 then conv3x3."""
+    return conv(F.interpolate(x, scale_factor=2.0, mode='nearest'), W, f'{p}.conv')
+
+
+def vq_block(x, W, p, kind):
+    if kind == 'conv':
+        return conv(x, W, p)
+    if kind == 'res':
+        return resblock(x, W, p)
+    if kind == 'attn':
+        return attnblock(x, W, p)
+    if kind == 'down':
+        return downsample(x, W, p)
+    if kind == 'up':
+        return upsample(x, W, p)
+    if kind == 'norm':
+        return group_norm(x, W, p)
+    raise ValueError(kind)
+
+
+def encoder_forward(x, W, prefix, cfg, taps=()):
+    """VQ:288-292 (Encoder.forward) + the feature taps of KA:1034-1037."""
+    feats = {}
+    for i, (kind, _, _) in enumerate(encoder_blocks(cfg)):
+        x = vq_block(x, W, f'{prefix}.blocks.{i}', kind)
+        if i in taps:
+            feats[str(x.shape[-1])] = x
+    return x, feats
+
+
+# ----------------------------------------------------------------------------- attention pieces
+def layer_norm(x, W, p):
+    return F.layer_norm(x, (x.shape[-1],), W[f'{p}.weight'], W[f'{p}.bias'], eps=1e-5)
+
+
+def linear(x, W, p):
+    return F.linear(x, W[f'{p}.weight'], W.get(f'{p}.bias'))
+
+
+def geglu_ff(x, W, p):
+    """diffusers FeedForward(activation_fn='geglu') as used at KA:495-496, 595-596:
+    h, g = Linear(d, 8d)(x).chunk(2, -1);  Linear(4d, d)(h * gelu_erf(g)).   [parity unpinned]"""
+    h, g = linear(x, W, f'{p}.net.0.proj').chunk(2, dim=-1)
+    return linear(h * F.gelu(g), W, f'{p}.net.2')
+
+
+def _heads_to_batch(t, heads):
+    """KA:103-108."""
+    b, n, d = t.shape
+    return t.reshape(b, n, heads, d // heads).permute(0, 2, 1, 3).reshape(b * heads, n, d // heads)
+
+
+def _batch_to_heads(t, heads):
+    """KA:110-115."""
+    bh, n, d = t.shape
+    return t.reshape(bh // heads, heads, n, d).permute(0, 2, 1, 3).reshape(bh // heads, n, d * heads)
+
+
+def _attention(q, k, v, scale):
+    """KA:200-241 -- baddbmm(beta=0, alpha=scale), softmax(-1), bmm."""
+    s = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype), q, k.transpose(-1, -2),
+                      beta=0, alpha=scale)
+    return torch.bmm(s.softmax(dim=-1), v)
+
+
+def cross_attention(x, ctx, W, p, heads, dim_head):
+    """KA:137-197 (CrossAttention.forward, plain branch): bias-free q/k/v, to_out with bias."""
+    ctx = x if ctx is None else ctx
+    q = _heads_to_batch(linear(x, W, f'{p}.to_q'), heads)
+    k = _heads_to_batch(linear(ctx, W, f'{p}.to_k'), heads)
+    v = _heads_to_batch(linear(ctx, W, f'{p}.to_v'), heads)
+    o = _batch_to_heads(_attention(q, k, v, dim_head ** -0.5), heads)
+    return linear(o, W, f'{p}.to_out.0')
+
+
+def sparse_causal_attention(x, W, p, heads, dim_head, video_length):
+    """KA:686-748 -- keys/values of frame f = concat(tokens of frame 0, tokens of frame f-1 (0 for f=0))."""
+    q = _heads_to_batch(linear(x, W, f'{p}.to_q'), heads)
+    k = linear(x, W, f'{p}.to_k')
+    v = linear(x, W, f'{p}.to_v')
+    former = torch.arange(video_length) - 1
+    former[0] = 0
+    bf, d, c = k.shape
+    b = bf // video_length
+
+    def gather(t):
+        t = t.reshape(b, video_length, d, c)
+        t = torch.cat([t[:, [0] * video_length], t[:, former]], dim=2)
+        return t.reshape(bf, 2 * d, c)
+
+    k = _heads_to_batch(gather(k), heads)
+    v = _heads_to_batch(gather(v), heads)
+    o = _batch_to_heads(_attention(q, k, v, dim_head ** -0.5), heads)
+    return linear(o, W, f'{p}.to_out.0')
+
+
+def basic_transformer_block(h, W, p, heads, dim_head, video_length):
+    """KA:640-682 -- x += SC-attn(LN1 x); x += FF(LN3 x); temporal: x += attn_temp(LN_temp x) over frames."""
+    h = sparse_causal_attention(layer_norm(h, W, f'{p}.norm1'), W, f'{p}.attn1', heads, dim_head, video_length) + h
+    h = geglu_ff(layer_norm(h, W, f'{p}.norm3'), W, f'{p}.ff') + h
+    bf, d, c = h.shape
+    b = bf // video_length
+    t = h.reshape(b, video_length, d, c).permute(0, 2, 1, 3).reshape(b * d, video_length, c)
+    t = cross_attention(layer_norm(t, W, f'{p}.norm_temp'), None, W, f'{p}.attn_temp', heads, dim_head) + t
+    return t.reshape(b, d, video_length, c).permute(0, 2, 1, 3).reshape(bf, d, c)
+
+
+def kalman_calc_gain(z_codes, W, cfg):
+    """KA:801-821 -- z_codes [B,T,C,H,W] -> gains [B,T,1,H,W] in (0,1)."""
+    b, t, c, hh, ww = z_codes.shape
+    heads, dh = cfg['n_head'], cfg['kalman_attn_head_dim']
+    h = z_codes.reshape(b * t, c, hh * ww).permute(0, 2, 1)
+    for i in range(cfg['num_uncertainty_layers']):
+        h = basic_transformer_block(h, W, f'kalman_filter.uncertainty_estimator.{i}', heads, dh, t)
+    h = h.permute(0, 2, 1).reshape(b * t, c, hh, ww)
+    for i in range(3):
+        h = resblock(h, W, f'kalman_filter.kalman_gain_calculator.{i}')
+    g = torch.sigmoid(conv(h, W, 'kalman_filter.kalman_gain_calculator.3', padding=0))
+    return g.reshape(b, t, 1, hh, ww)
+
+
+def flow_warp(x, flow_nhwc):
+    """AU:113-144 -- bilinear grid_sample, zeros padding, align_corners=True; flow[...,0]=dx, [...,1]=dy."""
+    _, _, h, w = x.shape
+    gy, gx = torch.meshgrid(torch.arange(0, h, dtype=x.dtype), torch.arange(0, w, dtype=x.dtype), indexing='ij')
+    vx = 2.0 * (gx + flow_nhwc[..., 0]) / max(w - 1, 1) - 1.0
+    vy = 2.0 * (gy + flow_nhwc[..., 1]) / max(h - 1, 1) - 1.0
+    return F.grid_sample(x, torch.stack((vx, vy), dim=3), mode='bilinear', padding_mode='zeros', align_corners=True)
+
+
+def transformer_sa_layer(x, pos, W, p, nhead):
+    """KA:423-439 -- pre-LN; q=k=LN(x)+pos, v=LN(x); nn.MultiheadAttention (packed in_proj, q scaled by
+    Dh^-0.5 after projection); +res; LN; Linear-GELU(erf)-Linear; +res.  x: [L,B,D] sequence-first."""
+    L, B, D = x.shape
+    dh = D // nhead
+    x2 = layer_norm(x, W, f'{p}.norm1')
+    qk_in = x2 + pos
+    wi, bi = W[f'{p}.self_attn.in_proj_weight'], W[f'{p}.self_attn.in_proj_bias']
+    q = F.linear(qk_in, wi[:D], bi[:D])
+    k = F.linear(qk_in, wi[D:2 * D], bi[D:2 * D])
+    v = F.linear(x2, wi[2 * D:], bi[2 * D:])
+
+    def split(t):   # [L,B,D] -> [B*nhead, L, dh]
+        return t.reshape(L, B * nhead, dh).transpose(0, 1)
+
+    q, k, v = split(q) * (dh ** -0.5), split(k), split(v)
+    a = torch.bmm(torch.softmax(torch.bmm(q, k.transpose(-2, -1)), dim=-1), v)      # [B*nhead, L, dh]
+    a = a.transpose(0, 1).reshape(L, B, D)
+    x = x + linear(a, W, f'{p}.self_attn.out_proj')
+    x2 = layer_norm(x, W, f'{p}.norm2')
+    return x + linear(F.gelu(linear(x2, W, f'{p}.linear1')), W, f'{p}.linear2')
+
+
+def predict_codes(z_hat, W, cfg):
+    """KA:1073-1087 -- tokens -> 9 transformer layers -> logits [B,HW,1024] -> argmax indices [B,HW]."""
+    b = z_hat.shape[0]
+    pos = W['position_emb'].unsqueeze(1).repeat(1, b, 1)
+    q = linear(z_hat.flatten(2).permute(2, 0, 1), W, 'feat_emb')
+    for i in range(cfg['n_layers']):
+        q = transformer_sa_layer(q, pos, W, f'ft_layers.{i}', cfg['n_head'])
+    logits = F.linear(layer_norm(q, W, 'idx_pred_layer.0'), W['idx_pred_layer.1.weight']).permute(1, 0, 2)
+    # softmax is monotone: topk(softmax(l),1) == argmax(l) away from exact ties
+    return logits, logits.argmax(dim=2)
+
+
+def codebook_lookup(idx, W, b, side, emb_dim):
+    """VQ:78-91 -- one-hot x embedding == gather rows; [B,HW] -> [B,C,side,side]."""
+    return W['quantize.embedding.weight'][idx.reshape(-1)].reshape(b, side, side, emb_dim).permute(0, 3, 1, 2).contiguous()
+
+
+def cft_fuse(enc_feat, dec_feat, W, p, w=1):
+    """KA:465-472 -- Fuse_sft_block: e=ResBlock(cat[enc,dec]); dec + w*(dec*scale(e) + shift(e))."""
+    e = resblock(torch.cat([enc_feat, dec_feat], dim=1), W, f'{p}.encode_enc')
+    scale = conv(F.leaky_relu(conv(e, W, f'{p}.scale.0'), 0.2), W, f'{p}.scale.2')
+    shift = conv(F.leaky_relu(conv(e, W, f'{p}.shift.0'), 0.2), W, f'{p}.shift.2')
+    return dec_feat + w * (dec_feat * scale + shift)
+
+
+def cfa_fuse(curr, prev, W, p, heads, dim_head):
+    """KA:519-541 -- post-norm cross-frame attention: a=attn(curr,prev); y=LN(a)+curr; LN(ff(y))+y."""
+    B, C, H, Wd = curr.shape
+    c = curr.flatten(2).permute(0, 2, 1)
+    pv = prev.flatten(2).permute(0, 2, 1)
+    y = layer_norm(cross_attention(c, pv, W, f'{p}.attn', heads, dim_head), W, f'{p}.norm1') + c
+    z = layer_norm(geglu_ff(y, W, f'{p}.ff'), W, f'{p}.norm2') + y
+    return z.permute(0, 2, 1).reshape(B, C, H, Wd)
+
+
+# ----------------------------------------------------------------------------- GMFlow
+def _instance_norm(x):
+    """GM/backbone.py:7,41 -- nn.InstanceNorm2d default: eps 1e-5, no affine, biased variance."""
+    return F.instance_norm(x, eps=1e-5)
+
+
+def _gm_resblock(x, W, p, stride):
+    """GM/backbone.py:6-36."""
+    y = F.relu(_instance_norm(F.conv2d(x, W[f'{p}.conv1.weight'], None, stride=stride, padding=1)))
+    y = F.relu(_instance_norm(F.conv2d(y, W[f'{p}.conv2.weight'], None, stride=1, padding=1)))
+    if f'{p}.downsample.0.weight' in W:
+        x = _instance_norm(F.conv2d(x, W[f'{p}.downsample.0.weight'], W[f'{p}.downsample.0.bias'], stride=stride))
+    return F.relu(x + y)
+
+
+def gm_backbone(x, W, p):
+    """GM/backbone.py:99-117 -- 7x7 s2 conv, IN, ReLU, three 2-block stages (s1,s2,s2), 1x1 conv."""
+    x = F.relu(_instance_norm(F.conv2d(x, W[f'{p}.conv1.weight'], None, stride=2, padding=3)))
+    for li, stride in ((1, 1), (2, 2), (3, 2)):
+        x = _gm_resblock(x, W, f'{p}.layer{li}.0', stride)
+        x = _gm_resblock(x, W, f'{p}.layer{li}.1', 1)
+    return F.conv2d(x, W[f'{p}.conv2.weight'], W[f'{p}.conv2.bias'])
+
+
+def _split_feature(x, k):
+    """GM/utils.py:5-31 (channel-first): [B,C,H,W] -> [B*k*k, C, H/k, W/k]."""
+    b, c, h, w = x.shape
+    return x.view(b, c, k, h // k, k, w // k).permute(0, 2, 4, 1, 3, 5).reshape(b * k * k, c, h // k, w // k)
+
+
+def _merge_splits(x, k):
+    """GM/utils.py:34-52 (channel-first)."""
+    b, c, h, w = x.shape
+    nb = b // k // k
+    return x.view(nb, k, k, c, h, w).permute(0, 3, 1, 4, 2, 5).contiguous().view(nb, c, k * h, k * w)
+
+
+def _split_cl(x, k):
+    """channel-last split: [B,H,W,C] -> [B*k*k, H/k, W/k, C]."""
+    b, h, w, c = x.shape
+    return x.view(b, k, h // k, k, w // k, c).permute(0, 1, 3, 2, 4, 5).reshape(b * k * k, h // k, w // k, c)
+
+
+def _merge_cl(x, k):
+    b, h, w, c = x.shape
+    nb = b // k // k
+    return x.view(nb, k, k, h, w, c).permute(0, 1, 3, 2, 4, 5).contiguous().view(nb, k * h, k * w, c)
+
+
+def sine_position(b, h, w, num_pos_feats=64, temperature=10000.0):
+    """GM/position.py:26-46 -- normalised cumsum * 2pi, interleaved sin/cos, cat(pos_y, pos_x) -> [B,2F,H,W]."""
+    mask = torch.ones((b, h, w))
+    y_embed = mask.cumsum(1, dtype=torch.float32)
+    x_embed = mask.cumsum(2, dtype=torch.float32)
+    eps, scale = 1e-6, 2 * math.pi
+    y_embed = y_embed / (y_embed[:, -1:, :] + eps) * scale
+    x_embed = x_embed / (x_embed[:, :, -1:] + eps) * scale
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * (dim_t // 2) / num_pos_feats)
+    pos_x = x_embed[:, :, :, None] / dim_t
+    pos_y = y_embed[:, :, :, None] / dim_t
+    pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+
+
+def feature_add_position(f0, f1, splits, channels):
+    """GM/utils.py:66-86 -- sine position per window (attn_splits=2 -> per 32x32 window at 64x64)."""
+    f0s, f1s = _split_feature(f0, splits), _split_feature(f1, splits)
+    pos = sine_position(f0s.shape[0], f0s.shape[2], f0s.shape[3], channels // 2)
+    return _merge_splits(f0s + pos, splits), _merge_splits(f1s + pos, splits)
+
+
+def shift_window_mask(h, w, wh, ww, sh, sw):
+    """GM/transformer.py:19-43 -- region ids of the rolled image -> additive 0/-100 mask [k*k, L, L]."""
+    img = torch.zeros((1, h, w, 1))
+    cnt = 0
+    for hs in (slice(0, -wh), slice(-wh, -sh), slice(-sh, None)):
+        for ws in (slice(0, -ww), slice(-ww, -sw), slice(-sw, None)):
+            img[:, hs, ws, :] = cnt
+            cnt += 1
+    mw = _split_cl(img, w // ww).view(-1, wh * ww)
+    m = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0)
+
+
+def _window_attention(q, k, v, splits, with_shift, h, w, mask):
+    """GM/transformer.py:46-105 -- single-head attention inside (optionally shifted) windows."""
+    b, _, c = q.shape
+    wh, ww = h // splits, w // splits
+    q, k, v = (t.view(b, h, w, c) for t in (q, k, v))
+    if with_shift:
+        q, k, v = (torch.roll(t, shifts=(-(wh // 2), -(ww // 2)), dims=(1, 2)) for t in (q, k, v))
+    q, k, v = (_split_cl(t, splits).reshape(b * splits * splits, -1, c) for t in (q, k, v))
+    scores = torch.matmul(q, k.permute(0, 2, 1)) / (c ** 0.5)
+    if with_shift:
+        scores = scores + mask.repeat(b, 1, 1)
+    out = torch.matmul(torch.softmax(scores, dim=-1), v)
+    out = _merge_cl(out.view(b * splits * splits, wh, ww, c), splits)
+    if with_shift:
+        out = torch.roll(out, shifts=(wh // 2, ww // 2), dims=(1, 2))
+    return out.reshape(b, -1, c)
+
+
+def _gm_layer(source, target, W, p, ffn, splits, with_shift, h, w, mask):
+    """GM/transformer.py:148-187 (TransformerLayer.forward)."""
+    q = F.linear(source, W[f'{p}.q_proj.weight'])
+    k = F.linear(target, W[f'{p}.k_proj.weight'])
+    v = F.linear(target, W[f'{p}.v_proj.weight'])
+    msg = _window_attention(q, k, v, splits, with_shift, h, w, mask)
+    msg = layer_norm(F.linear(msg, W[f'{p}.merge.weight']), W, f'{p}.norm1')
+    if ffn:
+        x = torch.cat([source, msg], dim=-1)
+        x = F.linear(F.gelu(F.linear(x, W[f'{p}.mlp.0.weight'])), W[f'{p}.mlp.2.weight'])
+        msg = layer_norm(x, W, f'{p}.norm2')
+    return source + msg
+
+
+def gm_transformer(f0, f1, W, p, splits):
+    """GM/transformer.py:277-322 (FeatureTransformer.forward): 6 blocks of self-attn + cross-attn-FFN on
+    [f0;f1] vs [f1;f0]; odd blocks use shifted windows."""
+    b, c, h, w = f0.shape
+    f0 = f0.flatten(-2).permute(0, 2, 1)
+    f1 = f1.flatten(-2).permute(0, 2, 1)
+    wh, ww = h // splits, w // splits
+    mask = shift_window_mask(h, w, wh, ww, wh // 2, ww // 2)
+    c0 = torch.cat((f0, f1), dim=0)
+    c1 = torch.cat((f1, f0), dim=0)
+    for i in range(GMFLOW['num_layers']):
+        shift = (i % 2 == 1)
+        c0 = _gm_layer(c0, c0, W, f'{p}.layers.{i}.self_attn', False, splits, shift, h, w, mask)
+        c0 = _gm_layer(c0, c1, W, f'{p}.layers.{i}.cross_attn_ffn', True, splits, shift, h, w, mask)
+        c1 = torch.cat(c0.chunk(2, dim=0)[::-1], dim=0)
+    f0, f1 = c0.chunk(2, dim=0)
+    f0 = f0.view(b, h, w, c).permute(0, 3, 1, 2).contiguous()
+    f1 = f1.view(b, h, w, c).permute(0, 3, 1, 2).contiguous()
+    return f0, f1
+
+
+def coords_grid(b, h, w):
+    """GM/geometry.py:5-22 -- [B,2,H,W], channel 0 = x, channel 1 = y."""
+    y, x = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+    return torch.stack([x, y], dim=0).float()[None].repeat(b, 1, 1, 1)
+
+
+def global_correlation_softmax(f0, f1):
+    """GM/matching.py:7-36 -- softmax over all targets of f0.f1/sqrt(C); flow = E[grid] - grid."""
+    b, c, h, w = f0.shape
+    a = f0.view(b, c, -1).permute(0, 2, 1)
+    corr = torch.matmul(a, f1.view(b, c, -1)) / (c ** 0.5)
+    grid0 = coords_grid(b, h, w)
+    grid = grid0.view(b, 2, -1).permute(0, 2, 1)
+    prob = F.softmax(corr, dim=-1)
+    corresp = torch.matmul(prob, grid).view(b, h, w, 2).permute(0, 3, 1, 2)
+    return corresp - grid0
+
+
+def feature_flow_attention(f0, flow, W, p):
+    """GM/transformer.py:343-374 -- q=Wq f0+bq; k = Wk q + bk (sic, K from projected Q); softmax(qk/sqrt C) flow."""
+    b, c, h, w = f0.shape
+    q = f0.view(b, c, h * w).permute(0, 2, 1)
+    q = F.linear(q, W[f'{p}.q_proj.weight'], W[f'{p}.q_proj.bias'])
+    k = F.linear(q, W[f'{p}.k_proj.weight'], W[f'{p}.k_proj.bias'])
+    v = flow.view(b, flow.size(1), h * w).permute(0, 2, 1)
+    prob = torch.softmax(torch.matmul(q, k.permute(0, 2, 1)) / (c ** 0.5), dim=-1)
+    return torch.matmul(prob, v).view(b, h, w, v.size(-1)).permute(0, 3, 1, 2)
+
+
+def convex_upsample(flow, feature, W, p, k=8):
+    """GM/gmflow.py:67-90 -- mask = conv1x1(relu(conv3x3(cat[flow,feat]))); softmax over 9; unfold(k*flow)."""
+    x = torch.cat((flow, feature), dim=1)
+    m = F.conv2d(F.relu(F.conv2d(x, W[f'{p}.0.weight'], W[f'{p}.0.bias'], padding=1)), W[f'{p}.2.weight'], W[f'{p}.2.bias'])
+    b, fc, h, w = flow.shape
+    m = torch.softmax(m.view(b, 1, 9, k, k, h, w), dim=2)
+    up = F.unfold(k * flow, [3, 3], padding=1).view(b, fc, 9, 1, 1, h, w)
+    up = torch.sum(m * up, dim=2).permute(0, 1, 4, 2, 5, 3)
+    return up.reshape(b, fc, k * h, k * w)
+
+
+def gmflow_forward(im1, im2, W, prefix='flownet.model'):
+    """GF:40-66 + GM/gmflow.py:92-170 with attn_splits=[2], corr_radius=[-1], prop_radius=[-1], 1 scale.
+    im1, im2: [N,3,H,W] in [-1,1].  Returns flow [N,2,H,W] (backward flow im1 -> im2 grid)."""
+    im1 = (im1 + 1) / 2 * 255
+    im2 = (im2 + 1) / 2 * 255
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    im1 = (im1 / 255. - mean) / std
+    im2 = (im2 / 255. - mean) / std
+    feats = gm_backbone(torch.cat((im1, im2), dim=0), W, f'{prefix}.backbone')
+    f0, f1 = torch.chunk(feats, 2, 0)
+    f0, f1 = feature_add_position(f0, f1, 2, GMFLOW['feature_channels'])
+    f0, f1 = gm_transformer(f0, f1, W, f'{prefix}.transformer', 2)
+    flow = global_correlation_softmax(f0, f1)
+    flow = feature_flow_attention(f0, flow, W, f'{prefix}.feature_flow_attn')
+    return convex_upsample(flow, f0, W, f'{prefix}.upsampler', GMFLOW['upsample_factor'])
+
+
+def get_flow(x, W):
+    """KA:976-986 -- flownet(x[:,1:], x[:,:-1]) -> [B,T-1,2,H,W]."""
+    b, t, c, h, w = x.shape
+    x1 = x[:, :-1].reshape(-1, c, h, w)
+    x2 = x[:, 1:].reshape(-1, c, h, w)
+    return gmflow_forward(x2, x1, W).view(b, t - 1, 2, h, w)
+
+
+# ----------------------------------------------------------------------------- KEEP.forward
+@torch.no_grad()
+def keep_forward(x, W, cfg=None, need_upscale=False, return_aux=False, force_indices=None):
+    """KA:1008-1145 (eval branch).  x: [B,T,3,H,W] fp32 in [-1,1] -> [B,T,3,H,W] fp32 (unclamped).
+
+    ``force_indices`` ([B,T,HW] int64) injects code indices (parity tests use it to separate index
+    flips from arithmetic drift)."""
+    cfg = dict(DEFAULT_ARCH, **(cfg or {}))
+    T = x.shape[1]
+    if need_upscale:                                                      # KA:1020-1023
+        x = F.interpolate(x.flatten(0, 1), scale_factor=4, mode='bilinear').unflatten(0, (-1, T))
+    b, t, c, h, w = x.shape
+    flows = get_flow(x, W) if t > 1 else None                             # KA:1026
+    enc_taps = [FUSE_ENCODER_BLOCK[s] for s in cfg['cft_list']]
+    z, feats = encoder_forward(x.reshape(-1, c, h, w), W, 'encoder', cfg, enc_taps)      # KA:1030-1039
+    enc_feat = {k: v.reshape(b, t, *v.shape[1:]) for k, v in feats.items()}
+    z_codes = z.reshape(b, t, *z.shape[1:])
+    gains = kalman_calc_gain(z_codes, W, cfg)                             # KA:1046
+    cft_at = {FUSE_GENERATOR_BLOCK[s]: s for s in cfg['cft_list']}
+    cfa_at = {FUSE_GENERATOR_BLOCK[s]: s for s in cfg['cfa_list']}
+    gblocks = generator_blocks(cfg)
+    side = int(math.sqrt(cfg['latent_size']))
+    outs, all_idx, all_logits, z_hats = [], [], [], []
+    cross_prev, prev_out = {}, None
+    for i in range(t):
+        if i == 0:
+            z_hat = z_codes[:, 0]
+        else:                                                             # KA:1067-1070, 790-799
+            warped = flow_warp(prev_out, flows[:, i - 1].permute(0, 2, 3, 1))
+            z_prime, _ = encoder_forward(warped, W, 'hq_encoder', cfg)
+            g = gains[:, i]
+            z_hat = (1 - g) * z_codes[:, i] + g * z_prime
+        logits, idx = predict_codes(z_hat, W, cfg)                        # KA:1073-1087
+        if force_indices is not None:
+            idx = force_indices[:, i]
+        y = codebook_lookup(idx, W, b, side, cfg['emb_dim'])              # KA:1088-1089
+        for j, (kind, _, _) in enumerate(gblocks):                        # KA:1101-1125
+            y = vq_block(y, W, f'generator.blocks.{j}', kind)
+            if j in cft_at:
+                s = cft_at[j]
+                y = cft_fuse(enc_feat[s][:, i], y, W, f'cft.{s}', cfg['cond'])
+            if j in cfa_at:
+                s = cfa_at[j]
+                if i > 0:
+                    y = cfa_fuse(y, cross_prev[s], W, f'cfa.{s}', cfg['cfa_nhead'], cfg['cfa_dim'])
+                cross_prev[s] = y
+        prev_out = y
+        outs.append(y)
+        all_idx.append(idx)
+        all_logits.append(logits)
+        z_hats.append(z_hat)
+    out = torch.stack(outs, dim=1)
+    if not return_aux:
+        return out
+    return out, {'indices': torch.stack(all_idx, 1), 'logits': torch.stack(all_logits, 1), 'gains': gains,
+                 'z_codes': z_codes, 'z_hat': torch.stack(z_hats, 1), 'flows': flows, 'enc_feat': enc_feat}
+
+
+def nearest_codes(z, W):
+    """VQ:37-48 (VectorQuantizer.forward, index part): argmin_j ||z||^2 + ||e_j||^2 - 2 z.e_j; z [B,C,H,W]."""
+    e = W['quantize.embedding.weight']
+    zf = z.permute(0, 2, 3, 1).reshape(-1, e.shape[1])
+    d = (zf ** 2).sum(dim=1, keepdim=True) + (e ** 2).sum(1) - 2 * torch.matmul(zf, e.t())
+    return torch.argmin(d, dim=1)

@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""bench.py -- headline metric of BASELINE.json: restored 512x512 face frames/s on T=20 clips.
+
+    python bench.py --gpus 1 --steps K --warmup W [--clips B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...
+
+One "step" = one pass of the hot path (KEEP.forward on the HIP engine) over one batch of synthetic input:
+B independent 20-frame 512x512 clips per GPU (config.workload), inputs already resident in HBM.  Multi-GPU is
+weak scaling: every rank runs its own B clips; the only collective is the one-off RCCL broadcast of the packed
+weights (outside the timed region).  value = (N * B * 20 * K) / max-over-ranks wall time.
+
+Also on the JSON line:
+  roofline      dominant kernel (conv_f32<128x128>, the 3x3 implicit-GEMM convolution): algorithmic FLOPs of its
+                launches in one clip-batch / their summed HIP-event durations, vs the fp32 MFMA peak (157.3 TF);
+  cpu_baseline  the CPU oracle (a port of the reference algorithm, PyTorch-CPU fp32) timed on this box's host cores on
+                a bounded sample (one T=2 clip), rank 0 / N=1 only -- a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+load_package()
+from comfyui_keep_amd.engine import dist as kdist  # noqa: E402
+from comfyui_keep_amd.engine import ops, synth  # noqa: E402
+from comfyui_keep_amd.engine.arch import DEFAULT_ARCH  # noqa: E402
+from comfyui_keep_amd.engine.net import KeepNet  # noqa: E402
+
+T_CLIP = 20
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+FLOP_PER_FRAME_T20 = 1038.5e9         # SURVEY.md 8d (reference graph, 2 FLOP/MAC)
+
+
+def build_net(rank, world):
+    net = KeepNet(**DEFAULT_ARCH)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    if rank == 0:
+        net.load_state_dict(synth.synth_state_dict(seed=0), strict=True)
+        net.to(dev)
+        index, blob = net._index, net.packed_blob()
+    else:
+        index, blob = None, None
+    if world > 1:
+        t0 = time.time()
+        index, blob = kdist.broadcast_packed_weights(index, blob, src=0)
+        torch.cuda.synchronize()
+        if rank != 0:
+            net.adopt_packed(index, blob)
+        if rank == 0:
+            print(f"[bench] RCCL weight broadcast: {blob.numel() * 4 / 1e6:.0f} MB in {time.time() - t0:.3f}s",
+                  file=sys.stderr)
+    return net.eval()
+
+
+def conv_roofline(net, x):
+    """One instrumented clip-batch: every keep_conv2d launch bracketed by HIP events on the launch stream."""
+    ops.PROFILE = []
+    net(x)
+    torch.cuda.synchronize()
+    rec, ops.PROFILE = ops.PROFILE, None
+    by = {}
+    for cfg, flops, split_k, e0, e1 in rec:
+        d = by.setdefault((cfg, split_k > 1), [0.0, 0.0, 0])
+        d[0] += flops
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += 1
+    key = ('conv_f32<128x128>', False)
+    flops, secs, n = by[key]
+    tf = flops / secs / 1e12
+    detail = {f"{k[0]}{'+splitK' if k[1] else ''}": {"launches": v[2], "gflop": round(v[0] / 1e9, 1),
+                                                      "ms": round(v[1] * 1e3, 2),
+                                                      "tflops": round(v[0] / v[1] / 1e12, 1)} for k, v in by.items()}
+    return {"bound": "mfma", "kernel": "conv_f32_kernel<2,2,2,2> (128x128 tile, fp32 MFMA)", "achieved": round(tf, 2),
+            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": None, "launches_per_step": n, "avg_launch_ms": round(secs / n * 1e3, 4),
+            "algorithmic_gflop_per_launch": round(flops / n / 1e9, 2), "all_conv_kernels": detail}
+
+
+def cpu_baseline():
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import keep_oracle as O
+    W = synth.synth_state_dict(seed=0)
+    x = synth.synth_clip(T=2, B=1, seed=1234)
+    threads = torch.get_num_threads()
+    t0 = time.time()
+    O.keep_forward(x, W)
+    dt = time.time() - t0
+    return {"value": round(2 / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"one B=1 T=2 512x512 synthetic clip (2 frames, {dt:.1f}s, torch CPU fp32, {threads} threads); "
+                      f"a T=2 clip costs 854 GFLOP/frame vs 1038 at T=20"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--clips', type=int, default=int(os.environ.get('KEEP_BENCH_CLIPS', '2')),
+                    help='independent T=20 clips per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank, world, local = kdist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local)
+    net = build_net(rank, world)
+    B = args.clips
+    x = synth.synth_clip(T=T_CLIP, B=B, seed=1234 + rank, phase=0.37 * rank).cuda()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        net(x)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = net(x)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        frames = world * B * T_CLIP * args.steps
+        fps = frames / dt
+        line = {
+            "metric": "restored 512x512 face frames/sec, T=20 clip", "value": round(fps, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{B} independent clips x T={T_CLIP} x 512x512 per GPU (BASELINE configs[1], "
+                                   f"fp32-in/fp32-accumulate MFMA policy), KEEP config, synthetic weights seed 0",
+                       "clips_per_gpu": B, "clip_length": T_CLIP, "parallelism": f"dp{world} over clips"},
+            "whole_net_tflops": round(fps * FLOP_PER_FRAME_T20 / 1e12, 2),
+            "roofline": conv_roofline(net, x),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

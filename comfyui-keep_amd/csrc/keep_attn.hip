@@ -1,0 +1,294 @@
+// keep_attention: fused softmax(scale * Q K^T + mask) V on the CDNA4 matrix cores (fp32 in / fp32 accumulate),
+// flash style -- the L x L score matrix (64 MB per GMFlow pair in the reference) never leaves the CU.
+//
+// One wave owns 32 query rows.  Per 32-key tile:
+//   S^T (keys x queries) = K . Q^T   with v_mfma_f32_32x32x2_f32, A = K tile, B = Q tile, both K-major in LDS
+//   C/D layout: lane (q = lane&31, h = lane>>5) holds keys kr(r,h) = (r&3) + 8*(r>>2) + 4*h, r = 0..15, of ITS query
+//   -> the softmax row reduction is 15 in-lane ops + one cross-half shuffle (no LDS, no 5-step butterfly);
+//   P.V: the MFMA k index is free to be ANY key order as long as A and B agree, so step r uses k=0 <-> key kr(r,0)
+//   and k=1 <-> key kr(r,1): the A operand of step r is simply the lane's own p[r] register -- P is never moved,
+//   transposed or staged -- and B is V[kr(r,h)][dv = lane&31].
+//   O (queries x dv) comes out with rows = queries spread over registers, so the per-query rescale factors are
+//   fetched with 16 wave shuffles per tile.
+// Token addressing modes (plain / sparse-causal keys / shifted windows with region mask) are pure index math at
+// tile-load time, so the window partition, roll, key concatenation and batch swap of the reference cost no HBM pass.
+#include <math.h>
+
+#include "keep_common.h"
+
+struct AttnP {
+  const float* q;
+  const float* k;
+  const float* v;
+  float* o;
+  long q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, o_bs, o_ts, o_hs;
+  int B, H, Lq, Lk, D, Dv;
+  float scale;
+  int mode, T, seg_len;
+  int img_h, img_w, ksplit, shift, kv_rot, n_img;
+  int nslices;  // dv slices per head
+};
+
+// window-mode: token t of window-batch bw -> (image, pixel index)
+__device__ __forceinline__ void win_decode(const AttnP& p, int bw, int t, int rot, int& img, int& pix) {
+  const int k2 = p.ksplit * p.ksplit;
+  img = bw / k2;
+  const int widx = bw - img * k2;
+  const int wy = widx / p.ksplit, wx = widx - wy * p.ksplit;
+  const int wh = p.img_h / p.ksplit, ww = p.img_w / p.ksplit;
+  const int ty = t / ww, tx = t - ty * ww;
+  int y = wy * wh + ty + p.shift;
+  int x = wx * ww + tx + p.shift;
+  if (y >= p.img_h) y -= p.img_h;
+  if (x >= p.img_w) x -= p.img_w;
+  pix = y * p.img_w + x;
+  if (rot) {
+    img += rot;
+    if (img >= p.n_img) img -= p.n_img;
+  }
+}
+
+// region id of a window-local token in the ROLLED frame (GM/transformer.py:24-35)
+__device__ __forceinline__ int win_region(const AttnP& p, int bw, int t) {
+  const int k2 = p.ksplit * p.ksplit;
+  const int widx = bw % k2;
+  const int wy = widx / p.ksplit, wx = widx - wy * p.ksplit;
+  const int wh = p.img_h / p.ksplit, ww = p.img_w / p.ksplit;
+  const int ty = t / ww, tx = t - ty * ww;
+  const int yr = wy * wh + ty, xr = wx * ww + tx;
+  const int sh = wh / 2, sw = ww / 2;
+  const int ih = yr < p.img_h - wh ? 0 : (yr < p.img_h - sh ? 1 : 2);
+  const int iw = xr < p.img_w - ww ? 0 : (xr < p.img_w - sw ? 1 : 2);
+  return ih * 3 + iw;
+}
+
+__device__ __forceinline__ long q_offset(const AttnP& p, int b, int t, long bs, long ts) {
+  if (p.mode == 2) {
+    int img, pix;
+    win_decode(p, b, t, 0, img, pix);
+    return (long)img * bs + (long)pix * ts;
+  }
+  return (long)b * bs + (long)t * ts;
+}
+
+__device__ __forceinline__ long kv_offset(const AttnP& p, int b, int t, long bs, long ts) {
+  if (p.mode == 2) {
+    int img, pix;
+    win_decode(p, b, t, p.kv_rot, img, pix);
+    return (long)img * bs + (long)pix * ts;
+  }
+  if (p.mode == 1) {
+    const int f = b % p.T;
+    int src, tt;
+    if (t < p.seg_len) {
+      src = b - f;
+      tt = t;
+    } else {
+      src = (f == 0) ? b : b - 1;
+      tt = t - p.seg_len;
+    }
+    return (long)src * bs + (long)tt * ts;
+  }
+  return (long)b * bs + (long)t * ts;
+}
+
+template <int WAVES, int DVT>
+__global__ __launch_bounds__(64 * WAVES) void attn_f32_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int QP = p.D + 1;          // odd pitch: 32 rows -> 32 distinct banks
+  constexpr int DVS = DVT * 32;    // dv slice handled by this block
+  float* Qs = smem;                              // [WAVES*32][QP]
+  float* Ks = Qs + WAVES * 32 * QP;              // [32][QP]
+  float* Vs = Ks + 32 * QP;                      // [32][DVS]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int b = blockIdx.z;
+  const int head = blockIdx.y / p.nslices;
+  const int dv0 = (blockIdx.y - head * p.nslices) * DVS;
+  const int q0 = blockIdx.x * (WAVES * 32);
+  constexpr int NT = 64 * WAVES;
+
+  // ---- stage the block's Q tile (zero rows beyond Lq)
+  for (int idx = tid; idx < WAVES * 32 * p.D; idx += NT) {
+    const int row = idx / p.D, d = idx - row * p.D;
+    const int t = q0 + row;
+    float val = 0.f;
+    if (t < p.Lq) val = p.q[q_offset(p, b, t, p.q_bs, p.q_ts) + (long)head * p.q_hs + d];
+    Qs[row * QP + d] = val;
+  }
+
+  const int my_q = q0 + wave * 32 + l31;  // query owned by this lane in the S^T layout
+  int my_region = 0;
+  if (p.mode == 2 && p.shift > 0 && my_q < p.Lq) my_region = win_region(p, b, my_q);
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 o[DVT];
+#pragma unroll
+  for (int j = 0; j < DVT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+
+  const float* Qw = Qs + wave * 32 * QP;
+  const int ntiles = (p.Lk + 31) / 32;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();  // previous tile fully consumed (also orders the Q staging before first use)
+    for (int idx = tid; idx < 32 * p.D; idx += NT) {
+      const int row = idx / p.D, d = idx - row * p.D;
+      const int t = kt * 32 + row;
+      float val = 0.f;
+      if (t < p.Lk) val = p.k[kv_offset(p, b, t, p.k_bs, p.k_ts) + (long)head * p.k_hs + d];
+      Ks[row * QP + d] = val;
+    }
+    for (int idx = tid; idx < 32 * DVS; idx += NT) {
+      const int row = idx / DVS, d = idx - row * DVS;
+      const int t = kt * 32 + row;
+      float val = 0.f;
+      if (t < p.Lk && dv0 + d < p.Dv) val = p.v[kv_offset(p, b, t, p.v_bs, p.v_ts) + (long)head * p.v_hs + dv0 + d];
+      Vs[row * DVS + d] = val;
+    }
+    __syncthreads();
+
+    // ---- S^T = K . Q^T
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const float* kp = Ks + l31 * QP + lhi;
+    const float* qp = Qw + l31 * QP + lhi;
+    for (int d2 = 0; d2 < p.D; d2 += 2) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[d2], qp[d2], s, 0, 0, 0);
+
+    // ---- scale, mask, online softmax (row = this lane's query)
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      float val = s[r] * p.scale;
+      if (p.mode == 2 && p.shift > 0 && key < p.Lk) {
+        if (win_region(p, b, key) != my_region) val += -100.0f;
+      }
+      if (key >= p.Lk) val = -INFINITY;
+      s[r] = val;
+      mloc = fmaxf(mloc, val);
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = expf(m_run - m_new);  // first tile: exp(-inf) = 0
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = expf(s[r] - m_new);
+      s[r] = pv;
+      lsum += pv;
+    }
+    lsum += __shfl_xor(lsum, 32);
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+
+    // ---- rescale O: its rows (queries) sit at (r&3)+8*(r>>2)+4*lhi -> fetch that query's alpha
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const float ar = __shfl(alpha, qrow);
+#pragma unroll
+      for (int j = 0; j < DVT; ++j) o[j][r] *= ar;
+    }
+    // ---- O += P . V   (step r: k=0 <-> key kr(r,0), k=1 <-> key kr(r,1); A operand = own p[r])
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int krow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const float* vp = Vs + krow * DVS + l31;
+#pragma unroll
+      for (int j = 0; j < DVT; ++j) o[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[r], vp[j * 32], o[j], 0, 0, 0);
+    }
+  }
+
+  // ---- normalise and store: O rows = queries (r&3)+8*(r>>2)+4*lhi, cols = dv0 + j*32 + l31
+  const float inv_l = 1.0f / l_run;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    const float il = __shfl(inv_l, qrow);
+    const int t = q0 + wave * 32 + qrow;
+    if (t < p.Lq) {
+      const long base = q_offset(p, b, t, p.o_bs, p.o_ts) + (long)head * p.o_hs;
+#pragma unroll
+      for (int j = 0; j < DVT; ++j) {
+        const int dv = dv0 + j * 32 + l31;
+        if (dv < p.Dv) p.o[base + dv] = o[j][r] * il;
+      }
+    }
+  }
+}
+
+template <int WAVES, int DVT>
+static int launch_attn(const AttnP& p, hipStream_t st) {
+  const size_t lds = (size_t)(WAVES * 32 * (p.D + 1) + 32 * (p.D + 1) + 32 * DVT * 32) * sizeof(float);
+  if (lds > 160 * 1024) {
+    keep_set_error("keep_attention: LDS need %zu B exceeds 160 KiB (D=%d)", lds, p.D);
+    return KEEP_EINVAL;
+  }
+  static bool attr_set = false;  // per instantiation; idempotent, benign if raced
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_f32_kernel<WAVES, DVT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      keep_set_error("keep_attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return KEEP_EHIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid(cdiv(p.Lq, WAVES * 32), p.H * p.nslices, p.B);
+  hipLaunchKernelGGL((attn_f32_kernel<WAVES, DVT>), grid, dim3(64 * WAVES), lds, st, p);
+  KEEP_LAUNCH_CHECK("keep_attention");
+  return KEEP_OK;
+}
+
+extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
+  KEEP_REQUIRE(a != nullptr, "keep_attention: null args");
+  KEEP_REQUIRE(a->q && a->k && a->v && a->o, "keep_attention: null tensor pointer");
+  KEEP_REQUIRE(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0 && a->D > 0 && a->Dv > 0, "keep_attention: bad dims");
+  KEEP_REQUIRE(a->D % 2 == 0 && a->D <= 512, "keep_attention: D=%d must be even and <= 512", a->D);
+  KEEP_REQUIRE(a->mode >= 0 && a->mode <= 2, "keep_attention: bad mode %d", a->mode);
+  if (a->mode == 1)
+    KEEP_REQUIRE(a->T > 0 && a->seg_len > 0 && a->Lk == 2 * a->seg_len && a->B % a->T == 0,
+                 "keep_attention: sparse-causal mode needs Lk == 2*seg_len and B %% T == 0");
+  if (a->mode == 2) {
+    KEEP_REQUIRE(a->ksplit > 0 && a->img_h % a->ksplit == 0 && a->img_w % a->ksplit == 0, "keep_attention: bad window split");
+    const int wh = a->img_h / a->ksplit, ww = a->img_w / a->ksplit;
+    KEEP_REQUIRE(a->Lq == wh * ww && a->Lk == wh * ww, "keep_attention: window mode needs Lq == Lk == window size");
+    KEEP_REQUIRE(a->n_img > 0 && a->B == a->n_img * a->ksplit * a->ksplit, "keep_attention: B != n_img*ksplit^2");
+    KEEP_REQUIRE(a->shift >= 0 && a->shift < wh && a->shift < ww, "keep_attention: bad shift");
+    KEEP_REQUIRE(a->kv_rot >= 0 && a->kv_rot < a->n_img, "keep_attention: bad kv_rot");
+  }
+  AttnP p;
+  p.q = a->q; p.k = a->k; p.v = a->v; p.o = a->o;
+  p.q_bs = a->q_bs; p.q_ts = a->q_ts; p.q_hs = a->q_hs;
+  p.k_bs = a->k_bs; p.k_ts = a->k_ts; p.k_hs = a->k_hs;
+  p.v_bs = a->v_bs; p.v_ts = a->v_ts; p.v_hs = a->v_hs;
+  p.o_bs = a->o_bs; p.o_ts = a->o_ts; p.o_hs = a->o_hs;
+  p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.D = a->D; p.Dv = a->Dv;
+  p.scale = a->scale; p.mode = a->mode; p.T = a->T; p.seg_len = a->seg_len;
+  p.img_h = a->img_h; p.img_w = a->img_w; p.ksplit = a->ksplit; p.shift = a->shift; p.kv_rot = a->kv_rot;
+  p.n_img = a->n_img;
+  hipStream_t st = (hipStream_t)stream;
+  // dv slice per block: 32 / 64 / 128 columns
+  const int dvt = a->Dv <= 32 ? 1 : (a->Dv <= 64 ? 2 : 4);
+  p.nslices = cdiv(a->Dv, dvt * 32);
+  // waves per block bounded by the Q tile's LDS footprint
+  const int waves = a->D <= 128 ? 4 : (a->D <= 256 ? 2 : 1);
+  if (waves == 4) {
+    if (dvt == 1) return launch_attn<4, 1>(p, st);
+    if (dvt == 2) return launch_attn<4, 2>(p, st);
+    return launch_attn<4, 4>(p, st);
+  }
+  if (waves == 2) {
+    if (dvt == 1) return launch_attn<2, 1>(p, st);
+    if (dvt == 2) return launch_attn<2, 2>(p, st);
+    return launch_attn<2, 4>(p, st);
+  }
+  if (dvt == 1) return launch_attn<1, 1>(p, st);
+  if (dvt == 2) return launch_attn<1, 2>(p, st);
+  return launch_attn<1, 4>(p, st);
+}

@@ -1,0 +1,630 @@
+// HBM-bound kernels of the KEEP hot path: normalisation statistics, LayerNorm, GEGLU, argmax + codebook gather,
+// Kalman blend, bilinear flow warp, convex flow upsampling, layout / elementwise helpers.  All are one read of the
+// inputs + one write of the outputs with coalesced channel-contiguous (NHWC) accesses; reductions are wave-level
+// (64-lane shuffles) with an LDS step across waves.
+#include <math.h>
+
+#include "keep_common.h"
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ channel stats
+// grid (P, N), block 256.  Thread t owns channel(s) c = t % C (+256 stride when C > 256) and walks the chunk's
+// pixels with stride 256/C: consecutive lanes read consecutive channels of one pixel (coalesced).
+__global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int HW,
+                                                         int C, int ld, int P) {
+  __shared__ float red[2][256];
+  const int n = blockIdx.y, pch = blockIdx.x;
+  const int per = (HW + P - 1) / P;
+  const int p0 = pch * per, p1 = min(HW, p0 + per);
+  const int tid = threadIdx.x;
+  const float* xb = x + (long)n * HW * ld;
+  for (int cbase = 0; cbase < C; cbase += 256) {
+    const int cw = min(256, C - cbase);       // channels handled in this pass
+    const int lanes_per_pix = cw;             // threads [0, cw*rows) active
+    const int rows = 256 / cw > 0 ? 256 / cw : 1;
+    float s = 0.f, ss = 0.f;
+    if (tid < rows * cw) {
+      const int c = cbase + tid % cw;
+      for (int px = p0 + tid / cw; px < p1; px += rows) {
+        const float v = xb[(long)px * ld + c];
+        s += v;
+        ss += v * v;
+      }
+    }
+    red[0][tid] = s;
+    red[1][tid] = ss;
+    __syncthreads();
+    if (tid < cw) {
+      float a = 0.f, b2 = 0.f;
+      for (int r = 0; r < rows; ++r) {
+        a += red[0][r * cw + tid];
+        b2 += red[1][r * cw + tid];
+      }
+      float* dst = part + (((long)n * P + pch) * C + cbase + tid) * 2;
+      dst[0] = a;
+      dst[1] = b2;
+    }
+    __syncthreads();
+    (void)lanes_per_pix;
+  }
+}
+
+extern "C" int32_t keep_chan_stats(const float* x, float* part, int32_t N, int32_t HW, int32_t C, int32_t ld, int32_t P,
+                                   void* stream) {
+  KEEP_REQUIRE(x && part && N > 0 && HW > 0 && C > 0 && ld >= C && P > 0 && P <= HW, "keep_chan_stats: bad args");
+  hipLaunchKernelGGL(chan_stats_kernel, dim3(P, N), dim3(256), 0, (hipStream_t)stream, x, part, HW, C, ld, P);
+  KEEP_LAUNCH_CHECK("keep_chan_stats");
+  return KEEP_OK;
+}
+
+// grid (G, N), block 64: reduce P x (C/G) partials in double, write scale/shift for the group's channels.
+__global__ __launch_bounds__(64) void norm_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ scale,
+                                                           float* __restrict__ shift, int HW, int C, int G, int P,
+                                                           float eps) {
+  const int g = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+  const int cpg = C / G;
+  const int total = P * cpg;
+  double s = 0.0, ss = 0.0;
+  for (int i = lane; i < total; i += 64) {
+    const int pch = i / cpg, cc = i - pch * cpg;
+    const float* src = part + (((long)n * P + pch) * C + g * cpg + cc) * 2;
+    s += (double)src[0];
+    ss += (double)src[1];
+  }
+  s = wave_sum_d(s);
+  ss = wave_sum_d(ss);
+  const double cnt = (double)HW * cpg;
+  const double mean = s / cnt;
+  double var = ss / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int cc = lane; cc < cpg; cc += 64) {
+    const int c = g * cpg + cc;
+    const float ga = gamma ? gamma[c] : 1.f;
+    const float be = beta ? beta[c] : 0.f;
+    const float sc = ga * rstd;
+    scale[(long)n * C + c] = sc;
+    shift[(long)n * C + c] = be - (float)mean * sc;
+  }
+}
+
+extern "C" int32_t keep_norm_finalize(const float* part, const float* gamma, const float* beta, float* scale,
+                                      float* shift, int32_t N, int32_t HW, int32_t C, int32_t G, int32_t P, float eps,
+                                      void* stream) {
+  KEEP_REQUIRE(part && scale && shift && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && P > 0,
+               "keep_norm_finalize: bad args (C=%d G=%d)", C, G);
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(G, N), dim3(64), 0, (hipStream_t)stream, part, gamma, beta, scale, shift,
+                     HW, C, G, P, eps);
+  KEEP_LAUNCH_CHECK("keep_norm_finalize");
+  return KEEP_OK;
+}
+
+__global__ void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, float* __restrict__ out, long total, long per_n, int C,
+                                  int act) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / per_n;
+    const int c = (int)(i % C);
+    float v = x[i] * scale[n * C + c] + shift[n * C + c];
+    out[i] = act_apply(v, act);
+  }
+}
+
+extern "C" int32_t keep_affine_act(const float* x, const float* scale, const float* shift, float* out, int32_t N,
+                                   int32_t HW, int32_t C, int32_t act, void* stream) {
+  KEEP_REQUIRE(x && scale && shift && out && N > 0 && HW > 0 && C > 0, "keep_affine_act: bad args");
+  const long total = (long)N * HW * C;
+  int blocks = cdiv(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(affine_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out, total,
+                     (long)HW * C, C, act);
+  KEEP_LAUNCH_CHECK("keep_affine_act");
+  return KEEP_OK;
+}
+
+__global__ void gm_join_kernel(const float* __restrict__ a, const float* __restrict__ sa, const float* __restrict__ ha,
+                               const float* __restrict__ b, const float* __restrict__ sb, const float* __restrict__ hb,
+                               float* __restrict__ out, long total, long per_n, int C) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / per_n;
+    const int c = (int)(i % C);
+    float xa = a[i];
+    if (sa) xa = xa * sa[n * C + c] + ha[n * C + c];
+    float yb = b[i] * sb[n * C + c] + hb[n * C + c];
+    yb = yb > 0.f ? yb : 0.f;
+    const float v = xa + yb;
+    out[i] = v > 0.f ? v : 0.f;
+  }
+}
+
+extern "C" int32_t keep_gm_join(const float* a, const float* sa, const float* ha, const float* b, const float* sb,
+                                const float* hb, float* out, int32_t N, int32_t HW, int32_t C, void* stream) {
+  KEEP_REQUIRE(a && b && sb && hb && out && N > 0 && HW > 0 && C > 0, "keep_gm_join: bad args");
+  KEEP_REQUIRE((sa == nullptr) == (ha == nullptr), "keep_gm_join: sa/ha must pair");
+  const long total = (long)N * HW * C;
+  int blocks = cdiv(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gm_join_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, sa, ha, b, sb, hb, out, total,
+                     (long)HW * C, C);
+  KEEP_LAUNCH_CHECK("keep_gm_join");
+  return KEEP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// one wave per row; C <= 1024 (C/64 <= 16 values per lane kept in registers); two-pass mean/variance.
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ res,
+                                                        float* __restrict__ out, const float* __restrict__ pos,
+                                                        int pos_rows, float* __restrict__ out2, int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (long)row * C;
+  float v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = lane + j * 64;
+    v[j] = c < C ? xr[c] : 0.f;
+    s += v[j];
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = lane + j * 64;
+    const float d = c < C ? v[j] - mean : 0.f;
+    q += d * d;
+  }
+  const float var = wave_sum(q) / (float)C;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = lane + j * 64;
+    if (c < C) {
+      const float y = (v[j] - mean) * rstd * gamma[c] + beta[c];
+      out[(long)row * C + c] = res ? y + res[(long)row * C + c] : y;
+      if (out2) out2[(long)row * C + c] = y + pos[(long)(row % pos_rows) * C + c];
+    }
+  }
+}
+
+extern "C" int32_t keep_layernorm(const float* x, const float* gamma, const float* beta, const float* res, float* out,
+                                  const float* pos, int32_t pos_rows, float* out2, int32_t M, int32_t C, float eps,
+                                  void* stream) {
+  KEEP_REQUIRE(x && gamma && beta && out && M > 0 && C > 0 && C <= 1024, "keep_layernorm: bad args (C=%d)", C);
+  KEEP_REQUIRE(!out2 || (pos && pos_rows > 0), "keep_layernorm: out2 requires pos");
+  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, res, out, pos,
+                     pos_rows > 0 ? pos_rows : 1, out2, M, C, eps);
+  KEEP_LAUNCH_CHECK("keep_layernorm");
+  return KEEP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ GEGLU
+__global__ void geglu_kernel(const float* __restrict__ x, float* __restrict__ out, long total, int F) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / F;
+    const int j = (int)(i - m * F);
+    const float h = x[m * 2 * F + j];
+    const float g = x[m * 2 * F + F + j];
+    out[i] = h * (0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)));
+  }
+}
+
+extern "C" int32_t keep_geglu(const float* x, float* out, int32_t M, int32_t F, void* stream) {
+  KEEP_REQUIRE(x && out && M > 0 && F > 0, "keep_geglu: bad args");
+  const long total = (long)M * F;
+  int blocks = cdiv(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(geglu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, total, F);
+  KEEP_LAUNCH_CHECK("keep_geglu");
+  return KEEP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ argmax + gather
+// one wave per token: 64 lanes scan the logits row (coalesced), wave arg-max with lowest-index tie-break,
+// then the wave copies the chosen codebook row.
+__global__ __launch_bounds__(256) void argmax_gather_kernel(const float* __restrict__ logits,
+                                                            const float* __restrict__ codebook,
+                                                            const int* __restrict__ force_idx, int* __restrict__ idx,
+                                                            float* __restrict__ margin, float* __restrict__ out, int M,
+                                                            int ncodes, int dim) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* lr = logits + (long)row * ncodes;
+  float best = -INFINITY, second = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = lane; j < ncodes; j += 64) {
+    const float v = lr[j];
+    if (v > best) {
+      second = best;
+      best = v;
+      bi = j;
+    } else if (v > second) {
+      second = v;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o);
+    const float os = __shfl_xor(second, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ob > best || (ob == best && oi < bi)) {
+      second = fmaxf(best, os);
+      best = ob;
+      bi = oi;
+    } else {
+      second = fmaxf(second, ob);
+    }
+  }
+  int sel = bi;
+  if (force_idx) sel = force_idx[row];
+  if (lane == 0) {
+    if (idx) idx[row] = sel;
+    if (margin) margin[row] = best - second;
+  }
+  const float* cb = codebook + (long)sel * dim;
+  for (int d = lane; d < dim; d += 64) out[(long)row * dim + d] = cb[d];
+}
+
+extern "C" int32_t keep_argmax_gather(const float* logits, const float* codebook, const int32_t* force_idx, int32_t* idx,
+                                      float* margin, float* out, int32_t M, int32_t ncodes, int32_t dim, void* stream) {
+  KEEP_REQUIRE(logits && codebook && out && M > 0 && ncodes > 0 && dim > 0, "keep_argmax_gather: bad args");
+  hipLaunchKernelGGL(argmax_gather_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, logits, codebook,
+                     force_idx, idx, margin, out, M, ncodes, dim);
+  KEEP_LAUNCH_CHECK("keep_argmax_gather");
+  return KEEP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ VQ nearest code
+// one block (256 threads) per 8 tokens: z rows staged in LDS, each thread scans ncodes/256 code rows; distance
+// |z|^2 + |e|^2 - 2 z.e evaluated in the reference's order (VQ:43-44); block arg-min, lowest index on ties.
+__global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                         int* __restrict__ idx, int M, int ncodes, int dim) {
+  extern __shared__ float zs[];  // [8][dim] + reduction scratch
+  __shared__ float rbest[8][256];
+  __shared__ int ribest[8][256];
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.x * 8;
+  for (int i = tid; i < 8 * dim; i += 256) {
+    const int r = i / dim, d = i - r * dim;
+    zs[i] = (m0 + r < M) ? z[(long)(m0 + r) * dim + d] : 0.f;
+  }
+  __syncthreads();
+  float z2[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    float s = 0.f;
+    for (int d = 0; d < dim; ++d) s += zs[r * dim + d] * zs[r * dim + d];
+    z2[r] = s;
+  }
+  float best[8];
+  int bi[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    best[r] = INFINITY;
+    bi[r] = 0x7fffffff;
+  }
+  for (int j = tid; j < ncodes; j += 256) {
+    const float* e = cb + (long)j * dim;
+    float e2 = 0.f, dot[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) dot[r] = 0.f;
+    for (int d = 0; d < dim; ++d) {
+      const float ev = e[d];
+      e2 += ev * ev;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) dot[r] += zs[r * dim + d] * ev;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float dist = z2[r] + e2 - 2.f * dot[r];
+      if (dist < best[r]) {
+        best[r] = dist;
+        bi[r] = j;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    rbest[r][tid] = best[r];
+    ribest[r][tid] = bi[r];
+  }
+  __syncthreads();
+  if (tid < 8 && m0 + tid < M) {
+    float b = INFINITY;
+    int i0 = 0x7fffffff;
+    for (int t = 0; t < 256; ++t) {
+      const float v = rbest[tid][t];
+      const int vi = ribest[tid][t];
+      if (v < b || (v == b && vi < i0)) {
+        b = v;
+        i0 = vi;
+      }
+    }
+    idx[m0 + tid] = i0;
+  }
+}
+
+extern "C" int32_t keep_vq_nearest(const float* z, const float* codebook, int32_t* idx, int32_t M, int32_t ncodes,
+                                   int32_t dim, void* stream) {
+  KEEP_REQUIRE(z && codebook && idx && M > 0 && ncodes > 0 && dim > 0 && dim <= 1024, "keep_vq_nearest: bad args");
+  hipLaunchKernelGGL(vq_nearest_kernel, dim3(cdiv(M, 8)), dim3(256), 8 * dim * sizeof(float), (hipStream_t)stream, z,
+                     codebook, idx, M, ncodes, dim);
+  KEEP_LAUNCH_CHECK("keep_vq_nearest");
+  return KEEP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Kalman blend
+__global__ void kalman_update_kernel(const float* __restrict__ zc, const float* __restrict__ zp,
+                                     const float* __restrict__ g, float* __restrict__ out, long total, int C) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const float gg = g[i / C];
+    out[i] = (1.0f - gg) * zc[i] + gg * zp[i];
+  }
+}
+
+extern "C" int32_t keep_kalman_update(const float* z_code, const float* z_prime, const float* gain, float* out, int32_t N,
+                                      int32_t HW, int32_t C, void* stream) {
+  KEEP_REQUIRE(z_code && z_prime && gain && out && N > 0 && HW > 0 && C > 0, "keep_kalman_update: bad args");
+  const long total = (long)N * HW * C;
+  int blocks = cdiv(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(kalman_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z_code, z_prime, gain, out,
+                     total, C);
+  KEEP_LAUNCH_CHECK("keep_kalman_update");
+  return KEEP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ flow warp
+// grid_sample(bilinear, zeros, align_corners=True): with the reference's normalisation 2v/(W-1)-1 and the
+// un-normalisation ((g+1)/2)*(W-1) the sample position is v = x + flow_x up to fp rounding; we follow the same
+// fp32 operation sequence so borderline floor() decisions match.
+__global__ void flow_warp_kernel(const float* __restrict__ x, const float* __restrict__ flow, float* __restrict__ out,
+                                 int N, int H, int W, int C) {
+  const long npix = (long)N * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / ((long)H * W));
+    const int r = (int)(i - (long)n * H * W);
+    const int oy = r / W, ox = r - oy * W;
+    const float fx = flow[i * 2 + 0], fy = flow[i * 2 + 1];
+    const float wm1 = (float)max(W - 1, 1), hm1 = (float)max(H - 1, 1);
+    const float gx = 2.0f * ((float)ox + fx) / wm1 - 1.0f;
+    const float gy = 2.0f * ((float)oy + fy) / hm1 - 1.0f;
+    const float sx = ((gx + 1.f) / 2.f) * (float)(W - 1);
+    const float sy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+    const float x0f = floorf(sx), y0f = floorf(sy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float tx = sx - x0f, ty = sy - y0f;
+    const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const float* xb = x + (long)n * H * W * C;
+    for (int c = 0; c < C; ++c) {
+      float acc = 0.f;
+      if (vy0 && vx0) acc += xb[((long)y0 * W + x0) * C + c] * w00;
+      if (vy0 && vx1) acc += xb[((long)y0 * W + x1) * C + c] * w01;
+      if (vy1 && vx0) acc += xb[((long)y1 * W + x0) * C + c] * w10;
+      if (vy1 && vx1) acc += xb[((long)y1 * W + x1) * C + c] * w11;
+      out[i * C + c] = acc;
+    }
+  }
+}
+
+extern "C" int32_t keep_flow_warp(const float* x, const float* flow, float* out, int32_t N, int32_t H, int32_t W,
+                                  int32_t C, void* stream) {
+  KEEP_REQUIRE(x && flow && out && N > 0 && H > 0 && W > 0 && C > 0, "keep_flow_warp: bad args");
+  const long npix = (long)N * H * W;
+  int blocks = cdiv(npix, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(flow_warp_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, flow, out, N, H, W, C);
+  KEEP_LAUNCH_CHECK("keep_flow_warp");
+  return KEEP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ convex upsample
+// one thread per (n, y, x, sub-pixel ky,kx): softmax over the 9 taps of mask[..., tap*k*k + ky*k + kx], weighted sum
+// of k*flow over the zero-padded 3x3 neighbourhood (unfold order tap = (dy+1)*3 + (dx+1)).
+__global__ void convex_upsample_kernel(const float* __restrict__ mask, const float* __restrict__ flow,
+                                       float* __restrict__ out, int N, int H, int W, int k) {
+  const int kk = k * k;
+  const long total = (long)N * H * W * kk;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int sub = (int)(i % kk);
+    const long pix = i / kk;
+    const int n = (int)(pix / ((long)H * W));
+    const int r = (int)(pix - (long)n * H * W);
+    const int y = r / W, x = r - y * W;
+    const int ky = sub / k, kx = sub - ky * k;
+    const float* mp = mask + pix * (9L * kk) + sub;
+    float mv[9], mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      mv[t] = mp[(long)t * kk];
+      mx = fmaxf(mx, mv[t]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      mv[t] = expf(mv[t] - mx);
+      den += mv[t];
+    }
+    float ax = 0.f, ay = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const float* fp = flow + (((long)n * H + yy) * W + xx) * 2;
+        const float wgt = mv[t] / den;
+        ax += wgt * ((float)k * fp[0]);
+        ay += wgt * ((float)k * fp[1]);
+      }
+    }
+    const long oy = (long)y * k + ky, ox = (long)x * k + kx;
+    float* op = out + (((long)n * H * k + oy) * ((long)W * k) + ox) * 2;
+    op[0] = ax;
+    op[1] = ay;
+  }
+}
+
+extern "C" int32_t keep_convex_upsample(const float* mask, const float* flow, float* out, int32_t N, int32_t H, int32_t W,
+                                        int32_t k, void* stream) {
+  KEEP_REQUIRE(mask && flow && out && N > 0 && H > 0 && W > 0 && k > 0, "keep_convex_upsample: bad args");
+  const long total = (long)N * H * W * k * k;
+  int blocks = cdiv(total, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(convex_upsample_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask, flow, out, N, H, W, k);
+  KEEP_LAUNCH_CHECK("keep_convex_upsample");
+  return KEEP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ layout helpers
+// [N,C,HW] -> [N,HW,C] through a 64-pixel LDS tile so both sides are coalesced (C small: 2..3 on this path).
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ out, int C,
+                                                           int HW, int mode) {
+  extern __shared__ float tile[];  // [C][256]
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * 256;
+  const int tid = threadIdx.x;
+  for (int c = 0; c < C; ++c) {
+    const int px = p0 + tid;
+    float v = px < HW ? x[((long)n * C + c) * HW + px] : 0.f;
+    if (mode == 1) {  // GF:56-57 then GM/utils.py:55-63, same op order
+      const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
+      const float stdv = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+      v = (v + 1.f) / 2.f * 255.f;
+      v = (v / 255.f - mean) / stdv;
+    }
+    tile[c * 256 + tid] = v;
+  }
+  __syncthreads();
+  const int npx = min(256, HW - p0);
+  for (int i = tid; i < npx * C; i += 256) {
+    const int px = i / C, c = i - px * C;
+    out[((long)n * HW + p0) * C + i] = tile[c * 256 + px];
+  }
+}
+
+extern "C" int32_t keep_nchw_to_nhwc(const float* x, float* out, int32_t N, int32_t C, int32_t HW, int32_t mode,
+                                     void* stream) {
+  KEEP_REQUIRE(x && out && N > 0 && C > 0 && C <= 16 && HW > 0, "keep_nchw_to_nhwc: bad args (C=%d)", C);
+  KEEP_REQUIRE(mode == 0 || (mode == 1 && C == 3), "keep_nchw_to_nhwc: mode 1 needs C == 3");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 256), N), dim3(256), C * 256 * sizeof(float),
+                     (hipStream_t)stream, x, out, C, HW, mode);
+  KEEP_LAUNCH_CHECK("keep_nchw_to_nhwc");
+  return KEEP_OK;
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int C,
+                                                           int HW) {
+  extern __shared__ float tile[];  // [256][C] as read
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * 256;
+  const int tid = threadIdx.x;
+  const int npx = min(256, HW - p0);
+  for (int i = tid; i < npx * C; i += 256) tile[i] = x[((long)n * HW + p0) * C + i];
+  __syncthreads();
+  if (tid < npx)
+    for (int c = 0; c < C; ++c) out[((long)n * C + c) * HW + p0 + tid] = tile[tid * C + c];
+}
+
+extern "C" int32_t keep_nhwc_to_nchw(const float* x, float* out, int32_t N, int32_t C, int32_t HW, void* stream) {
+  KEEP_REQUIRE(x && out && N > 0 && C > 0 && C <= 16 && HW > 0, "keep_nhwc_to_nchw: bad args (C=%d)", C);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(HW, 256), N), dim3(256), C * 256 * sizeof(float),
+                     (hipStream_t)stream, x, out, C, HW);
+  KEEP_LAUNCH_CHECK("keep_nhwc_to_nchw");
+  return KEEP_OK;
+}
+
+__global__ void add_bcast_kernel(const float* __restrict__ a, const float* __restrict__ t, float* __restrict__ out,
+                                 long total, long tsize, float alpha) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    out[i] = a[i] + alpha * t[i % tsize];
+}
+
+extern "C" int32_t keep_add_bcast(const float* a, const float* t, float* out, int64_t total, int64_t tsize, float alpha,
+                                  void* stream) {
+  KEEP_REQUIRE(a && t && out && total > 0 && tsize > 0, "keep_add_bcast: bad args");
+  int blocks = cdiv(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(add_bcast_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, t, out, (long)total,
+                     (long)tsize, alpha);
+  KEEP_LAUNCH_CHECK("keep_add_bcast");
+  return KEEP_OK;
+}
+
+__global__ void concat2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long M,
+                               int C1, int C2) {
+  const int C = C1 + C2;
+  const long total = M * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / C;
+    const int c = (int)(i - m * C);
+    out[i] = c < C1 ? a[m * C1 + c] : b[m * C2 + (c - C1)];
+  }
+}
+
+extern "C" int32_t keep_concat2(const float* a, const float* b, float* out, int64_t M, int32_t C1, int32_t C2,
+                                void* stream) {
+  KEEP_REQUIRE(a && b && out && M > 0 && C1 > 0 && C2 > 0, "keep_concat2: bad args");
+  const long total = (long)M * (C1 + C2);
+  int blocks = cdiv(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(concat2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)M, C1, C2);
+  KEEP_LAUNCH_CHECK("keep_concat2");
+  return KEEP_OK;
+}
+
+// img_util.py:66-90: clamp(-1,1) -> (x+1)/2 -> *255 -> round half to even -> uint8, RGB -> BGR
+__global__ void tensor2img_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, long npix) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = x[i * 3 + c];
+      v = fminf(fmaxf(v, -1.f), 1.f);
+      v = (v - (-1.f)) / 2.f;
+      v = rintf(v * 255.0f);
+      out[i * 3 + (2 - c)] = (uint8_t)v;
+    }
+  }
+}
+
+extern "C" int32_t keep_tensor2img(const float* x, uint8_t* out, int64_t npix, void* stream) {
+  KEEP_REQUIRE(x && out && npix > 0, "keep_tensor2img: bad args");
+  int blocks = cdiv(npix, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(tensor2img_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)npix);
+  KEEP_LAUNCH_CHECK("keep_tensor2img");
+  return KEEP_OK;
+}
+
+// keep_processor.py:258-259: float32(u8 / 255.) (float64 divide, then cast) -> (x - 0.5) / 0.5, BGR -> RGB
+__global__ void img2tensor_kernel(const uint8_t* __restrict__ x, float* __restrict__ out, long npix) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = (float)((double)x[i * 3 + (2 - c)] / 255.0);
+      out[i * 3 + c] = (v - 0.5f) / 0.5f;
+    }
+  }
+}
+
+extern "C" int32_t keep_img2tensor(const uint8_t* x, float* out, int64_t npix, void* stream) {
+  KEEP_REQUIRE(x && out && npix > 0, "keep_img2tensor: bad args");
+  int blocks = cdiv(npix, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(img2tensor_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)npix);
+  KEEP_LAUNCH_CHECK("keep_img2tensor");
+  return KEEP_OK;
+}

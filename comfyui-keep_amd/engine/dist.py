@@ -1,0 +1,64 @@
+"""Multi-GPU: one process per GPU, independent clips sharded data-parallel.
+
+The path has NO exchange step: clips share no state (keep_arch.py:1050,1064,1113), so the only collective
+is the one-off broadcast of the packed weight blob (633 MB fp32) from rank 0 -- ``torch.distributed``
+backend ``nccl`` is RCCL on ROCm, i.e. one ncclBroadcast over xGMI.  Results are gathered on the host by
+clip index (uint8 frames), not by a GPU collective.  The same code runs on ``gloo`` for the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's env (RANK/WORLD_SIZE/MASTER_*).  Returns
+    (rank, world, local_rank); a no-op (0, 1, 0) when not launched distributed."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1:
+        return 0, 1, 0
+    rank = int(os.environ['RANK'])
+    local = int(os.environ.get('LOCAL_RANK', rank))
+    if not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_clips(n_clips, rank, world):
+    """Static round-robin: clip c runs on rank c % world.  Returns this rank's clip indices (ascending)."""
+    return list(range(rank, n_clips, world))
+
+
+def broadcast_packed_weights(index, blob, src=0):
+    """Rank ``src`` passes (index, blob tensor); others pass (None, None) and receive both.
+    ``blob`` lives on the device the backend moves (cuda for nccl/RCCL, cpu for gloo)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return index, blob
+    rank = dist.get_rank()
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    meta = [index, None if blob is None else int(blob.numel())] if rank == src else [None, None]
+    dist.broadcast_object_list(meta, src=src)
+    index, numel = meta
+    if rank != src:
+        blob = torch.empty(numel, dtype=torch.float32, device=dev)
+    dist.broadcast(blob, src=src)
+    return index, blob
+
+
+def gather_by_clip(local_results, n_clips, rank, world):
+    """local_results: {clip_index: uint8 numpy array}.  Returns the full list on rank 0 (host gather)."""
+    if not dist.is_initialized() or world == 1:
+        return [local_results[i] for i in range(n_clips)]
+    buckets = [None] * world if rank == 0 else None
+    dist.gather_object(local_results, buckets, dst=0)
+    if rank != 0:
+        return None
+    merged = {}
+    for b in buckets:
+        merged.update(b)
+    return [merged[i] for i in range(n_clips)]

@@ -1,0 +1,138 @@
+"""ctypes binding of ``libkeep_hip.so`` (the C-ABI declared in ``include/keep_hip.h``).
+
+This is the host side of the drop-in boundary: plain pointers and sizes cross it, torch only
+supplies device memory (``tensor.data_ptr()``) and the stream.  There is NO fallback: if the
+library is missing, was built for another ABI version, or the device is not gfx950, loading
+raises -- the product path never silently runs on anything but the hand-written kernels.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')
+ABI_VERSION = 1
+
+F32, BF16 = 0, 1
+PRO_NONE, PRO_SWISH, PRO_RELU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [('inp', _vp), ('weight', _vp), ('bias', _vp), ('out', _vp), ('pro_scale', _vp), ('pro_shift', _vp),
+                ('residual', _vp), ('aux', _vp), ('workspace', _vp)] + \
+               [(n, _i32) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad_t', 'pad_l', 'Ho', 'Wo',
+                                    'in_ld', 'out_ld', 'res_ld', 'upsample', 'pro_act', 'epi_act')] + \
+               [('aux_w', _f32), ('split_k', _i32), ('dtype', _i32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [('q', _vp), ('k', _vp), ('v', _vp), ('o', _vp)] + \
+               [(n, _i64) for n in ('q_bs', 'q_ts', 'q_hs', 'k_bs', 'k_ts', 'k_hs', 'v_bs', 'v_ts', 'v_hs',
+                                    'o_bs', 'o_ts', 'o_hs')] + \
+               [(n, _i32) for n in ('B', 'H', 'Lq', 'Lk', 'D', 'Dv')] + [('scale', _f32), ('mode', _i32)] + \
+               [(n, _i32) for n in ('T', 'seg_len', 'img_h', 'img_w', 'ksplit', 'shift', 'kv_rot', 'n_img')]
+
+
+# name -> argtypes (restype is always int32 status); every symbol include/keep_hip.h declares
+_SIGNATURES = {
+    'keep_conv2d': [C.POINTER(ConvArgs), _vp],
+    'keep_attention': [C.POINTER(AttnArgs), _vp],
+    'keep_chan_stats': [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    'keep_norm_finalize': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    'keep_affine_act': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    'keep_gm_join': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    'keep_layernorm': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp],
+    'keep_geglu': [_vp, _vp, _i32, _i32, _vp],
+    'keep_argmax_gather': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    'keep_vq_nearest': [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    'keep_kalman_update': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    'keep_flow_warp': [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    'keep_convex_upsample': [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    'keep_nchw_to_nhwc': [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    'keep_nhwc_to_nchw': [_vp, _vp, _i32, _i32, _i32, _vp],
+    'keep_add_bcast': [_vp, _vp, _vp, _i64, _i64, _f32, _vp],
+    'keep_concat2': [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
+    'keep_tensor2img': [_vp, _vp, _i64, _vp],
+    'keep_img2tensor': [_vp, _vp, _i64, _vp],
+}
+EXPORTED_SYMBOLS = ['keep_abi_version', 'keep_last_error', 'keep_device_ok'] + list(_SIGNATURES)
+
+_lib = None
+_device_checked = set()
+
+
+class KeepHipError(RuntimeError):
+    pass
+
+
+def load(check_device=True):
+    """dlopen the library, bind every symbol, verify the ABI version (and gfx950 when asked)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KeepHipError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+                f"There is no CPU/PyTorch fallback for the KEEP hot path.")
+        lib = C.CDLL(LIB_PATH)
+        lib.keep_abi_version.restype = _i32
+        lib.keep_last_error.restype = C.c_char_p
+        lib.keep_device_ok.restype = _i32
+        lib.keep_device_ok.argtypes = [_i32]
+        ver = lib.keep_abi_version()
+        if ver != ABI_VERSION:
+            raise KeepHipError(f"libkeep_hip.so ABI version {ver} != expected {ABI_VERSION}; rebuild")
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(lib, name)            # AttributeError if the symbol is missing
+            fn.restype = _i32
+            fn.argtypes = argtypes
+        _lib = lib
+    if check_device:
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+        if dev is None:
+            raise KeepHipError("no HIP device visible: the KEEP hot path runs on MI355X (gfx950) only")
+        if dev not in _device_checked:
+            rc = _lib.keep_device_ok(dev)
+            if rc != 0:
+                raise KeepHipError(_lib.keep_last_error().decode())
+            _device_checked.add(dev)
+    return _lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise KeepHipError(f"{what} failed (code {rc}): {_lib.keep_last_error().decode()}")
+
+
+def call(name, *args):
+    """Invoke a flat-signature entry point on torch's current stream; tensors are passed as pointers."""
+    lib = load()
+    conv = [(_ptr(a) if isinstance(a, torch.Tensor) or a is None else a) for a in args]
+    _check(getattr(lib, name)(*conv, _stream()), name)
+
+
+def conv2d(**kw):
+    lib = load()
+    a = ConvArgs()
+    for k, v in kw.items():
+        setattr(a, k, _ptr(v) if (isinstance(v, torch.Tensor) or v is None) else v)
+    _check(lib.keep_conv2d(C.byref(a), _stream()), 'keep_conv2d')
+
+
+def attention(**kw):
+    lib = load()
+    a = AttnArgs()
+    for k, v in kw.items():
+        setattr(a, k, _ptr(v) if (isinstance(v, torch.Tensor) or v is None) else v)
+    _check(lib.keep_attention(C.byref(a), _stream()), 'keep_attention')

@@ -1,0 +1,489 @@
+"""KeepNet -- the MI355X engine behind ``keep_model.keep_net``: ``KEEP.forward``
+(reference keep_arch.py:1008-1145, eval branch) as a sequence of hand-written gfx950 kernels.
+
+Contract kept from the reference ``nn.Module``: ``KeepNet(**arch)``,
+``load_state_dict(sd, strict=True)``, ``.to(device)``, ``.eval()``, ``.parameters()``,
+``__call__(x[B,T,3,H,W] fp32 device tensor in [-1,1], need_upscale=False) -> same shape, unclamped``.
+
+Design: activations channels-last (feature maps [N,H,W,C] == token matrices [N*H*W,C],
+so every ``rearrange`` of the reference is free); GroupNorm/InstanceNorm are applied lazily as a
+per-(image,channel) affine in the consuming convolution's prologue; attention never materialises
+scores; window partition / roll / key concatenation / [f0;f1] swap are index math inside the
+attention kernel.  B independent clips ride the batch axis of every kernel.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import hiplib as L
+from . import ops
+from .arch import (CHANNELS, DEFAULT_ARCH, FUSE_ENCODER_BLOCK, FUSE_GENERATOR_BLOCK, GMFLOW, encoder_blocks,
+                   generator_blocks)
+from .weights import logical_tensors, pack_blob, validate_state_dict, views
+
+_KNOWN_KW = set(DEFAULT_ARCH) | {
+    'gumbel_straight_through', 'gumbel_kl_weight', 'vqgan_path', 'fix_modules', 'flownet_path', 'cfa_nlayers',
+    'cross_residual', 'mask_ratio'}
+
+
+class KeepNet:
+    def __init__(self, **arch):
+        unknown = set(arch) - _KNOWN_KW
+        if unknown:
+            raise TypeError(f"KeepNet got unexpected architecture keys {sorted(unknown)}")
+        self.cfg = dict(DEFAULT_ARCH, **{k: v for k, v in arch.items() if k in DEFAULT_ARCH})
+        if self.cfg['quantizer_type'] != 'nearest':
+            raise NotImplementedError("only the 'nearest' quantizer is on the KEEP inference path")
+        if arch.get('cross_residual', True) is not True:
+            raise NotImplementedError("cross_residual=False is not used by any shipped KEEP config")
+        self._sd = None            # reference-layout fp32 CPU tensors (what load_state_dict received)
+        self._blob = None          # packed numpy blob + index
+        self._index = None
+        self._dev_blob = None      # device copy
+        self.w = None              # name -> device view
+        self.device = torch.device('cpu')
+        self.training = False
+        self._const = {}           # per-shape device constants (position tables, grids)
+        self.last_aux = None
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def load_state_dict(self, state_dict, strict=True):
+        if strict:
+            validate_state_dict(state_dict, self.cfg)
+        self._sd = {k: v.detach().to(torch.float32).cpu() for k, v in state_dict.items()}
+        self._blob, self._index = pack_blob(logical_tensors(self._sd, self.cfg))
+        self._dev_blob, self.w = None, None
+        if self.device.type == 'cuda':
+            self._upload()
+        return self
+
+    def state_dict(self):
+        return dict(self._sd or {})
+
+    def parameters(self):
+        return iter((self._sd or {}).values())
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("KeepNet is an inference engine (the reference trains with BasicSR)")
+        return self.eval()
+
+    def _upload(self, from_blob=None):
+        L.load(check_device=True)       # fails loudly: no library / not gfx950 -> no silent fallback
+        if from_blob is None:
+            from_blob = torch.from_numpy(self._blob)
+        self._dev_blob = from_blob.to(self.device, non_blocking=False)
+        self.w = views(self._dev_blob, self._index)
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == 'cuda':
+            if device.index is None:
+                device = torch.device('cuda', torch.cuda.current_device())
+            changed = (self.device != device) or self._dev_blob is None
+            self.device = device
+            if self._blob is not None and changed:
+                with torch.cuda.device(device):
+                    self._upload()
+        else:
+            self.device = device
+            self._dev_blob, self.w = None, None
+            self._const = {}
+        return self
+
+    def packed_blob(self):
+        """Device blob (for the RCCL weight broadcast, engine/dist.py)."""
+        return self._dev_blob
+
+    def adopt_packed(self, index, dev_blob):
+        """Install a packed blob received from another rank."""
+        self._index, self._dev_blob = index, dev_blob
+        self.device = dev_blob.device
+        self.w = views(dev_blob, index)
+
+    # ------------------------------------------------------------------ building blocks (VQGAN)
+    def _gn(self, x, p):
+        return ops.norm_affine(x, self.w[f'{p}.weight'], self.w[f'{p}.bias'], 32, 1e-6)
+
+    def _resblock(self, x, p):
+        """VQ:170-181."""
+        w = self.w
+        h = ops.conv(x, w[f'{p}.conv1.weight'], w[f'{p}.conv1.bias'], pro=self._gn(x, f'{p}.norm1'),
+                     pro_act=L.PRO_SWISH)
+        sc = x
+        if f'{p}.conv_out.weight' in w:
+            sc = ops.linear(x, w[f'{p}.conv_out.weight'], w[f'{p}.conv_out.bias'])
+        return ops.conv(h, w[f'{p}.conv2.weight'], w[f'{p}.conv2.bias'], pro=self._gn(h, f'{p}.norm2'),
+                        pro_act=L.PRO_SWISH, residual=sc)
+
+    def _attnblock(self, x, p):
+        """VQ:219-243: GN -> q,k,v (one GEMM) -> fused attention (1 head, d=C) -> proj_out + x."""
+        w = self.w
+        N, H, Wd, C = x.shape
+        HW = H * Wd
+        qkv = ops.linear(x.view(N * HW, C), w[f'{p}.qkv.weight'], w[f'{p}.qkv.bias'], pro=self._gn(x, f'{p}.norm'),
+                         n_img=N)
+        o = ops.empty((N * HW, C), x)
+        s3 = (HW * 3 * C, 3 * C, 0)
+        ops.attention(qkv, ops.offset(qkv, C), ops.offset(qkv, 2 * C), o, B=N, H=1, Lq=HW, Lk=HW, D=C, Dv=C,
+                      scale=int(C) ** (-0.5), q_str=s3, k_str=s3, v_str=s3, o_str=(HW * C, C, 0))
+        y = ops.linear(o, w[f'{p}.proj_out.weight'], w[f'{p}.proj_out.bias'], residual=x.view(N * HW, C))
+        return y.view(N, H, Wd, C)
+
+    def _vq_stack(self, x, prefix, blocks, taps=(), hook=None):
+        """Encoder.forward / Generator.forward (VQ:288-292, 339-343) over NHWC maps.
+        ``hook(j, x) -> x`` runs after block j (generator CFT/CFA taps, KA:1104-1121)."""
+        w = self.w
+        feats = {}
+        pending = None            # a bare GroupNorm block folds into the next conv's prologue (no swish)
+        for i, (kind, _, _) in enumerate(blocks):
+            p = f'{prefix}.blocks.{i}'
+            if kind == 'conv':
+                x = ops.conv(x, w[f'{p}.weight'], w[f'{p}.bias'], pro=pending)
+                pending = None
+            elif kind == 'res':
+                x = self._resblock(x, p)
+            elif kind == 'attn':
+                x = self._attnblock(x, p)
+            elif kind == 'down':
+                x = ops.conv(x, w[f'{p}.conv.weight'], w[f'{p}.conv.bias'], down=True)
+            elif kind == 'up':
+                x = ops.conv(x, w[f'{p}.conv.weight'], w[f'{p}.conv.bias'], upsample=True)
+            elif kind == 'norm':
+                pending = self._gn(x, p)
+            if i in taps:
+                feats[str(x.shape[2])] = x
+            if hook is not None and kind != 'norm':
+                x = hook(i, x)
+        return x, feats
+
+    # ------------------------------------------------------------------ code prediction (KA:1073-1089)
+    def _predict_codes(self, z_hat, force_idx=None, want_aux=False):
+        w, cfg = self.w, self.cfg
+        B = z_hat.shape[0]
+        Ltok = z_hat.shape[1] * z_hat.shape[2]
+        D, nh = cfg['dim_embd'], cfg['n_head']
+        dh = D // nh
+        q = ops.linear(z_hat.view(B * Ltok, -1), w['feat_emb.weight'], w['feat_emb.bias'])
+        pos = w['position_emb']
+        for i in range(cfg['n_layers']):
+            p = f'ft_layers.{i}'
+            x2, qk_in = ops.layernorm(q, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], pos=pos)
+            wi, bi = w[f'{p}.self_attn.in_proj_weight'], w[f'{p}.self_attn.in_proj_bias']
+            qk = ops.linear(qk_in, wi[:2 * D], bi[:2 * D])
+            v = ops.linear(x2, wi[2 * D:], bi[2 * D:])
+            o = ops.empty((B * Ltok, D), q)
+            ops.attention(qk, ops.offset(qk, D), v, o, B=B, H=nh, Lq=Ltok, Lk=Ltok, D=dh, Dv=dh, scale=dh ** -0.5,
+                          q_str=(Ltok * 2 * D, 2 * D, dh), k_str=(Ltok * 2 * D, 2 * D, dh),
+                          v_str=(Ltok * D, D, dh), o_str=(Ltok * D, D, dh))
+            q = ops.linear(o, w[f'{p}.self_attn.out_proj.weight'], w[f'{p}.self_attn.out_proj.bias'], residual=q)
+            x2 = ops.layernorm(q, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'])
+            h = ops.linear(x2, w[f'{p}.linear1.weight'], w[f'{p}.linear1.bias'], act=L.ACT_GELU)
+            q = ops.linear(h, w[f'{p}.linear2.weight'], w[f'{p}.linear2.bias'], residual=q)
+        xl = ops.layernorm(q, w['idx_pred_layer.0.weight'], w['idx_pred_layer.0.bias'])
+        logits = ops.linear(xl, w['idx_pred_layer.1.weight'])
+        cb = w['quantize.embedding.weight']
+        quant = ops.empty((B * Ltok, cb.shape[1]), q)
+        idx = torch.empty((B * Ltok,), dtype=torch.int32, device=q.device)
+        margin = ops.empty((B * Ltok,), q) if want_aux else None
+        L.call('keep_argmax_gather', logits, cb, force_idx, idx, margin, quant, B * Ltok, cb.shape[0], cb.shape[1])
+        side = z_hat.shape[1]
+        return quant.view(B, side, z_hat.shape[2], cb.shape[1]), idx.view(B, Ltok), \
+            (None if margin is None else margin.view(B, Ltok))
+
+    # ------------------------------------------------------------------ CFT / CFA
+    def _cft(self, enc, dec, p):
+        """KA:465-472: dec + cond*(dec*scale(e) + shift(e)), e = ResBlock(cat[enc, dec])."""
+        w = self.w
+        C = dec.shape[-1]
+        e = self._resblock(ops.concat2(enc, dec), f'{p}.encode_enc')
+        ss = ops.conv(e, w[f'{p}.ss0.weight'], w[f'{p}.ss0.bias'], act=L.ACT_LRELU02)          # [.., 2C]
+        scale = ops.conv(ss, w[f'{p}.scale.2.weight'], w[f'{p}.scale.2.bias'], cin=C, in_off=0)
+        return ops.conv(ss, w[f'{p}.shift.2.weight'], w[f'{p}.shift.2.bias'], cin=C, in_off=C, residual=dec,
+                        aux=scale, aux_w=self.cfg['cond'])
+
+    def _cfa(self, curr, prev, p):
+        """KA:519-541 (post-norm): a = attn(curr, prev); y = LN(a)+curr; LN(ff(y))+y."""
+        w, cfg = self.w, self.cfg
+        B, H, Wd, C = curr.shape
+        Ltok = H * Wd
+        nh, dh = cfg['cfa_nhead'], cfg['cfa_dim']
+        inner = nh * dh
+        c = curr.view(B * Ltok, C)
+        q = ops.linear(c, w[f'{p}.attn.to_q.weight'])
+        kv = ops.linear(prev.view(B * Ltok, C), w[f'{p}.attn.to_kv.weight'])
+        o = ops.empty((B * Ltok, inner), curr)
+        ops.attention(q, kv, ops.offset(kv, inner), o, B=B, H=nh, Lq=Ltok, Lk=Ltok, D=dh, Dv=dh, scale=dh ** -0.5,
+                      q_str=(Ltok * inner, inner, dh), k_str=(Ltok * 2 * inner, 2 * inner, dh),
+                      v_str=(Ltok * 2 * inner, 2 * inner, dh), o_str=(Ltok * inner, inner, dh))
+        a = ops.linear(o, w[f'{p}.attn.to_out.0.weight'], w[f'{p}.attn.to_out.0.bias'])
+        y = ops.layernorm(a, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], res=c)
+        f = ops.geglu(ops.linear(y, w[f'{p}.ff.net.0.proj.weight'], w[f'{p}.ff.net.0.proj.bias']))
+        f = ops.linear(f, w[f'{p}.ff.net.2.weight'], w[f'{p}.ff.net.2.bias'])
+        z = ops.layernorm(f, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], res=y)
+        return z.view(B, H, Wd, C)
+
+    # ------------------------------------------------------------------ Kalman gain (KA:801-821)
+    def _kalman_gain(self, z, B, T):
+        """z [B*T,h,w,C] (clip-major) -> gains [B*T, h*w]."""
+        w, cfg = self.w, self.cfg
+        BT, Hh, Ww, C = z.shape
+        Ltok = Hh * Ww
+        nh, dh = cfg['n_head'], cfg['kalman_attn_head_dim']
+        inner = nh * dh
+        h = z.reshape(BT * Ltok, C)
+        for i in range(cfg['num_uncertainty_layers']):
+            p = f'kalman_filter.uncertainty_estimator.{i}'
+            # sparse-causal spatial attention (KA:686-748): keys = [frame 0 ; frame f-1]
+            x1 = ops.layernorm(h, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'])
+            qkv = ops.linear(x1, w[f'{p}.attn1.to_qkv.weight'])
+            o = ops.empty((BT * Ltok, inner), h)
+            s3 = (Ltok * 3 * inner, 3 * inner, dh)
+            ops.attention(qkv, ops.offset(qkv, inner), ops.offset(qkv, 2 * inner), o, B=BT, H=nh, Lq=Ltok,
+                          Lk=2 * Ltok, D=dh, Dv=dh, scale=dh ** -0.5, q_str=s3, k_str=s3, v_str=s3,
+                          o_str=(Ltok * inner, inner, dh), mode=1, T=T, seg_len=Ltok)
+            h = ops.linear(o, w[f'{p}.attn1.to_out.0.weight'], w[f'{p}.attn1.to_out.0.bias'], residual=h)
+            # GEGLU feed-forward (KA:669)
+            x3 = ops.layernorm(h, w[f'{p}.norm3.weight'], w[f'{p}.norm3.bias'])
+            f = ops.geglu(ops.linear(x3, w[f'{p}.ff.net.0.proj.weight'], w[f'{p}.ff.net.0.proj.bias']))
+            h = ops.linear(f, w[f'{p}.ff.net.2.weight'], w[f'{p}.ff.net.2.bias'], residual=h)
+            # temporal attention over the T frames of each spatial token (KA:671-680): strided, no rearrange
+            xt = ops.layernorm(h, w[f'{p}.norm_temp.weight'], w[f'{p}.norm_temp.bias'])
+            qkv = ops.linear(xt, w[f'{p}.attn_temp.to_qkv.weight'])
+            o = ops.empty((BT * Ltok, inner), h)
+            for b in range(B):
+                qb = ops.offset(qkv, b * T * Ltok * 3 * inner)
+                st = (3 * inner, Ltok * 3 * inner, dh)          # batch = spatial token, token = frame
+                ops.attention(qb, ops.offset(qb, inner), ops.offset(qb, 2 * inner),
+                              ops.offset(o, b * T * Ltok * inner), B=Ltok, H=nh, Lq=T, Lk=T, D=dh, Dv=dh,
+                              scale=dh ** -0.5, q_str=st, k_str=st, v_str=st, o_str=(inner, Ltok * inner, dh))
+            h = ops.linear(o, w[f'{p}.attn_temp.to_out.0.weight'], w[f'{p}.attn_temp.to_out.0.bias'], residual=h)
+        m = h.view(BT, Hh, Ww, C)
+        for i in range(3):
+            m = self._resblock(m, f'kalman_filter.kalman_gain_calculator.{i}')
+        g = ops.linear(m.view(BT * Ltok, C), w['kalman_filter.kalman_gain_calculator.3.weight'],
+                       w['kalman_filter.kalman_gain_calculator.3.bias'], act=L.ACT_SIGMOID)
+        return g.view(BT, Ltok)
+
+    # ------------------------------------------------------------------ GMFlow (GF:40-66, GM/gmflow.py:92-170)
+    def _gm_consts(self, h8, w8, dev):
+        key = ('gm', h8, w8, str(dev))
+        if key not in self._const:
+            C = GMFLOW['feature_channels']
+            wh, ww = h8 // 2, w8 // 2
+            # GM/position.py:26-46 on a (wh x ww) window, then tiled 2x2 (GM/utils.py:66-86)
+            npf = C // 2
+            ye = torch.arange(1, wh + 1, dtype=torch.float32).view(wh, 1).expand(wh, ww)
+            xe = torch.arange(1, ww + 1, dtype=torch.float32).view(1, ww).expand(wh, ww)
+            eps, sc = 1e-6, 2 * math.pi
+            ye = ye / (float(wh) + eps) * sc
+            xe = xe / (float(ww) + eps) * sc
+            dim_t = torch.arange(npf, dtype=torch.float32)
+            dim_t = 10000.0 ** (2 * (dim_t // 2) / npf)
+            px = xe[:, :, None] / dim_t
+            py = ye[:, :, None] / dim_t
+            px = torch.stack((px[:, :, 0::2].sin(), px[:, :, 1::2].cos()), dim=3).flatten(2)
+            py = torch.stack((py[:, :, 0::2].sin(), py[:, :, 1::2].cos()), dim=3).flatten(2)
+            win = torch.cat((py, px), dim=2)                       # [wh, ww, C]
+            table = win.repeat(2, 2, 1).contiguous()               # [h8, w8, C]
+            gy, gx = torch.meshgrid(torch.arange(h8), torch.arange(w8), indexing='ij')
+            grid = torch.stack([gx, gy], dim=-1).float().reshape(h8 * w8, 2).contiguous()   # (x, y) per token
+            self._const[key] = (table.to(dev), grid.to(dev))
+        return self._const[key]
+
+    def _inorm(self, x):
+        return ops.norm_affine(x, None, None, x.shape[-1], 1e-5)
+
+    def _gm_resblock(self, x, p, stride):
+        """GM/backbone.py:25-36."""
+        w = self.w
+        c1 = ops.conv(x, w[f'{p}.conv1.weight'], None, stride=stride, pad=1)
+        c2 = ops.conv(c1, w[f'{p}.conv2.weight'], None, pro=self._inorm(c1), pro_act=L.PRO_RELU)
+        s2, h2 = self._inorm(c2)
+        N, H, Wd, C = c2.shape
+        out = torch.empty_like(c2)
+        if f'{p}.downsample.0.weight' in w:
+            d = ops.conv(x, w[f'{p}.downsample.0.weight'].view(C, 1, 1, -1), w[f'{p}.downsample.0.bias'], stride=stride,
+                         pad=0, ksize=1)
+            sd, hd = self._inorm(d)
+            L.call('keep_gm_join', d, sd, hd, c2, s2, h2, out, N, H * Wd, C)
+        else:
+            L.call('keep_gm_join', x, None, None, c2, s2, h2, out, N, H * Wd, C)
+        return out
+
+    def _gm_layer(self, c0, p, ffn, h8, w8, shift, kv_rot, n_img):
+        """GM/transformer.py:148-187 with the window partition inside the attention kernel."""
+        w = self.w
+        C = c0.shape[-1]
+        Ltok = h8 * w8
+        qkv = ops.linear(c0, w[f'{p}.qkv.weight'])
+        o = torch.empty_like(c0)
+        s3 = (Ltok * 3 * C, 3 * C, 0)
+        ops.attention(qkv, ops.offset(qkv, C), ops.offset(qkv, 2 * C), o, B=n_img * 4, H=1, Lq=Ltok // 4,
+                      Lk=Ltok // 4, D=C, Dv=C, scale=1.0 / (C ** 0.5), q_str=s3, k_str=s3, v_str=s3,
+                      o_str=(Ltok * C, C, 0), mode=2, img_h=h8, img_w=w8, ksplit=2, shift=shift, kv_rot=kv_rot,
+                      n_img=n_img)
+        m = ops.linear(o, w[f'{p}.merge.weight'])
+        if not ffn:
+            return ops.layernorm(m, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], res=c0)
+        m = ops.layernorm(m, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'])
+        hmid = ops.linear(ops.concat2(c0, m), w[f'{p}.mlp.0.weight'], act=L.ACT_GELU)
+        m2 = ops.linear(hmid, w[f'{p}.mlp.2.weight'])
+        return ops.layernorm(m2, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], res=c0)
+
+    def _gmflow(self, im1, im2):
+        """im1, im2 [P,3,H,W] NCHW in [-1,1] -> backward flow [P,H,W,2] (channels-last: (dx, dy))."""
+        w = self.w
+        pfx = 'flownet.model'
+        P, _, H, Wd = im1.shape
+        img = ops.nchw_to_nhwc(torch.cat([im1, im2], dim=0), mode=1)                      # [2P,H,W,3] normalised
+        f = ops.conv(img, w[f'{pfx}.backbone.conv1.weight'], None, stride=2, pad=3, ksize=7)
+        s, hh = self._inorm(f)
+        x = torch.empty_like(f)
+        L.call('keep_affine_act', f, s, hh, x, f.shape[0], f.shape[1] * f.shape[2], f.shape[3], L.ACT_RELU)
+        for li, stride in ((1, 1), (2, 2), (3, 2)):
+            x = self._gm_resblock(x, f'{pfx}.backbone.layer{li}.0', stride)
+            x = self._gm_resblock(x, f'{pfx}.backbone.layer{li}.1', 1)
+        feat = ops.linear(x, w[f'{pfx}.backbone.conv2.weight'], w[f'{pfx}.backbone.conv2.bias'])   # [2P,h8,w8,C]
+        n_img, h8, w8, C = feat.shape
+        Ltok = h8 * w8
+        table, grid = self._gm_consts(h8, w8, feat.device)
+        c0 = ops.add_bcast(feat, table).view(n_img * Ltok, C)
+        wsz = h8 // 2
+        for i in range(GMFLOW['num_layers']):
+            shift = wsz // 2 if i % 2 == 1 else 0
+            lp = f'{pfx}.transformer.layers.{i}'
+            c0 = self._gm_layer(c0, f'{lp}.self_attn', False, h8, w8, shift, 0, n_img)
+            c0 = self._gm_layer(c0, f'{lp}.cross_attn_ffn', True, h8, w8, shift, P, n_img)
+        f0 = c0[:P * Ltok]
+        f1 = c0[P * Ltok:]
+        sF = (Ltok * C, C, 0)
+        # global correlation soft-argmax (GM/matching.py:15-34): V = pixel grid, shared by all pairs
+        corr = ops.empty((P * Ltok, 2), f0)
+        ops.attention(f0, f1, grid, corr, B=P, H=1, Lq=Ltok, Lk=Ltok, D=C, Dv=2, scale=1.0 / (C ** 0.5),
+                      q_str=sF, k_str=sF, v_str=(0, 2, 0), o_str=(Ltok * 2, 2, 0))
+        flow = ops.add_bcast(corr, grid, alpha=-1.0)
+        # flow propagation (GM/transformer.py:363-372): k projected from the projected q
+        fp = f'{pfx}.feature_flow_attn'
+        q = ops.linear(f0, w[f'{fp}.q_proj.weight'], w[f'{fp}.q_proj.bias'])
+        k = ops.linear(q, w[f'{fp}.k_proj.weight'], w[f'{fp}.k_proj.bias'])
+        flow2 = ops.empty((P * Ltok, 2), f0)
+        ops.attention(q, k, flow, flow2, B=P, H=1, Lq=Ltok, Lk=Ltok, D=C, Dv=2, scale=1.0 / (C ** 0.5),
+                      q_str=sF, k_str=sF, v_str=(Ltok * 2, 2, 0), o_str=(Ltok * 2, 2, 0))
+        # convex upsampling (GM/gmflow.py:75-88)
+        cat = ops.concat2(flow2, f0).view(P, h8, w8, C + 2)
+        m = ops.conv(cat, w[f'{pfx}.upsampler.0.weight'], w[f'{pfx}.upsampler.0.bias'], act=L.ACT_RELU)
+        mask = ops.linear(m, w[f'{pfx}.upsampler.2.weight'], w[f'{pfx}.upsampler.2.bias'])
+        k8 = GMFLOW['upsample_factor']
+        up = ops.empty((P, h8 * k8, w8 * k8, 2), f0)
+        L.call('keep_convex_upsample', mask, flow2, up, P, h8, w8, k8)
+        return up
+
+    # ------------------------------------------------------------------ KEEP.forward
+    @torch.no_grad()
+    def __call__(self, x, need_upscale=False, force_indices=None, return_aux=False):
+        if self.w is None:
+            raise RuntimeError("KeepNet: weights are not on a device (load_state_dict + .to('cuda') first)")
+        if x.dim() != 5 or x.shape[2] != 3:
+            raise ValueError(f"expected [B,T,3,H,W], got {tuple(x.shape)}")
+        cfg = self.cfg
+        x = x.to(device=self.device, dtype=torch.float32)
+        if need_upscale:
+            # KA:1020-1023; never taken from the processor (always need_upscale=False) -- host-side resize only
+            Tn = x.shape[1]
+            x = torch.nn.functional.interpolate(x.flatten(0, 1), scale_factor=4, mode='bilinear').unflatten(0, (-1, Tn))
+        x = x.contiguous()
+        B, T, _, H, Wd = x.shape
+        if H % 32 or Wd % 32:
+            raise ValueError("H and W must be multiples of 32")
+        with torch.cuda.device(self.device):
+            return self._forward(x, B, T, H, Wd, force_indices, return_aux)
+
+    def _frame(self, t5, i):
+        """[B,T,...] -> frame i as a contiguous [B,...] (free view when B == 1)."""
+        return t5[:, i].contiguous()
+
+    def _forward(self, x, B, T, H, Wd, force_indices, return_aux):
+        cfg = self.cfg
+        # K1: flows for all T-1 pairs (KA:976-986): flownet(x[:,1:], x[:,:-1])
+        flows = None
+        if T > 1:
+            flows = self._gmflow(x[:, 1:].reshape(-1, 3, H, Wd), x[:, :-1].reshape(-1, 3, H, Wd))
+            flows = flows.view(B, T - 1, H, Wd, 2)
+        # K2: LQ encoder over all B*T frames, stash CFT taps
+        xn = ops.nchw_to_nhwc(x.view(B * T, 3, H, Wd))
+        taps = [FUSE_ENCODER_BLOCK[s] for s in cfg['cft_list']]
+        z, feats = self._vq_stack(xn, 'encoder', encoder_blocks(cfg), taps)
+        enc_feat = {k: v.view(B, T, *v.shape[1:]) for k, v in feats.items()}
+        zc = z.view(B, T, *z.shape[1:])
+        # K3: Kalman gains over the whole clip
+        gains = self._kalman_gain(z, B, T).view(B, T, -1)
+        cft_at = {FUSE_GENERATOR_BLOCK[s]: s for s in cfg['cft_list']}
+        cfa_at = {FUSE_GENERATOR_BLOCK[s]: s for s in cfg['cfa_list']}
+        gblocks = generator_blocks(cfg)
+        out_nhwc = ops.empty((B, T, H, Wd, 3), x)
+        idx_all, margin_all = [], []
+        cross_prev = {}
+        prev_out = None
+        fi = None
+        if force_indices is not None:
+            fi = force_indices.to(device=self.device, dtype=torch.int32).contiguous()
+        for i in range(T):
+            z_i = self._frame(zc, i)
+            if i == 0:
+                z_hat = z_i
+            else:                                                        # K4 (KA:1067-1070)
+                warped = torch.empty_like(prev_out)
+                L.call('keep_flow_warp', prev_out, self._frame(flows, i - 1), warped, B, H, Wd, 3)
+                z_prime, _ = self._vq_stack(warped, 'hq_encoder', encoder_blocks(cfg))
+                z_hat = torch.empty_like(z_i)
+                L.call('keep_kalman_update', z_i, z_prime, self._frame(gains, i), z_hat, B,
+                       z_i.shape[1] * z_i.shape[2], z_i.shape[3])
+            quant, idx, margin = self._predict_codes(                    # K5, K6
+                z_hat, None if fi is None else self._frame(fi, i).view(-1), return_aux)
+            idx_all.append(idx)
+            margin_all.append(margin)
+
+            def hook(j, y, i=i):                                         # K7 taps (KA:1104-1121)
+                if j in cft_at:
+                    s = cft_at[j]
+                    y = self._cft(self._frame(enc_feat[s], i), y, f'cft.{s}')
+                if j in cfa_at:
+                    s = cfa_at[j]
+                    if i > 0:
+                        y = self._cfa(y, cross_prev[s], f'cfa.{s}')
+                    cross_prev[s] = y
+                return y
+
+            y, _ = self._vq_stack(quant, 'generator', gblocks, hook=hook)
+            prev_out = y
+            out_nhwc[:, i].copy_(y)
+        out = ops.nhwc_to_nchw(out_nhwc.view(B * T, H, Wd, 3)).view(B, T, 3, H, Wd)
+        if return_aux:
+            aux = {'indices': torch.stack(idx_all, 1), 'margins': torch.stack(margin_all, 1), 'gains': gains,
+                   'flows': flows, 'z_codes': zc}
+            self.last_aux = aux
+            return out, aux
+        return out
+
+    # ------------------------------------------------------------------ independent clips (hot loop #1)
+    def run_clips(self, clips, need_upscale=False):
+        """list of [1,T_i,3,H,W] -> list of restored clips.  Clips share no state (KA:1050,1064,1113), so
+        equal-length clips are stacked on the batch axis; results equal the sequential loop."""
+        order = {}
+        for n, c in enumerate(clips):
+            order.setdefault((c.shape[1], c.shape[3], c.shape[4]), []).append(n)
+        outs = [None] * len(clips)
+        max_b = 4
+        for _, ids in order.items():
+            for s in range(0, len(ids), max_b):
+                grp = ids[s:s + max_b]
+                res = self(torch.cat([clips[n] for n in grp], dim=0), need_upscale=need_upscale)
+                for k, n in enumerate(grp):
+                    outs[n] = res[k:k + 1]
+        return outs

@@ -1,0 +1,177 @@
+"""Tensor-level wrappers over the C-ABI: shape bookkeeping + output allocation only.
+
+All activations are channels-last fp32 device tensors: feature maps ``[N,H,W,C]``, token
+matrices ``[M,C]`` (same memory).  torch is used for allocation (caching allocator -> safe
+inside hipGraph capture) and views; every arithmetic op is a ``libkeep_hip.so`` kernel.
+"""
+import math
+
+import torch
+
+from . import hiplib as L
+
+# below this many matrix-core waves a conv launch cannot fill 256 CUs x 4 SIMDs -> split K
+_TARGET_WAVES = 1024
+
+# bench.py's roofline leg: when a list, every keep_conv2d launch is bracketed by HIP events on the launch stream
+# and appended as (tile_config, algorithmic_flops, start_event, end_event)
+PROFILE = None
+
+
+def tile_config(M, Cout):
+    """Name of the kernel instantiation keep_conv.hip selects (keep in sync)."""
+    if Cout <= 32:
+        return 'conv_f32<128x32>'
+    if Cout <= 64 or M <= 4096:
+        return 'conv_f32<64x64>'
+    return 'conv_f32<128x128>'
+
+
+def empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _tile_blocks(M, Cout):
+    """Mirror of the tile selection in keep_conv.hip (keep in sync)."""
+    if Cout <= 32:
+        return math.ceil(M / 128) * math.ceil(Cout / 32)
+    if Cout <= 64 or M <= 4096:
+        return math.ceil(M / 64) * math.ceil(Cout / 64)
+    return math.ceil(M / 128) * math.ceil(Cout / 128)
+
+
+def pick_split_k(M, Cout, nsteps):
+    waves = _tile_blocks(M, Cout) * 4
+    if waves >= _TARGET_WAVES or nsteps < 8:
+        return 1
+    s = min(_TARGET_WAVES // waves, nsteps // 4, 32)
+    return max(1, s)
+
+
+def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=False, pro=None, pro_act=L.PRO_NONE,
+         act=L.ACT_NONE, residual=None, aux=None, aux_w=1.0, cin=None, in_off=0, out=None, split_k=None):
+    """x [N,H,W,ld] -> [N,Ho,Wo,Cout].  ``w`` packed [Cout,KH,KW,Cin].  ``cin``/``in_off`` select a channel
+    slice of a wider input buffer.  ``down`` = VQGAN Downsample geometry (pad right/bottom only, stride 2)."""
+    N, H, W, ld = x.shape
+    Cout = w.shape[0]
+    Cin = ld if cin is None else cin
+    KH = KW = ksize
+    assert w.numel() == Cout * KH * KW * Cin, (w.shape, Cout, KH, KW, Cin)
+    Hv, Wv = (2 * H, 2 * W) if upsample else (H, W)
+    if down:
+        stride, pad_t, pad_l = 2, 0, 0
+        Ho, Wo = Hv // 2, Wv // 2
+    else:
+        pad_t = pad_l = pad
+        Ho = (Hv + 2 * pad - KH) // stride + 1
+        Wo = (Wv + 2 * pad - KW) // stride + 1
+    if out is None:
+        out = empty((N, Ho, Wo, Cout), x)
+    M = N * Ho * Wo
+    nsteps = KH * KW * math.ceil(Cin / 16)
+    if split_k is None:
+        split_k = pick_split_k(M, Cout, nsteps)
+    ws = empty((split_k * M * Cout,), x) if split_k > 1 else None
+    xin = x if in_off == 0 else x.view(-1)[in_off:]
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        PROFILE.append((tile_config(M, Cout), 2.0 * M * Cout * KH * KW * Cin, split_k, e0, e1))
+        e0.record()
+    L.conv2d(inp=xin, weight=w, bias=bias, out=out, pro_scale=None if pro is None else pro[0],
+             pro_shift=None if pro is None else pro[1], residual=residual, aux=aux, workspace=ws,
+             N=N, H=H, W=W, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=stride, pad_t=pad_t, pad_l=pad_l, Ho=Ho, Wo=Wo,
+             in_ld=ld, out_ld=out.shape[-1], res_ld=0 if residual is None else residual.shape[-1],
+             upsample=int(upsample), pro_act=pro_act, epi_act=act, aux_w=float(aux_w), split_k=split_k, dtype=L.F32)
+    if PROFILE is not None:
+        PROFILE[-1][4].record()
+    return out
+
+
+def linear(x, w, bias=None, *, act=L.ACT_NONE, residual=None, pro=None, pro_act=L.PRO_NONE, cin=None, in_off=0,
+           n_img=1):
+    """x [M,ld] (or any [...,ld]) @ w[Cout,Cin]^T.  ``n_img``>1 makes the prologue per-image: rows are n_img
+    images of M/n_img pixels each (1x1 conv on a feature map)."""
+    shp = x.shape
+    ld = shp[-1]
+    M = x.numel() // ld
+    x4 = x.reshape(n_img, M // n_img, 1, ld)
+    res4 = None if residual is None else residual.reshape(n_img, M // n_img, 1, residual.shape[-1])
+    y = conv(x4, w, bias, stride=1, pad=0, ksize=1, pro=pro, pro_act=pro_act, act=act, residual=res4, cin=cin,
+             in_off=in_off)
+    return y.reshape(*shp[:-1], w.shape[0])
+
+
+def norm_affine(x, gamma, beta, groups, eps):
+    """GroupNorm / InstanceNorm statistics of x [N,H,W,C] -> (scale, shift) [N,C] for a conv prologue.
+    groups == C and gamma=None -> InstanceNorm2d(affine=False)."""
+    N, H, W, C = x.shape
+    HW = H * W
+    P = max(1, min(HW // 64, 1024))
+    part = empty((N, P, C, 2), x)
+    L.call('keep_chan_stats', x, part, N, HW, C, C, P)
+    scale = empty((N, C), x)
+    shift = empty((N, C), x)
+    L.call('keep_norm_finalize', part, gamma, beta, scale, shift, N, HW, C, groups, P, float(eps))
+    return scale, shift
+
+
+def layernorm(x, gamma, beta, *, res=None, pos=None, eps=1e-5):
+    """LN over the last dim.  Returns y (+res); with ``pos`` ([P,C], broadcast over rows mod P) also y+pos."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    out = torch.empty_like(x)
+    out2 = torch.empty_like(x) if pos is not None else None
+    L.call('keep_layernorm', x, gamma, beta, res, out, pos, 0 if pos is None else pos.shape[0], out2, M, C, float(eps))
+    return out if pos is None else (out, out2)
+
+
+def geglu(x):
+    F = x.shape[-1] // 2
+    M = x.numel() // (2 * F)
+    out = empty((*x.shape[:-1], F), x)
+    L.call('keep_geglu', x, out, M, F)
+    return out
+
+
+def attention(q, k, v, o, *, B, H, Lq, Lk, D, Dv, scale, q_str, k_str, v_str, o_str, mode=0, T=0, seg_len=0,
+              img_h=0, img_w=0, ksplit=0, shift=0, kv_rot=0, n_img=0):
+    """Strides are (batch, token, head) element strides."""
+    L.attention(q=q, k=k, v=v, o=o,
+                q_bs=q_str[0], q_ts=q_str[1], q_hs=q_str[2], k_bs=k_str[0], k_ts=k_str[1], k_hs=k_str[2],
+                v_bs=v_str[0], v_ts=v_str[1], v_hs=v_str[2], o_bs=o_str[0], o_ts=o_str[1], o_hs=o_str[2],
+                B=B, H=H, Lq=Lq, Lk=Lk, D=D, Dv=Dv, scale=float(scale), mode=mode, T=T, seg_len=seg_len,
+                img_h=img_h, img_w=img_w, ksplit=ksplit, shift=shift, kv_rot=kv_rot, n_img=n_img)
+    return o
+
+
+def offset(t, off):
+    """Flat view of ``t`` starting ``off`` elements in (channel-slice pointer for strided kernels)."""
+    return t.view(-1)[off:] if off else t
+
+
+def concat2(a, b):
+    C1, C2 = a.shape[-1], b.shape[-1]
+    M = a.numel() // C1
+    out = empty((*a.shape[:-1], C1 + C2), a)
+    L.call('keep_concat2', a, b, out, M, C1, C2)
+    return out
+
+
+def add_bcast(a, t, alpha=1.0):
+    out = torch.empty_like(a)
+    L.call('keep_add_bcast', a, t, out, a.numel(), t.numel(), float(alpha))
+    return out
+
+
+def nchw_to_nhwc(x, mode=0):
+    N, C, H, W = x.shape
+    out = empty((N, H, W, C), x)
+    L.call('keep_nchw_to_nhwc', x, out, N, C, H * W, mode)
+    return out
+
+
+def nhwc_to_nchw(x):
+    N, H, W, C = x.shape
+    out = empty((N, C, H, W), x)
+    L.call('keep_nhwc_to_nchw', x, out, N, C, H * W)
+    return out

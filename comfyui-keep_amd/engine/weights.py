@@ -1,0 +1,114 @@
+"""Weight ingestion: reference ``state_dict`` (896 fp32 tensors, keep_model_loader.py:99-121) ->
+ONE packed fp32 blob in kernel-friendly layouts + an index of named views.
+
+Layouts
+  * conv weights ``[Cout,Cin,KH,KW]`` -> ``[Cout,KH,KW,Cin]`` (K-contiguous rows for the implicit GEMM;
+    activations are NHWC so both MFMA operands stream along the reduction axis);
+  * linear weights stay ``[out,in]``;
+  * projections that read the same input are concatenated so they run as one GEMM:
+      AttnBlock q|k|v (VQ:190-210)            -> ``<p>.qkv``      [3C, C]
+      Kalman attn1 / attn_temp to_q|k|v       -> ``<p>.to_qkv``   [3*inner, C]   (KA:693-702, 145-169)
+      CFA to_k|to_v (both read the prev frame)-> ``<p>.to_kv``    [2*inner, C]   (KA:168-169)
+      GMFlow q|k|v_proj                       -> ``<p>.qkv``      [3C, C]        (GM/transformer.py:161-163)
+      CFT scale.0|shift.0 (both read e)       -> ``<p>.ss0``      [2C,3,3,C]     (KA:468-469)
+The blob is what travels: one H2D copy per ``load_device()`` and one RCCL broadcast per node (8e).
+"""
+import numpy as np
+import torch
+
+from .arch import DEFAULT_ARCH, encoder_blocks, generator_blocks, state_dict_spec
+
+_ALIGN = 64  # elements (256 B): every view 16-byte aligned for float4 loads
+
+
+def validate_state_dict(sd, cfg):
+    """strict=True semantics of nn.Module.load_state_dict: exact key set and shapes."""
+    spec = state_dict_spec(cfg)
+    missing = [k for k in spec if k not in sd]
+    unexpected = [k for k in sd if k not in spec]
+    bad = [f'{k}: {tuple(sd[k].shape)} vs {tuple(spec[k])}' for k in spec if k in sd and tuple(sd[k].shape) != tuple(spec[k])]
+    if missing or unexpected or bad:
+        msg = 'Error(s) in loading state_dict for KEEP:'
+        if missing:
+            msg += f'\n\tMissing key(s): {missing[:8]}{" ..." if len(missing) > 8 else ""}'
+        if unexpected:
+            msg += f'\n\tUnexpected key(s): {unexpected[:8]}{" ..." if len(unexpected) > 8 else ""}'
+        if bad:
+            msg += f'\n\tsize mismatch: {bad[:8]}'
+        raise RuntimeError(msg)
+    return spec
+
+
+def _conv_pack(w):
+    return w.permute(0, 2, 3, 1).contiguous()
+
+
+def logical_tensors(sd, cfg=None):
+    """name -> fp32 CPU tensor in kernel layout (fused / permuted as described above)."""
+    cfg = dict(DEFAULT_ARCH, **(cfg or {}))
+    out = {}
+    consumed = set()
+
+    def take(name):
+        consumed.add(name)
+        return sd[name].detach().to(torch.float32).cpu()
+
+    def cat(names):
+        return torch.cat([take(n) for n in names], dim=0)
+
+    # --- fused groups
+    for prefix, blocks in (('encoder', encoder_blocks(cfg)), ('hq_encoder', encoder_blocks(cfg)),
+                           ('generator', generator_blocks(cfg))):
+        for i, (kind, cin, _) in enumerate(blocks):
+            if kind == 'attn':
+                p = f'{prefix}.blocks.{i}'
+                out[f'{p}.qkv.weight'] = cat([f'{p}.{n}.weight' for n in 'qkv']).reshape(3 * cin, cin)
+                out[f'{p}.qkv.bias'] = cat([f'{p}.{n}.bias' for n in 'qkv'])
+    for i in range(cfg['num_uncertainty_layers']):
+        for a in ('attn1', 'attn_temp'):
+            p = f'kalman_filter.uncertainty_estimator.{i}.{a}'
+            out[f'{p}.to_qkv.weight'] = cat([f'{p}.to_{n}.weight' for n in 'qkv'])
+    for sz in cfg['cfa_list']:
+        p = f'cfa.{sz}.attn'
+        out[f'{p}.to_kv.weight'] = cat([f'{p}.to_{n}.weight' for n in 'kv'])
+    for sz in cfg['cft_list']:
+        p = f'cft.{sz}'
+        out[f'{p}.ss0.weight'] = _conv_pack(cat([f'{p}.scale.0.weight', f'{p}.shift.0.weight']))
+        out[f'{p}.ss0.bias'] = cat([f'{p}.scale.0.bias', f'{p}.shift.0.bias'])
+    for name in list(sd.keys()):
+        if name.startswith('flownet.model.transformer.layers.') and name.endswith('.q_proj.weight'):
+            p = name[:-len('.q_proj.weight')]
+            out[f'{p}.qkv.weight'] = cat([f'{p}.{n}_proj.weight' for n in 'qkv'])
+    # --- everything else: conv weights permuted, the rest as is
+    for name, t in sd.items():
+        if name in consumed:
+            continue
+        t = t.detach().to(torch.float32).cpu()
+        if t.dim() == 4:
+            t = _conv_pack(t)
+            if t.shape[1] == 1 and t.shape[2] == 1:
+                t = t.reshape(t.shape[0], t.shape[3])          # 1x1 conv == linear
+        out[name] = t.contiguous()
+    return out
+
+
+def pack_blob(tensors):
+    """dict name->CPU tensor -> (flat fp32 numpy blob, index name -> (offset, shape))."""
+    index, off = {}, 0
+    for name, t in tensors.items():
+        index[name] = (off, tuple(t.shape))
+        off += (t.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+    blob = np.zeros(off, dtype=np.float32)
+    for name, t in tensors.items():
+        o, _ = index[name]
+        blob[o:o + t.numel()] = t.reshape(-1).numpy()
+    return blob, index
+
+
+def views(blob_t, index):
+    """Named views into a (device) blob tensor."""
+    out = {}
+    for name, (off, shape) in index.items():
+        n = int(np.prod(shape))
+        out[name] = blob_t[off:off + n].view(shape)
+    return out

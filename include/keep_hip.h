@@ -1,0 +1,186 @@
+/* keep_hip.h -- C-ABI of libkeep_hip.so: the gfx950 (MI355X / CDNA4) kernels behind the KEEP
+ * inference hot path.
+ *
+ * Boundary: the reference hot path is 100 % stock PyTorch ops -- it has NO native/FFI
+ * layer of its own for this path -- so this ABI is defined by the build.  Each entry point names the
+ * reference arithmetic it replaces (file:line under /root/reference/modules/deps/wm_basicsr/archs/;
+ * KA = keep_arch.py, VQ = vqgan_arch.py, AU = arch_util.py, GM = gmflow/gmflow/).  The reference-side
+ * binding a maintainer would add is the ctypes stub shown in INTEGRATION.md (engine/hiplib.py here).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch tensor.data_ptr()); the library never
+ *     allocates, frees or retains memory; workspaces are caller-provided;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream), has no
+ *     hidden synchronisation and no global mutable state -> capturable in a hipGraph, thread-safe per stream;
+ *   - activations are channels-last: [N, H, W, C] (tokens [B, L, C] are the same memory);
+ *   - returns 0 on success, KEEP_EINVAL (-1) bad argument/shape, KEEP_EUNSUP (-2) unsupported dtype/arch,
+ *     KEEP_EHIP (-3) HIP runtime error; keep_last_error() gives a thread-local message.
+ */
+#ifndef KEEP_HIP_H
+#define KEEP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KEEP_ABI_VERSION 1
+#define KEEP_OK 0
+#define KEEP_EINVAL (-1)
+#define KEEP_EUNSUP (-2)
+#define KEEP_EHIP (-3)
+
+/* storage dtypes of activation tensors */
+#define KEEP_F32 0
+#define KEEP_BF16 1
+
+/* prologue activation applied to the (affine-normalised) conv input */
+#define KEEP_PRO_NONE 0
+#define KEEP_PRO_SWISH 1 /* x*sigmoid(x)            VQ:20-22 */
+#define KEEP_PRO_RELU 2  /* GM/backbone.py:30-31    */
+
+/* epilogue activation applied to acc+bias */
+#define KEEP_ACT_NONE 0
+#define KEEP_ACT_RELU 1
+#define KEEP_ACT_LRELU02 2 /* LeakyReLU(0.2)        KA:449,454 */
+#define KEEP_ACT_GELU 3    /* exact erf GELU        KA:437, GM/transformer.py:141 */
+#define KEEP_ACT_SIGMOID 4 /* KA:771 */
+
+int32_t keep_abi_version(void);
+const char* keep_last_error(void);
+/* 0 if device `dev` is a gfx950 part this library was built for, KEEP_EUNSUP otherwise */
+int32_t keep_device_ok(int32_t dev);
+
+/* ------------------------------------------------------------------------------------------------
+ * keep_conv2d -- implicit-GEMM convolution / linear layer on the matrix cores.
+ * Replaces torch conv2d / F.linear call sites: VQ:170-181 (ResBlock convs), VQ:135-139 (Downsample:
+ * pad_t=pad_l=0, stride 2, Ho=H/2 -> the missing bottom/right taps read zeros), VQ:148-152 (Upsample:
+ * `upsample`=1 folds the nearest x2 into the gather), VQ:190-217,241 (1x1 convs), KA:448-455 (CFT convs),
+ * KA:78-87,145,168-169,193 (attention projections), KA:391-393,437 (MLP), GM/backbone.py (IN+ReLU convs),
+ * GM/gmflow.py:45-47 (upsampler convs).
+ *   out[n,oy,ox,co] = epi( bias[co] + sum_{kh,kw,ci} w[co,kh,kw,ci] * pro(in[n, oy*s-pt+kh, ox*s-pl+kw, ci]) )
+ *   pro(x) = act_pro(x*pro_scale[n,ci] + pro_shift[n,ci])  (zero padding is applied AFTER pro)
+ *   epi(v) = r + aux_w*(r*aux + act(v))   if aux        (CFT: dec + w*(dec*scale + shift), KA:470-471)
+ *          = act(v) + r                   if residual   (ResBlock / attention residual)
+ *          = act(v)                       otherwise
+ * A linear layer over M tokens is N=1,H=M,W=1,KH=KW=1.  `in_ld`/`out_ld` are the pixel strides (elements)
+ * of in/out (>= Cin/Cout) so slices of wider buffers can be read/written in place.
+ * split_k>1: `workspace` must hold split_k*M*Cout floats; partial sums are reduced deterministically.
+ */
+typedef struct {
+  const void* in;         /* [N,H,W,in_ld]                                   */
+  const float* weight;    /* [Cout][KH][KW][Cin] fp32 (packed by the host)   */
+  const float* bias;      /* [Cout] or NULL                                  */
+  void* out;              /* [N,Ho,Wo,out_ld]                                */
+  const float* pro_scale; /* [N,Cin] or NULL                                 */
+  const float* pro_shift; /* [N,Cin] or NULL                                 */
+  const void* residual;   /* [N,Ho,Wo,res_ld] or NULL                        */
+  const void* aux;        /* [N,Ho,Wo,Cout] or NULL (requires residual)      */
+  float* workspace;       /* split-K partials or NULL                        */
+  int32_t N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo;
+  int32_t in_ld, out_ld, res_ld;
+  int32_t upsample; /* 1: `in` is [N,H,W,*] and is read as its nearest x2 upsampling [N,2H,2W,*] */
+  int32_t pro_act, epi_act;
+  float aux_w;
+  int32_t split_k;
+  int32_t dtype; /* KEEP_F32 */
+} keep_conv2d_args;
+int32_t keep_conv2d(const keep_conv2d_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * keep_attention -- fused softmax(scale * Q K^T + mask) V  (flash style: scores never reach HBM).
+ * Replaces: VQ:226-239 (AttnBlock), KA:205-234 (CrossAttention._attention, used by CFA KA:527 and the
+ * Kalman blocks KA:653,679), nn.MultiheadAttention inside KA:431, GM/transformer.py:8-16,46-105 (swin
+ * window attention), GM/matching.py:15-34 (global correlation soft-argmax: V = pixel grid),
+ * GM/transformer.py:368-372 (flow propagation: V = flow).
+ * Element offset of token t, head h, batch b of X in {q,k,v,o}:  b*x_bs + t*x_ts + h*x_hs.
+ *   mode 0: plain.
+ *   mode 1: sparse-causal keys (KA:704-716): batch b is frame f=b%T of a clip; key/value token t of the
+ *           2*seg_len keys comes from frame 0 (t<seg_len) or frame max(f-1,0) (t>=seg_len) of the same clip.
+ *   mode 2: (shifted) window attention on an img_h x img_w token grid cut into ksplit x ksplit windows
+ *           (GM/transformer.py:46-105): batch = image*ksplit^2 + window, tokens are window-local, rolled by
+ *           `shift`; shift>0 adds the -100 cross-region mask (GM/transformer.py:19-43).  Keys/values are read
+ *           from image (image + kv_rot) % n_img  (the [f0;f1] vs [f1;f0] pairing, GM/transformer.py:301-314).
+ */
+typedef struct {
+  const float* q;
+  const float* k;
+  const float* v;
+  float* o;
+  int64_t q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, o_bs, o_ts, o_hs;
+  int32_t B, H, Lq, Lk, D, Dv;
+  float scale;
+  int32_t mode;
+  int32_t T, seg_len;                           /* mode 1 */
+  int32_t img_h, img_w, ksplit, shift, kv_rot, n_img; /* mode 2 */
+} keep_attention_args;
+int32_t keep_attention(const keep_attention_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Normalisation statistics.  GroupNorm(32, eps 1e-6) VQ:16-17 and InstanceNorm2d(eps 1e-5, no affine)
+ * GM/backbone.py:7,41 are applied lazily: statistics are reduced here into per-(n,channel) scale/shift
+ * that the consuming keep_conv2d applies in its prologue.
+ *   keep_chan_stats:   part[n][p][c] = (sum, sumsq) of x[n, pixels of chunk p, c]   (P chunks per image)
+ *   keep_norm_finalize: groups of C/G channels -> mean/var (biased) -> scale = gamma*rstd, shift = beta-mean*scale
+ */
+int32_t keep_chan_stats(const float* x, float* part, int32_t N, int32_t HW, int32_t C, int32_t ld, int32_t P,
+                        void* stream);
+int32_t keep_norm_finalize(const float* part, const float* gamma, const float* beta, float* scale, float* shift,
+                           int32_t N, int32_t HW, int32_t C, int32_t G, int32_t P, float eps, void* stream);
+/* out = act(x*scale[n,c]+shift[n,c]) materialised (only where no conv consumes it: GM residual join) */
+int32_t keep_affine_act(const float* x, const float* scale, const float* shift, float* out, int32_t N, int32_t HW,
+                        int32_t C, int32_t act, void* stream);
+/* GM/backbone.py:36: out = relu( (a*sa+ha) + relu(b*sb+hb) ); sa/ha may be NULL (identity shortcut) */
+int32_t keep_gm_join(const float* a, const float* sa, const float* ha, const float* b, const float* sb,
+                     const float* hb, float* out, int32_t N, int32_t HW, int32_t C, void* stream);
+
+/* LayerNorm(eps 1e-5) over the last dim of [M,C] (KA:395-396,491-492,597; GM/transformer.py:134,145).
+ *   y = LN(x)*gamma+beta;  out = y + (res ? res : 0);  out2 (optional) = y + pos[m % pos_rows]  (KA:429-430) */
+int32_t keep_layernorm(const float* x, const float* gamma, const float* beta, const float* res, float* out,
+                       const float* pos, int32_t pos_rows, float* out2, int32_t M, int32_t C, float eps,
+                       void* stream);
+
+/* GEGLU gate (diffusers FeedForward, KA:495-496,595-596): out[m,j] = x[m,j] * gelu_erf(x[m,F+j]), x is [M,2F] */
+int32_t keep_geglu(const float* x, float* out, int32_t M, int32_t F, void* stream);
+
+/* KA:1085-1089 + VQ:78-91: idx[m] = argmax_j logits[m,j] (lowest index on ties); out[m,:] = codebook[idx[m],:].
+ * force_idx (optional) overrides the argmax (parity tests).  margin (optional) = top1-top2 logit gap. */
+int32_t keep_argmax_gather(const float* logits, const float* codebook, const int32_t* force_idx, int32_t* idx,
+                           float* margin, float* out, int32_t M, int32_t ncodes, int32_t dim, void* stream);
+
+/* VQ:37-48 true nearest-neighbour code search: idx[m] = argmin_j |z_m|^2 + |e_j|^2 - 2 z_m.e_j  (next-row 8f-3) */
+int32_t keep_vq_nearest(const float* z, const float* codebook, int32_t* idx, int32_t M, int32_t ncodes, int32_t dim,
+                        void* stream);
+
+/* KA:796-799: z_hat = (1-g)*z_code + g*z_prime, g [N,HW] broadcast over C */
+int32_t keep_kalman_update(const float* z_code, const float* z_prime, const float* gain, float* out, int32_t N,
+                           int32_t HW, int32_t C, void* stream);
+
+/* AU:113-144 flow_warp: bilinear grid_sample(zeros, align_corners=True) of x [N,H,W,C] by flow [N,H,W,2] */
+int32_t keep_flow_warp(const float* x, const float* flow, float* out, int32_t N, int32_t H, int32_t W, int32_t C,
+                       void* stream);
+
+/* GM/gmflow.py:75-88 convex upsampling: mask [N,H,W,9*k*k] (channel = tap*k*k + ky*k + kx), flow [N,H,W,2]
+ * -> out [N,kH,kW,2] */
+int32_t keep_convex_upsample(const float* mask, const float* flow, float* out, int32_t N, int32_t H, int32_t W,
+                             int32_t k, void* stream);
+
+/* layout / elementwise helpers */
+/* [N,C,H,W] -> [N,H,W,C];  mode 1 additionally applies GMFlow's input normalisation (GF:56-57, GM/utils.py:55-63) */
+int32_t keep_nchw_to_nhwc(const float* x, float* out, int32_t N, int32_t C, int32_t HW, int32_t mode, void* stream);
+int32_t keep_nhwc_to_nchw(const float* x, float* out, int32_t N, int32_t C, int32_t HW, void* stream);
+/* out[n,i] = a[n,i] + alpha * t[i % tsize]   (position tables, grid subtraction) */
+int32_t keep_add_bcast(const float* a, const float* t, float* out, int64_t total, int64_t tsize, float alpha,
+                       void* stream);
+/* out[m, 0:C1] = a[m,:], out[m, C1:C1+C2] = b[m,:] */
+int32_t keep_concat2(const float* a, const float* b, float* out, int64_t M, int32_t C1, int32_t C2, void* stream);
+/* img_util.py:66-90 tensor2img: fp32 [N,H,W,3] RGB -> uint8 [N,H,W,3] BGR, clamp[-1,1], round-half-even */
+int32_t keep_tensor2img(const float* x, uint8_t* out, int64_t npix, void* stream);
+/* keep_processor.py:258-259: uint8 BGR [N,H,W,3] -> fp32 NHWC RGB (float32(u8/255.) - 0.5)/0.5 */
+int32_t keep_img2tensor(const uint8_t* x, float* out, int64_t npix, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KEEP_HIP_H */

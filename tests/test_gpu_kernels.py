@@ -1,0 +1,326 @@
+"""GPU suite (-m gpu): every libkeep_hip.so kernel, called through the C-ABI, against the CPU oracle
+(torch fp32 ops / oracle/keep_oracle.py) on the same seeded inputs.  fp32-in / fp32-accumulate MFMA
+path: tolerance 2e-4 relative to the output scale per op (re-association only), indices bit-exact.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import keep_oracle as O
+from conftest import GOLDEN, op_input
+from comfyui_keep_amd.engine import hiplib as L
+from comfyui_keep_amd.engine import ops, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def check(got, ref, tol=TOL, what=''):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f'{what}: non-finite output'
+    err = (got - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    assert err <= tol * scale, f'{what}: max abs err {err:.3e} (scale {scale:.3g})'
+
+
+def pack(w):
+    return dev(w.permute(0, 2, 3, 1))
+
+
+def rnd(name, shape, scale=1.0):
+    return op_input(name, shape, scale)
+
+
+# ------------------------------------------------------------------------------------------------ conv
+@pytest.mark.parametrize("cin,cout,hw,n", [(64, 64, 32, 2), (128, 256, 16, 1), (32, 48, 24, 3), (256, 128, 64, 1)])
+def test_conv3x3_plain(cin, cout, hw, n):
+    x, w, b = rnd('cx', (n, cin, hw, hw)), rnd('cw', (cout, cin, 3, 3), 0.05), rnd('cb', (cout,))
+    y = ops.conv(dev(nhwc(x)), pack(w), dev(b), split_k=1)
+    check(nchw(y), F.conv2d(x, w, b, padding=1), what='conv3x3')
+
+
+def test_conv3x3_splitk_matches():
+    x, w, b = rnd('sx', (1, 512, 16, 16)), rnd('sw', (512, 512, 3, 3), 0.02), rnd('sb', (512,))
+    ref = F.conv2d(x, w, b, padding=1)
+    for sk in (1, 4, 9, 32):
+        check(nchw(ops.conv(dev(nhwc(x)), pack(w), dev(b), split_k=sk)), ref, what=f'split_k={sk}')
+    check(nchw(ops.conv(dev(nhwc(x)), pack(w), dev(b))), ref, what='auto split')
+
+
+def test_conv_prologue_groupnorm_swish_residual():
+    """the ResBlock pattern: GN(32, eps 1e-6) + swish folded into the conv prologue, residual in the epilogue."""
+    x = rnd('gx', (2, 64, 32, 32), 2.0) + 0.5
+    gamma, beta = rnd('gg', (64,)) * 0.2 + 1, rnd('gb', (64,)) * 0.2
+    w, b, res = rnd('gw', (128, 64, 3, 3), 0.05), rnd('gbi', (128,)), rnd('gr', (2, 128, 32, 32))
+    xd = dev(nhwc(x))
+    pro = ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6)
+    y = ops.conv(xd, pack(w), dev(b), pro=pro, pro_act=L.PRO_SWISH, residual=dev(nhwc(res)))
+    h = F.group_norm(x, 32, gamma, beta, eps=1e-6)
+    ref = F.conv2d(h * torch.sigmoid(h), w, b, padding=1) + res
+    check(nchw(y), ref, what='gn+swish+conv+res')
+
+
+def test_conv_instance_norm_relu_prologue():
+    x = rnd('ix', (3, 96, 16, 16), 3.0) - 1.0
+    w = rnd('iw', (96, 96, 3, 3), 0.05)
+    xd = dev(nhwc(x))
+    pro = ops.norm_affine(xd, None, None, 96, 1e-5)
+    y = ops.conv(xd, pack(w), None, pro=pro, pro_act=L.PRO_RELU)
+    check(nchw(y), F.conv2d(F.relu(F.instance_norm(x, eps=1e-5)), w, None, padding=1), what='in+relu+conv')
+
+
+def test_conv_downsample_and_upsample():
+    x, w, b = rnd('dx', (2, 128, 16, 16)), rnd('dw', (128, 128, 3, 3), 0.05), rnd('db', (128,))
+    y = ops.conv(dev(nhwc(x)), pack(w), dev(b), down=True)
+    check(nchw(y), F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2), what='downsample')
+    y = ops.conv(dev(nhwc(x)), pack(w), dev(b), upsample=True)
+    check(nchw(y), F.conv2d(F.interpolate(x, scale_factor=2.0, mode='nearest'), w, b, padding=1), what='upsample')
+
+
+def test_conv_7x7_s2_cin3_and_cin130_and_small_cout():
+    x, w = rnd('7x', (2, 3, 64, 64)), rnd('7w', (64, 3, 7, 7), 0.1)
+    check(nchw(ops.conv(dev(nhwc(x)), pack(w), None, stride=2, pad=3, ksize=7)), F.conv2d(x, w, None, stride=2, padding=3),
+          what='7x7s2')
+    x, w, b = rnd('ux', (1, 130, 8, 8)), rnd('uw', (256, 130, 3, 3), 0.05), rnd('ub', (256,))
+    check(nchw(ops.conv(dev(nhwc(x)), pack(w), dev(b), act=L.ACT_RELU)), F.relu(F.conv2d(x, w, b, padding=1)), what='cin130')
+    x, w, b = rnd('ox', (1, 64, 32, 32)), rnd('ow', (3, 64, 3, 3), 0.05), rnd('ob', (3,))
+    check(nchw(ops.conv(dev(nhwc(x)), pack(w), dev(b))), F.conv2d(x, w, b, padding=1), what='cout3')
+    x, w = rnd('3x', (2, 3, 32, 32)), rnd('3w', (64, 3, 3, 3), 0.2)
+    check(nchw(ops.conv(dev(nhwc(x)), pack(w), None)), F.conv2d(x, w, None, padding=1), what='cin3')
+
+
+def test_linear_epilogues_and_slices():
+    x, w, b = rnd('lx', (300, 256)), rnd('lw', (512, 256), 0.06), rnd('lb', (512,))
+    res = rnd('lr', (300, 512))
+    check(ops.linear(dev(x), dev(w), dev(b), act=L.ACT_GELU), F.gelu(F.linear(x, w, b)), what='gelu')
+    check(ops.linear(dev(x), dev(w), dev(b), residual=dev(res)), F.linear(x, w, b) + res, what='residual')
+    check(ops.linear(dev(x), dev(w[:1, :]), dev(b[:1]), act=L.ACT_SIGMOID), torch.sigmoid(F.linear(x, w[:1], b[:1])), what='sigmoid')
+    # channel-slice input: second half of a [M,512] buffer
+    xx = rnd('lxx', (300, 512))
+    y = ops.conv(dev(xx).view(1, 300, 1, 512), dev(w), dev(b), pad=0, ksize=1, cin=256, in_off=256)
+    check(y.view(300, 512), F.linear(xx[:, 256:], w, b), what='in_off slice')
+
+
+def test_conv_cft_epilogue():
+    dec, aux = rnd('fd', (1, 64, 16, 16)), rnd('fa', (1, 64, 16, 16))
+    x, w, b = rnd('fx', (1, 64, 16, 16)), rnd('fw', (64, 64, 3, 3), 0.05), rnd('fb', (64,))
+    y = ops.conv(dev(nhwc(x)), pack(w), dev(b), residual=dev(nhwc(dec)), aux=dev(nhwc(aux)), aux_w=0.7)
+    check(nchw(y), dec + 0.7 * (dec * aux + F.conv2d(x, w, b, padding=1)), what='cft epilogue')
+    y = ops.conv(dev(nhwc(x)), pack(w), dev(b), act=L.ACT_LRELU02)
+    check(nchw(y), F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2), what='lrelu')
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def ref_attn(q, k, v, scale, mask=None):
+    s = torch.einsum('bhqd,bhkd->bhqk', q, k) * scale
+    if mask is not None:
+        s = s + mask
+    return torch.einsum('bhqk,bhkd->bhqd', s.softmax(-1), v)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,D,Dv", [(2, 8, 256, 256, 64, 64), (1, 1, 64, 64, 512, 512), (2, 4, 96, 96, 256, 256),
+                                            (3, 2, 50, 77, 48, 48), (1, 1, 256, 256, 128, 2), (2, 1, 40, 40, 128, 128)])
+def test_attention_plain(B, H, Lq, Lk, D, Dv):
+    q, k, v = rnd('aq', (B, Lq, H, D)), rnd('ak', (B, Lk, H, D)), rnd('av', (B, Lk, H, Dv))
+    scale = D ** -0.5 * 3.0
+    o = torch.empty(B, Lq, H, Dv, device='cuda')
+    ops.attention(dev(q), dev(k), dev(v), o, B=B, H=H, Lq=Lq, Lk=Lk, D=D, Dv=Dv, scale=scale,
+                  q_str=(Lq * H * D, H * D, D), k_str=(Lk * H * D, H * D, D), v_str=(Lk * H * Dv, H * Dv, Dv),
+                  o_str=(Lq * H * Dv, H * Dv, Dv))
+    ref = ref_attn(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), scale).permute(0, 2, 1, 3)
+    check(o, ref, what=f'attn {B, H, Lq, Lk, D, Dv}')
+
+
+def test_attention_packed_qkv_and_peaked_softmax():
+    """q|k|v packed in one buffer (strided heads) and large-magnitude scores (online-softmax rescale path)."""
+    B, Lt, H, D = 2, 160, 4, 64
+    qkv = rnd('pq', (B, Lt, 3 * H * D), 4.0)
+    o = torch.empty(B, Lt, H * D, device='cuda')
+    qd = dev(qkv)
+    s3 = (Lt * 3 * H * D, 3 * H * D, D)
+    ops.attention(qd, ops.offset(qd, H * D), ops.offset(qd, 2 * H * D), o, B=B, H=H, Lq=Lt, Lk=Lt, D=D, Dv=D, scale=1.0,
+                  q_str=s3, k_str=s3, v_str=s3, o_str=(Lt * H * D, H * D, D))
+    q, k, v = (t.reshape(B, Lt, H, D).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=-1))
+    check(o.view(B, Lt, H, D), ref_attn(q, k, v, 1.0).permute(0, 2, 1, 3), what='packed/peaked')
+
+
+def test_attention_sparse_causal_mode():
+    """KA:704-716: keys of frame f = [tokens of frame 0 ; tokens of frame max(f-1,0)]."""
+    Bc, T, Lt, H, D = 2, 3, 64, 8, 48
+    inner = H * D
+    qkv = rnd('sq', (Bc * T, Lt, 3 * inner))
+    qd = dev(qkv)
+    o = torch.empty(Bc * T, Lt, inner, device='cuda')
+    s3 = (Lt * 3 * inner, 3 * inner, D)
+    ops.attention(qd, ops.offset(qd, inner), ops.offset(qd, 2 * inner), o, B=Bc * T, H=H, Lq=Lt, Lk=2 * Lt, D=D, Dv=D,
+                  scale=D ** -0.5, q_str=s3, k_str=s3, v_str=s3, o_str=(Lt * inner, inner, D), mode=1, T=T, seg_len=Lt)
+    q, k, v = qkv.chunk(3, dim=-1)
+    former = torch.arange(T) - 1
+    former[0] = 0
+
+    def gather(t):
+        t = t.reshape(Bc, T, Lt, inner)
+        return torch.cat([t[:, [0] * T], t[:, former]], dim=2).reshape(Bc * T, 2 * Lt, inner)
+
+    hs = lambda t: t.reshape(t.shape[0], t.shape[1], H, D).permute(0, 2, 1, 3)  # noqa: E731
+    ref = ref_attn(hs(q), hs(gather(k)), hs(gather(v)), D ** -0.5).permute(0, 2, 1, 3).reshape(Bc * T, Lt, inner)
+    check(o, ref, what='sparse causal')
+
+
+@pytest.mark.parametrize("T", [2, 3, 20])
+def test_attention_temporal_strided(T):
+    """KA:671-680: batch = spatial token, tokens = frames, read in place from [(f d) c]."""
+    Lt, H, D = 16, 8, 48
+    inner = H * D
+    qkv = rnd('tq', (T, Lt, 3 * inner))
+    qd = dev(qkv)
+    o = torch.empty(T, Lt, inner, device='cuda')
+    st = (3 * inner, Lt * 3 * inner, D)
+    ops.attention(qd, ops.offset(qd, inner), ops.offset(qd, 2 * inner), o, B=Lt, H=H, Lq=T, Lk=T, D=D, Dv=D,
+                  scale=D ** -0.5, q_str=st, k_str=st, v_str=st, o_str=(inner, Lt * inner, D))
+    q, k, v = (t.permute(1, 0, 2).reshape(Lt, T, H, D).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=-1))
+    ref = ref_attn(q, k, v, D ** -0.5).permute(0, 2, 1, 3).reshape(Lt, T, inner).permute(1, 0, 2)
+    check(o, ref, what=f'temporal T={T}')
+
+
+@pytest.mark.parametrize("shift", [0, 1])
+def test_attention_swin_windows(shift):
+    """GM/transformer.py:46-105 incl. roll, 2x2 windows, -100 region mask and the [f0;f1]/[f1;f0] key swap."""
+    P, h8, w8, C = 2, 8, 8, 128
+    n_img, Lt = 2 * P, h8 * w8
+    q, k, v = rnd('wq', (n_img, Lt, C)), rnd('wk', (n_img, Lt, C)), rnd('wv', (n_img, Lt, C))
+    sh = (h8 // 2) // 2 if shift else 0
+    o = torch.empty(n_img, Lt, C, device='cuda')
+    s = (Lt * C, C, 0)
+    ops.attention(dev(q), dev(k), dev(v), o, B=n_img * 4, H=1, Lq=Lt // 4, Lk=Lt // 4, D=C, Dv=C, scale=1 / C ** 0.5,
+                  q_str=s, k_str=s, v_str=s, o_str=s, mode=2, img_h=h8, img_w=w8, ksplit=2, shift=sh, kv_rot=P, n_img=n_img)
+    mask = O.shift_window_mask(h8, w8, h8 // 2, w8 // 2, h8 // 4, w8 // 4)
+    kr, vr = torch.cat([k[P:], k[:P]]), torch.cat([v[P:], v[:P]])
+    ref = O._window_attention(q, kr, vr, 2, bool(shift), h8, w8, mask)
+    check(o, ref, what=f'swin shift={sh}')
+
+
+# ------------------------------------------------------------------------------------------------ small kernels
+def test_layernorm_variants():
+    x, g, b = rnd('nx', (300, 512), 3.0) + 1.0, rnd('ng', (512,)) * 0.2 + 1, rnd('nb', (512,)) * 0.2
+    res, pos = rnd('nr', (300, 512)), rnd('np', (100, 512))
+    ref = F.layer_norm(x, (512,), g, b, 1e-5)
+    check(ops.layernorm(dev(x), dev(g), dev(b)), ref, 2e-5, 'ln')
+    check(ops.layernorm(dev(x), dev(g), dev(b), res=dev(res)), ref + res, 2e-5, 'ln+res')
+    y, y2 = ops.layernorm(dev(x), dev(g), dev(b), pos=dev(pos))
+    check(y, ref, 2e-5, 'ln (dual)')
+    check(y2, ref + pos.repeat(3, 1), 2e-5, 'ln+pos')
+    x = rnd('nx2', (70, 128))
+    check(ops.layernorm(dev(x), dev(g[:128]), dev(b[:128])), F.layer_norm(x, (128,), g[:128], b[:128], 1e-5), 2e-5, 'ln128')
+
+
+def test_geglu_concat_addbcast():
+    x = rnd('gx', (77, 2048), 2.0)
+    h, g = x.chunk(2, dim=-1)
+    check(ops.geglu(dev(x)), h * F.gelu(g), 1e-5, 'geglu')
+    a, b = rnd('ca', (50, 2)), rnd('cb', (50, 128))
+    assert torch.equal(ops.concat2(dev(a), dev(b)).cpu(), torch.cat([a, b], -1))
+    t = rnd('bt', (64, 128))
+    assert torch.allclose(ops.add_bcast(dev(rnd('ba', (3, 64, 128))), dev(t), -1.0).cpu(), rnd('ba', (3, 64, 128)) - t)
+
+
+def test_argmax_gather_and_ties():
+    logits = rnd('al', (512, 1024), 4.0)
+    logits[7, 100] = logits[7, 900] = 50.0            # exact tie -> lowest index
+    cb = rnd('acb', (1024, 256))
+    out = torch.empty(512, 256, device='cuda')
+    idx = torch.empty(512, dtype=torch.int32, device='cuda')
+    margin = torch.empty(512, device='cuda')
+    L.call('keep_argmax_gather', dev(logits), dev(cb), None, idx, margin, out, 512, 1024, 256)
+    ref_idx = logits.argmax(-1)
+    ref_idx[7] = 100
+    assert torch.equal(idx.cpu().long(), ref_idx)
+    assert torch.equal(out.cpu(), cb[ref_idx])
+    top2 = logits.topk(2, -1).values
+    assert torch.allclose(margin.cpu(), top2[:, 0] - top2[:, 1], atol=1e-6)
+    force = torch.arange(512, dtype=torch.int32, device='cuda') % 1024
+    L.call('keep_argmax_gather', dev(logits), dev(cb), force, idx, None, out, 512, 1024, 256)
+    assert torch.equal(out.cpu(), cb[force.cpu().long()])
+
+
+def test_vq_nearest(synth_weights):
+    z = op_input('vq_nn', (1, 256, 8, 8), 0.7)
+    cb = synth_weights['quantize.embedding.weight']
+    idx = torch.empty(64, dtype=torch.int32, device='cuda')
+    L.call('keep_vq_nearest', dev(nhwc(z)).view(64, 256), dev(cb), idx, 64, 1024, 256)
+    gold = np.load(os.path.join(GOLDEN, 'ops.npz'))['vq_nn_idx']
+    assert np.array_equal(idx.cpu().numpy(), gold)
+
+
+def test_kalman_update_and_flow_warp():
+    zc, zp, g = rnd('ku_z', (1, 256, 8, 8)), rnd('ku_zp', (1, 256, 8, 8)), (rnd('ku_g', (1, 1, 8, 8)) + 1) / 2
+    out = torch.empty(1, 8, 8, 256, device='cuda')
+    L.call('keep_kalman_update', dev(nhwc(zc)), dev(nhwc(zp)), dev(g.view(1, 64)), out, 1, 64, 256)
+    check(nchw(out), torch.from_numpy(np.load(os.path.join(GOLDEN, 'ops.npz'))['kalman_update']), 1e-6, 'kalman update')
+    img, flo = rnd('warp_img', (2, 3, 32, 32)), rnd('warp_flow', (2, 32, 32, 2), 6.0)
+    out = torch.empty(2, 32, 32, 3, device='cuda')
+    L.call('keep_flow_warp', dev(nhwc(img)), dev(flo), out, 2, 32, 32, 3)
+    check(nchw(out), torch.from_numpy(np.load(os.path.join(GOLDEN, 'ops.npz'))['warp']), 1e-5, 'flow warp (golden)')
+    big = rnd('warp_flow2', (2, 32, 32, 2), 40.0)      # mostly out of range -> zero padding
+    L.call('keep_flow_warp', dev(nhwc(img)), dev(big), out, 2, 32, 32, 3)
+    check(nchw(out), O.flow_warp(img, big), 1e-5, 'flow warp (far)')
+
+
+def test_convex_upsample_and_layouts():
+    mask, flow = rnd('um', (2, 576, 6, 5), 3.0), rnd('uf', (2, 2, 6, 5), 5.0)
+    out = torch.empty(2, 48, 40, 2, device='cuda')
+    L.call('keep_convex_upsample', dev(nhwc(mask)), dev(nhwc(flow)), out, 2, 6, 5, 8)
+    m = torch.softmax(mask.view(2, 1, 9, 8, 8, 6, 5), dim=2)
+    up = F.unfold(8 * flow, [3, 3], padding=1).view(2, 2, 9, 1, 1, 6, 5)
+    ref = torch.sum(m * up, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(2, 2, 48, 40)
+    check(nchw(out), ref, 1e-5, 'convex upsample')
+    x = rnd('lx', (3, 3, 40, 24))
+    assert torch.equal(ops.nchw_to_nhwc(dev(x)).cpu(), nhwc(x))
+    assert torch.equal(ops.nhwc_to_nchw(dev(nhwc(x))).cpu(), x)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    check(nchw(ops.nchw_to_nhwc(dev(x), mode=1)), (((x + 1) / 2 * 255) / 255. - mean) / std, 1e-6, 'gmflow prep')
+
+
+def test_tensor2img_img2tensor_bit_exact():
+    from comfyui_keep_amd.modules import utils as U
+    x = rnd('t2i', (2, 3, 64, 64), 1.3)
+    x[0, :, 0, :8] = torch.tensor([-1.2, -1.0, -0.5 / 255, 0.0, 1.0 / 255, 1.0, 1.3, 0.00392156862])
+    out = torch.empty(2, 64, 64, 3, dtype=torch.uint8, device='cuda')
+    L.call('keep_tensor2img', dev(nhwc(x)), out, 2 * 64 * 64)
+    for n in range(2):
+        assert np.array_equal(out[n].cpu().numpy(), U.net_output_to_bgr_u8(x[n]))
+    crops = [synth.ramp_image(64, 64), synth.ramp_image(64, 64)[::-1].copy()]
+    u8 = torch.from_numpy(np.stack(crops)).cuda()
+    f = torch.empty(2, 64, 64, 3, device='cuda')
+    L.call('keep_img2tensor', u8, f, 2 * 64 * 64)
+    assert torch.equal(nchw(f).cpu(), U.crops_to_net_input(crops))
+
+
+def test_bad_arguments_fail_loudly():
+    with pytest.raises(L.KeepHipError, match='dtype'):
+        x = torch.zeros(1, 8, 8, 16, device='cuda')
+        L.conv2d(inp=x, weight=x, out=x, N=1, H=8, W=8, Cin=16, Cout=16, KH=1, KW=1, stride=1, Ho=8, Wo=8, in_ld=16,
+                 out_ld=16, split_k=1, dtype=L.BF16)
+    with pytest.raises(L.KeepHipError, match='even'):
+        q = torch.zeros(4, 33, device='cuda')
+        ops.attention(q, q, q, q, B=1, H=1, Lq=4, Lk=4, D=33, Dv=33, scale=1.0, q_str=(0, 33, 0), k_str=(0, 33, 0),
+                      v_str=(0, 33, 0), o_str=(0, 33, 0))

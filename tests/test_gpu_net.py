@@ -1,0 +1,173 @@
+"""GPU suite (-m gpu): module-level and whole-network parity of the HIP engine (engine/net.py, every op through
+the C-ABI) against (a) the committed golden vectors generated from the imported reference and (b) the CPU oracle
+on the same seeded inputs.
+
+Tolerance (fp32-in / fp32-accumulate MFMA policy): max-abs <= 1e-3 on network outputs (BASELINE.json north_star),
+tighter per module.  Code indices: bit-exact wherever the reference's top-1/top-2 logit margin exceeds 1e-3
+(exact ties are undefined behaviour in the reference: topk documents no order).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import keep_oracle as O
+from conftest import GOLDEN, op_input
+from comfyui_keep_amd.engine import arch, ops, synth
+from comfyui_keep_amd.engine.arch import DEFAULT_ARCH, encoder_blocks, generator_blocks
+
+pytestmark = pytest.mark.gpu
+OPS = np.load(os.path.join(GOLDEN, 'ops.npz'))
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def close(got, ref, tol, what):
+    ref = torch.from_numpy(ref) if isinstance(ref, np.ndarray) else ref
+    got = got.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what
+    err = (got - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    assert err <= tol * scale, f'{what}: max abs err {err:.3e} (scale {scale:.3g}, tol {tol})'
+
+
+def test_resblock_down_up_attn_vs_golden(gpu_net):
+    net = gpu_net
+    close(nchw(net._resblock(nhwc(op_input('res_same', (1, 128, 16, 16))), 'encoder.blocks.5')), OPS['res_same'], 3e-4, 'res')
+    close(nchw(net._resblock(nhwc(op_input('res_proj', (1, 64, 16, 16))), 'encoder.blocks.4')), OPS['res_proj'], 3e-4, 'res proj')
+    w = net.w
+    y = ops.conv(nhwc(op_input('down', (1, 128, 16, 16))), w['encoder.blocks.6.conv.weight'], w['encoder.blocks.6.conv.bias'], down=True)
+    close(nchw(y), OPS['down'], 3e-4, 'down')
+    y = ops.conv(nhwc(op_input('up', (1, 128, 8, 8))), w['generator.blocks.17.conv.weight'], w['generator.blocks.17.conv.bias'], upsample=True)
+    close(nchw(y), OPS['up'], 3e-4, 'up')
+    close(nchw(net._attnblock(nhwc(op_input('attn', (1, 512, 8, 8))), 'encoder.blocks.17')), OPS['attn'], 3e-4, 'attnblock')
+
+
+def test_cft_cfa_vs_golden(gpu_net):
+    net = gpu_net
+    y = net._cft(nhwc(op_input('cft_enc', (1, 256, 8, 8))), nhwc(op_input('cft_dec', (1, 256, 8, 8))), 'cft.32')
+    close(nchw(y), OPS['cft'], 3e-4, 'cft')
+    y = net._cfa(nhwc(op_input('cfa_curr', (1, 256, 8, 8))), nhwc(op_input('cfa_prev', (1, 256, 8, 8))), 'cfa.32')
+    close(nchw(y), OPS['cfa'], 3e-4, 'cfa')
+
+
+def test_kalman_gain_vs_golden_and_batched(gpu_net, synth_weights):
+    z = op_input('kalman_z', (1, 3, 256, 8, 8))
+    g = gpu_net._kalman_gain(nhwc(z[0]), 1, 3)
+    close(g.view(1, 3, 1, 8, 8), OPS['kalman_gain'], 2e-4, 'kalman gain')
+    # two clips on the batch axis == each clip alone (clips share no state)
+    z2 = torch.cat([z, op_input('kalman_z2', (1, 3, 256, 8, 8))], 0)
+    g2 = gpu_net._kalman_gain(nhwc(z2.flatten(0, 1)), 2, 3).view(2, 3, 64)
+    ref = O.kalman_calc_gain(z2, synth_weights, DEFAULT_ARCH).view(2, 3, 64)
+    close(g2, ref, 2e-4, 'kalman gain B=2')
+
+
+def test_code_prediction_vs_oracle(gpu_net, synth_weights):
+    z = op_input('codes_z', (2, 256, 16, 16), 1.5)
+    quant, idx, margin = gpu_net._predict_codes(nhwc(z), want_aux=True)
+    logits, ref_idx = O.predict_codes(z, synth_weights, DEFAULT_ARCH)
+    top2 = logits.topk(2, -1).values
+    ref_margin = top2[..., 0] - top2[..., 1]
+    safe = ref_margin > 1e-3
+    assert safe.float().mean() > 0.9
+    assert torch.equal(idx.cpu().long()[safe], ref_idx[safe])
+    close(margin, ref_margin, 2e-4, 'logit margins')
+    ref_q = O.codebook_lookup(idx.cpu().long(), synth_weights, 2, 16, 256)
+    assert torch.equal(nchw(quant), ref_q)
+
+
+def test_gmflow_vs_golden(gpu_net):
+    a = synth.synth_clip(T=2, B=1, size=64, seed=99)[0]
+    flow = gpu_net._gmflow(a[1:2].cuda(), a[0:1].cuda())
+    close(nchw(flow), OPS['gmflow64'], 5e-4, 'gmflow 64x64')
+
+
+def test_encoder_and_generator_stacks_vs_golden(gpu_net):
+    z, _ = gpu_net._vq_stack(nhwc(op_input('encoder64', (1, 3, 64, 64))), 'encoder', encoder_blocks(DEFAULT_ARCH))
+    close(nchw(z), OPS['encoder64'], 5e-4, 'encoder 64x64')
+    y, _ = gpu_net._vq_stack(nhwc(op_input('generator_2x2', (1, 256, 2, 2), 0.7)), 'generator', generator_blocks(DEFAULT_ARCH))
+    close(nchw(y), OPS['generator_2x2'], 5e-4, 'generator from 2x2')
+
+
+def _digest(frames):
+    T, C, H, Wd = frames.shape
+    return frames[:, :, 7::H // 32, 5::Wd // 32][:, :, :32, :32]
+
+
+def _full_forward_check(net, gold_name, T):
+    g = np.load(os.path.join(GOLDEN, gold_name))
+    x = synth.synth_clip(T=T, B=1, seed=1234).cuda()
+    out, aux = net(x, need_upscale=False, return_aux=True)
+    idx = aux['indices'][0].cpu().numpy().astype(np.int16)
+    safe = g['margins'] > 1e-3
+    agree = (idx == g['indices'])
+    report = {'index_agreement': float(agree.mean()), 'safe_fraction': float(safe.mean()),
+              'gain_err': float(np.abs(aux['gains'][0].cpu().numpy() - g['gains']).max()),
+              'flow_err': float(np.abs(_digest(aux['flows'][0].permute(0, 3, 1, 2).cpu()).numpy() - g['flow_grid']).max()),
+              'flow_scale': float(np.abs(g['flow_grid']).max())}
+    print(gold_name, report)
+    assert report['flow_err'] <= 1e-3 * max(1.0, report['flow_scale']), report
+    assert report['gain_err'] <= 2e-4, report
+    assert agree[safe].all(), report
+    # arithmetic drift with the reference's indices injected (separates index flips from drift)
+    forced = torch.from_numpy(g['indices'].astype(np.int32)).view(1, T, -1)
+    out_f = net(x, need_upscale=False, force_indices=forced)
+    err_f = np.abs(_digest(out_f[0].cpu()).numpy() - g['out_grid']).max()
+    print(gold_name, 'max-abs pixel diff (reference indices injected):', err_f)
+    assert err_f <= 1e-3, err_f
+    if agree.all():
+        err = np.abs(_digest(out[0].cpu()).numpy() - g['out_grid']).max()
+        print(gold_name, 'max-abs pixel diff (free running):', err)
+        assert err <= 1e-3, err
+        st = out[0].cpu().reshape(T, 3, -1)
+        stats = torch.stack([st.mean(-1), st.std(-1), st.min(-1).values, st.max(-1).values], -1).numpy()
+        assert np.abs(stats - g['out_stats']).max() <= 2e-3
+    return out
+
+
+def test_full_forward_T3_vs_reference_golden(gpu_net):
+    _full_forward_check(gpu_net, 'keep_forward_T3.npz', 3)
+
+
+def test_full_forward_asian_T2_vs_reference_golden():
+    from comfyui_keep_amd.engine.net import KeepNet
+    cfg = dict(DEFAULT_ARCH, cft_list=['32', '64', '128', '256'], temp_reg_list=[])
+    net = KeepNet(**cfg)
+    net.load_state_dict(synth.synth_state_dict(cfg, seed=0), strict=True)
+    _full_forward_check(net.to('cuda').eval(), 'keep_forward_asian_T2.npz', 2)
+
+
+def test_batched_clips_equal_sequential(gpu_net):
+    """Independent clips on the batch axis give the same result as one at a time (hot loop #1 semantics)."""
+    x = torch.cat([synth.synth_clip(T=2, B=1, seed=1234), synth.synth_clip(T=2, B=1, seed=77, phase=1.0)], 0).cuda()
+    both, aux = gpu_net(x, return_aux=True)
+    for b in range(2):
+        one, aux1 = gpu_net(x[b:b + 1], return_aux=True)
+        assert torch.equal(aux1['indices'][0], aux['indices'][b])
+        assert (one[0] - both[b]).abs().max().item() <= 1e-4
+    outs = gpu_net.run_clips([x[0:1], x[1:2]])
+    assert (outs[1] - both[1:2]).abs().max().item() <= 1e-4
+
+
+def test_processor_runs_on_engine(gpu_net):
+    """Config 1 (BASELINE.json configs[0]) through the drop-in processor: aligned 512x512 face, T=2 duplicate."""
+    import test_host_logic as H   # installs the ComfyUI stubs
+    from comfyui_keep_amd.modules.keep_processor import KEEPFaceProcessor
+    from comfyui_keep_amd.modules.keep_model_loader import KEEPModelPack
+    from comfyui_keep_amd.modules import utils as U
+    pack = KEEPModelPack(gpu_net, H._Helper(), None, None, 'KEEP')
+    pack.device = torch.device('cuda')
+    img = synth.ramp_image()
+    out = KEEPFaceProcessor(pack).process_image(img, 1.0, True, True, False)
+    assert out.shape == (512, 512, 3) and out.dtype == np.uint8
+    x = U.crops_to_net_input([img]).unsqueeze(0).cuda()
+    ref = gpu_net(torch.cat([x, x], 1))[:, 0]
+    assert np.array_equal(out, U.net_output_to_bgr_u8(ref[0]))

@@ -1,0 +1,255 @@
+"""CPU suite: host-side logic of the drop-in surface -- converters (P4), clip chunking / ordering (P1-P3),
+weight ingestion (P5), node surface (8b), C-ABI exports."""
+import ctypes
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+# ------------------------------------------------------------------ stub ComfyUI runtime for the node surface
+def _install_comfy_stub():
+    if 'comfy' in sys.modules:
+        return
+    comfy = types.ModuleType('comfy')
+    mm = types.ModuleType('comfy.model_management')
+    mm.get_torch_device = lambda: torch.device('cpu')
+    mm.unet_offload_device = lambda: torch.device('cpu')
+    mm.soft_empty_cache = lambda: None
+    cu = types.ModuleType('comfy.utils')
+
+    class ProgressBar:
+        last = None
+
+        def __init__(self, total):
+            self.total, self.current = total, 0
+            ProgressBar.last = self
+
+        def update(self, n):
+            self.current += n
+
+    cu.ProgressBar = ProgressBar
+    cu.tiled_scale = None
+    comfy.model_management, comfy.utils = mm, cu
+    fp = types.ModuleType('folder_paths')
+    fp.models_dir = '/nonexistent/models'
+    sys.modules.update({'comfy': comfy, 'comfy.model_management': mm, 'comfy.utils': cu, 'folder_paths': fp})
+
+
+_install_comfy_stub()
+import importlib  # noqa: E402
+
+nodes = importlib.import_module('comfyui_keep_amd.nodes')
+from comfyui_keep_amd.modules import utils as U  # noqa: E402
+from comfyui_keep_amd.modules.keep_model_loader import KEEPModelPack, convert_legacy_keys, select_params  # noqa: E402
+from comfyui_keep_amd.modules.keep_processor import KEEPFaceProcessor, split_clips  # noqa: E402
+from comfyui_keep_amd.engine import synth  # noqa: E402
+
+
+def test_node_surface():
+    assert set(nodes.NODE_CLASS_MAPPINGS) == {'KEEP_ModelLoader', 'KEEP_FaceUpscaleImage', 'KEEP_ProcessImageSequence'}
+    assert nodes.NODE_DISPLAY_NAME_MAPPINGS == {
+        'KEEP_ModelLoader': 'Load KEEP Models', 'KEEP_FaceUpscaleImage': 'KEEP Single Image',
+        'KEEP_ProcessImageSequence': 'KEEP Image Sequence'}
+    seq = nodes.KEEP_ProcessImageSequenceNode
+    req = seq.INPUT_TYPES()['required']
+    assert list(req) == ['images', 'keep_model', 'final_upscale_factor', 'has_aligned_frames', 'only_center_face',
+                         'draw_bounding_box', 'max_clip_length']
+    assert req['max_clip_length'][1]['default'] == 20 and req['max_clip_length'][1]['max'] == 100
+    assert req['final_upscale_factor'][1] == {**req['final_upscale_factor'][1], 'default': 1.0, 'min': 0.5, 'max': 4.0, 'step': 0.1}
+    assert seq.RETURN_TYPES == ('IMAGE',) and seq.FUNCTION == 'process_sequence' and seq.CATEGORY == 'ComfyUI-KEEP'
+    ld = nodes.KEEP_ModelLoaderNode
+    assert ld.RETURN_TYPES == ('KEEP_MODEL_PACK',) and ld.FUNCTION == 'load_model_pack'
+    it = ld.INPUT_TYPES()
+    assert it['required']['model'][0] == ['KEEP', 'Asian']
+    assert it['required']['detection_model'][0] == ['retinaface_resnet50', 'retinaface_mobile0.25', 'YOLOv5l', 'YOLOv5n']
+    assert set(it['optional']) == {'bg_upscale_model', 'face_upscale_model'}
+
+
+def test_processing_nodes_never_raise():
+    img = torch.zeros(1, 8, 8, 3)
+    assert nodes.KEEP_FaceUpscaleImageNode().upscale_face_image(img, "not a pack", 1.0, True, True, False) == (None,)
+
+    class Boom:
+        def __call__(self, *a, **k):
+            raise RuntimeError("boom")
+
+        def to(self, d):
+            return self
+
+    class Helper:
+        pass
+
+    pack = KEEPModelPack(Boom(), Helper(), None, None, 'KEEP')
+    out = nodes.KEEP_ProcessImageSequenceNode().process_sequence(torch.zeros(2, 512, 512, 3), pack, 1.0, True, True, False, 20)
+    assert out == (None,)
+
+
+def test_config_table():
+    a = U.KEEP_MODEL_CONFIGS['KEEP']['architecture']
+    assert a['cft_list'] == ['16', '32', '64'] and a['temp_reg_list'] == ['32'] and a['kalman_attn_head_dim'] == 48
+    assert U.KEEP_MODEL_CONFIGS['Asian']['architecture']['cft_list'] == ['32', '64', '128', '256']
+    assert a['fix_modules'] == ['quantize', 'generator'] and a['latent_size'] == 256 and a['mask_ratio'] == 0.
+
+
+def test_converters_edge_values():
+    # comfy_image_to_cv2 truncates; channel order flips
+    img = torch.tensor([[[[0.999, 0.5, 0.0]]]])
+    assert U.comfy_image_to_cv2(img).tolist() == [[[0, 127, 254]]]
+    # tensor2img: clamp, (x+1)/2*255, round half to even, RGB->BGR
+    vals = torch.tensor([-1.2, -1.0, -0.5 / 255, 0.0, 1.0 / 255, 1.0, 1.3, 0.00392156862])
+    t = vals.view(1, 1, -1).repeat(3, 1, 1)
+    got = U.net_output_to_bgr_u8(t)[0, :, 0]
+    exp = np.round((np.clip(vals.numpy(), -1, 1) + 1) / 2 * 255.0).astype(np.uint8)
+    assert got.tolist() == exp.tolist()
+    assert got[3] == 128 and got[0] == 0 and got[6] == 255            # 127.5 -> 128 (half to even)
+    # crops -> net input: float32(u8/255.) then (x-0.5)/0.5, BGR->RGB
+    crop = synth.ramp_image(4, 4)
+    x = U.crops_to_net_input([crop])
+    ref = ((crop / 255.).astype(np.float32)[..., ::-1].transpose(2, 0, 1) - np.float32(0.5)) / np.float32(0.5)
+    assert np.array_equal(x[0].numpy(), ref)
+    # round trip of exact grid values
+    assert np.array_equal(U.net_output_to_bgr_u8(x[0]), crop)
+
+
+@pytest.mark.parametrize("n,l", [(1, 20), (2, 20), (19, 20), (20, 20), (21, 20), (41, 20), (5, 1)])
+def test_chunk_boundaries(n, l):
+    chunks = split_clips(n, l)
+    assert chunks[0][0] == 0 and chunks[-1][1] == n
+    assert all(e - s <= l and e > s for s, e in chunks)
+    assert all(chunks[i][1] == chunks[i + 1][0] for i in range(len(chunks) - 1))
+    assert len(chunks) == -(-n // l)
+
+
+class _RecordingNet:
+    """keep_net stand-in: output = input + clip_index, records the clip lengths it was given."""
+
+    def __init__(self):
+        self.calls = []
+
+    def __call__(self, x, need_upscale=True):
+        assert need_upscale is False
+        self.calls.append(x.shape[1])
+        return x + float(len(self.calls))
+
+    def to(self, d):
+        return self
+
+
+class _Helper:
+    def clean_all(self):
+        pass
+
+
+def _pack(net):
+    return KEEPModelPack(net, _Helper(), None, None, 'KEEP')
+
+
+def test_sequence_clip_loop_aligned():
+    net = _RecordingNet()
+    proc = KEEPFaceProcessor(_pack(net))
+    frames = torch.rand(41, 512, 512, 3)
+    out = proc.process_image_sequence(frames, 1.0, True, True, False, max_clip_length=20)
+    assert net.calls == [20, 20, 2]                    # 41 = 20 + 20 + 1, the singleton is duplicated to T=2
+    assert len(proc.last_restored_faces) == 41
+    # reference quirk P2: aligned sequences return the (resized) input, restored faces are discarded
+    assert out.shape == (41, 512, 512, 3)
+    assert torch.equal(out, (frames * 255).to(torch.uint8).float() / 255.0)
+    from comfy.utils import ProgressBar
+    assert ProgressBar.last.current == 41 * 3          # no paste ticks on the aligned path (Appendix A.2)
+
+
+def test_single_image_aligned_duplicates_to_T2():
+    net = _RecordingNet()
+    proc = KEEPFaceProcessor(_pack(net))
+    img = synth.ramp_image()
+    out = proc.process_image(img, 1.0, True, True, False)
+    assert net.calls == [2] and out.shape == (512, 512, 3) and out.dtype == np.uint8
+
+
+def test_legacy_key_conversion_and_param_selection():
+    sd = {'cross_fuse.16.norm1.weight': 1, 'fuse_convs_dict.32.scale.0.bias': 2, 'encoder.blocks.0.weight': 3}
+    out = convert_legacy_keys(sd)
+    assert set(out) == {'cfa.16.norm1.weight', 'cft.32.scale.0.bias', 'encoder.blocks.0.weight'}
+    assert select_params({'params_ema': 'a', 'params': 'b'}) == 'a'
+    assert select_params({'params': 'b'}) == 'b'
+    plain = {'x': 1}
+    assert select_params(plain) is plain
+
+
+def test_strict_load_rejects_bad_state_dict(synth_weights):
+    from comfyui_keep_amd.engine.net import KeepNet
+    from comfyui_keep_amd.engine.arch import DEFAULT_ARCH
+    net = KeepNet(**DEFAULT_ARCH)
+    bad = dict(synth_weights)
+    bad.pop('position_emb')
+    with pytest.raises(RuntimeError, match='Missing key'):
+        net.load_state_dict(bad, strict=True)
+    bad = dict(synth_weights, extra=torch.zeros(1))
+    with pytest.raises(RuntimeError, match='Unexpected key'):
+        net.load_state_dict(bad, strict=True)
+
+
+def test_packed_blob_layouts(synth_weights):
+    from comfyui_keep_amd.engine.weights import logical_tensors, pack_blob, views
+    lt = logical_tensors(synth_weights)
+    w = synth_weights['encoder.blocks.1.conv1.weight']
+    assert torch.equal(lt['encoder.blocks.1.conv1.weight'], w.permute(0, 2, 3, 1))
+    assert lt['encoder.blocks.17.qkv.weight'].shape == (1536, 512)
+    assert torch.equal(lt['encoder.blocks.17.qkv.weight'][512:1024], synth_weights['encoder.blocks.17.k.weight'].view(512, 512))
+    assert lt['cft.32.ss0.weight'].shape == (512, 3, 3, 256)
+    assert lt['cfa.16.attn.to_kv.weight'].shape == (2048, 512)
+    assert lt['flownet.model.transformer.layers.0.self_attn.qkv.weight'].shape == (384, 128)
+    assert 'encoder.blocks.17.q.weight' not in lt
+    blob, index = pack_blob(lt)
+    v = views(torch.from_numpy(blob), index)
+    assert all(off % 64 == 0 for off, _ in index.values())
+    assert torch.equal(v['position_emb'], synth_weights['position_emb'])
+    n_in = sum(t.numel() for t in synth_weights.values())
+    assert sum(t.numel() for t in lt.values()) == n_in
+
+
+def test_face_tracking_restatement():
+    from comfyui_keep_amd.modules.face_tracks import interpolate_sequence, smooth_center_face, track_faces
+    s = np.array([1.0, np.nan, 3.0, np.nan, np.nan, 6.0])
+    assert np.allclose(interpolate_sequence(s), [1, 2, 3, 4, 5, 6])
+    lm = lambda cx: np.tile(np.array([[cx, 10.0]]), (5, 1))  # noqa: E731
+    tracks = track_faces([[lm(10), lm(300)], [lm(305), lm(12)], [], [lm(14)]])
+    assert len(tracks) == 3                                    # the face re-appearing after a gap starts a new track
+    assert np.allclose(tracks[0][1], lm(12)) and np.allclose(tracks[1][1], lm(305))
+    assert np.isnan(tracks[0][2]).all() and np.isnan(tracks[0][3]).all()
+    sm = smooth_center_face([[lm(10)], [], [lm(30)]])
+    assert sm[0].shape == (3, 5, 2) and not np.isnan(sm[0]).any()
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from comfyui_keep_amd.engine import hiplib
+    header = open(os.path.join(ROOT, 'include', 'keep_hip.h')).read()
+    declared = set(re.findall(r'\b(keep_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(hiplib.EXPORTED_SYMBOLS)
+    assert os.path.exists(hiplib.LIB_PATH), "run `python __graft_entry__.py` (build) first"
+    lib = ctypes.CDLL(hiplib.LIB_PATH)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    lib.keep_abi_version.restype = ctypes.c_int32
+    assert lib.keep_abi_version() == hiplib.ABI_VERSION
+    hiplib.load(check_device=False)                             # binds every signature
+    # argument validation is host-side C: callable without a GPU
+    lib.keep_last_error.restype = ctypes.c_char_p
+    lib.keep_conv2d.restype = ctypes.c_int32
+    assert lib.keep_conv2d(None, None) == -1 and b'null args' in lib.keep_last_error()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'comfyui-keep_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'keep_oracle' not in src and 'ref_import' not in src and 'import oracle' not in src, f

@@ -316,25 +316,33 @@ class KeepNet:
             L.call('keep_gm_join', x, None, None, c2, s2, h2, out, N, H * Wd, C)
         return out
 
-    def _gm_layer(self, c0, p, ffn, h8, w8, shift, kv_rot, n_img):
-        """GM/transformer.py:148-187 with the window partition inside the attention kernel."""
+    def _gm_layer(self, src, tgt, p, ffn, h8, w8, shift, kv_rot, n_img):
+        """GM/transformer.py:148-187 with the window partition inside the attention kernel.
+        ``tgt`` holds the target tokens in SOURCE image order; image i attends to image (i+kv_rot) % n_img of it."""
         w = self.w
-        C = c0.shape[-1]
+        C = src.shape[-1]
         Ltok = h8 * w8
-        qkv = ops.linear(c0, w[f'{p}.qkv.weight'])
-        o = torch.empty_like(c0)
-        s3 = (Ltok * 3 * C, 3 * C, 0)
-        ops.attention(qkv, ops.offset(qkv, C), ops.offset(qkv, 2 * C), o, B=n_img * 4, H=1, Lq=Ltok // 4,
-                      Lk=Ltok // 4, D=C, Dv=C, scale=1.0 / (C ** 0.5), q_str=s3, k_str=s3, v_str=s3,
-                      o_str=(Ltok * C, C, 0), mode=2, img_h=h8, img_w=w8, ksplit=2, shift=shift, kv_rot=kv_rot,
-                      n_img=n_img)
+        wqkv = w[f'{p}.qkv.weight']
+        o = torch.empty_like(src)
+        if tgt is src:
+            qkv = ops.linear(src, wqkv)
+            q, k, v = qkv, ops.offset(qkv, C), ops.offset(qkv, 2 * C)
+            sq = skv = (Ltok * 3 * C, 3 * C, 0)
+        else:
+            q = ops.linear(src, wqkv[:C])
+            kv = ops.linear(tgt, wqkv[C:])
+            k, v = kv, ops.offset(kv, C)
+            sq, skv = (Ltok * C, C, 0), (Ltok * 2 * C, 2 * C, 0)
+        ops.attention(q, k, v, o, B=n_img * 4, H=1, Lq=Ltok // 4, Lk=Ltok // 4, D=C, Dv=C, scale=1.0 / (C ** 0.5),
+                      q_str=sq, k_str=skv, v_str=skv, o_str=(Ltok * C, C, 0), mode=2, img_h=h8, img_w=w8, ksplit=2,
+                      shift=shift, kv_rot=kv_rot, n_img=n_img)
         m = ops.linear(o, w[f'{p}.merge.weight'])
         if not ffn:
-            return ops.layernorm(m, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], res=c0)
+            return ops.layernorm(m, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], res=src)
         m = ops.layernorm(m, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'])
-        hmid = ops.linear(ops.concat2(c0, m), w[f'{p}.mlp.0.weight'], act=L.ACT_GELU)
+        hmid = ops.linear(ops.concat2(src, m), w[f'{p}.mlp.0.weight'], act=L.ACT_GELU)
         m2 = ops.linear(hmid, w[f'{p}.mlp.2.weight'])
-        return ops.layernorm(m2, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], res=c0)
+        return ops.layernorm(m2, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], res=src)
 
     def _gmflow(self, im1, im2):
         """im1, im2 [P,3,H,W] NCHW in [-1,1] -> backward flow [P,H,W,2] (channels-last: (dx, dy))."""
@@ -358,8 +366,10 @@ class KeepNet:
         for i in range(GMFLOW['num_layers']):
             shift = wsz // 2 if i % 2 == 1 else 0
             lp = f'{pfx}.transformer.layers.{i}'
-            c0 = self._gm_layer(c0, f'{lp}.self_attn', False, h8, w8, shift, 0, n_img)
-            c0 = self._gm_layer(c0, f'{lp}.cross_attn_ffn', True, h8, w8, shift, P, n_img)
+            # the cross-attention target is the swapped INPUT of this block (concat1 is refreshed only after
+            # the block, GM/transformer.py:308-317), not the output of its self-attention
+            s_att = self._gm_layer(c0, c0, f'{lp}.self_attn', False, h8, w8, shift, 0, n_img)
+            c0 = self._gm_layer(s_att, c0, f'{lp}.cross_attn_ffn', True, h8, w8, shift, P, n_img)
         f0 = c0[:P * Ltok]
         f1 = c0[P * Ltok:]
         sF = (Ltok * C, C, 0)
@@ -386,7 +396,7 @@ class KeepNet:
 
     # ------------------------------------------------------------------ KEEP.forward
     @torch.no_grad()
-    def __call__(self, x, need_upscale=False, force_indices=None, return_aux=False):
+    def __call__(self, x, need_upscale=False, force_indices=None, return_aux=False, force_flows=None):
         if self.w is None:
             raise RuntimeError("KeepNet: weights are not on a device (load_state_dict + .to('cuda') first)")
         if x.dim() != 5 or x.shape[2] != 3:
@@ -402,17 +412,19 @@ class KeepNet:
         if H % 32 or Wd % 32:
             raise ValueError("H and W must be multiples of 32")
         with torch.cuda.device(self.device):
-            return self._forward(x, B, T, H, Wd, force_indices, return_aux)
+            return self._forward(x, B, T, H, Wd, force_indices, return_aux, force_flows)
 
     def _frame(self, t5, i):
         """[B,T,...] -> frame i as a contiguous [B,...] (free view when B == 1)."""
         return t5[:, i].contiguous()
 
-    def _forward(self, x, B, T, H, Wd, force_indices, return_aux):
+    def _forward(self, x, B, T, H, Wd, force_indices, return_aux, force_flows=None):
         cfg = self.cfg
         # K1: flows for all T-1 pairs (KA:976-986): flownet(x[:,1:], x[:,:-1])
         flows = None
-        if T > 1:
+        if force_flows is not None:      # parity tests: inject the oracle's flows [B,T-1,2,H,W] (isolates GMFlow drift)
+            flows = force_flows.to(device=self.device, dtype=torch.float32).permute(0, 1, 3, 4, 2).contiguous()
+        elif T > 1:
             flows = self._gmflow(x[:, 1:].reshape(-1, 3, H, Wd), x[:, :-1].reshape(-1, 3, H, Wd))
             flows = flows.view(B, T - 1, H, Wd, 2)
         # K2: LQ encoder over all B*T frames, stash CFT taps

@@ -103,34 +103,64 @@ def _digest(frames):
 
 
 def _full_forward_check(net, gold_name, T):
+    """Golden vectors come from the imported reference.  Frame 0 does not depend on the optical flow and is asserted
+    strictly.  Later frames see the flow only through the code indices (z_hat -> transformer -> argmax); with the
+    synthetic weights GMFlow produces flows of hundreds of pixels, so fp32 re-association in its 4096-way softmaxes
+    (~5e-5 relative, ~1e-2 px) moves a few logits by more than the smallest margins: there we assert agreement on
+    confidently-decided tokens and >= 99 % overall, and pin the arithmetic with the reference's indices injected.
+    The strict all-frames check runs against the oracle with its flows injected (next test)."""
     g = np.load(os.path.join(GOLDEN, gold_name))
     x = synth.synth_clip(T=T, B=1, seed=1234).cuda()
     out, aux = net(x, need_upscale=False, return_aux=True)
     idx = aux['indices'][0].cpu().numpy().astype(np.int16)
-    safe = g['margins'] > 1e-3
     agree = (idx == g['indices'])
-    report = {'index_agreement': float(agree.mean()), 'safe_fraction': float(safe.mean()),
+    report = {'index_agreement': float(agree.mean()), 'frame0_agreement': float(agree[0].mean()),
               'gain_err': float(np.abs(aux['gains'][0].cpu().numpy() - g['gains']).max()),
-              'flow_err': float(np.abs(_digest(aux['flows'][0].permute(0, 3, 1, 2).cpu()).numpy() - g['flow_grid']).max()),
-              'flow_scale': float(np.abs(g['flow_grid']).max())}
+              'flow_err_px': float(np.abs(_digest(aux['flows'][0].permute(0, 3, 1, 2).cpu()).numpy() - g['flow_grid']).max()),
+              'flow_scale_px': float(np.abs(g['flow_grid']).max()),
+              'disagreeing_margins': g['margins'][~agree].tolist()}
     print(gold_name, report)
-    assert report['flow_err'] <= 1e-3 * max(1.0, report['flow_scale']), report
+    assert report['flow_err_px'] <= 2e-4 * max(1.0, report['flow_scale_px']), report
     assert report['gain_err'] <= 2e-4, report
-    assert agree[safe].all(), report
+    assert agree[0][g['margins'][0] > 1e-3].all(), report
+    assert agree[g['margins'] > 0.1].all() and agree.mean() >= 0.99, report
     # arithmetic drift with the reference's indices injected (separates index flips from drift)
     forced = torch.from_numpy(g['indices'].astype(np.int32)).view(1, T, -1)
     out_f = net(x, need_upscale=False, force_indices=forced)
     err_f = np.abs(_digest(out_f[0].cpu()).numpy() - g['out_grid']).max()
     print(gold_name, 'max-abs pixel diff (reference indices injected):', err_f)
     assert err_f <= 1e-3, err_f
+    st = out_f[0].cpu().reshape(T, 3, -1)
+    stats = torch.stack([st.mean(-1), st.std(-1), st.min(-1).values, st.max(-1).values], -1).numpy()
+    assert np.abs(stats - g['out_stats']).max() <= 2e-3
     if agree.all():
         err = np.abs(_digest(out[0].cpu()).numpy() - g['out_grid']).max()
         print(gold_name, 'max-abs pixel diff (free running):', err)
         assert err <= 1e-3, err
-        st = out[0].cpu().reshape(T, 3, -1)
-        stats = torch.stack([st.mean(-1), st.std(-1), st.min(-1).values, st.max(-1).values], -1).numpy()
-        assert np.abs(stats - g['out_stats']).max() <= 2e-3
     return out
+
+
+def test_full_forward_T3_vs_oracle_flows_injected(gpu_net, synth_weights):
+    """All frames strict: the oracle's flows are injected so that the only differences left are fp32
+    re-association in the conv / attention stacks; indices must agree wherever the oracle's margin > 1e-3 and the
+    free-running output must be within 1e-3 max-abs of the oracle on EVERY pixel."""
+    x = synth.synth_clip(T=3, B=1, seed=1234)
+    ref, raux = O.keep_forward(x, synth_weights, return_aux=True)
+    out, aux = gpu_net(x.cuda(), return_aux=True, force_flows=raux['flows'])
+    top2 = raux['logits'].topk(2, -1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-3
+    agree = aux['indices'].cpu().long() == raux['indices']
+    print('safe fraction', safe.float().mean().item(), 'agreement', agree.float().mean().item())
+    assert agree[safe].all()
+    assert (aux['gains'].cpu() - raux['gains'].view(1, 3, -1)).abs().max().item() <= 2e-4
+    if agree.all():
+        err = (out.cpu() - ref).abs().max().item()
+        print('max-abs pixel diff, all pixels, free running:', err)
+        assert err <= 1e-3
+    own = gpu_net(x.cuda(), return_aux=True)[1]['flows']            # the engine's own GMFlow vs the oracle's
+    ferr = (own.permute(0, 1, 4, 2, 3).cpu() - raux['flows']).abs().max().item()
+    print('flow max-abs diff (px):', ferr, 'flow scale', raux['flows'].abs().max().item())
+    assert ferr <= 2e-4 * raux['flows'].abs().max().item()
 
 
 def test_full_forward_T3_vs_reference_golden(gpu_net):
@@ -152,9 +182,9 @@ def test_batched_clips_equal_sequential(gpu_net):
     for b in range(2):
         one, aux1 = gpu_net(x[b:b + 1], return_aux=True)
         assert torch.equal(aux1['indices'][0], aux['indices'][b])
-        assert (one[0] - both[b]).abs().max().item() <= 1e-4
+        assert (one[0] - both[b]).abs().max().item() <= 5e-4   # split-K factors depend on the batch size
     outs = gpu_net.run_clips([x[0:1], x[1:2]])
-    assert (outs[1] - both[1:2]).abs().max().item() <= 1e-4
+    assert (outs[1] - both[1:2]).abs().max().item() <= 5e-4
 
 
 def test_processor_runs_on_engine(gpu_net):

@@ -34,6 +34,7 @@ from comfyui_keep_amd.engine.arch import DEFAULT_ARCH  # noqa: E402
 from comfyui_keep_amd.engine.net import KeepNet  # noqa: E402
 
 T_CLIP = 20
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA (no sparsity)
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 FLOP_PER_FRAME_T20 = 1038.5e9         # SURVEY.md 8d (reference graph, 2 FLOP/MAC)
 
@@ -71,14 +72,15 @@ def conv_roofline(net, x):
         d[0] += flops
         d[1] += e0.elapsed_time(e1) * 1e-3
         d[2] += 1
-    key = ('conv_f32<128x128>', False)
+    key = ('conv_f32<128x128>', False) if net.precision == 'fp32' else ('conv_bf16<128x128>', False)
+    peak = PEAK_F32_MFMA_TFLOPS if net.precision == 'fp32' else PEAK_BF16_MFMA_TFLOPS
     flops, secs, n = by[key]
     tf = flops / secs / 1e12
     detail = {f"{k[0]}{'+splitK' if k[1] else ''}": {"launches": v[2], "gflop": round(v[0] / 1e9, 1),
                                                       "ms": round(v[1] * 1e3, 2),
                                                       "tflops": round(v[0] / v[1] / 1e12, 1)} for k, v in by.items()}
-    return {"bound": "mfma", "kernel": "conv_f32_kernel<2,2,2,2> (128x128 tile, fp32 MFMA)", "achieved": round(tf, 2),
-            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+    return {"bound": "mfma", "kernel": f"conv_{'f32' if net.precision == 'fp32' else 'bf16'}_kernel<2,2,2,2> (128x128 tile)",
+            "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
             "traffic": None, "launches_per_step": n, "avg_launch_ms": round(secs / n * 1e3, 4),
             "algorithmic_gflop_per_launch": round(flops / n / 1e9, 2), "all_conv_kernels": detail}
 
@@ -105,12 +107,15 @@ def main():
     ap.add_argument('--clips', type=int, default=int(os.environ.get('KEEP_BENCH_CLIPS', '2')),
                     help='independent T=20 clips per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default=os.environ.get('KEEP_BENCH_PRECISION', 'fp32'), choices=['fp32', 'bf16'],
+                    help="MFMA operand policy: fp32 (parity <= 1e-3) or bf16 (conv/linear operands bf16, fp32 accumulate)")
     args = ap.parse_args()
 
     rank, world, local = kdist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     torch.cuda.set_device(local)
     net = build_net(rank, world)
+    net.set_precision(args.precision)
     B = args.clips
     x = synth.synth_clip(T=T_CLIP, B=B, seed=1234 + rank, phase=0.37 * rank).cuda()
 
@@ -140,9 +145,9 @@ def main():
         line = {
             "metric": "restored 512x512 face frames/sec, T=20 clip", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == 'fp32' else "bf16", "data": "synthetic",
             "config": {"workload": f"{B} independent clips x T={T_CLIP} x 512x512 per GPU (BASELINE configs[1], "
-                                   f"fp32-in/fp32-accumulate MFMA policy), KEEP config, synthetic weights seed 0",
+                                   f"{args.precision} MFMA-operand policy, fp32 accumulate + storage), KEEP config, synthetic weights seed 0",
                        "clips_per_gpu": B, "clip_length": T_CLIP, "parallelism": f"dp{world} over clips"},
             "whole_net_tflops": round(fps * FLOP_PER_FRAME_T20 / 1e12, 2),
             "roofline": conv_roofline(net, x),

@@ -92,11 +92,51 @@ __device__ __forceinline__ long kv_offset(const AttnP& p, int b, int t, long bs,
   return (long)b * bs + (long)t * ts;
 }
 
+// Loads one [32 x ncols] fp32 tile (rows = key/query tokens, cols contiguous) global -> LDS (row pitch `pitch`),
+// float4 along the contiguous axis; row offsets (window / sparse-causal index math) are computed once per float4.
+template <int NT, bool IS_Q>
+__device__ __forceinline__ void load_tile_direct(const AttnP& p, const float* base, long bs, long ts, long hoff,
+                                                 int b, int t0, int tmax, int nrows, int c0, int ncols, int cmax,
+                                                 float* dst, int pitch, int tid, bool vec) {
+  if (vec) {
+    const int c4n = ncols >> 2;
+    for (int i = tid; i < nrows * c4n; i += NT) {
+      const int row = i / c4n, c = (i - row * c4n) << 2;
+      const int t = t0 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < tmax && c0 + c < cmax) {
+        const long off = (IS_Q ? q_offset(p, b, t, bs, ts) : kv_offset(p, b, t, bs, ts)) + hoff + c0 + c;
+        v = *reinterpret_cast<const float4*>(base + off);
+      }
+      float* d = dst + row * pitch + c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  } else {
+    for (int i = tid; i < nrows * ncols; i += NT) {
+      const int row = i / ncols, c = i - row * ncols;
+      const int t = t0 + row;
+      float v = 0.f;
+      if (t < tmax && c0 + c < cmax)
+        v = base[(IS_Q ? q_offset(p, b, t, bs, ts) : kv_offset(p, b, t, bs, ts)) + hoff + c0 + c];
+      dst[row * pitch + c] = v;
+    }
+  }
+}
+
+// WAVES waves x 32 queries per block; QK depth processed in chunks of DC = min(D,128) so the Q tile of the
+// block fits LDS for every head size (D = 512 for the VQGAN AttnBlock): LDS = (WAVES*32 + 32)*(DC+1) + 32*DVS floats.
+// With a single chunk (D <= 128) and 4 waves, the NEXT key tile's K and V are prefetched into registers while the
+// current tile is on the matrix cores.
 template <int WAVES, int DVT>
 __global__ __launch_bounds__(64 * WAVES) void attn_f32_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int QP = p.D + 1;          // odd pitch: 32 rows -> 32 distinct banks
   constexpr int DVS = DVT * 32;    // dv slice handled by this block
+  constexpr int NT = 64 * WAVES;
+  constexpr bool CAN_PREFETCH = (WAVES == 4);
+  constexpr int PF = 4;            // float4 per thread per prefetched tile (32 x 128 floats / 256 threads)
+  const int DC = p.D < 128 ? p.D : 128;
+  const int nch = p.D / DC;
+  const int QP = DC + 1;           // odd pitch: 32 rows -> 32 distinct banks
   float* Qs = smem;                              // [WAVES*32][QP]
   float* Ks = Qs + WAVES * 32 * QP;              // [32][QP]
   float* Vs = Ks + 32 * QP;                      // [32][DVS]
@@ -109,16 +149,16 @@ __global__ __launch_bounds__(64 * WAVES) void attn_f32_kernel(AttnP p) {
   const int head = blockIdx.y / p.nslices;
   const int dv0 = (blockIdx.y - head * p.nslices) * DVS;
   const int q0 = blockIdx.x * (WAVES * 32);
-  constexpr int NT = 64 * WAVES;
+  const long qh = (long)head * p.q_hs, kh = (long)head * p.k_hs, vh = (long)head * p.v_hs;
+  const bool qk_vec = (DC % 4 == 0) && (p.q_ts % 4 == 0) && (p.q_bs % 4 == 0) && (p.q_hs % 4 == 0) &&
+                      (p.k_ts % 4 == 0) && (p.k_bs % 4 == 0) && (p.k_hs % 4 == 0) &&
+                      ((uintptr_t)p.q % 16 == 0) && ((uintptr_t)p.k % 16 == 0);
+  const bool v_vec = (p.Dv % 4 == 0) && (p.v_ts % 4 == 0) && (p.v_bs % 4 == 0) && (p.v_hs % 4 == 0) &&
+                     ((uintptr_t)p.v % 16 == 0);
+  const bool prefetch = CAN_PREFETCH && nch == 1 && qk_vec && v_vec;
 
-  // ---- stage the block's Q tile (zero rows beyond Lq)
-  for (int idx = tid; idx < WAVES * 32 * p.D; idx += NT) {
-    const int row = idx / p.D, d = idx - row * p.D;
-    const int t = q0 + row;
-    float val = 0.f;
-    if (t < p.Lq) val = p.q[q_offset(p, b, t, p.q_bs, p.q_ts) + (long)head * p.q_hs + d];
-    Qs[row * QP + d] = val;
-  }
+  if (nch == 1)
+    load_tile_direct<NT, true>(p, p.q, p.q_bs, p.q_ts, qh, b, q0, p.Lq, WAVES * 32, 0, DC, p.D, Qs, QP, tid, qk_vec);
 
   const int my_q = q0 + wave * 32 + l31;  // query owned by this lane in the S^T layout
   int my_region = 0;
@@ -132,32 +172,77 @@ __global__ __launch_bounds__(64 * WAVES) void attn_f32_kernel(AttnP p) {
     for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
 
   const float* Qw = Qs + wave * 32 * QP;
+  const float* kp = Ks + l31 * QP + lhi;
+  const float* qp = Qw + l31 * QP + lhi;
   const int ntiles = (p.Lk + 31) / 32;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    __syncthreads();  // previous tile fully consumed (also orders the Q staging before first use)
-    for (int idx = tid; idx < 32 * p.D; idx += NT) {
-      const int row = idx / p.D, d = idx - row * p.D;
-      const int t = kt * 32 + row;
-      float val = 0.f;
-      if (t < p.Lk) val = p.k[kv_offset(p, b, t, p.k_bs, p.k_ts) + (long)head * p.k_hs + d];
-      Ks[row * QP + d] = val;
-    }
-    for (int idx = tid; idx < 32 * DVS; idx += NT) {
-      const int row = idx / DVS, d = idx - row * DVS;
-      const int t = kt * 32 + row;
-      float val = 0.f;
-      if (t < p.Lk && dv0 + d < p.Dv) val = p.v[kv_offset(p, b, t, p.v_bs, p.v_ts) + (long)head * p.v_hs + dv0 + d];
-      Vs[row * DVS + d] = val;
-    }
-    __syncthreads();
 
-    // ---- S^T = K . Q^T
+  // ---- register prefetch state (single-chunk path)
+  float4 kreg[PF], vreg[PF];
+  const int kc4n = DC >> 2, vc4n = DVS >> 2;
+  auto pf_issue = [&](int kt) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int i = tid + u * NT;
+      kreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      vreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < 32 * kc4n) {
+        const int row = i / kc4n, c = (i - row * kc4n) << 2;
+        const int t = kt * 32 + row;
+        if (t < p.Lk) kreg[u] = *reinterpret_cast<const float4*>(p.k + kv_offset(p, b, t, p.k_bs, p.k_ts) + kh + c);
+      }
+      if (i < 32 * vc4n) {
+        const int row = i / vc4n, c = (i - row * vc4n) << 2;
+        const int t = kt * 32 + row;
+        if (t < p.Lk && dv0 + c < p.Dv)
+          vreg[u] = *reinterpret_cast<const float4*>(p.v + kv_offset(p, b, t, p.v_bs, p.v_ts) + vh + dv0 + c);
+      }
+    }
+  };
+  auto pf_commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int i = tid + u * NT;
+      if (i < 32 * kc4n) {
+        const int row = i / kc4n, c = (i - row * kc4n) << 2;
+        float* d = Ks + row * QP + c;
+        d[0] = kreg[u].x; d[1] = kreg[u].y; d[2] = kreg[u].z; d[3] = kreg[u].w;
+      }
+      if (i < 32 * vc4n) {
+        const int row = i / vc4n, c = (i - row * vc4n) << 2;
+        *reinterpret_cast<float4*>(Vs + row * DVS + c) = vreg[u];
+      }
+    }
+  };
+
+  if (prefetch) {
+    pf_issue(0);
+    pf_commit();
+  }
+
+  for (int kt = 0; kt < ntiles; ++kt) {
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
-    const float* kp = Ks + l31 * QP + lhi;
-    const float* qp = Qw + l31 * QP + lhi;
-    for (int d2 = 0; d2 < p.D; d2 += 2) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[d2], qp[d2], s, 0, 0, 0);
+
+    if (prefetch) {
+      __syncthreads();                         // tile kt (and Q) visible in LDS
+      if (kt + 1 < ntiles) pf_issue(kt + 1);   // next tile's loads fly during the MFMAs below
+      for (int d2 = 0; d2 < DC; d2 += 2) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[d2], qp[d2], s, 0, 0, 0);
+    } else {
+      for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();                       // previous chunk / tile fully consumed
+        if (nch > 1)
+          load_tile_direct<NT, true>(p, p.q, p.q_bs, p.q_ts, qh, b, q0, p.Lq, WAVES * 32, ch * DC, DC, p.D, Qs, QP,
+                                     tid, qk_vec);
+        load_tile_direct<NT, false>(p, p.k, p.k_bs, p.k_ts, kh, b, kt * 32, p.Lk, 32, ch * DC, DC, p.D, Ks, QP, tid,
+                                    qk_vec);
+        if (ch == 0)
+          load_tile_direct<NT, false>(p, p.v, p.v_bs, p.v_ts, vh, b, kt * 32, p.Lk, 32, dv0, DVS, p.Dv, Vs, DVS, tid,
+                                      v_vec);
+        __syncthreads();
+        for (int d2 = 0; d2 < DC; d2 += 2) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[d2], qp[d2], s, 0, 0, 0);
+      }
+    }
 
     // ---- scale, mask, online softmax (row = this lane's query)
     float mloc = -INFINITY;
@@ -202,6 +287,10 @@ __global__ __launch_bounds__(64 * WAVES) void attn_f32_kernel(AttnP p) {
 #pragma unroll
       for (int j = 0; j < DVT; ++j) o[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[r], vp[j * 32], o[j], 0, 0, 0);
     }
+    if (prefetch && kt + 1 < ntiles) {
+      __syncthreads();                         // every wave is done reading tile kt
+      pf_commit();
+    }
   }
 
   // ---- normalise and store: O rows = queries (r&3)+8*(r>>2)+4*lhi, cols = dv0 + j*32 + l31
@@ -224,11 +313,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_f32_kernel(AttnP p) {
 
 template <int WAVES, int DVT>
 static int launch_attn(const AttnP& p, hipStream_t st) {
-  const size_t lds = (size_t)(WAVES * 32 * (p.D + 1) + 32 * (p.D + 1) + 32 * DVT * 32) * sizeof(float);
-  if (lds > 160 * 1024) {
-    keep_set_error("keep_attention: LDS need %zu B exceeds 160 KiB (D=%d)", lds, p.D);
-    return KEEP_EINVAL;
-  }
+  const int DC = p.D < 128 ? p.D : 128;
+  const size_t lds = (size_t)((WAVES * 32 + 32) * (DC + 1) + 32 * DVT * 32) * sizeof(float);
   static bool attr_set = false;  // per instantiation; idempotent, benign if raced
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_f32_kernel<WAVES, DVT>,
@@ -249,7 +335,7 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
   KEEP_REQUIRE(a != nullptr, "keep_attention: null args");
   KEEP_REQUIRE(a->q && a->k && a->v && a->o, "keep_attention: null tensor pointer");
   KEEP_REQUIRE(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0 && a->D > 0 && a->Dv > 0, "keep_attention: bad dims");
-  KEEP_REQUIRE(a->D % 2 == 0 && a->D <= 512, "keep_attention: D=%d must be even and <= 512", a->D);
+  KEEP_REQUIRE(a->D % 2 == 0 && (a->D <= 128 || a->D % 128 == 0), "keep_attention: D=%d must be even and (<= 128 or a multiple of 128)", a->D);
   KEEP_REQUIRE(a->mode >= 0 && a->mode <= 2, "keep_attention: bad mode %d", a->mode);
   if (a->mode == 1)
     KEEP_REQUIRE(a->T > 0 && a->seg_len > 0 && a->Lk == 2 * a->seg_len && a->B % a->T == 0,
@@ -276,19 +362,13 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
   // dv slice per block: 32 / 64 / 128 columns
   const int dvt = a->Dv <= 32 ? 1 : (a->Dv <= 64 ? 2 : 4);
   p.nslices = cdiv(a->Dv, dvt * 32);
-  // waves per block bounded by the Q tile's LDS footprint
-  const int waves = a->D <= 128 ? 4 : (a->D <= 256 ? 2 : 1);
-  if (waves == 4) {
-    if (dvt == 1) return launch_attn<4, 1>(p, st);
-    if (dvt == 2) return launch_attn<4, 2>(p, st);
-    return launch_attn<4, 4>(p, st);
+  // one wave per block for tiny query counts (temporal attention over T frames), else 4 (one per SIMD)
+  if (a->Lq <= 32) {
+    if (dvt == 1) return launch_attn<1, 1>(p, st);
+    if (dvt == 2) return launch_attn<1, 2>(p, st);
+    return launch_attn<1, 4>(p, st);
   }
-  if (waves == 2) {
-    if (dvt == 1) return launch_attn<2, 1>(p, st);
-    if (dvt == 2) return launch_attn<2, 2>(p, st);
-    return launch_attn<2, 4>(p, st);
-  }
-  if (dvt == 1) return launch_attn<1, 1>(p, st);
-  if (dvt == 2) return launch_attn<1, 2>(p, st);
-  return launch_attn<1, 4>(p, st);
+  if (dvt == 1) return launch_attn<4, 1>(p, st);
+  if (dvt == 2) return launch_attn<4, 2>(p, st);
+  return launch_attn<4, 4>(p, st);
 }

@@ -18,6 +18,7 @@
 struct ConvP {
   const float* in;
   const float* w;
+  const unsigned short* wb;  // bf16 copy of w (same layout), KEEP_MMA_BF16 only
   const float* bias;
   float* out;
   const float* pro_scale;
@@ -34,6 +35,7 @@ struct ConvP {
   int cchunks;  // ceil(Cin/BK)
   int nsteps;   // KH*KW*cchunks
   int vec_ok;   // Cin%4==0 && in_ld%4==0 -> float4 loads
+  int in_bf16;  // input tensor is bf16 (halo kernel only)
 };
 
 __device__ __forceinline__ float epilogue_one(const ConvP& p, float v, long m, int co) {
@@ -106,8 +108,15 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
   const bool b_valid = b_co < p.Cout;
   const long w_rowoff = (long)b_co * p.KH * p.KW * p.Cin;
 
+  // Raw operands of the NEXT K step live in registers while the current step is on the matrix cores; the
+  // normalisation affine + activation is applied only when they are written to LDS (stage), so the global loads
+  // stay in flight across the whole MFMA loop instead of being waited for right after issue.
   float a_reg[A_CPT];
+  float a_sc[A_CPT];
+  float a_sh[A_CPT];
   float b_reg[B_CPT];
+  bool a_ok = false;
+  int a_ca = 0;
 
   auto fetch = [&](int s) {
     const int tap = s / p.cchunks;
@@ -117,11 +126,12 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
     // ---- A
     const int iy = a_oy * p.stride - p.pad_t + kh;
     const int ix = a_ox * p.stride - p.pad_l + kw;
-    const bool pix_ok = a_mvalid && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+    a_ok = a_mvalid && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
     const int sy = p.upsample ? (iy >> 1) : iy;
     const int sx = p.upsample ? (ix >> 1) : ix;
     const int ca = c0 + a_kq;
-    if (pix_ok) {
+    a_ca = ca;
+    if (a_ok) {
       const float* src = p.in + (((long)a_n * p.H + sy) * p.W + sx) * p.in_ld + ca;
       if (p.vec_ok && (A_CPT % 4 == 0) && ca + A_CPT <= p.Cin) {
 #pragma unroll
@@ -132,26 +142,28 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
           if (j + 2 < A_CPT) a_reg[j + 2] = v.z;
           if (j + 3 < A_CPT) a_reg[j + 3] = v.w;
         }
-      } else {
+        if (a_scale) {
 #pragma unroll
-        for (int j = 0; j < A_CPT; ++j) a_reg[j] = (ca + j < p.Cin) ? src[j] : 0.f;
-      }
-      if (a_scale) {
-#pragma unroll
-        for (int j = 0; j < A_CPT; ++j) {
-          if (ca + j < p.Cin) {
-            float v = a_reg[j] * a_scale[ca + j] + a_shift[ca + j];
-            a_reg[j] = pro_apply(v, p.pro_act);
+          for (int j = 0; j < A_CPT; j += 4) {
+            float4 sc = *reinterpret_cast<const float4*>(a_scale + ca + j);
+            float4 sh = *reinterpret_cast<const float4*>(a_shift + ca + j);
+            a_sc[j] = sc.x; a_sh[j] = sh.x;
+            if (j + 1 < A_CPT) { a_sc[j + 1] = sc.y; a_sh[j + 1] = sh.y; }
+            if (j + 2 < A_CPT) { a_sc[j + 2] = sc.z; a_sh[j + 2] = sh.z; }
+            if (j + 3 < A_CPT) { a_sc[j + 3] = sc.w; a_sh[j + 3] = sh.w; }
           }
         }
-      } else if (p.pro_act != KEEP_PRO_NONE) {
+      } else {
 #pragma unroll
-        for (int j = 0; j < A_CPT; ++j)
-          if (ca + j < p.Cin) a_reg[j] = pro_apply(a_reg[j], p.pro_act);
+        for (int j = 0; j < A_CPT; ++j) {
+          const bool cok = ca + j < p.Cin;
+          a_reg[j] = cok ? src[j] : 0.f;
+          if (a_scale) {
+            a_sc[j] = cok ? a_scale[ca + j] : 0.f;
+            a_sh[j] = cok ? a_shift[ca + j] : 0.f;
+          }
+        }
       }
-    } else {
-#pragma unroll
-      for (int j = 0; j < A_CPT; ++j) a_reg[j] = 0.f;
     }
     // ---- B
     const int cb = c0 + b_kq;
@@ -178,7 +190,15 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
 
   auto stage = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < A_CPT; ++j) As[buf][(a_kq + j) * LDA + a_row] = a_reg[j];
+    for (int j = 0; j < A_CPT; ++j) {
+      float v = 0.f;
+      if (a_ok && a_ca + j < p.Cin) {
+        v = a_reg[j];
+        if (a_scale) v = v * a_sc[j] + a_sh[j];
+        v = pro_apply(v, p.pro_act);
+      }
+      As[buf][(a_kq + j) * LDA + a_row] = v;
+    }
 #pragma unroll
     for (int j = 0; j < B_CPT; ++j) Bs[buf][(b_kq + j) * LDB + b_row] = b_reg[j];
   };
@@ -248,6 +268,427 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ bf16 MFMA
+// Same implicit GEMM, operands rounded to bf16 when staged (v_mfma_f32_32x32x16_bf16, fp32 accumulate, 16x the f32
+// MFMA rate).  Activations stay fp32 in HBM: the normalisation affine + activation run in fp32 on the way in and
+// only the MFMA operand is rounded (RNE, v_cvt_pk_bf16_f32); weights come from a bf16 copy.  K step = 64 channels of
+// one tap.  LDS tiles are row-major [row][64 bf16] with a 144-byte pitch (9 x 16-B slots, odd): the 32x32x16
+// fragment (8 consecutive k per lane) is one ds_read_b128, conflict-free within each 16-lane service group, and the
+// staging ds_write_b128 of 8 lanes covers 8 distinct slots.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#define BK16 64
+#define PITCH16 72  // bf16 elements per LDS row (144 B)
+
+__device__ __forceinline__ float pro_apply_fast(float v, int act) {
+  if (act == KEEP_PRO_SWISH) return v * __frcp_rn(1.0f + __expf(-v));
+  if (act == KEEP_PRO_RELU) return v > 0.f ? v : 0.f;
+  return v;
+}
+
+template <int WGM, int WGN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
+  constexpr int BM = WGM * TM * 32;
+  constexpr int BN = WGN * TN * 32;
+  constexpr int A_IT = BM * 8 / 256;  // 16-byte (8 x bf16) pieces per thread per K step
+  constexpr int B_IT = BN * 8 / 256;
+  static_assert(WGM * WGN == 4, "4 waves");
+  static_assert(A_IT >= 1 && B_IT >= 1, "tile config");
+
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * PITCH16];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * PITCH16];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN;
+  const int wn = wave % WGN;
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int z = blockIdx.z;
+  const int cchunks = (p.Cin + BK16 - 1) / BK16;
+  const int nsteps = p.KH * p.KW * cchunks;
+  const int per = (nsteps + p.split_k - 1) / p.split_k;
+  const int s_begin = z * per;
+  const int s_end = min(nsteps, s_begin + per);
+
+  // staging roles: piece = tid + it*256 -> row = piece >> 3, 8-channel group = piece & 7 (= tid & 7, constant)
+  const int grp = tid & 7;
+  const int row0 = tid >> 3;  // + it*32
+  const int Hv = p.upsample ? 2 * p.H : p.H;
+  const int Wv = p.upsample ? 2 * p.W : p.W;
+  const int hw = p.Ho * p.Wo;
+  int a_n[A_IT], a_oy[A_IT], a_ox[A_IT];
+  bool a_mv[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const long m = m0 + row0 + it * 32;
+    a_mv[it] = m < p.M;
+    a_n[it] = 0; a_oy[it] = 0; a_ox[it] = 0;
+    if (a_mv[it]) {
+      a_n[it] = (int)(m / hw);
+      const int r = (int)(m - (long)a_n[it] * hw);
+      a_oy[it] = r / p.Wo;
+      a_ox[it] = r - a_oy[it] * p.Wo;
+    }
+  }
+  const long wrow_stride = (long)p.KH * p.KW * p.Cin;
+
+  float a_raw[A_IT][8];
+  bool a_ok[A_IT];
+  uint4 b_raw[B_IT];
+  int a_c = 0;   // first channel of this thread's group in the pending step
+  // all rows of the tile in one image -> this thread's 8 scale/shift values are the same for all its pieces and
+  // are prefetched with the operands (the common case: H*W is a multiple of the tile height)
+  const long m_last = (m0 + BM - 1 < p.M) ? (m0 + BM - 1) : (long)p.M - 1;
+  const bool uni_n = p.pro_scale && ((m0 / hw) == (m_last / hw));
+  const long uni_off = (m0 / hw) * (long)p.Cin;
+  float u_sc[8], u_sh[8];
+
+  auto fetch = [&](int s) {
+    const int tap = s / cchunks;
+    const int c0 = (s - tap * cchunks) * BK16;
+    const int kh = tap / p.KW;
+    const int kw = tap - kh * p.KW;
+    const int ca = c0 + grp * 8;
+    a_c = ca;
+    if (uni_n) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool cok = ca + j < p.Cin;
+        u_sc[j] = cok ? p.pro_scale[uni_off + ca + j] : 0.f;
+        u_sh[j] = cok ? p.pro_shift[uni_off + ca + j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int iy = a_oy[it] * p.stride - p.pad_t + kh;
+      const int ix = a_ox[it] * p.stride - p.pad_l + kw;
+      a_ok[it] = a_mv[it] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv && ca < p.Cin;
+      if (a_ok[it]) {
+        const int sy = p.upsample ? (iy >> 1) : iy;
+        const int sx = p.upsample ? (ix >> 1) : ix;
+        const float* src = p.in + (((long)a_n[it] * p.H + sy) * p.W + sx) * p.in_ld + ca;
+        if (p.vec_ok && ca + 8 <= p.Cin) {
+          const float4 v0 = *reinterpret_cast<const float4*>(src);
+          const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+          a_raw[it][0] = v0.x; a_raw[it][1] = v0.y; a_raw[it][2] = v0.z; a_raw[it][3] = v0.w;
+          a_raw[it][4] = v1.x; a_raw[it][5] = v1.y; a_raw[it][6] = v1.z; a_raw[it][7] = v1.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a_raw[it][j] = (ca + j < p.Cin) ? src[j] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int co = n0 + row0 + it * 32;
+      b_raw[it] = make_uint4(0u, 0u, 0u, 0u);
+      if (co < p.Cout && ca < p.Cin) {
+        const unsigned short* src = p.wb + (long)co * wrow_stride + (long)tap * p.Cin + ca;
+        if ((p.Cin & 7) == 0) {
+          b_raw[it] = *reinterpret_cast<const uint4*>(src);
+        } else {
+          unsigned short t[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t[j] = (ca + j < p.Cin) ? src[j] : (unsigned short)0;
+          b_raw[it] = make_uint4(t[0] | ((unsigned)t[1] << 16), t[2] | ((unsigned)t[3] << 16),
+                                 t[4] | ((unsigned)t[5] << 16), t[6] | ((unsigned)t[7] << 16));
+        }
+      }
+    }
+  };
+
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      bf16x8 h;
+      if (a_ok[it]) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = a_raw[it][j];
+        if (uni_n) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = v[j] * u_sc[j] + u_sh[j];
+        } else if (p.pro_scale) {
+          const float* sc = p.pro_scale + (long)a_n[it] * p.Cin + a_c;
+          const float* sh = p.pro_shift + (long)a_n[it] * p.Cin + a_c;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (a_c + j < p.Cin) v[j] = v[j] * sc[j] + sh[j];
+        }
+        if (p.pro_act != KEEP_PRO_NONE) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = pro_apply_fast(v[j], p.pro_act);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (__bf16)((a_c + j < p.Cin) ? v[j] : 0.f);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (__bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(&As[buf][(row0 + it * 32) * PITCH16 + grp * 8]) = h;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+      *reinterpret_cast<uint4*>(&Bs[buf][(row0 + it * 32) * PITCH16 + grp * 8]) = b_raw[it];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31;
+  const int lhi = lane >> 5;
+  const int a_f0 = (wm * TM * 32 + l31) * PITCH16 + lhi * 8;
+  const int b_f0 = (wn * TN * 32 + l31) * PITCH16 + lhi * 8;
+
+  if (s_begin < s_end) {
+    fetch(s_begin);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+      const bool more = (s + 1 < s_end);
+      if (more) fetch(s + 1);
+      const __bf16* Ab = As[buf];
+      const __bf16* Bb = Bs[buf];
+#pragma unroll
+      for (int ks = 0; ks < BK16 / 16; ++ks) {
+        bf16x8 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + a_f0 + i * 32 * PITCH16 + ks * 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + b_f0 + j * 32 * PITCH16 + ks * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) stage(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int co = n0 + wn * TN * 32 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const long m = m0 + wm * TM * 32 + i * 32 + row;
+        if (m < p.M && co < p.Cout) {
+          float v = acc[i][j][r];
+          if (p.split_k > 1) {
+            p.ws[((long)z * p.M + m) * p.Cout + co] = v;
+          } else {
+            p.out[m * p.out_ld + co] = epilogue_one(p, v, m, co);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ 3x3 halo kernel
+// The hot convolution (3x3, stride 1, pad 1; 85 % of the network's FLOPs) as a direct conv from an LDS-resident
+// spatial tile instead of an im2col gather: a block owns an 8 x 32 pixel output tile x 64 output channels; per
+// 32-channel chunk of Cin it stages the 10 x 34 input halo ONCE (21.8 KB bf16) plus the 9 x 64 x 32 weight slab
+// (36.9 KB) and runs all 9 taps x 2 k-substeps from LDS: 72 MFMA 32x32x16 per wave per barrier pair, the 9-fold tap
+// reuse is served by LDS (ds_read_b128, conflict-free with the 80-byte pixel pitch) instead of 9 trips to L1/L2.
+// Per-CU global traffic: ~25 B/clk at full MFMA rate vs ~95 B/clk for the gather kernel on fp32 activations.
+// The input is either fp32 (rounded to bf16 while staging) or a bf16 tensor that already carries the
+// normalisation + activation (keep_norm_act_bf16), so no transcendental sits between load and LDS.
+// The NEXT chunk's halo + weights are prefetched into registers while the current chunk is on the matrix cores;
+// 73 KB of LDS -> 2 blocks per CU so one block's staging overlaps the other's MFMA phase.
+// `upsample` folds nearest x2 into the halo addressing; split-K splits the Cin chunks (small maps at small batch).
+#define HALO_TH 8
+#define HALO_TW 32
+#define HALO_W (HALO_TW + 2)
+#define HALO_PIX ((HALO_TH + 2) * HALO_W)   // 340
+#define HPITCH 40                            // bf16 elements per LDS pixel/weight row (80 B)
+#define HALO_IT 6                            // ceil(340*4 / 256) 16-byte pieces per thread
+
+__device__ __forceinline__ int xcd_remap(int id, int total) {
+  // blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of logical ids so that neighbouring
+  // tiles (shared halo rows, shared weight slab) meet in one L2.  Bijective for any total (guide T1).
+  const int q = total >> 3, r = total & 7;
+  const int xcd = id & 7, slot = id >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+template <bool IN_BF16>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles_x, int tiles_y, int ncb) {
+  __shared__ __attribute__((aligned(16))) __bf16 Hs[HALO_PIX * HPITCH];
+  __shared__ __attribute__((aligned(16))) __bf16 Ws[9 * 64 * HPITCH];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int total = gridDim.x;
+  const int lid = xcd_remap(blockIdx.x, total);
+  const int cb = lid % ncb;
+  int t = lid / ncb;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int n = t / tiles_y;
+  const int oy0 = ty * HALO_TH, ox0 = tx * HALO_TW;
+  const int n0 = cb * 64;
+  const int z = blockIdx.z;
+
+  const int nchunks = p.Cin >> 5;
+  const int per = (nchunks + p.split_k - 1) / p.split_k;
+  const int ch_begin = z * per;
+  const int ch_end = min(nchunks, ch_begin + per);
+
+  const int Hv = p.upsample ? 2 * p.H : p.H;
+  const int Wv = p.upsample ? 2 * p.W : p.W;
+
+  // ---- chunk-invariant staging geometry
+  const int g = tid & 3;                 // 8-channel group within the 32-channel chunk
+  int h_off[HALO_IT];                    // element offset of (pixel, group) inside image n, -1 = zero padding / unused
+#pragma unroll
+  for (int it = 0; it < HALO_IT; ++it) {
+    const int hp = (tid >> 2) + it * 64;
+    h_off[it] = -1;
+    if (hp < HALO_PIX) {
+      const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
+        const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+        h_off[it] = (sy * p.W + sx) * p.in_ld + g * 8;
+      }
+    }
+  }
+  const long w_base = ((long)(n0 + (tid >> 2)) * 9) * p.Cin + g * 8;   // + tap*Cin + c0
+  const long img_off = (long)n * p.H * p.W * p.in_ld;
+  const unsigned short* in16 = reinterpret_cast<const unsigned short*>(p.in) + img_off;
+  const float* in32 = p.in + img_off;
+
+  uint4 hreg[HALO_IT];                   // bf16 input: one 16-B piece each
+  float4 hlo[IN_BF16 ? 1 : HALO_IT], hhi[IN_BF16 ? 1 : HALO_IT];   // fp32 input: 8 floats per piece
+  uint4 wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7, wr8;   // named: a 9-element array is left in scratch by hipcc
+#define KEEP_TAPS(X) X(0, wr0) X(1, wr1) X(2, wr2) X(3, wr3) X(4, wr4) X(5, wr5) X(6, wr6) X(7, wr7) X(8, wr8)
+
+  auto fetch = [&](int ch) {
+    const int c0 = ch << 5;
+#pragma unroll
+    for (int it = 0; it < HALO_IT; ++it) {
+      if (IN_BF16) {
+        hreg[it] = make_uint4(0u, 0u, 0u, 0u);
+        if (h_off[it] >= 0) hreg[it] = *reinterpret_cast<const uint4*>(in16 + h_off[it] + c0);
+      } else {
+        hlo[IN_BF16 ? 0 : it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        hhi[IN_BF16 ? 0 : it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h_off[it] >= 0) {
+          const float* src = in32 + h_off[it] + c0;
+          hlo[IN_BF16 ? 0 : it] = *reinterpret_cast<const float4*>(src);
+          hhi[IN_BF16 ? 0 : it] = *reinterpret_cast<const float4*>(src + 4);
+        }
+      }
+    }
+#define KEEP_WLOAD(TAP, R) R = *reinterpret_cast<const uint4*>(p.wb + w_base + (long)(TAP) * p.Cin + c0);
+    KEEP_TAPS(KEEP_WLOAD)
+#undef KEEP_WLOAD
+  };
+
+  auto stage = [&]() {
+#pragma unroll
+    for (int it = 0; it < HALO_IT; ++it) {
+      const int hp = (tid >> 2) + it * 64;
+      if (hp < HALO_PIX) {
+        if (IN_BF16) {
+          *reinterpret_cast<uint4*>(&Hs[hp * HPITCH + g * 8]) = hreg[it];
+        } else {
+          const float4 a = hlo[IN_BF16 ? 0 : it], b = hhi[IN_BF16 ? 0 : it];
+          bf16x8 h;
+          h[0] = (__bf16)a.x; h[1] = (__bf16)a.y; h[2] = (__bf16)a.z; h[3] = (__bf16)a.w;
+          h[4] = (__bf16)b.x; h[5] = (__bf16)b.y; h[6] = (__bf16)b.z; h[7] = (__bf16)b.w;
+          *reinterpret_cast<bf16x8*>(&Hs[hp * HPITCH + g * 8]) = h;
+        }
+      }
+    }
+#define KEEP_WSTORE(TAP, R) *reinterpret_cast<uint4*>(&Ws[((TAP) * 64 + (tid >> 2)) * HPITCH + g * 8]) = R;
+    KEEP_TAPS(KEEP_WSTORE)
+#undef KEEP_WSTORE
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int a_base = ((2 * wave) * HALO_W + l31) * HPITCH + lhi * 8;   // + (i+kh)*HALO_W*HPITCH + kw*HPITCH + ks*16
+  const int b_base = l31 * HPITCH + lhi * 8;                           // + (tap*64 + j*32)*HPITCH + ks*16
+
+  if (ch_begin < ch_end) {
+    fetch(ch_begin);
+    stage();
+    __syncthreads();
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+      const bool more = ch + 1 < ch_end;
+      if (more) fetch(ch + 1);
+#pragma unroll 1
+      for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              af[i] = *reinterpret_cast<const bf16x8*>(&Hs[a_base + ((i + kh) * HALO_W + kw) * HPITCH + ks * 16]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              bfr[j] = *reinterpret_cast<const bf16x8*>(&Ws[b_base + ((kh * 3 + kw) * 64 + j * 32) * HPITCH + ks * 16]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();           // every wave is done with this chunk's LDS image
+      if (more) {
+        stage();
+        __syncthreads();
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int oy = oy0 + 2 * wave + i;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int co = n0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int xc = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const long m = ((long)n * p.Ho + oy) * p.Wo + ox0 + xc;
+        float v = acc[i][j][r];
+        if (p.split_k > 1) {
+          p.ws[((long)z * p.M + m) * p.Cout + co] = v;
+        } else {
+          p.out[m * p.out_ld + co] = epilogue_one(p, v, m, co);
+        }
+      }
+    }
+  }
+}
+
 __global__ void conv_splitk_reduce_kernel(ConvP p) {
   const long total = (long)p.M * p.Cout;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -261,8 +702,8 @@ __global__ void conv_splitk_reduce_kernel(ConvP p) {
 
 extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
   KEEP_REQUIRE(a != nullptr, "keep_conv2d: null args");
-  if (a->dtype != KEEP_F32) {
-    keep_set_error("keep_conv2d: dtype %d not supported (fp32 only in this build)", a->dtype);
+  if (a->dtype != KEEP_F32 && !(a->dtype == KEEP_BF16 && a->mma == KEEP_MMA_BF16)) {
+    keep_set_error("keep_conv2d: dtype %d not supported (fp32 input, or bf16 input with KEEP_MMA_BF16)", a->dtype);
     return KEEP_EUNSUP;
   }
   KEEP_REQUIRE(a->in && a->weight && a->out, "keep_conv2d: null tensor pointer");
@@ -281,9 +722,13 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
     KEEP_REQUIRE((long)(a->Ho - 1) * a->stride - a->pad_t < Hv && (long)(a->Wo - 1) * a->stride - a->pad_l < Wv,
                  "keep_conv2d: output extent %dx%d inconsistent with input %dx%d", a->Ho, a->Wo, Hv, Wv);
   }
+  KEEP_REQUIRE(a->mma == KEEP_MMA_F32 || a->mma == KEEP_MMA_BF16, "keep_conv2d: bad mma %d", a->mma);
+  KEEP_REQUIRE(a->mma == KEEP_MMA_F32 || (a->weight_bf16 && (uintptr_t)a->weight_bf16 % 16 == 0),
+               "keep_conv2d: KEEP_MMA_BF16 needs a 16-byte aligned weight_bf16");
   ConvP p;
   p.in = (const float*)a->in;
   p.w = a->weight;
+  p.wb = (const unsigned short*)a->weight_bf16;
   p.bias = a->bias;
   p.out = (float*)a->out;
   p.pro_scale = a->pro_scale;
@@ -304,10 +749,45 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
   if (p.split_k > p.nsteps) p.split_k = p.nsteps;
   p.vec_ok = (a->Cin % 4 == 0 && a->in_ld % 4 == 0 && ((uintptr_t)a->in % 16 == 0)) ? 1 : 0;
   KEEP_REQUIRE((uintptr_t)a->weight % 16 == 0, "keep_conv2d: weight pointer must be 16-byte aligned");
+  KEEP_REQUIRE(!a->pro_scale || ((uintptr_t)a->pro_scale % 16 == 0 && (uintptr_t)a->pro_shift % 16 == 0),
+               "keep_conv2d: pro_scale/pro_shift must be 16-byte aligned");
 
   hipStream_t st = (hipStream_t)stream;
   dim3 block(256);
-  if (a->Cout <= 32) {
+  p.in_bf16 = (a->dtype == KEEP_BF16) ? 1 : 0;
+  const bool halo_ok = a->mma == KEEP_MMA_BF16 && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 &&
+                       a->pad_l == 1 && (a->Cin % 32 == 0) && (a->Cout % 64 == 0) && (a->Ho % HALO_TH == 0) &&
+                       (a->Wo % HALO_TW == 0) && a->Ho == (a->upsample ? 2 * a->H : a->H) &&
+                       a->Wo == (a->upsample ? 2 * a->W : a->W) && !a->pro_scale && a->pro_act == KEEP_PRO_NONE &&
+                       (a->in_ld % 8 == 0) && ((uintptr_t)a->in % 16 == 0);
+  if (p.in_bf16 && !halo_ok) {
+    keep_set_error("keep_conv2d: bf16 input tensors are only accepted by the 3x3 stride-1 halo path "
+                   "(Cin%%32, Cout%%64, Ho%%8, Wo%%32, no prologue)");
+    return KEEP_EUNSUP;
+  }
+  if (halo_ok) {
+    const int nchunks = a->Cin / 32;
+    if (p.split_k > nchunks) p.split_k = nchunks;
+    const int tiles_x = a->Wo / HALO_TW, tiles_y = a->Ho / HALO_TH, ncb = a->Cout / 64;
+    dim3 grid(a->N * tiles_x * tiles_y * ncb, 1, p.split_k);
+    if (p.in_bf16)
+      hipLaunchKernelGGL((conv3x3_halo_kernel<true>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
+    else
+      hipLaunchKernelGGL((conv3x3_halo_kernel<false>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
+  } else if (a->mma == KEEP_MMA_BF16) {
+    const int steps16 = a->KH * a->KW * ((a->Cin + BK16 - 1) / BK16);
+    if (p.split_k > steps16) p.split_k = steps16;
+    if (a->Cout <= 32) {
+      dim3 grid(cdiv(M, 128), cdiv(a->Cout, 32), p.split_k);
+      hipLaunchKernelGGL((conv_bf16_kernel<4, 1, 1, 1>), grid, block, 0, st, p);
+    } else if (a->Cout <= 64 || M <= 4096) {
+      dim3 grid(cdiv(M, 64), cdiv(a->Cout, 64), p.split_k);
+      hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 1, 1>), grid, block, 0, st, p);
+    } else {
+      dim3 grid(cdiv(M, 128), cdiv(a->Cout, 128), p.split_k);
+      hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 2, 2>), grid, block, 0, st, p);
+    }
+  } else if (a->Cout <= 32) {
     dim3 grid(cdiv(M, 128), cdiv(a->Cout, 32), p.split_k);
     hipLaunchKernelGGL((conv_f32_kernel<4, 1, 1, 1>), grid, block, 0, st, p);
   } else if (a->Cout <= 64 || M <= 4096) {

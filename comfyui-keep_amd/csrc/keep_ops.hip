@@ -133,6 +133,54 @@ extern "C" int32_t keep_affine_act(const float* x, const float* scale, const flo
   return KEEP_OK;
 }
 
+// out_bf16 = bf16( act_pro( x*scale[n,c] + shift[n,c] ) ): the normalise+activate pass that feeds the 3x3 halo
+// convolution (8 channels per thread: two float4 loads, one 16-byte store; RNE via v_cvt_pk_bf16_f32).
+typedef __attribute__((ext_vector_type(8))) __bf16 ops_bf16x8;
+__global__ void norm_act_bf16_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, ops_bf16x8* __restrict__ out, long total8,
+                                     long per_n8, int C8, int act) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(x)[2 * i];
+    const float4 b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (scale) {
+      const long n = i / per_n8;
+      const int c = (int)(i % C8) * 8;
+      const float4 s0 = *reinterpret_cast<const float4*>(scale + n * C8 * 8 + c);
+      const float4 s1 = *reinterpret_cast<const float4*>(scale + n * C8 * 8 + c + 4);
+      const float4 h0 = *reinterpret_cast<const float4*>(shift + n * C8 * 8 + c);
+      const float4 h1 = *reinterpret_cast<const float4*>(shift + n * C8 * 8 + c + 4);
+      const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+    }
+    ops_bf16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = v[j];
+      if (act == KEEP_PRO_SWISH) t = t * __frcp_rn(1.0f + __expf(-t));
+      else if (act == KEEP_PRO_RELU) t = t > 0.f ? t : 0.f;
+      h[j] = (__bf16)t;
+    }
+    out[i] = h;
+  }
+}
+
+extern "C" int32_t keep_norm_act_bf16(const float* x, const float* scale, const float* shift, void* out, int32_t N,
+                                      int32_t HW, int32_t C, int32_t act, void* stream) {
+  KEEP_REQUIRE(x && out && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "keep_norm_act_bf16: bad args (C=%d)", C);
+  KEEP_REQUIRE((scale == nullptr) == (shift == nullptr), "keep_norm_act_bf16: scale/shift must pair");
+  KEEP_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0, "keep_norm_act_bf16: 16-byte alignment");
+  const long total8 = (long)N * HW * C / 8;
+  int blocks = cdiv(total8, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(norm_act_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+                     (ops_bf16x8*)out, total8, (long)HW * C / 8, C / 8, act);
+  KEEP_LAUNCH_CHECK("keep_norm_act_bf16");
+  return KEEP_OK;
+}
+
 __global__ void gm_join_kernel(const float* __restrict__ a, const float* __restrict__ sa, const float* __restrict__ ha,
                                const float* __restrict__ b, const float* __restrict__ sb, const float* __restrict__ hb,
                                float* __restrict__ out, long total, long per_n, int C) {

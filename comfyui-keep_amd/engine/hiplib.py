@@ -12,9 +12,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 F32, BF16 = 0, 1
+MMA_F32, MMA_BF16 = 0, 1
 PRO_NONE, PRO_SWISH, PRO_RELU = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 
@@ -26,7 +27,7 @@ class ConvArgs(C.Structure):
                 ('residual', _vp), ('aux', _vp), ('workspace', _vp)] + \
                [(n, _i32) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad_t', 'pad_l', 'Ho', 'Wo',
                                     'in_ld', 'out_ld', 'res_ld', 'upsample', 'pro_act', 'epi_act')] + \
-               [('aux_w', _f32), ('split_k', _i32), ('dtype', _i32)]
+               [('aux_w', _f32), ('split_k', _i32), ('dtype', _i32), ('mma', _i32), ('weight_bf16', _vp)]
 
 
 class AttnArgs(C.Structure):
@@ -44,6 +45,7 @@ _SIGNATURES = {
     'keep_chan_stats': [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     'keep_norm_finalize': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     'keep_affine_act': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    'keep_norm_act_bf16': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     'keep_gm_join': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     'keep_layernorm': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp],
     'keep_geglu': [_vp, _vp, _i32, _i32, _vp],

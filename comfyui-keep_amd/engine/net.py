@@ -12,6 +12,7 @@ scores; window partition / roll / key concatenation / [f0;f1] swap are index mat
 attention kernel.  B independent clips ride the batch axis of every kernel.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -46,6 +47,9 @@ class KeepNet:
         self.training = False
         self._const = {}           # per-shape device constants (position tables, grids)
         self.last_aux = None
+        self._dev_blob16 = None    # bf16 twin of the packed blob (same offsets) for the bf16-MFMA policy
+        self.precision = 'fp32'
+        self.set_precision(os.environ.get('KEEP_AMD_PRECISION', 'fp32'))
 
     # ------------------------------------------------------------------ nn.Module-like surface
     def load_state_dict(self, state_dict, strict=True):
@@ -73,11 +77,30 @@ class KeepNet:
             raise NotImplementedError("KeepNet is an inference engine (the reference trains with BasicSR)")
         return self.eval()
 
+    def set_precision(self, precision):
+        """'fp32': f32 MFMA everywhere (the <=1e-3 parity policy).  'bf16': convolutions / linear layers round their
+        MFMA operands to bf16 (fp32 accumulate, fp32 activations in HBM); attention, norms, softmax stay fp32."""
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        self.precision = precision
+        if precision == 'bf16' and self._dev_blob is not None and self._dev_blob16 is None:
+            self._dev_blob16 = self._dev_blob.to(torch.bfloat16)
+        return self
+
+    def _activate_precision(self):
+        if self.precision == 'bf16':
+            if self._dev_blob16 is None:
+                self._dev_blob16 = self._dev_blob.to(torch.bfloat16)
+            ops.set_precision(L.MMA_BF16, self._dev_blob, self._dev_blob16)
+        else:
+            ops.set_precision(L.MMA_F32, self._dev_blob, None)
+
     def _upload(self, from_blob=None):
         L.load(check_device=True)       # fails loudly: no library / not gfx950 -> no silent fallback
         if from_blob is None:
             from_blob = torch.from_numpy(self._blob)
         self._dev_blob = from_blob.to(self.device, non_blocking=False)
+        self._dev_blob16 = None
         self.w = views(self._dev_blob, self._index)
 
     def to(self, device):
@@ -92,7 +115,7 @@ class KeepNet:
                     self._upload()
         else:
             self.device = device
-            self._dev_blob, self.w = None, None
+            self._dev_blob, self._dev_blob16, self.w = None, None, None
             self._const = {}
         return self
 
@@ -102,7 +125,7 @@ class KeepNet:
 
     def adopt_packed(self, index, dev_blob):
         """Install a packed blob received from another rank."""
-        self._index, self._dev_blob = index, dev_blob
+        self._index, self._dev_blob, self._dev_blob16 = index, dev_blob, None
         self.device = dev_blob.device
         self.w = views(dev_blob, index)
 
@@ -412,6 +435,7 @@ class KeepNet:
         if H % 32 or Wd % 32:
             raise ValueError("H and W must be multiples of 32")
         with torch.cuda.device(self.device):
+            self._activate_precision()
             return self._forward(x, B, T, H, Wd, force_indices, return_aux, force_flows)
 
     def _frame(self, t5, i):

@@ -13,6 +13,28 @@ from . import hiplib as L
 # below this many matrix-core waves a conv launch cannot fill 256 CUs x 4 SIMDs -> split K
 _TARGET_WAVES = 1024
 
+# matrix-core operand precision of keep_conv2d launches (L.MMA_F32 = parity policy, L.MMA_BF16 = speed policy) and the
+# weight blobs the bf16 twins of fp32 weight views are resolved from (same element offsets in both blobs)
+MMA = L.MMA_F32
+_BLOB32 = None
+_BLOB16 = None
+
+
+def set_precision(mma, blob32=None, blob16=None):
+    global MMA, _BLOB32, _BLOB16
+    MMA, _BLOB32, _BLOB16 = mma, blob32, blob16
+
+
+def bf16_twin(w):
+    """bf16 copy of an fp32 weight view that lives inside the registered packed blob."""
+    if _BLOB32 is None or _BLOB16 is None:
+        raise RuntimeError("bf16 policy needs the packed weight blobs registered (ops.set_precision)")
+    off = (w.data_ptr() - _BLOB32.data_ptr()) // 4
+    if off < 0 or off + w.numel() > _BLOB32.numel() or not w.is_contiguous():
+        raise RuntimeError("weight view is not inside the packed blob; pass wb= explicitly")
+    return _BLOB16[off:off + w.numel()]
+
+
 # bench.py's roofline leg: when a list, every keep_conv2d launch is bracketed by HIP events on the launch stream
 # and appended as (tile_config, algorithmic_flops, start_event, end_event)
 PROFILE = None
@@ -49,7 +71,8 @@ def pick_split_k(M, Cout, nsteps):
 
 
 def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=False, pro=None, pro_act=L.PRO_NONE,
-         act=L.ACT_NONE, residual=None, aux=None, aux_w=1.0, cin=None, in_off=0, out=None, split_k=None):
+         act=L.ACT_NONE, residual=None, aux=None, aux_w=1.0, cin=None, in_off=0, out=None, split_k=None, wb=None,
+         mma=None):
     """x [N,H,W,ld] -> [N,Ho,Wo,Cout].  ``w`` packed [Cout,KH,KW,Cin].  ``cin``/``in_off`` select a channel
     slice of a wider input buffer.  ``down`` = VQGAN Downsample geometry (pad right/bottom only, stride 2)."""
     N, H, W, ld = x.shape
@@ -68,20 +91,40 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
     if out is None:
         out = empty((N, Ho, Wo, Cout), x)
     M = N * Ho * Wo
-    nsteps = KH * KW * math.ceil(Cin / 16)
+    mma = MMA if mma is None else mma
+    if mma == L.MMA_BF16 and wb is None:
+        wb = bf16_twin(w)
+    in_dtype = L.F32
+    halo = (mma == L.MMA_BF16 and ksize == 3 and stride == 1 and not down and pad == 1 and Cin % 32 == 0
+            and Cout % 64 == 0 and Ho % 8 == 0 and Wo % 32 == 0 and ld % 8 == 0 and in_off % 8 == 0)
+    if halo and (pro is not None or pro_act != L.PRO_NONE):
+        # 3x3 halo path: normalise + activate once per element into a bf16 tensor (instead of 9x inside the gather)
+        assert in_off == 0 and Cin == ld
+        x16 = torch.empty((N, H, W, ld), dtype=torch.bfloat16, device=x.device)
+        L.call('keep_norm_act_bf16', x, None if pro is None else pro[0], None if pro is None else pro[1], x16,
+               N, H * W, ld, pro_act)
+        x, pro, pro_act, in_dtype = x16, None, L.PRO_NONE, L.BF16
+    nsteps = KH * KW * math.ceil(Cin / (64 if mma == L.MMA_BF16 else 16))
     if split_k is None:
-        split_k = pick_split_k(M, Cout, nsteps)
+        if halo:     # 8x32-pixel x 64-channel tiles; split over the 32-channel Cin chunks
+            waves = (M // 256) * (Cout // 64) * 4
+            split_k = 1 if waves >= _TARGET_WAVES else max(1, min(_TARGET_WAVES // waves, Cin // 64, 16))
+        else:
+            split_k = pick_split_k(M, Cout, nsteps)
     ws = empty((split_k * M * Cout,), x) if split_k > 1 else None
     xin = x if in_off == 0 else x.view(-1)[in_off:]
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        PROFILE.append((tile_config(M, Cout), 2.0 * M * Cout * KH * KW * Cin, split_k, e0, e1))
+        PROFILE.append(('conv3x3_halo_bf16' if halo else
+                        tile_config(M, Cout).replace('f32', 'bf16' if mma == L.MMA_BF16 else 'f32'),
+                        2.0 * M * Cout * KH * KW * Cin, split_k, e0, e1))
         e0.record()
     L.conv2d(inp=xin, weight=w, bias=bias, out=out, pro_scale=None if pro is None else pro[0],
              pro_shift=None if pro is None else pro[1], residual=residual, aux=aux, workspace=ws,
              N=N, H=H, W=W, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=stride, pad_t=pad_t, pad_l=pad_l, Ho=Ho, Wo=Wo,
              in_ld=ld, out_ld=out.shape[-1], res_ld=0 if residual is None else residual.shape[-1],
-             upsample=int(upsample), pro_act=pro_act, epi_act=act, aux_w=float(aux_w), split_k=split_k, dtype=L.F32)
+             upsample=int(upsample), pro_act=pro_act, epi_act=act, aux_w=float(aux_w), split_k=split_k, dtype=in_dtype,
+             mma=mma, weight_bf16=wb if mma == L.MMA_BF16 else None)
     if PROFILE is not None:
         PROFILE[-1][4].record()
     return out

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KEEP_ABI_VERSION 1
+#define KEEP_ABI_VERSION 2
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -34,6 +34,13 @@ extern "C" {
 /* storage dtypes of activation tensors */
 #define KEEP_F32 0
 #define KEEP_BF16 1
+
+/* matrix-core operand precision (accumulation is always fp32):
+ *   KEEP_MMA_F32  v_mfma_f32_32x32x2_f32   exact f32 products, 157 TFLOP/s peak  -- the <=1e-3 parity policy
+ *   KEEP_MMA_BF16 v_mfma_f32_32x32x16_bf16 operands rounded to bf16 (RNE) when staged into LDS, 2.5 PFLOP/s peak;
+ *                 activations stay fp32 in HBM, weights come from the caller's bf16 copy (`weight_bf16`) */
+#define KEEP_MMA_F32 0
+#define KEEP_MMA_BF16 1
 
 /* prologue activation applied to the (affine-normalised) conv input */
 #define KEEP_PRO_NONE 0
@@ -85,6 +92,8 @@ typedef struct {
   float aux_w;
   int32_t split_k;
   int32_t dtype; /* KEEP_F32 */
+  int32_t mma;   /* KEEP_MMA_F32 | KEEP_MMA_BF16 */
+  const void* weight_bf16; /* [Cout][KH][KW][Cin] bf16, required when mma == KEEP_MMA_BF16 */
 } keep_conv2d_args;
 int32_t keep_conv2d(const keep_conv2d_args* a, void* stream);
 
@@ -131,6 +140,10 @@ int32_t keep_norm_finalize(const float* part, const float* gamma, const float* b
 /* out = act(x*scale[n,c]+shift[n,c]) materialised (only where no conv consumes it: GM residual join) */
 int32_t keep_affine_act(const float* x, const float* scale, const float* shift, float* out, int32_t N, int32_t HW,
                         int32_t C, int32_t act, void* stream);
+/* out (bf16 [N,HW,C]) = bf16( act_pro(x*scale[n,c]+shift[n,c]) ); scale/shift NULL = plain cast.  The normalise +
+ * activate pass in front of the 3x3 halo convolution under KEEP_MMA_BF16 (keep_conv2d with dtype = KEEP_BF16). */
+int32_t keep_norm_act_bf16(const float* x, const float* scale, const float* shift, void* out, int32_t N, int32_t HW,
+                           int32_t C, int32_t act, void* stream);
 /* GM/backbone.py:36: out = relu( (a*sa+ha) + relu(b*sb+hb) ); sa/ha may be NULL (identity shortcut) */
 int32_t keep_gm_join(const float* a, const float* sa, const float* ha, const float* b, const float* sb,
                      const float* hb, float* out, int32_t N, int32_t HW, int32_t C, void* stream);

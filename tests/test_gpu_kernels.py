@@ -324,3 +324,66 @@ def test_bad_arguments_fail_loudly():
         q = torch.zeros(4, 33, device='cuda')
         ops.attention(q, q, q, q, B=1, H=1, Lq=4, Lk=4, D=33, Dv=33, scale=1.0, q_str=(0, 33, 0), k_str=(0, 33, 0),
                       v_str=(0, 33, 0), o_str=(0, 33, 0))
+
+
+# ------------------------------------------------------------------------------------------------ bf16 MFMA policy
+def bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("cin,cout,hw,n,k", [(64, 64, 32, 2, 3), (128, 256, 16, 1, 3), (96, 128, 16, 2, 3),
+                                             (256, 128, 64, 1, 3), (512, 512, 16, 1, 1), (130, 256, 8, 1, 3),
+                                             (3, 64, 32, 2, 3), (64, 3, 32, 1, 3)])
+def test_conv_bf16_operands_exact_products(cin, cout, hw, n, k):
+    """bf16 policy: operands are RNE-rounded to bf16 when staged, products accumulate in fp32 -> equals an fp32 conv of
+    the rounded operands up to accumulation order."""
+    x, w, b = rnd('bx', (n, cin, hw, hw)), rnd('bw', (cout, cin, k, k), 0.05), rnd('bb', (cout,))
+    wp = pack(w)
+    y = ops.conv(dev(nhwc(x)), wp, dev(b), pad=k // 2, ksize=k, mma=L.MMA_BF16, wb=wp.to(torch.bfloat16))
+    check(nchw(y), F.conv2d(bf16r(x), bf16r(w), b, padding=k // 2), 2e-5, f'bf16 conv {cin}->{cout} k{k}')
+
+
+def test_conv_bf16_prologue_epilogue_splitk_upsample():
+    x = rnd('gx', (2, 64, 32, 32), 2.0) + 0.5
+    gamma, beta = rnd('gg', (64,)) * 0.2 + 1, rnd('gb', (64,)) * 0.2
+    w, b, res = rnd('gw', (128, 64, 3, 3), 0.05), rnd('gbi', (128,)), rnd('gr', (2, 128, 32, 32))
+    xd, wp = dev(nhwc(x)), pack(w)
+    wb = wp.to(torch.bfloat16)
+    pro = ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6)
+    h = F.group_norm(x, 32, gamma, beta, eps=1e-6)
+    ref = F.conv2d(bf16r(h * torch.sigmoid(h)), bf16r(w), b, padding=1) + res
+    for sk in (1, 3):
+        y = ops.conv(xd, wp, dev(b), pro=pro, pro_act=L.PRO_SWISH, residual=dev(nhwc(res)), mma=L.MMA_BF16, wb=wb, split_k=sk)
+        # the activated value is rounded to bf16 after a fast-exp swish: a 1-ulp input difference moves a bf16 rounding
+        check(nchw(y), ref, 2e-3, f'bf16 gn+swish+conv+res split_k={sk}')
+    y = ops.conv(xd, wp, dev(b), upsample=True, mma=L.MMA_BF16, wb=wb)
+    check(nchw(y), F.conv2d(bf16r(F.interpolate(x, scale_factor=2.0, mode='nearest')), bf16r(w), b, padding=1), 2e-5, 'bf16 up')
+    y = ops.conv(xd, wp, dev(b), down=True, mma=L.MMA_BF16, wb=wb)
+    check(nchw(y), F.conv2d(F.pad(bf16r(x), (0, 1, 0, 1)), bf16r(w), b, stride=2), 2e-5, 'bf16 down')
+
+
+def test_conv_bf16_halo_paths():
+    """3x3 halo kernel: fp32 input, bf16 pre-activated input (GN + swish via keep_norm_act_bf16), upsampled input,
+    channel-slice input, CFT epilogue, split-K -- against fp32 convs of the bf16-rounded operands."""
+    x = rnd('hx', (2, 64, 32, 64), 2.0) + 0.3
+    w, b = rnd('hw', (128, 64, 3, 3), 0.05), rnd('hb', (128,))
+    xd, wp = dev(nhwc(x)), pack(w)
+    wb = wp.to(torch.bfloat16)
+    for sk in (1, 2):
+        y = ops.conv(xd, wp, dev(b), mma=L.MMA_BF16, wb=wb, split_k=sk)
+        check(nchw(y), F.conv2d(bf16r(x), bf16r(w), b, padding=1), 2e-5, f'halo fp32-in split_k={sk}')
+    gamma, beta = rnd('hg', (64,)) * 0.2 + 1, rnd('hbt', (64,)) * 0.2
+    pro = ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6)
+    res = rnd('hr', (2, 128, 32, 64))
+    y = ops.conv(xd, wp, dev(b), pro=pro, pro_act=L.PRO_SWISH, residual=dev(nhwc(res)), mma=L.MMA_BF16, wb=wb)
+    h = F.group_norm(x, 32, gamma, beta, eps=1e-6)
+    check(nchw(y), F.conv2d(bf16r(h * torch.sigmoid(h)), bf16r(w), b, padding=1) + res, 2e-3, 'halo gn+swish')
+    xs = rnd('hxs', (1, 64, 16, 16))
+    y = ops.conv(dev(nhwc(xs)), wp, dev(b), upsample=True, mma=L.MMA_BF16, wb=wb)
+    check(nchw(y), F.conv2d(bf16r(F.interpolate(xs, scale_factor=2.0, mode='nearest')), bf16r(w), b, padding=1), 2e-5,
+          'halo upsample')
+    xw = rnd('hxw', (1, 128, 32, 32))            # slice: second 64 channels of a 128-wide buffer
+    dec, aux = rnd('hd', (1, 128, 32, 32)), rnd('ha', (1, 128, 32, 32))
+    y = ops.conv(dev(nhwc(xw)), wp, dev(b), cin=64, in_off=64, residual=dev(nhwc(dec)), aux=dev(nhwc(aux)), aux_w=1.0,
+                 mma=L.MMA_BF16, wb=wb)
+    check(nchw(y), dec + dec * aux + F.conv2d(bf16r(xw[:, 64:]), bf16r(w), b, padding=1), 2e-5, 'halo slice + cft')

@@ -201,3 +201,28 @@ def test_processor_runs_on_engine(gpu_net):
     x = U.crops_to_net_input([img]).unsqueeze(0).cuda()
     ref = gpu_net(torch.cat([x, x], 1))[:, 0]
     assert np.array_equal(out, U.net_output_to_bgr_u8(ref[0]))
+
+
+def test_bf16_policy_quality_report(gpu_net):
+    """bf16-MFMA policy (conv / linear operands rounded to bf16, fp32 accumulate and storage): measured against the
+    reference golden -- index agreement and max-abs pixel error with the reference indices injected.  Code indices
+    are an argmax over 1024 logits, so bf16 operand rounding (2^-9 relative) flips low-margin tokens: reported, and
+    bounded loosely here; the <=1e-3 bound is the fp32 policy's."""
+    g = np.load(os.path.join(GOLDEN, 'keep_forward_T3.npz'))
+    x = synth.synth_clip(T=3, B=1, seed=1234).cuda()
+    gpu_net.set_precision('bf16')
+    try:
+        out, aux = gpu_net(x, return_aux=True)
+        idx = aux['indices'][0].cpu().numpy().astype(np.int16)
+        agree = idx == g['indices']
+        forced = torch.from_numpy(g['indices'].astype(np.int32)).view(1, 3, -1)
+        out_f = gpu_net(x, force_indices=forced)
+        err_f = np.abs(_digest(out_f[0].cpu()).numpy() - g['out_grid']).max()
+        gain_err = np.abs(aux['gains'][0].cpu().numpy() - g['gains']).max()
+        print('bf16 policy: index agreement', agree.mean(), 'frame0', agree[0].mean(), 'confident(>0.5)',
+              agree[g['margins'] > 0.5].mean(), 'gain err', gain_err, 'max-abs pixel diff (ref indices):', err_f)
+        assert torch.isfinite(out).all()
+        assert agree[0].mean() >= 0.9 and agree[g['margins'] > 0.5].mean() >= 0.97
+        assert err_f <= 0.15 and gain_err <= 0.05
+    finally:
+        gpu_net.set_precision('fp32')

@@ -110,6 +110,67 @@ extern "C" int32_t keep_norm_finalize(const float* part, const float* gamma, con
   return KEEP_OK;
 }
 
+// Small maps (H*W <= 4096): one block per (image, group) reduces the whole group in one go and writes scale/shift
+// directly -- one launch instead of partial-stats + finalize, and 32*N blocks instead of a handful.
+__global__ __launch_bounds__(256) void group_stats_small_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ scale,
+                                                                float* __restrict__ shift, int HW, int C, int G, float eps) {
+  __shared__ double red[2][4];
+  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / G;
+  const float* xb = x + (long)n * HW * C + g * cpg;
+  double s = 0.0, ss = 0.0;
+  if ((cpg & 3) == 0) {
+    const int c4 = cpg >> 2;
+    for (int i = tid; i < HW * c4; i += 256) {
+      const int px = i / c4, c = (i - px * c4) << 2;
+      const float4 v = *reinterpret_cast<const float4*>(xb + (long)px * C + c);
+      s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  } else {
+    for (int i = tid; i < HW * cpg; i += 256) {
+      const int px = i / cpg, c = i - px * cpg;
+      const float v = xb[(long)px * C + c];
+      s += (double)v;
+      ss += (double)v * v;
+    }
+  }
+  s = wave_sum_d(s);
+  ss = wave_sum_d(ss);
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = s;
+    red[1][tid >> 6] = ss;
+  }
+  __syncthreads();
+  s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  ss = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const double cnt = (double)HW * cpg;
+  const double mean = s / cnt;
+  double var = ss / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int cc = tid; cc < cpg; cc += 256) {
+    const int c = g * cpg + cc;
+    const float ga = gamma ? gamma[c] : 1.f;
+    const float be = beta ? beta[c] : 0.f;
+    const float sc = ga * rstd;
+    scale[(long)n * C + c] = sc;
+    shift[(long)n * C + c] = be - (float)mean * sc;
+  }
+}
+
+extern "C" int32_t keep_group_stats(const float* x, const float* gamma, const float* beta, float* scale, float* shift,
+                                    int32_t N, int32_t HW, int32_t C, int32_t G, float eps, void* stream) {
+  KEEP_REQUIRE(x && scale && shift && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "keep_group_stats: bad args");
+  KEEP_REQUIRE((uintptr_t)x % 16 == 0 && C % 4 == 0, "keep_group_stats: needs 16-byte aligned x and C %% 4 == 0");
+  hipLaunchKernelGGL(group_stats_small_kernel, dim3(G, N), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, scale,
+                     shift, HW, C, G, eps);
+  KEEP_LAUNCH_CHECK("keep_group_stats");
+  return KEEP_OK;
+}
+
 __global__ void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                   const float* __restrict__ shift, float* __restrict__ out, long total, long per_n, int C,
                                   int act) {

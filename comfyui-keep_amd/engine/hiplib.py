@@ -44,6 +44,7 @@ _SIGNATURES = {
     'keep_attention': [C.POINTER(AttnArgs), _vp],
     'keep_chan_stats': [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     'keep_norm_finalize': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    'keep_group_stats': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     'keep_affine_act': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     'keep_norm_act_bf16': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     'keep_gm_join': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],

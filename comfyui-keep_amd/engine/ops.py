@@ -62,11 +62,16 @@ def _tile_blocks(M, Cout):
     return math.ceil(M / 128) * math.ceil(Cout / 128)
 
 
-def pick_split_k(M, Cout, nsteps):
+def pick_split_k(M, Cout, nsteps, bf16=False):
     waves = _tile_blocks(M, Cout) * 4
     if waves >= _TARGET_WAVES or nsteps < 8:
         return 1
-    s = min(_TARGET_WAVES // waves, nsteps // 4, 32)
+    # small layers are latency-bound (one global round trip per K step): oversubscribe the CUs 4x so that several
+    # blocks per CU overlap their loads, keeping >= 2 K steps per split
+    if bf16:
+        s = min(4 * _TARGET_WAVES // waves, nsteps // 2, 32)
+    else:
+        s = min(_TARGET_WAVES // waves, nsteps // 4, 32)
     return max(1, s)
 
 
@@ -110,7 +115,7 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
             waves = (M // 256) * (Cout // 64) * 4
             split_k = 1 if waves >= _TARGET_WAVES else max(1, min(_TARGET_WAVES // waves, Cin // 64, 16))
         else:
-            split_k = pick_split_k(M, Cout, nsteps)
+            split_k = pick_split_k(M, Cout, nsteps, mma == L.MMA_BF16)
     ws = empty((split_k * M * Cout,), x) if split_k > 1 else None
     xin = x if in_off == 0 else x.view(-1)[in_off:]
     if PROFILE is not None:
@@ -149,11 +154,15 @@ def norm_affine(x, gamma, beta, groups, eps):
     groups == C and gamma=None -> InstanceNorm2d(affine=False)."""
     N, H, W, C = x.shape
     HW = H * W
+    scale = empty((N, C), x)
+    shift = empty((N, C), x)
+    if HW * (C // groups) <= 32768 and C % 4 == 0 and groups * N >= 16:
+        # small maps: one block per (image, group), one launch
+        L.call('keep_group_stats', x, gamma, beta, scale, shift, N, HW, C, groups, float(eps))
+        return scale, shift
     P = max(1, min(HW // 64, 1024))
     part = empty((N, P, C, 2), x)
     L.call('keep_chan_stats', x, part, N, HW, C, C, P)
-    scale = empty((N, C), x)
-    shift = empty((N, C), x)
     L.call('keep_norm_finalize', part, gamma, beta, scale, shift, N, HW, C, groups, P, float(eps))
     return scale, shift
 

@@ -137,6 +137,9 @@ int32_t keep_chan_stats(const float* x, float* part, int32_t N, int32_t HW, int3
                         void* stream);
 int32_t keep_norm_finalize(const float* part, const float* gamma, const float* beta, float* scale, float* shift,
                            int32_t N, int32_t HW, int32_t C, int32_t G, int32_t P, float eps, void* stream);
+/* one-launch variant for small maps: one block per (image, group) reduces H*W*(C/G) values and writes scale/shift */
+int32_t keep_group_stats(const float* x, const float* gamma, const float* beta, float* scale, float* shift, int32_t N,
+                         int32_t HW, int32_t C, int32_t G, float eps, void* stream);
 /* out = act(x*scale[n,c]+shift[n,c]) materialised (only where no conv consumes it: GM residual join) */
 int32_t keep_affine_act(const float* x, const float* scale, const float* shift, float* out, int32_t N, int32_t HW,
                         int32_t C, int32_t act, void* stream);

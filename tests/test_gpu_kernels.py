@@ -387,3 +387,16 @@ def test_conv_bf16_halo_paths():
     y = ops.conv(dev(nhwc(xw)), wp, dev(b), cin=64, in_off=64, residual=dev(nhwc(dec)), aux=dev(nhwc(aux)), aux_w=1.0,
                  mma=L.MMA_BF16, wb=wb)
     check(nchw(y), dec + dec * aux + F.conv2d(bf16r(xw[:, 64:]), bf16r(w), b, padding=1), 2e-5, 'halo slice + cft')
+
+
+def test_group_stats_small_matches_two_pass():
+    x = rnd('gsx', (3, 512, 16, 16), 2.0) + 0.7
+    gamma, beta = rnd('gsg', (512,)) * 0.2 + 1, rnd('gsb', (512,)) * 0.2
+    xd = dev(nhwc(x))
+    sc, sh = ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6)       # one-launch path (small map)
+    h = F.group_norm(x, 32, gamma, beta, eps=1e-6)
+    got = nhwc(x) * sc.cpu()[:, None, None, :] + sh.cpu()[:, None, None, :]
+    check(got, nhwc(h), 2e-5, 'group stats small')
+    sc2, sh2 = ops.norm_affine(xd, None, None, 512, 1e-5)                # instance norm, C groups
+    got = nhwc(x) * sc2.cpu()[:, None, None, :] + sh2.cpu()[:, None, None, :]
+    check(got, nhwc(F.instance_norm(x, eps=1e-5)), 2e-5, 'instance stats small')

@@ -7,7 +7,7 @@ import sys
 
 db = sqlite3.connect(sys.argv[1])
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-rows = list(db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"  # durations in us))
+rows = list(db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))  # durations in us
 tot = sum(r[2] for r in rows)
 print(f"# kernels: {len(rows)}   total kernel time: {tot / 1e3:.2f} ms   per pass ({passes} passes): {tot / 1e3 / passes:.2f} ms")
 print(f"{'kernel':70s} {'calls':>8s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s} {'ms/pass':>9s}")

@@ -331,12 +331,201 @@ static int launch_attn(const AttnP& p, hipStream_t st) {
   return KEEP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ bf16 MFMA variant
+// Same algorithm with v_mfma_f32_32x32x16_bf16 (Q, K, V and P rounded to bf16, fp32 accumulate, fp32 softmax).
+//   S^T = K . Q^T : fragments are 8 consecutive d per lane (one ds_read_b128) from row-major bf16 tiles, pitch DC+8.
+//   P . V : a 16-key MFMA step s takes the lane's OWN registers p[8s..8s+7] (keys (j&3) + 16s + 8(j>>2) + 4h of
+//   its query) as the A operand, so P never moves; the matching B operand is one 16-byte read of V^T stored with the
+//   keys of each row permuted into exactly that order: pos(key) = ((key>>4)*2 + ((key>>2)&1))*8 + (((key>>3)&1)<<2 | key&3).
+typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
+
+__device__ __forceinline__ int vt_pos(int key) {
+  return (((key >> 4) << 1) + ((key >> 2) & 1)) * 8 + ((((key >> 3) & 1) << 2) | (key & 3));
+}
+
+template <int WAVES, int DVT>
+__global__ __launch_bounds__(64 * WAVES) void attn_bf16_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+  constexpr int DVS = DVT * 32;
+  constexpr int NT = 64 * WAVES;
+  constexpr int VP = 40;                 // V^T row pitch in bf16 (32 keys + 8 pad = 80 B)
+  const int DC = p.D < 128 ? p.D : 128;
+  const int nch = p.D / DC;
+  const int QP = DC + 8;                 // bf16 elements; (DC+8)*2 B is an odd number of 16-B slots for DC % 16 == 0
+  __bf16* Qs = smem16;                               // [WAVES*32][QP]
+  __bf16* Ks = Qs + WAVES * 32 * QP;                 // [32][QP]
+  __bf16* Vt = Ks + 32 * QP;                         // [DVS][VP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int b = blockIdx.z;
+  const int head = blockIdx.y / p.nslices;
+  const int dv0 = (blockIdx.y - head * p.nslices) * DVS;
+  const int q0 = blockIdx.x * (WAVES * 32);
+  const long qh = (long)head * p.q_hs, kh = (long)head * p.k_hs, vh = (long)head * p.v_hs;
+  const int g8n = DC >> 3;               // 8-column groups per row
+
+  // fp32 rows -> bf16 LDS rows, 8 columns per piece
+  auto stage_rows = [&](const float* base, long bs, long ts, long hoff, bool is_q, int t0, int tmax, int nrows,
+                        int c0, __bf16* dst) {
+    for (int i = tid; i < nrows * g8n; i += NT) {
+      const int row = i / g8n, c = (i - row * g8n) << 3;
+      const int t = t0 + row;
+      abf16x8 h;
+      if (t < tmax) {
+        const float* src = base + (is_q ? q_offset(p, b, t, bs, ts) : kv_offset(p, b, t, bs, ts)) + hoff + c0 + c;
+        const float4 a = *reinterpret_cast<const float4*>(src);
+        const float4 c4 = *reinterpret_cast<const float4*>(src + 4);
+        h[0] = (__bf16)a.x; h[1] = (__bf16)a.y; h[2] = (__bf16)a.z; h[3] = (__bf16)a.w;
+        h[4] = (__bf16)c4.x; h[5] = (__bf16)c4.y; h[6] = (__bf16)c4.z; h[7] = (__bf16)c4.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (__bf16)0.f;
+      }
+      *reinterpret_cast<abf16x8*>(dst + row * QP + c) = h;
+    }
+  };
+  // V tile -> V^T with permuted key order; lane <-> dv column (coalesced 4-byte reads), key pairs packed per dword
+  auto stage_vt = [&](int kt) {
+    for (int i = tid; i < 16 * DVS; i += NT) {
+      const int pair = i / DVS, dv = i - pair * DVS;
+      const int k0 = pair * 2;
+      const int t = kt * 32 + k0;
+      float v0 = 0.f, v1 = 0.f;
+      if (dv0 + dv < p.Dv) {
+        if (t < p.Lk) v0 = p.v[kv_offset(p, b, t, p.v_bs, p.v_ts) + vh + dv0 + dv];
+        if (t + 1 < p.Lk) v1 = p.v[kv_offset(p, b, t + 1, p.v_bs, p.v_ts) + vh + dv0 + dv];
+      }
+      __bf16* d = Vt + dv * VP + vt_pos(k0);         // vt_pos(k0+1) = vt_pos(k0) + 1 for even k0
+      d[0] = (__bf16)v0;
+      d[1] = (__bf16)v1;
+    }
+  };
+
+  if (nch == 1) stage_rows(p.q, p.q_bs, p.q_ts, qh, true, q0, p.Lq, WAVES * 32, 0, Qs);
+
+  const int my_q = q0 + wave * 32 + l31;
+  int my_region = 0;
+  if (p.mode == 2 && p.shift > 0 && my_q < p.Lq) my_region = win_region(p, b, my_q);
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 o[DVT];
+#pragma unroll
+  for (int j = 0; j < DVT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+
+  const __bf16* kp = Ks + l31 * QP + lhi * 8;
+  const __bf16* qp = Qs + (wave * 32 + l31) * QP + lhi * 8;
+  const int ntiles = (p.Lk + 31) / 32;
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    for (int ch = 0; ch < nch; ++ch) {
+      __syncthreads();
+      if (nch > 1) stage_rows(p.q, p.q_bs, p.q_ts, qh, true, q0, p.Lq, WAVES * 32, ch * DC, Qs);
+      stage_rows(p.k, p.k_bs, p.k_ts, kh, false, kt * 32, p.Lk, 32, ch * DC, Ks);
+      if (ch == 0) stage_vt(kt);
+      __syncthreads();
+      for (int d = 0; d < DC; d += 16)
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(kp + d),
+                                                    *reinterpret_cast<const abf16x8*>(qp + d), s, 0, 0, 0);
+    }
+
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      float val = s[r] * p.scale;
+      if (p.mode == 2 && p.shift > 0 && key < p.Lk) {
+        if (win_region(p, b, key) != my_region) val += -100.0f;
+      }
+      if (key >= p.Lk) val = -INFINITY;
+      s[r] = val;
+      mloc = fmaxf(mloc, val);
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __expf(m_run - m_new);
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = __expf(s[r] - m_new);
+      s[r] = pv;
+      lsum += pv;
+    }
+    lsum += __shfl_xor(lsum, 32);
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const float ar = __shfl(alpha, qrow);
+#pragma unroll
+      for (int j = 0; j < DVT; ++j) o[j][r] *= ar;
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      abf16x8 pa;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pa[j] = (__bf16)s[st * 8 + j];
+#pragma unroll
+      for (int j = 0; j < DVT; ++j) {
+        const abf16x8 vb = *reinterpret_cast<const abf16x8*>(Vt + (j * 32 + l31) * VP + (st * 2 + lhi) * 8);
+        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vb, o[j], 0, 0, 0);
+      }
+    }
+  }
+
+  const float inv_l = 1.0f / l_run;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    const float il = __shfl(inv_l, qrow);
+    const int t = q0 + wave * 32 + qrow;
+    if (t < p.Lq) {
+      const long base = q_offset(p, b, t, p.o_bs, p.o_ts) + (long)head * p.o_hs;
+#pragma unroll
+      for (int j = 0; j < DVT; ++j) {
+        const int dv = dv0 + j * 32 + l31;
+        if (dv < p.Dv) p.o[base + dv] = o[j][r] * il;
+      }
+    }
+  }
+}
+
+template <int WAVES, int DVT>
+static int launch_attn_bf16(const AttnP& p, hipStream_t st) {
+  const int DC = p.D < 128 ? p.D : 128;
+  const size_t lds = (size_t)((WAVES * 32 + 32) * (DC + 8) + DVT * 32 * 40) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bf16_kernel<WAVES, DVT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      keep_set_error("keep_attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return KEEP_EHIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid(cdiv(p.Lq, WAVES * 32), p.H * p.nslices, p.B);
+  hipLaunchKernelGGL((attn_bf16_kernel<WAVES, DVT>), grid, dim3(64 * WAVES), lds, st, p);
+  KEEP_LAUNCH_CHECK("keep_attention(bf16)");
+  return KEEP_OK;
+}
+
 extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
   KEEP_REQUIRE(a != nullptr, "keep_attention: null args");
   KEEP_REQUIRE(a->q && a->k && a->v && a->o, "keep_attention: null tensor pointer");
   KEEP_REQUIRE(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0 && a->D > 0 && a->Dv > 0, "keep_attention: bad dims");
   KEEP_REQUIRE(a->D % 2 == 0 && (a->D <= 128 || a->D % 128 == 0), "keep_attention: D=%d must be even and (<= 128 or a multiple of 128)", a->D);
   KEEP_REQUIRE(a->mode >= 0 && a->mode <= 2, "keep_attention: bad mode %d", a->mode);
+  KEEP_REQUIRE(a->mma == KEEP_MMA_F32 || a->mma == KEEP_MMA_BF16, "keep_attention: bad mma %d", a->mma);
   if (a->mode == 1)
     KEEP_REQUIRE(a->T > 0 && a->seg_len > 0 && a->Lk == 2 * a->seg_len && a->B % a->T == 0,
                  "keep_attention: sparse-causal mode needs Lk == 2*seg_len and B %% T == 0");
@@ -362,6 +551,21 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
   // dv slice per block: 32 / 64 / 128 columns
   const int dvt = a->Dv <= 32 ? 1 : (a->Dv <= 64 ? 2 : 4);
   p.nslices = cdiv(a->Dv, dvt * 32);
+  if (a->mma == KEEP_MMA_BF16) {
+    // bf16 operands: needs 16-byte-aligned fp32 rows and D a multiple of 16
+    const bool ok = (a->D % 16 == 0) && (a->q_ts % 4 == 0) && (a->q_bs % 4 == 0) && (a->q_hs % 4 == 0) &&
+                    (a->k_ts % 4 == 0) && (a->k_bs % 4 == 0) && (a->k_hs % 4 == 0) && ((uintptr_t)a->q % 16 == 0) &&
+                    ((uintptr_t)a->k % 16 == 0);
+    KEEP_REQUIRE(ok, "keep_attention: KEEP_MMA_BF16 needs D %% 16 == 0 and 16-byte aligned q/k rows");
+    if (a->Lq <= 32) {
+      if (dvt == 1) return launch_attn_bf16<1, 1>(p, st);
+      if (dvt == 2) return launch_attn_bf16<1, 2>(p, st);
+      return launch_attn_bf16<1, 4>(p, st);
+    }
+    if (dvt == 1) return launch_attn_bf16<4, 1>(p, st);
+    if (dvt == 2) return launch_attn_bf16<4, 2>(p, st);
+    return launch_attn_bf16<4, 4>(p, st);
+  }
   // one wave per block for tiny query counts (temporal attention over T frames), else 4 (one per SIMD)
   if (a->Lq <= 32) {
     if (dvt == 1) return launch_attn<1, 1>(p, st);

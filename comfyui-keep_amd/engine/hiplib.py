@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 F32, BF16 = 0, 1
 MMA_F32, MMA_BF16 = 0, 1
@@ -35,7 +35,7 @@ class AttnArgs(C.Structure):
                [(n, _i64) for n in ('q_bs', 'q_ts', 'q_hs', 'k_bs', 'k_ts', 'k_hs', 'v_bs', 'v_ts', 'v_hs',
                                     'o_bs', 'o_ts', 'o_hs')] + \
                [(n, _i32) for n in ('B', 'H', 'Lq', 'Lk', 'D', 'Dv')] + [('scale', _f32), ('mode', _i32)] + \
-               [(n, _i32) for n in ('T', 'seg_len', 'img_h', 'img_w', 'ksplit', 'shift', 'kv_rot', 'n_img')]
+               [(n, _i32) for n in ('T', 'seg_len', 'img_h', 'img_w', 'ksplit', 'shift', 'kv_rot', 'n_img', 'mma')]
 
 
 # name -> argtypes (restype is always int32 status); every symbol include/keep_hip.h declares

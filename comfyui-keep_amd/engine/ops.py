@@ -16,13 +16,14 @@ _TARGET_WAVES = 1024
 # matrix-core operand precision of keep_conv2d launches (L.MMA_F32 = parity policy, L.MMA_BF16 = speed policy) and the
 # weight blobs the bf16 twins of fp32 weight views are resolved from (same element offsets in both blobs)
 MMA = L.MMA_F32
+ATTN_MMA = L.MMA_F32
 _BLOB32 = None
 _BLOB16 = None
 
 
 def set_precision(mma, blob32=None, blob16=None):
-    global MMA, _BLOB32, _BLOB16
-    MMA, _BLOB32, _BLOB16 = mma, blob32, blob16
+    global MMA, ATTN_MMA, _BLOB32, _BLOB16
+    MMA, ATTN_MMA, _BLOB32, _BLOB16 = mma, mma, blob32, blob16
 
 
 def bf16_twin(w):
@@ -186,13 +187,16 @@ def geglu(x):
 
 
 def attention(q, k, v, o, *, B, H, Lq, Lk, D, Dv, scale, q_str, k_str, v_str, o_str, mode=0, T=0, seg_len=0,
-              img_h=0, img_w=0, ksplit=0, shift=0, kv_rot=0, n_img=0):
+              img_h=0, img_w=0, ksplit=0, shift=0, kv_rot=0, n_img=0, mma=None):
     """Strides are (batch, token, head) element strides."""
+    mma = ATTN_MMA if mma is None else mma
+    if mma == L.MMA_BF16 and (D % 16 or any(v % 4 for v in (*q_str, *k_str))):
+        mma = L.MMA_F32
     L.attention(q=q, k=k, v=v, o=o,
                 q_bs=q_str[0], q_ts=q_str[1], q_hs=q_str[2], k_bs=k_str[0], k_ts=k_str[1], k_hs=k_str[2],
                 v_bs=v_str[0], v_ts=v_str[1], v_hs=v_str[2], o_bs=o_str[0], o_ts=o_str[1], o_hs=o_str[2],
                 B=B, H=H, Lq=Lq, Lk=Lk, D=D, Dv=Dv, scale=float(scale), mode=mode, T=T, seg_len=seg_len,
-                img_h=img_h, img_w=img_w, ksplit=ksplit, shift=shift, kv_rot=kv_rot, n_img=n_img)
+                img_h=img_h, img_w=img_w, ksplit=ksplit, shift=shift, kv_rot=kv_rot, n_img=n_img, mma=mma)
     return o
 
 

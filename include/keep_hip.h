@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KEEP_ABI_VERSION 2
+#define KEEP_ABI_VERSION 3
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -123,6 +123,7 @@ typedef struct {
   int32_t mode;
   int32_t T, seg_len;                           /* mode 1 */
   int32_t img_h, img_w, ksplit, shift, kv_rot, n_img; /* mode 2 */
+  int32_t mma; /* KEEP_MMA_F32 | KEEP_MMA_BF16 (Q,K,V,P rounded to bf16; fp32 softmax + accumulate) */
 } keep_attention_args;
 int32_t keep_attention(const keep_attention_args* a, void* stream);
 

@@ -400,3 +400,53 @@ def test_group_stats_small_matches_two_pass():
     sc2, sh2 = ops.norm_affine(xd, None, None, 512, 1e-5)                # instance norm, C groups
     got = nhwc(x) * sc2.cpu()[:, None, None, :] + sh2.cpu()[:, None, None, :]
     check(got, nhwc(F.instance_norm(x, eps=1e-5)), 2e-5, 'instance stats small')
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,D,Dv", [(2, 8, 256, 256, 64, 64), (1, 1, 64, 64, 512, 512), (2, 4, 96, 96, 256, 256),
+                                            (3, 2, 50, 77, 48, 48), (1, 1, 256, 256, 128, 2), (2, 1, 40, 40, 128, 128),
+                                            (4, 8, 20, 20, 48, 48)])
+def test_attention_bf16_operands(B, H, Lq, Lk, D, Dv):
+    """bf16 policy: Q, K, V (and P) rounded to bf16, fp32 softmax/accumulate -> within bf16 resolution of the fp32
+    attention of the rounded operands."""
+    q, k, v = rnd('aq', (B, Lq, H, D)), rnd('ak', (B, Lk, H, D)), rnd('av', (B, Lk, H, Dv))
+    scale = D ** -0.5 * 3.0
+    o = torch.empty(B, Lq, H, Dv, device='cuda')
+    ops.attention(dev(q), dev(k), dev(v), o, B=B, H=H, Lq=Lq, Lk=Lk, D=D, Dv=Dv, scale=scale,
+                  q_str=(Lq * H * D, H * D, D), k_str=(Lk * H * D, H * D, D), v_str=(Lk * H * Dv, H * Dv, Dv),
+                  o_str=(Lq * H * Dv, H * Dv, Dv), mma=L.MMA_BF16)
+    ref = ref_attn(bf16r(q).permute(0, 2, 1, 3), bf16r(k).permute(0, 2, 1, 3), bf16r(v).permute(0, 2, 1, 3), scale)
+    check(o, ref.permute(0, 2, 1, 3), 6e-3, what=f'bf16 attn {B, H, Lq, Lk, D, Dv}')
+
+
+def test_attention_bf16_window_and_sparse_modes():
+    P, h8, w8, C = 2, 8, 8, 128
+    n_img, Lt = 2 * P, h8 * w8
+    q, k, v = rnd('wq', (n_img, Lt, C)), rnd('wk', (n_img, Lt, C)), rnd('wv', (n_img, Lt, C))
+    o = torch.empty(n_img, Lt, C, device='cuda')
+    s = (Lt * C, C, 0)
+    ops.attention(dev(q), dev(k), dev(v), o, B=n_img * 4, H=1, Lq=Lt // 4, Lk=Lt // 4, D=C, Dv=C, scale=1 / C ** 0.5,
+                  q_str=s, k_str=s, v_str=s, o_str=s, mode=2, img_h=h8, img_w=w8, ksplit=2, shift=2, kv_rot=P, n_img=n_img,
+                  mma=L.MMA_BF16)
+    mask = O.shift_window_mask(h8, w8, h8 // 2, w8 // 2, h8 // 4, w8 // 4)
+    kr, vr = torch.cat([k[P:], k[:P]]), torch.cat([v[P:], v[:P]])
+    check(o, O._window_attention(bf16r(q), bf16r(kr), bf16r(vr), 2, True, h8, w8, mask), 6e-3, 'bf16 swin')
+    Bc, T, Lt, H, D = 2, 3, 64, 8, 48
+    inner = H * D
+    qkv = rnd('sq', (Bc * T, Lt, 3 * inner))
+    qd = dev(qkv)
+    o = torch.empty(Bc * T, Lt, inner, device='cuda')
+    s3 = (Lt * 3 * inner, 3 * inner, D)
+    ops.attention(qd, ops.offset(qd, inner), ops.offset(qd, 2 * inner), o, B=Bc * T, H=H, Lq=Lt, Lk=2 * Lt, D=D, Dv=D,
+                  scale=D ** -0.5, q_str=s3, k_str=s3, v_str=s3, o_str=(Lt * inner, inner, D), mode=1, T=T, seg_len=Lt,
+                  mma=L.MMA_BF16)
+    qq, kk, vv = bf16r(qkv).chunk(3, dim=-1)
+    former = torch.arange(T) - 1
+    former[0] = 0
+
+    def gather(t):
+        t = t.reshape(Bc, T, Lt, inner)
+        return torch.cat([t[:, [0] * T], t[:, former]], dim=2).reshape(Bc * T, 2 * Lt, inner)
+
+    hs = lambda t: t.reshape(t.shape[0], t.shape[1], H, D).permute(0, 2, 1, 3)  # noqa: E731
+    ref = ref_attn(hs(qq), hs(gather(kk)), hs(gather(vv)), D ** -0.5).permute(0, 2, 1, 3).reshape(Bc * T, Lt, inner)
+    check(o, ref, 6e-3, 'bf16 sparse causal')

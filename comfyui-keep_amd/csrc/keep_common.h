@@ -41,6 +41,26 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
+// Abramowitz-Stegun 7.1.26: |erf error| <= 1.5e-7 (below bf16 and fp32-accumulation noise); ~12 instructions instead of
+// the ~40 of the exact erff -- the GELU epilogue of a 128x128 tile is 64 evaluations per thread.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float y = 1.0f - poly * __expf(-ax * ax);
+  return copysignf(y, x);
+}
+
+__device__ __forceinline__ float act_apply_fast(float v, int act) {
+  switch (act) {
+    case KEEP_ACT_RELU: return v > 0.f ? v : 0.f;
+    case KEEP_ACT_LRELU02: return v > 0.f ? v : 0.2f * v;
+    case KEEP_ACT_GELU: return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f));
+    case KEEP_ACT_SIGMOID: return __frcp_rn(1.0f + __expf(-v));
+    default: return v;
+  }
+}
+
 __device__ __forceinline__ float pro_apply(float v, int act) {
   if (act == KEEP_PRO_SWISH) return v * (1.0f / (1.0f + expf(-v)));
   if (act == KEEP_PRO_RELU) return v > 0.f ? v : 0.f;

@@ -11,6 +11,8 @@
 // is fetched into registers while tile k is on the matrix cores (one barrier per K step).
 // Small-spatial layers (16x16 .. 64x64 maps) under-fill 256 CUs with output tiles alone -> deterministic split-K
 // over the (tap, Cin-chunk) steps into a caller workspace + a reduce/epilogue kernel.
+#include <stdlib.h>
+
 #include "keep_common.h"
 
 #define BK 16
@@ -36,11 +38,17 @@ struct ConvP {
   int nsteps;   // KH*KW*cchunks
   int vec_ok;   // Cin%4==0 && in_ld%4==0 -> float4 loads
   int in_bf16;  // input tensor is bf16 (halo kernel only)
+  int fast;     // bf16 policy: fast-math epilogue activations
+  float* stats; // optional [N][P][Cout][2] per-tile (sum, sumsq) of the epilogue output, P = stats_P tiles per image
+  int stats_P;
+  int vec_epi;  // Cout/out_ld/res_ld %% 4 == 0 and aligned pointers -> LDS-staged float4 epilogue
+  int exp;      // dev-only ablation switch (KEEP_HALO_EXP), 0 in production
+  int flatk;    // Cin < 8: K = KH*KW*Cin flattened (element-wise gather) instead of tap-major chunks
 };
 
 __device__ __forceinline__ float epilogue_one(const ConvP& p, float v, long m, int co) {
   if (p.bias) v += p.bias[co];
-  v = act_apply(v, p.epi_act);
+  v = p.fast ? act_apply_fast(v, p.epi_act) : act_apply(v, p.epi_act);
   if (p.res) {
     float r = p.res[m * p.res_ld + co];
     if (p.aux) {
@@ -51,6 +59,141 @@ __device__ __forceinline__ float epilogue_one(const ConvP& p, float v, long m, i
     }
   }
   return v;
+}
+
+// Epilogue statistics for the NEXT normalisation (GroupNorm / InstanceNorm): every lane owns one output channel
+// (column) of its wave tile; (sum, sumsq) over the tile's rows are combined across the two half-waves by a shuffle
+// and across the waves that share the columns through `red` (LDS), then written as one partial per (tile, channel).
+template <int WGM, int WGN, int TN>
+__device__ __forceinline__ void emit_tile_stats(const ConvP& p, float (*red)[2], const float (&cs)[TN], const float (&css)[TN],
+                                                int wm, int wn, int lane, int n_img, int p_idx, int n0) {
+  const int l31 = lane & 31;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    float s = cs[j] + __shfl_xor(cs[j], 32);
+    float ss = css[j] + __shfl_xor(css[j], 32);
+    if (lane < 32) {
+      red[(wm * WGN + wn) * TN * 32 + j * 32 + l31][0] = s;
+      red[(wm * WGN + wn) * TN * 32 + j * 32 + l31][1] = ss;
+    }
+  }
+  __syncthreads();
+  constexpr int BNc = WGN * TN * 32;
+  for (int c = threadIdx.x; c < BNc; c += 256) {
+    const int wn_c = c / (TN * 32), rem = c - wn_c * (TN * 32);
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int m = 0; m < WGM; ++m) {
+      s += red[(m * WGN + wn_c) * TN * 32 + rem][0];
+      ss += red[(m * WGN + wn_c) * TN * 32 + rem][1];
+    }
+    const int co = n0 + c;
+    if (co < p.Cout) {
+      float* dst = p.stats + (((long)n_img * p.stats_P + p_idx) * p.Cout + co) * 2;
+      dst[0] = s;
+      dst[1] = ss;
+    }
+  }
+}
+
+// Epilogue through LDS (shared by the gather kernels): the MFMA C/D layout gives a lane one output channel x 16
+// rows -> 4-byte strided stores, issue-bound at ~2 TB/s.  Each wave parks its (TM*32 x TN*32) tile in LDS and reads it
+// back channel-contiguous: 16 bytes per lane, full rows per store instruction, float4 bias / residual / aux, and the
+// normalisation partial sums are lane-local (4 fixed channels per lane).  Needs Cout, out_ld, res_ld multiples of 4 and
+// 16-byte aligned pointers (p.vec_epi); otherwise the scalar path below is used.
+template <int WGM, int WGN, int TM, int TN>
+__device__ __forceinline__ void staged_epilogue(const ConvP& p, f32x16 (&acc)[TM][TN], float* lds, long m0, int n0,
+                                                int wm, int wn, int lane, int wave, int z) {
+  constexpr int WR = TM * 32, WC = TN * 32, EP = WC + 4;
+  constexpr int LPR = WC / 4;          // lanes per row (float4 each)
+  constexpr int RPI = 64 / LPR;        // rows per wave-instruction
+  const int l31 = lane & 31, lhi = lane >> 5;
+  float* et = lds + wave * WR * EP;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        et[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * EP + j * 32 + l31] = acc[i][j][r];
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): wave-local hand-off, LDS ops of one wave retire in order
+  const int c4 = (lane % LPR) * 4;
+  const int prow = lane / LPR;
+  const int co = n0 + wn * WC + c4;
+  const bool cok = co < p.Cout;
+  float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
+#pragma unroll 4
+  for (int it = 0; it < WR / RPI; ++it) {
+    const int px = it * RPI + prow;
+    const long m = m0 + wm * WR + px;
+    if (m >= p.M || !cok) continue;
+    const float4 v = *reinterpret_cast<const float4*>(et + px * EP + c4);
+    if (p.split_k > 1) {
+      *reinterpret_cast<float4*>(p.ws + ((long)z * p.M + m) * p.Cout + co) = v;
+      continue;
+    }
+    float e[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e[q] = p.fast ? act_apply_fast(e[q], p.epi_act) : act_apply(e[q], p.epi_act);
+    if (p.res) {
+      const float4 r4 = *reinterpret_cast<const float4*>(p.res + m * p.res_ld + co);
+      const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+      if (p.aux) {
+        const float4 a4 = *reinterpret_cast<const float4*>(p.aux + m * (long)p.Cout + co);
+        const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = rr[q] + p.aux_w * (rr[q] * aa[q] + e[q]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] += rr[q];
+      }
+    }
+    *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s4[q] += e[q];
+      ss4[q] += e[q] * e[q];
+    }
+  }
+  if (p.stats) {   // host guarantees split_k == 1 and H*W % BM == 0 (a tile never straddles two images)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+        s4[q] += __shfl_xor(s4[q], o);
+        ss4[q] += __shfl_xor(ss4[q], o);
+      }
+    }
+    __syncthreads();                     // all waves finished reading their staged tiles
+    float* red = lds;                    // [4 waves][WC][2]
+    if (lane < LPR) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        red[(wave * WC + c4 + q) * 2 + 0] = s4[q];
+        red[(wave * WC + c4 + q) * 2 + 1] = ss4[q];
+      }
+    }
+    __syncthreads();
+    constexpr int BNc = WGN * WC;
+    const int hw_o = p.Ho * p.Wo;
+    const int n_img = (int)(m0 / hw_o), p_idx = (int)((m0 % hw_o) / (WGM * WR));
+    for (int c = threadIdx.x; c < BNc; c += 256) {
+      const int wn_c = c / WC, rem = c - wn_c * WC;
+      float a = 0.f, b2 = 0.f;
+#pragma unroll
+      for (int mm = 0; mm < WGM; ++mm) {
+        a += red[((mm * WGN + wn_c) * WC + rem) * 2 + 0];
+        b2 += red[((mm * WGN + wn_c) * WC + rem) * 2 + 1];
+      }
+      if (n0 + c < p.Cout) {
+        float* dst = p.stats + (((long)n_img * p.stats_P + p_idx) * p.Cout + n0 + c) * 2;
+        dst[0] = a;
+        dst[1] = b2;
+      }
+    }
+  }
 }
 
 template <int WGM, int WGN, int TM, int TN>
@@ -66,8 +209,11 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
   static_assert(WGM * WGN == 4, "4 waves");
   static_assert(A_TPR >= 1 && B_TPR >= 1 && A_CPT >= 1 && B_CPT >= 1, "tile config");
 
-  __shared__ float As[2][BK * LDA];
-  __shared__ float Bs[2][BK * LDB];
+  constexpr int MAIN_F = 2 * BK * (LDA + LDB);
+  constexpr int EPI_F = 4 * (TM * 32) * (TN * 32 + 4);
+  __shared__ __attribute__((aligned(16))) float smem_f[MAIN_F > EPI_F ? MAIN_F : EPI_F];
+  float(*As)[BK * LDA] = reinterpret_cast<float(*)[BK * LDA]>(smem_f);
+  float(*Bs)[BK * LDB] = reinterpret_cast<float(*)[BK * LDB]>(smem_f + 2 * BK * LDA);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -246,6 +392,13 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
   }
 
   // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (p.vec_epi) {
+    staged_epilogue<WGM, WGN, TM, TN>(p, acc, smem_f, m0, n0, wm, wn, lane, wave, z);
+    return;
+  }
+  float cs[TN], css[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { cs[j] = 0.f; css[j] = 0.f; }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -260,11 +413,19 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
           if (p.split_k > 1) {
             p.ws[((long)z * p.M + m) * p.Cout + co] = v;
           } else {
-            p.out[m * p.out_ld + co] = epilogue_one(p, v, m, co);
+            v = epilogue_one(p, v, m, co);
+            p.out[m * p.out_ld + co] = v;
+            cs[j] += v;
+            css[j] += v * v;
           }
         }
       }
     }
+  }
+  if (p.stats) {   // host guarantees split_k == 1 and H*W %% BM == 0 (a tile never straddles two images)
+    __shared__ float red[4 * TM * 0 + WGM * WGN * TN * 32][2];
+    const int hw_o = p.Ho * p.Wo;
+    emit_tile_stats<WGM, WGN, TN>(p, red, cs, css, wm, wn, lane, (int)(m0 / hw_o), (int)((m0 % hw_o) / (WGM * TM * 32)), n0);
   }
 }
 
@@ -294,8 +455,11 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
   static_assert(WGM * WGN == 4, "4 waves");
   static_assert(A_IT >= 1 && B_IT >= 1, "tile config");
 
-  __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * PITCH16];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * PITCH16];
+  constexpr int MAIN_B = 2 * (BM + BN) * PITCH16 * 2;              // bytes
+  constexpr int EPI_B = 4 * (TM * 32) * (TN * 32 + 4) * 4;         // bytes
+  __shared__ __attribute__((aligned(16))) unsigned char smem_b[MAIN_B > EPI_B ? MAIN_B : EPI_B];
+  __bf16(*As)[BM * PITCH16] = reinterpret_cast<__bf16(*)[BM * PITCH16]>(smem_b);
+  __bf16(*Bs)[BN * PITCH16] = reinterpret_cast<__bf16(*)[BN * PITCH16]>(smem_b + 2 * BM * PITCH16 * 2);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -306,7 +470,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
   const int n0 = blockIdx.y * BN;
   const int z = blockIdx.z;
   const int cchunks = (p.Cin + BK16 - 1) / BK16;
-  const int nsteps = p.KH * p.KW * cchunks;
+  const int nsteps = p.flatk ? (p.KH * p.KW * p.Cin + BK16 - 1) / BK16 : p.KH * p.KW * cchunks;
   const int per = (nsteps + p.split_k - 1) / p.split_k;
   const int s_begin = z * per;
   const int s_end = min(nsteps, s_begin + per);
@@ -351,6 +515,43 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
     const int kw = tap - kh * p.KW;
     const int ca = c0 + grp * 8;
     a_c = ca;
+    if (p.flatk) {
+      // K = (kh, kw, c) flattened (Cin = 3: 27 or 147 real k's instead of 9 / 49 nearly empty 64-wide chunks)
+      const int kbase = s * BK16 + grp * 8;
+      const int ktot = p.KH * p.KW * p.Cin;
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) {
+        a_ok[it] = a_mv[it] && kbase < ktot;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = kbase + j;
+          float v = 0.f;
+          if (a_ok[it] && k < ktot) {
+            const int tp = k / p.Cin, c = k - tp * p.Cin;
+            const int kh2 = tp / p.KW, kw2 = tp - kh2 * p.KW;
+            const int iy = a_oy[it] * p.stride - p.pad_t + kh2;
+            const int ix = a_ox[it] * p.stride - p.pad_l + kw2;
+            if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
+              const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+              v = p.in[(((long)a_n[it] * p.H + sy) * p.W + sx) * p.in_ld + c];
+            }
+          }
+          a_raw[it][j] = v;
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < B_IT; ++it) {
+        const int co = n0 + row0 + it * 32;
+        unsigned short t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          t[j] = (co < p.Cout && kbase + j < ktot) ? p.wb[(long)co * ktot + kbase + j] : (unsigned short)0;
+        b_raw[it] = make_uint4(t[0] | ((unsigned)t[1] << 16), t[2] | ((unsigned)t[3] << 16),
+                               t[4] | ((unsigned)t[5] << 16), t[6] | ((unsigned)t[7] << 16));
+      }
+      a_c = 0;     // stage(): every element already validated, no per-channel mask / affine (host forbids a prologue)
+      return;
+    }
     if (uni_n) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -421,7 +622,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
           for (int j = 0; j < 8; ++j) v[j] = pro_apply_fast(v[j], p.pro_act);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) h[j] = (__bf16)((a_c + j < p.Cin) ? v[j] : 0.f);
+        for (int j = 0; j < 8; ++j) h[j] = (__bf16)((p.flatk || a_c + j < p.Cin) ? v[j] : 0.f);
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) h[j] = (__bf16)0.f;
@@ -475,6 +676,13 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
     }
   }
 
+  if (p.vec_epi) {
+    staged_epilogue<WGM, WGN, TM, TN>(p, acc, reinterpret_cast<float*>(smem_b), m0, n0, wm, wn, lane, wave, z);
+    return;
+  }
+  float cs[TN], css[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { cs[j] = 0.f; css[j] = 0.f; }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -489,11 +697,19 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
           if (p.split_k > 1) {
             p.ws[((long)z * p.M + m) * p.Cout + co] = v;
           } else {
-            p.out[m * p.out_ld + co] = epilogue_one(p, v, m, co);
+            v = epilogue_one(p, v, m, co);
+            p.out[m * p.out_ld + co] = v;
+            cs[j] += v;
+            css[j] += v * v;
           }
         }
       }
     }
+  }
+  if (p.stats) {   // host guarantees split_k == 1 and H*W %% BM == 0 (a tile never straddles two images)
+    __shared__ float red[4 * TM * 0 + WGM * WGN * TN * 32][2];
+    const int hw_o = p.Ho * p.Wo;
+    emit_tile_stats<WGM, WGN, TN>(p, red, cs, css, wm, wn, lane, (int)(m0 / hw_o), (int)((m0 % hw_o) / (WGM * TM * 32)), n0);
   }
 }
 
@@ -526,8 +742,10 @@ __device__ __forceinline__ int xcd_remap(int id, int total) {
 
 template <bool IN_BF16>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles_x, int tiles_y, int ncb) {
-  __shared__ __attribute__((aligned(16))) __bf16 Hs[HALO_PIX * HPITCH];
-  __shared__ __attribute__((aligned(16))) __bf16 Ws[9 * 64 * HPITCH];
+  // one LDS object: [halo | weights] during the main loop, [4 waves x 64 pixels x 68 floats] in the epilogue
+  __shared__ __attribute__((aligned(16))) __bf16 lds_all[HALO_PIX * HPITCH + 9 * 64 * HPITCH];
+  __bf16* Hs = lds_all;
+  __bf16* Ws = lds_all + HALO_PIX * HPITCH;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -638,9 +856,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles
     __syncthreads();
     for (int ch = ch_begin; ch < ch_end; ++ch) {
       const bool more = ch + 1 < ch_end;
-      if (more) fetch(ch + 1);
+      if (more && p.exp != 2) fetch(ch + 1);
 #pragma unroll 1
-      for (int kh = 0; kh < 3; ++kh) {
+      for (int kh = 0; kh < (p.exp == 1 ? 0 : 3); ++kh) {
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
 #pragma unroll
@@ -668,23 +886,92 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles
     }
   }
 
+  // ---- epilogue through LDS: the MFMA C/D layout gives a lane ONE output channel x 16 pixels (4-byte strided
+  // stores, 64 store instructions per wave, issue-bound: measured 2.1-2.5 TB/s).  Each wave parks its 64-pixel x
+  // 64-channel tile in LDS and reads it back channel-contiguous: 16 bytes per lane, 4 full 256-byte pixel rows per
+  // store instruction, float4 bias / residual / aux accesses, and the GroupNorm partial sums become lane-local
+  // (4 fixed channels per lane).
+  constexpr int EP = 68;                                   // floats per staged pixel row (64 + 4: conflict-free)
+  float* et = reinterpret_cast<float*>(lds_all) + wave * 64 * EP;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int oy = oy0 + 2 * wave + i;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int co = n0 + j * 32 + l31;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int xc = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        const long m = ((long)n * p.Ho + oy) * p.Wo + ox0 + xc;
-        float v = acc[i][j][r];
-        if (p.split_k > 1) {
-          p.ws[((long)z * p.M + m) * p.Cout + co] = v;
-        } else {
-          p.out[m * p.out_ld + co] = epilogue_one(p, v, m, co);
-        }
+        et[(i * 32 + xc) * EP + j * 32 + l31] = acc[i][j][r];
       }
+  // wave-local hand-off (same wave wrote and reads its region): LDS ops of one wave complete in order
+  __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0)
+  const int c4 = (lane & 15) * 4;                          // this lane's 4 channels within the 64
+  const int prow = lane >> 4;                              // pixel sub-row 0..3
+  float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
+  const int co = n0 + c4;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias && p.split_k == 1) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int px = it * 4 + prow;                          // 0..63 : row (px>>5), column (px&31)
+    const int oy = oy0 + 2 * wave + (px >> 5);
+    const long m = ((long)n * p.Ho + oy) * p.Wo + ox0 + (px & 31);
+    float4 v = *reinterpret_cast<const float4*>(et + px * EP + c4);
+    if (p.split_k > 1) {
+      *reinterpret_cast<float4*>(p.ws + ((long)z * p.M + m) * p.Cout + co) = v;
+      continue;
+    }
+    float e[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e[q] = act_apply_fast(e[q], p.epi_act);
+    if (p.res) {
+      const float4 r4 = *reinterpret_cast<const float4*>(p.res + m * p.res_ld + co);
+      const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+      if (p.aux) {
+        const float4 a4 = *reinterpret_cast<const float4*>(p.aux + m * (long)p.Cout + co);
+        const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = rr[q] + p.aux_w * (rr[q] * aa[q] + e[q]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] += rr[q];
+      }
+    }
+    if (p.exp != 3 || e[0] == 123.456f)
+      *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s4[q] += e[q];
+      ss4[q] += e[q] * e[q];
+    }
+  }
+  if (p.stats) {   // split_k == 1: combine the 4 pixel sub-rows (lanes +16, +32), then the 4 waves through LDS
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s4[q] += __shfl_xor(s4[q], 16);
+      s4[q] += __shfl_xor(s4[q], 32);
+      ss4[q] += __shfl_xor(ss4[q], 16);
+      ss4[q] += __shfl_xor(ss4[q], 32);
+    }
+    __syncthreads();                                       // every wave is done with its staged tile
+    float* red = reinterpret_cast<float*>(lds_all);        // [4 waves][64 ch][2]
+    if (lane < 16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        red[(wave * 64 + c4 + q) * 2 + 0] = s4[q];
+        red[(wave * 64 + c4 + q) * 2 + 1] = ss4[q];
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float a = 0.f, b2 = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) {
+        a += red[(wv * 64 + tid) * 2 + 0];
+        b2 += red[(wv * 64 + tid) * 2 + 1];
+      }
+      float* dst = p.stats + (((long)n * p.stats_P + (ty * tiles_x + tx)) * p.Cout + n0 + tid) * 2;
+      dst[0] = a;
+      dst[1] = b2;
     }
   }
 }
@@ -755,15 +1042,35 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   dim3 block(256);
   p.in_bf16 = (a->dtype == KEEP_BF16) ? 1 : 0;
+  p.fast = (a->mma == KEEP_MMA_BF16) ? 1 : 0;
+  p.vec_epi = (a->Cout % 4 == 0 && a->out_ld % 4 == 0 && (uintptr_t)a->out % 16 == 0 &&
+               (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&
+               (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0) &&
+               (!a->workspace || (uintptr_t)a->workspace % 16 == 0)) ? 1 : 0;
+  { const char* e = getenv("KEEP_HALO_EXP"); p.exp = e ? atoi(e) : 0; }
+  p.flatk = (a->mma == KEEP_MMA_BF16 && a->Cin < 8 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE) ? 1 : 0;
+  p.stats = a->stats_out;
+  p.stats_P = a->stats_P;
+  if (p.stats) {
+    KEEP_REQUIRE(a->split_k == 1, "keep_conv2d: stats_out requires split_k == 1");
+    KEEP_REQUIRE(a->stats_P > 0, "keep_conv2d: stats_out requires stats_P");
+  }
   const bool halo_ok = a->mma == KEEP_MMA_BF16 && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 &&
                        a->pad_l == 1 && (a->Cin % 32 == 0) && (a->Cout % 64 == 0) && (a->Ho % HALO_TH == 0) &&
                        (a->Wo % HALO_TW == 0) && a->Ho == (a->upsample ? 2 * a->H : a->H) &&
                        a->Wo == (a->upsample ? 2 * a->W : a->W) && !a->pro_scale && a->pro_act == KEEP_PRO_NONE &&
-                       (a->in_ld % 8 == 0) && ((uintptr_t)a->in % 16 == 0);
+                       (a->in_ld % 8 == 0) && ((uintptr_t)a->in % 16 == 0) && (a->out_ld % 4 == 0) &&
+                       ((uintptr_t)a->out % 16 == 0) && (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&
+                       (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0);
   if (p.in_bf16 && !halo_ok) {
     keep_set_error("keep_conv2d: bf16 input tensors are only accepted by the 3x3 stride-1 halo path "
                    "(Cin%%32, Cout%%64, Ho%%8, Wo%%32, no prologue)");
     return KEEP_EUNSUP;
+  }
+  if (p.stats) {
+    const long hw_o = (long)a->Ho * a->Wo;
+    const int bm = halo_ok ? 256 : ((a->Cout <= 32) ? 128 : ((a->Cout <= 64 || M <= 4096) ? 64 : 128));
+    KEEP_REQUIRE(hw_o % bm == 0 && a->stats_P == hw_o / bm, "keep_conv2d: stats_P=%d must equal Ho*Wo/%d", a->stats_P, bm);
   }
   if (halo_ok) {
     const int nchunks = a->Cin / 32;
@@ -775,7 +1082,7 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
     else
       hipLaunchKernelGGL((conv3x3_halo_kernel<false>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
   } else if (a->mma == KEEP_MMA_BF16) {
-    const int steps16 = a->KH * a->KW * ((a->Cin + BK16 - 1) / BK16);
+    const int steps16 = p.flatk ? (a->KH * a->KW * a->Cin + BK16 - 1) / BK16 : a->KH * a->KW * ((a->Cin + BK16 - 1) / BK16);
     if (p.split_k > steps16) p.split_k = steps16;
     if (a->Cout <= 32) {
       dim3 grid(cdiv(M, 128), cdiv(a->Cout, 32), p.split_k);

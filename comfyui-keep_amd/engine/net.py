@@ -137,12 +137,12 @@ class KeepNet:
         """VQ:170-181."""
         w = self.w
         h = ops.conv(x, w[f'{p}.conv1.weight'], w[f'{p}.conv1.bias'], pro=self._gn(x, f'{p}.norm1'),
-                     pro_act=L.PRO_SWISH)
+                     pro_act=L.PRO_SWISH, stats=True)
         sc = x
         if f'{p}.conv_out.weight' in w:
             sc = ops.linear(x, w[f'{p}.conv_out.weight'], w[f'{p}.conv_out.bias'])
         return ops.conv(h, w[f'{p}.conv2.weight'], w[f'{p}.conv2.bias'], pro=self._gn(h, f'{p}.norm2'),
-                        pro_act=L.PRO_SWISH, residual=sc)
+                        pro_act=L.PRO_SWISH, residual=sc, stats=True)
 
     def _attnblock(self, x, p):
         """VQ:219-243: GN -> q,k,v (one GEMM) -> fused attention (1 head, d=C) -> proj_out + x."""
@@ -167,16 +167,16 @@ class KeepNet:
         for i, (kind, _, _) in enumerate(blocks):
             p = f'{prefix}.blocks.{i}'
             if kind == 'conv':
-                x = ops.conv(x, w[f'{p}.weight'], w[f'{p}.bias'], pro=pending)
+                x = ops.conv(x, w[f'{p}.weight'], w[f'{p}.bias'], pro=pending, stats=True)
                 pending = None
             elif kind == 'res':
                 x = self._resblock(x, p)
             elif kind == 'attn':
                 x = self._attnblock(x, p)
             elif kind == 'down':
-                x = ops.conv(x, w[f'{p}.conv.weight'], w[f'{p}.conv.bias'], down=True)
+                x = ops.conv(x, w[f'{p}.conv.weight'], w[f'{p}.conv.bias'], down=True, stats=True)
             elif kind == 'up':
-                x = ops.conv(x, w[f'{p}.conv.weight'], w[f'{p}.conv.bias'], upsample=True)
+                x = ops.conv(x, w[f'{p}.conv.weight'], w[f'{p}.conv.bias'], upsample=True, stats=True)
             elif kind == 'norm':
                 pending = self._gn(x, p)
             if i in taps:
@@ -228,7 +228,7 @@ class KeepNet:
         ss = ops.conv(e, w[f'{p}.ss0.weight'], w[f'{p}.ss0.bias'], act=L.ACT_LRELU02)          # [.., 2C]
         scale = ops.conv(ss, w[f'{p}.scale.2.weight'], w[f'{p}.scale.2.bias'], cin=C, in_off=0)
         return ops.conv(ss, w[f'{p}.shift.2.weight'], w[f'{p}.shift.2.bias'], cin=C, in_off=C, residual=dec,
-                        aux=scale, aux_w=self.cfg['cond'])
+                        aux=scale, aux_w=self.cfg['cond'], stats=True)
 
     def _cfa(self, curr, prev, p):
         """KA:519-541 (post-norm): a = attn(curr, prev); y = LN(a)+curr; LN(ff(y))+y."""
@@ -325,14 +325,14 @@ class KeepNet:
     def _gm_resblock(self, x, p, stride):
         """GM/backbone.py:25-36."""
         w = self.w
-        c1 = ops.conv(x, w[f'{p}.conv1.weight'], None, stride=stride, pad=1)
-        c2 = ops.conv(c1, w[f'{p}.conv2.weight'], None, pro=self._inorm(c1), pro_act=L.PRO_RELU)
+        c1 = ops.conv(x, w[f'{p}.conv1.weight'], None, stride=stride, pad=1, stats=True)
+        c2 = ops.conv(c1, w[f'{p}.conv2.weight'], None, pro=self._inorm(c1), pro_act=L.PRO_RELU, stats=True)
         s2, h2 = self._inorm(c2)
         N, H, Wd, C = c2.shape
         out = torch.empty_like(c2)
         if f'{p}.downsample.0.weight' in w:
             d = ops.conv(x, w[f'{p}.downsample.0.weight'].view(C, 1, 1, -1), w[f'{p}.downsample.0.bias'], stride=stride,
-                         pad=0, ksize=1)
+                         pad=0, ksize=1, stats=True)
             sd, hd = self._inorm(d)
             L.call('keep_gm_join', d, sd, hd, c2, s2, h2, out, N, H * Wd, C)
         else:
@@ -373,7 +373,7 @@ class KeepNet:
         pfx = 'flownet.model'
         P, _, H, Wd = im1.shape
         img = ops.nchw_to_nhwc(torch.cat([im1, im2], dim=0), mode=1)                      # [2P,H,W,3] normalised
-        f = ops.conv(img, w[f'{pfx}.backbone.conv1.weight'], None, stride=2, pad=3, ksize=7)
+        f = ops.conv(img, w[f'{pfx}.backbone.conv1.weight'], None, stride=2, pad=3, ksize=7, stats=True)
         s, hh = self._inorm(f)
         x = torch.empty_like(f)
         L.call('keep_affine_act', f, s, hh, x, f.shape[0], f.shape[1] * f.shape[2], f.shape[3], L.ACT_RELU)

@@ -78,7 +78,7 @@ def pick_split_k(M, Cout, nsteps, bf16=False):
 
 def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=False, pro=None, pro_act=L.PRO_NONE,
          act=L.ACT_NONE, residual=None, aux=None, aux_w=1.0, cin=None, in_off=0, out=None, split_k=None, wb=None,
-         mma=None):
+         mma=None, stats=False):
     """x [N,H,W,ld] -> [N,Ho,Wo,Cout].  ``w`` packed [Cout,KH,KW,Cin].  ``cin``/``in_off`` select a channel
     slice of a wider input buffer.  ``down`` = VQGAN Downsample geometry (pad right/bottom only, stride 2)."""
     N, H, W, ld = x.shape
@@ -118,6 +118,13 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
         else:
             split_k = pick_split_k(M, Cout, nsteps, mma == L.MMA_BF16)
     ws = empty((split_k * M * Cout,), x) if split_k > 1 else None
+    # per-tile channel statistics of the output for the next GroupNorm / InstanceNorm (epilogue-fused)
+    part, stats_P = None, 0
+    if stats and split_k == 1:
+        bm = 256 if halo else (128 if Cout <= 32 else (64 if (Cout <= 64 or M <= 4096) else 128))
+        if (Ho * Wo) % bm == 0 and out.shape[-1] == Cout:
+            stats_P = (Ho * Wo) // bm
+            part = empty((N, stats_P, Cout, 2), x)
     xin = x if in_off == 0 else x.view(-1)[in_off:]
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -130,7 +137,9 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
              N=N, H=H, W=W, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=stride, pad_t=pad_t, pad_l=pad_l, Ho=Ho, Wo=Wo,
              in_ld=ld, out_ld=out.shape[-1], res_ld=0 if residual is None else residual.shape[-1],
              upsample=int(upsample), pro_act=pro_act, epi_act=act, aux_w=float(aux_w), split_k=split_k, dtype=in_dtype,
-             mma=mma, weight_bf16=wb if mma == L.MMA_BF16 else None)
+             mma=mma, weight_bf16=wb if mma == L.MMA_BF16 else None, stats_out=part, stats_P=stats_P)
+    if part is not None:
+        out._keep_stats = (part, stats_P)
     if PROFILE is not None:
         PROFILE[-1][4].record()
     return out
@@ -157,7 +166,13 @@ def norm_affine(x, gamma, beta, groups, eps):
     HW = H * W
     scale = empty((N, C), x)
     shift = empty((N, C), x)
-    if HW * (C // groups) <= 32768 and C % 4 == 0 and groups * N >= 16:
+    fused = getattr(x, '_keep_stats', None)
+    if fused is not None:      # the producing conv already reduced (sum, sumsq) per tile in its epilogue
+        part, P = fused
+        L.call('keep_norm_finalize', part, gamma, beta, scale, shift, N, HW, C, groups, P, float(eps))
+        return scale, shift
+    cpg = C // groups
+    if ((cpg % 4 == 0 and HW * cpg <= 32768) or HW <= 1024) and C % 4 == 0 and groups * N >= 16:
         # small maps: one block per (image, group), one launch
         L.call('keep_group_stats', x, gamma, beta, scale, shift, N, HW, C, groups, float(eps))
         return scale, shift

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KEEP_ABI_VERSION 3
+#define KEEP_ABI_VERSION 4
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -94,6 +94,12 @@ typedef struct {
   int32_t dtype; /* KEEP_F32 */
   int32_t mma;   /* KEEP_MMA_F32 | KEEP_MMA_BF16 */
   const void* weight_bf16; /* [Cout][KH][KW][Cin] bf16, required when mma == KEEP_MMA_BF16 */
+  /* optional: per-tile (sum, sumsq) of the epilogue OUTPUT per channel, [N][stats_P][Cout][2], for the next
+   * GroupNorm / InstanceNorm (keep_norm_finalize with P = stats_P): saves one full read of the activation.
+   * Needs split_k == 1 and Ho*Wo a multiple of the kernel's tile height (stats_P = Ho*Wo / tile height: 256 for
+   * the 3x3 halo path, else 128, or 64 when Cout <= 64 or N*Ho*Wo <= 4096). */
+  float* stats_out;
+  int32_t stats_P;
 } keep_conv2d_args;
 int32_t keep_conv2d(const keep_conv2d_args* a, void* stream);
 

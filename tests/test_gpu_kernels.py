@@ -450,3 +450,39 @@ def test_attention_bf16_window_and_sparse_modes():
     hs = lambda t: t.reshape(t.shape[0], t.shape[1], H, D).permute(0, 2, 1, 3)  # noqa: E731
     ref = ref_attn(hs(qq), hs(gather(kk)), hs(gather(vv)), D ** -0.5).permute(0, 2, 1, 3).reshape(Bc * T, Lt, inner)
     check(o, ref, 6e-3, 'bf16 sparse causal')
+
+
+@pytest.mark.parametrize("mma", [0, 1])
+def test_conv_epilogue_stats_match_standalone(mma):
+    """(sum, sumsq) emitted by the conv epilogue == statistics of the conv output (GroupNorm of the next layer)."""
+    x, w, b = rnd('esx', (2, 64, 32, 32)), rnd('esw', (128, 64, 3, 3), 0.05), rnd('esb', (128,))
+    res = rnd('esr', (2, 128, 32, 32))
+    gamma, beta = rnd('esg', (128,)) * 0.2 + 1, rnd('esbt', (128,)) * 0.2
+    wp = pack(w)
+    kw = dict(mma=mma, wb=wp.to(torch.bfloat16)) if mma else {}
+    y = ops.conv(dev(nhwc(x)), wp, dev(b), residual=dev(nhwc(res)), stats=True, split_k=1, **kw)
+    assert hasattr(y, '_keep_stats')
+    sc, sh = ops.norm_affine(y, dev(gamma), dev(beta), 32, 1e-6)
+    y2 = y.clone()                                       # no fused stats attached -> standalone kernels
+    sc2, sh2 = ops.norm_affine(y2, dev(gamma), dev(beta), 32, 1e-6)
+    check(sc, sc2, 1e-5, 'scale'); check(sh, sh2, 1e-5, 'shift')
+    h = F.group_norm(nchw(y).cpu(), 32, gamma, beta, eps=1e-6)
+    got = y.cpu() * sc.cpu()[:, None, None, :] + sh.cpu()[:, None, None, :]
+    check(got, nhwc(h), 2e-5, 'fused stats -> group norm')
+    # 1x1 / strided producers through the gather kernels
+    y = ops.conv(dev(nhwc(x)), dev(rnd('esw1', (96, 64)) * 0.1).view(96, 1, 1, 64), None, stride=2, pad=0, ksize=1, stats=True, split_k=1,
+                 **(dict(mma=1, wb=(dev(rnd('esw1', (96, 64)) * 0.1)).to(torch.bfloat16)) if mma else {}))
+    sc, sh = ops.norm_affine(y, None, None, 96, 1e-5)
+    sc2, sh2 = ops.norm_affine(y.clone(), None, None, 96, 1e-5)
+    check(sc, sc2, 1e-5, 'in scale'); check(sh, sh2, 1e-5, 'in shift')
+
+
+def test_conv_bf16_flat_k_small_cin():
+    x, w = rnd('7x', (2, 3, 64, 64)), rnd('7w', (64, 3, 7, 7), 0.1)
+    wp = pack(w)
+    y = ops.conv(dev(nhwc(x)), wp, None, stride=2, pad=3, ksize=7, mma=L.MMA_BF16, wb=wp.to(torch.bfloat16))
+    check(nchw(y), F.conv2d(bf16r(x), bf16r(w), None, stride=2, padding=3), 2e-5, 'flat-K 7x7 s2')
+    x, w, b = rnd('3x', (2, 3, 32, 32)), rnd('3w', (64, 3, 3, 3), 0.2), rnd('3b', (64,))
+    wp = pack(w)
+    y = ops.conv(dev(nhwc(x)), wp, dev(b), mma=L.MMA_BF16, wb=wp.to(torch.bfloat16), stats=True)
+    check(nchw(y), F.conv2d(bf16r(x), bf16r(w), b, padding=1), 2e-5, 'flat-K 3x3')

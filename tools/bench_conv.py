@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Micro-benchmark of keep_conv2d on the hot layer shapes (through the C-ABI), for rocprofv3 / PMC runs.
+   python tools/bench_conv.py [layer ...]   layers: c64_512 c128_256 up128_512 c256_64 c512_16 lin128"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+load_package()
+from comfyui_keep_amd.engine import hiplib as L  # noqa: E402
+from comfyui_keep_amd.engine import ops  # noqa: E402
+
+LAYERS = {  # name: (N, H, W, Cin, Cout, ksize, upsample)
+    'c64_512': (4, 512, 512, 64, 64, 3, False),
+    'c128_256': (4, 256, 256, 128, 128, 3, False),
+    'up128_512': (4, 256, 256, 128, 128, 3, True),
+    'c256_64': (4, 64, 64, 256, 256, 3, False),
+    'c512_16': (4, 16, 16, 512, 512, 3, False),
+    'lin128': (1, 622592, 1, 128, 128, 1, False),
+}
+
+
+def run(name, mma, in_bf16, iters=20):
+    N, H, W, Cin, Cout, k, up = LAYERS[name]
+    x = torch.randn(N, H, W, Cin, device='cuda')
+    w = torch.randn(Cout, k, k, Cin, device='cuda') * 0.05
+    b = torch.randn(Cout, device='cuda')
+    wb = w.to(torch.bfloat16)
+    pro = None
+    if in_bf16:
+        pro = (torch.ones(N, Cin, device='cuda'), torch.zeros(N, Cin, device='cuda'))
+    kw = dict(pad=k // 2, ksize=k, upsample=up, mma=mma, wb=wb, stats=True)
+    if pro is not None:
+        kw.update(pro=pro, pro_act=L.PRO_SWISH)
+    for _ in range(3):
+        y = ops.conv(x, w, b, **kw)
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    for _ in range(iters):
+        y = ops.conv(x, w, b, **kw)
+    torch.cuda.synchronize()
+    rec, ops.PROFILE = ops.PROFILE, None
+    ms = sum(e0.elapsed_time(e1) for *_, e0, e1 in rec) / len(rec)
+    fl = rec[0][1]
+    print(f"{name:10s} mma={'bf16' if mma else 'f32 '} pre-activated-bf16-input={in_bf16!s:5s} kernel={rec[0][0]:22s} "
+          f"{ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s (incl. the norm_act pass when present)")
+    return y
+
+
+if __name__ == '__main__':
+    names = sys.argv[1:] or list(LAYERS)
+    for n in names:
+        run(n, L.MMA_BF16, False)
+        if LAYERS[n][5] == 3:
+            run(n, L.MMA_BF16, True)

@@ -20,6 +20,9 @@ struct AttnP {
   const float* q;
   const float* k;
   const float* v;
+  const unsigned short* q16;  // bf16 inputs (attn_bf16in_kernel)
+  const unsigned short* k16;
+  const unsigned short* v16;
   float* o;
   long q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, o_bs, o_ts, o_hs;
   int B, H, Lq, Lk, D, Dv;
@@ -519,6 +522,285 @@ static int launch_attn_bf16(const AttnP& p, hipStream_t st) {
   return KEEP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ bf16-input variant
+// Q, K, V already live in HBM as bf16 (the projection GEMMs write bf16, halving the K/V traffic that every q-tile
+// block re-reads).  128 queries per block (4 waves), 64 keys per iteration (two 32x32 score tiles per wave) so each
+// barrier pair covers twice the MFMA work, token offsets / window region ids are computed once per tile into LDS
+// tables instead of per element, and with a single D chunk the next tile's K and V pieces are prefetched into
+// registers while the current tile is on the matrix cores.  V^T is staged key-permuted exactly like attn_bf16_kernel.
+template <int DVT>
+__global__ __launch_bounds__(256) void attn_bf16in_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int DVS = DVT * 32;
+  constexpr int NT = 256, KT = 64;
+  constexpr int VP = KT + 8;             // V^T row pitch (bf16): 144 B = 9 slots
+  constexpr int KPF = 4;                 // prefetched 16-byte K pieces per thread (64 rows x 16 groups / 256)
+  constexpr int VPF = (DVS / 8 + 3) / 4; // prefetched 16-byte V pieces per thread (lane = key, 4 waves share dv groups)
+  const int DC = p.D < 128 ? p.D : 128;
+  const int nch = p.D / DC;
+  const int QP = DC + 8;
+  const int g8n = DC >> 3;
+  long* qoff = reinterpret_cast<long*>(smem_raw);            // [128]
+  long* koff = qoff + 128;                                   // [64]
+  long* voff = koff + KT;                                    // [64]
+  int* kreg_tab = reinterpret_cast<int*>(voff + KT);         // [64] window region ids (mode 2, shift > 0)
+  __bf16* Qs = reinterpret_cast<__bf16*>(kreg_tab + KT);     // [128][QP]
+  __bf16* Ks = Qs + 128 * QP;                                // [64][QP]
+  __bf16* Vt = Ks + KT * QP;                                 // [DVS][VP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int b = blockIdx.z;
+  const int head = blockIdx.y / p.nslices;
+  const int dv0 = (blockIdx.y - head * p.nslices) * DVS;
+  const int q0 = blockIdx.x * 128;
+  const long qh = (long)head * p.q_hs, kh = (long)head * p.k_hs, vh = (long)head * p.v_hs;
+  const bool use_mask = (p.mode == 2 && p.shift > 0);
+
+  if (tid < 128) {
+    const int t = q0 + tid;
+    qoff[tid] = (t < p.Lq) ? q_offset(p, b, t, p.q_bs, p.q_ts) + qh : -1;
+  }
+  auto fill_tables = [&](int kt) {
+    if (tid < KT) {
+      const int t = kt * KT + tid;
+      const bool ok = t < p.Lk;
+      koff[tid] = ok ? kv_offset(p, b, t, p.k_bs, p.k_ts) + kh : -1;
+      voff[tid] = ok ? kv_offset(p, b, t, p.v_bs, p.v_ts) + vh : -1;
+      kreg_tab[tid] = (ok && use_mask) ? win_region(p, b, t) : 0;
+    }
+  };
+  auto stage_q = [&](int ch) {
+    for (int i = tid; i < 128 * g8n; i += NT) {
+      const int row = i / g8n, c = (i - row * g8n) << 3;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (qoff[row] >= 0) v = *reinterpret_cast<const uint4*>(p.q16 + qoff[row] + ch * DC + c);
+      *reinterpret_cast<uint4*>(Qs + row * QP + c) = v;
+    }
+  };
+  uint4 kpf[KPF], vpf[VPF];
+  auto k_issue = [&](int ch) {
+#pragma unroll
+    for (int u = 0; u < KPF; ++u) {
+      const int i = tid + u * NT;
+      kpf[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < KT * g8n) {
+        const int row = i / g8n, c = (i - row * g8n) << 3;
+        if (koff[row] >= 0) kpf[u] = *reinterpret_cast<const uint4*>(p.k16 + koff[row] + ch * DC + c);
+      }
+    }
+  };
+  auto k_commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < KPF; ++u) {
+      const int i = tid + u * NT;
+      if (i < KT * g8n) {
+        const int row = i / g8n, c = (i - row * g8n) << 3;
+        *reinterpret_cast<uint4*>(Ks + row * QP + c) = kpf[u];
+      }
+    }
+  };
+  auto v_issue = [&]() {    // lane <-> key, waves share the 8-column dv groups
+#pragma unroll
+    for (int u = 0; u < VPF; ++u) {
+      const int dg = wave + u * 4;
+      vpf[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (dg * 8 < DVS && dv0 + dg * 8 < p.Dv && voff[lane] >= 0)
+        vpf[u] = *reinterpret_cast<const uint4*>(p.v16 + voff[lane] + dv0 + dg * 8);
+    }
+  };
+  auto v_commit = [&]() {
+    const int pos = (lane >> 5) * 32 + vt_pos(lane & 31);
+#pragma unroll
+    for (int u = 0; u < VPF; ++u) {
+      const int dg = wave + u * 4;
+      if (dg * 8 < DVS) {
+        const unsigned w[4] = {vpf[u].x, vpf[u].y, vpf[u].z, vpf[u].w};
+        unsigned short* dst = reinterpret_cast<unsigned short*>(Vt) + (dg * 8) * VP + pos;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j * VP] = (unsigned short)(w[j >> 1] >> ((j & 1) * 16));
+      }
+    }
+  };
+
+  const int my_q = q0 + wave * 32 + l31;
+  int my_region = 0;
+  if (use_mask && my_q < p.Lq) my_region = win_region(p, b, my_q);
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 o[DVT];
+#pragma unroll
+  for (int j = 0; j < DVT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+
+  const __bf16* kp = Ks + l31 * QP + lhi * 8;
+  const __bf16* qp = Qs + (wave * 32 + l31) * QP + lhi * 8;
+  const int ntiles = (p.Lk + KT - 1) / KT;
+  const bool prefetch = (nch == 1);
+
+  fill_tables(0);
+  __syncthreads();                       // qoff + tables of tile 0 visible
+  if (prefetch) {
+    stage_q(0);
+    k_issue(0);
+    v_issue();
+    k_commit();
+    v_commit();
+  }
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    f32x16 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+    int kreg_l[2][16];
+    if (prefetch) {
+      __syncthreads();                   // LDS image of tile kt complete (K, V^T, region table); tables free to refill
+      if (use_mask) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) kreg_l[t][r] = kreg_tab[t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+      }
+      __syncthreads();                   // everyone has read the region table of tile kt
+      if (kt + 1 < ntiles) {
+        fill_tables(kt + 1);
+      }
+      for (int d = 0; d < DC; d += 16) {
+        const abf16x8 qf = *reinterpret_cast<const abf16x8*>(qp + d);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(kp + t * 32 * QP + d), qf,
+                                                         s[t], 0, 0, 0);
+      }
+      if (kt + 1 < ntiles) {
+        __syncthreads();                 // tables of tile kt+1 visible
+        k_issue(0);                      // next tile's loads fly during softmax + PV
+        v_issue();
+      }
+    } else {
+      for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();
+        if (ch == 0 && kt > 0) fill_tables(kt);
+        if (ch == 0) __syncthreads();
+        stage_q(ch);
+        k_issue(ch);
+        if (ch == 0) v_issue();
+        k_commit();
+        if (ch == 0) v_commit();
+        __syncthreads();
+        if (ch == 0 && use_mask) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) kreg_l[t][r] = kreg_tab[t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+        }
+        for (int d = 0; d < DC; d += 16) {
+          const abf16x8 qf = *reinterpret_cast<const abf16x8*>(qp + d);
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(kp + t * 32 * QP + d),
+                                                           qf, s[t], 0, 0, 0);
+        }
+      }
+    }
+
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * KT + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        float val = s[t][r] * p.scale;
+        if (use_mask && kreg_l[t][r] != my_region) val += -100.0f;
+        if (key >= p.Lk) val = -INFINITY;
+        s[t][r] = val;
+        mloc = fmaxf(mloc, val);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __expf(m_run - m_new);
+    float lsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __expf(s[t][r] - m_new);
+        s[t][r] = pv;
+        lsum += pv;
+      }
+    lsum += __shfl_xor(lsum, 32);
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const float ar = __shfl(alpha, qrow);
+#pragma unroll
+      for (int j = 0; j < DVT; ++j) o[j][r] *= ar;
+    }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      abf16x8 pa;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pa[j] = (__bf16)s[st >> 1][(st & 1) * 8 + j];
+#pragma unroll
+      for (int j = 0; j < DVT; ++j) {
+        const abf16x8 vb =
+            *reinterpret_cast<const abf16x8*>(Vt + (j * 32 + l31) * VP + (st >> 1) * 32 + ((st & 1) * 2 + lhi) * 8);
+        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vb, o[j], 0, 0, 0);
+      }
+    }
+    if (prefetch && kt + 1 < ntiles) {
+      __syncthreads();                   // every wave is done reading K / V^T of tile kt
+      k_commit();
+      v_commit();
+    }
+  }
+
+  const float inv_l = 1.0f / l_run;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    const float il = __shfl(inv_l, qrow);
+    const int t = q0 + wave * 32 + qrow;
+    if (t < p.Lq) {
+      const long base = q_offset(p, b, t, p.o_bs, p.o_ts) + (long)head * p.o_hs;
+#pragma unroll
+      for (int j = 0; j < DVT; ++j) {
+        const int dv = dv0 + j * 32 + l31;
+        if (dv < p.Dv) p.o[base + dv] = o[j][r] * il;
+      }
+    }
+  }
+}
+
+template <int DVT>
+static int launch_attn_bf16in(const AttnP& p, hipStream_t st) {
+  const int DC = p.D < 128 ? p.D : 128;
+  const size_t lds = (128 + 64 + 64) * sizeof(long) + 64 * sizeof(int) +
+                     (size_t)((128 + 64) * (DC + 8) + DVT * 32 * 72) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bf16in_kernel<DVT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) {
+      keep_set_error("keep_attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return KEEP_EHIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid(cdiv(p.Lq, 128), p.H * p.nslices, p.B);
+  hipLaunchKernelGGL((attn_bf16in_kernel<DVT>), grid, dim3(256), lds, st, p);
+  KEEP_LAUNCH_CHECK("keep_attention(bf16 inputs)");
+  return KEEP_OK;
+}
+
 extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
   KEEP_REQUIRE(a != nullptr, "keep_attention: null args");
   KEEP_REQUIRE(a->q && a->k && a->v && a->o, "keep_attention: null tensor pointer");
@@ -538,7 +820,8 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
     KEEP_REQUIRE(a->kv_rot >= 0 && a->kv_rot < a->n_img, "keep_attention: bad kv_rot");
   }
   AttnP p;
-  p.q = a->q; p.k = a->k; p.v = a->v; p.o = a->o;
+  p.q = (const float*)a->q; p.k = (const float*)a->k; p.v = (const float*)a->v; p.o = a->o;
+  p.q16 = (const unsigned short*)a->q; p.k16 = (const unsigned short*)a->k; p.v16 = (const unsigned short*)a->v;
   p.q_bs = a->q_bs; p.q_ts = a->q_ts; p.q_hs = a->q_hs;
   p.k_bs = a->k_bs; p.k_ts = a->k_ts; p.k_hs = a->k_hs;
   p.v_bs = a->v_bs; p.v_ts = a->v_ts; p.v_hs = a->v_hs;
@@ -551,6 +834,16 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
   // dv slice per block: 32 / 64 / 128 columns
   const int dvt = a->Dv <= 32 ? 1 : (a->Dv <= 64 ? 2 : 4);
   p.nslices = cdiv(a->Dv, dvt * 32);
+  if (a->in_dtype == KEEP_BF16) {
+    const bool ok = a->mma == KEEP_MMA_BF16 && (a->D % 16 == 0) && (a->Dv % 8 == 0) && (a->q_ts % 8 == 0) &&
+                    (a->q_bs % 8 == 0) && (a->q_hs % 8 == 0) && (a->k_ts % 8 == 0) && (a->k_bs % 8 == 0) &&
+                    (a->k_hs % 8 == 0) && (a->v_ts % 8 == 0) && (a->v_bs % 8 == 0) && (a->v_hs % 8 == 0) &&
+                    ((uintptr_t)a->q % 16 == 0) && ((uintptr_t)a->k % 16 == 0) && ((uintptr_t)a->v % 16 == 0);
+    KEEP_REQUIRE(ok, "keep_attention: bf16 inputs need KEEP_MMA_BF16, D %% 16 == 0, Dv %% 8 == 0 and 16-byte aligned rows");
+    if (dvt == 1) return launch_attn_bf16in<1>(p, st);
+    if (dvt == 2) return launch_attn_bf16in<2>(p, st);
+    return launch_attn_bf16in<4>(p, st);
+  }
   if (a->mma == KEEP_MMA_BF16) {
     // bf16 operands: needs 16-byte-aligned fp32 rows and D a multiple of 16
     const bool ok = (a->D % 16 == 0) && (a->q_ts % 4 == 0) && (a->q_bs % 4 == 0) && (a->q_hs % 4 == 0) &&

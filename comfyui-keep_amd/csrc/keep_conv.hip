@@ -41,6 +41,7 @@ struct ConvP {
   int fast;     // bf16 policy: fast-math epilogue activations
   float* stats; // optional [N][P][Cout][2] per-tile (sum, sumsq) of the epilogue output, P = stats_P tiles per image
   int stats_P;
+  int out_bf16; // write the output tensor as bf16 (gather kernels' staged epilogue only)
   int vec_epi;  // Cout/out_ld/res_ld %% 4 == 0 and aligned pointers -> LDS-staged float4 epilogue
   int exp;      // dev-only ablation switch (KEEP_HALO_EXP), 0 in production
   int flatk;    // Cin < 8: K = KH*KW*Cin flattened (element-wise gather) instead of tap-major chunks
@@ -150,7 +151,15 @@ __device__ __forceinline__ void staged_epilogue(const ConvP& p, f32x16 (&acc)[TM
         for (int q = 0; q < 4; ++q) e[q] += rr[q];
       }
     }
-    *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
+    if (p.out_bf16) {
+      typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+      bf16x4_t h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h[q] = (__bf16)e[q];
+      *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(p.out) + m * p.out_ld + co) = h;
+    } else {
+      *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       s4[q] += e[q];
@@ -1043,6 +1052,7 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
   dim3 block(256);
   p.in_bf16 = (a->dtype == KEEP_BF16) ? 1 : 0;
   p.fast = (a->mma == KEEP_MMA_BF16) ? 1 : 0;
+  p.out_bf16 = (a->out_dtype == KEEP_BF16) ? 1 : 0;
   p.vec_epi = (a->Cout % 4 == 0 && a->out_ld % 4 == 0 && (uintptr_t)a->out % 16 == 0 &&
                (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&
                (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0) &&
@@ -1059,7 +1069,7 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
                        a->pad_l == 1 && (a->Cin % 32 == 0) && (a->Cout % 64 == 0) && (a->Ho % HALO_TH == 0) &&
                        (a->Wo % HALO_TW == 0) && a->Ho == (a->upsample ? 2 * a->H : a->H) &&
                        a->Wo == (a->upsample ? 2 * a->W : a->W) && !a->pro_scale && a->pro_act == KEEP_PRO_NONE &&
-                       (a->in_ld % 8 == 0) && ((uintptr_t)a->in % 16 == 0) && (a->out_ld % 4 == 0) &&
+                       (a->out_dtype != KEEP_BF16) && (a->in_ld % 8 == 0) && ((uintptr_t)a->in % 16 == 0) && (a->out_ld % 4 == 0) &&
                        ((uintptr_t)a->out % 16 == 0) && (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&
                        (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0);
   if (p.in_bf16 && !halo_ok) {
@@ -1071,6 +1081,10 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
     const long hw_o = (long)a->Ho * a->Wo;
     const int bm = halo_ok ? 256 : ((a->Cout <= 32) ? 128 : ((a->Cout <= 64 || M <= 4096) ? 64 : 128));
     KEEP_REQUIRE(hw_o % bm == 0 && a->stats_P == hw_o / bm, "keep_conv2d: stats_P=%d must equal Ho*Wo/%d", a->stats_P, bm);
+  }
+  if (p.out_bf16) {
+    KEEP_REQUIRE(p.vec_epi && p.split_k == 1 && !a->residual,
+                 "keep_conv2d: bf16 output needs Cout/out_ld %% 4 == 0, aligned pointers, split_k == 1, no residual");
   }
   if (halo_ok) {
     const int nchunks = a->Cin / 32;

@@ -150,7 +150,7 @@ class KeepNet:
         N, H, Wd, C = x.shape
         HW = H * Wd
         qkv = ops.linear(x.view(N * HW, C), w[f'{p}.qkv.weight'], w[f'{p}.qkv.bias'], pro=self._gn(x, f'{p}.norm'),
-                         n_img=N)
+                         n_img=N, out_bf16=True)
         o = ops.empty((N * HW, C), x)
         s3 = (HW * 3 * C, 3 * C, 0)
         ops.attention(qkv, ops.offset(qkv, C), ops.offset(qkv, 2 * C), o, B=N, H=1, Lq=HW, Lk=HW, D=C, Dv=C,
@@ -198,8 +198,8 @@ class KeepNet:
             p = f'ft_layers.{i}'
             x2, qk_in = ops.layernorm(q, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], pos=pos)
             wi, bi = w[f'{p}.self_attn.in_proj_weight'], w[f'{p}.self_attn.in_proj_bias']
-            qk = ops.linear(qk_in, wi[:2 * D], bi[:2 * D])
-            v = ops.linear(x2, wi[2 * D:], bi[2 * D:])
+            qk = ops.linear(qk_in, wi[:2 * D], bi[:2 * D], out_bf16=True)
+            v = ops.linear(x2, wi[2 * D:], bi[2 * D:], out_bf16=True)
             o = ops.empty((B * Ltok, D), q)
             ops.attention(qk, ops.offset(qk, D), v, o, B=B, H=nh, Lq=Ltok, Lk=Ltok, D=dh, Dv=dh, scale=dh ** -0.5,
                           q_str=(Ltok * 2 * D, 2 * D, dh), k_str=(Ltok * 2 * D, 2 * D, dh),
@@ -238,8 +238,8 @@ class KeepNet:
         nh, dh = cfg['cfa_nhead'], cfg['cfa_dim']
         inner = nh * dh
         c = curr.view(B * Ltok, C)
-        q = ops.linear(c, w[f'{p}.attn.to_q.weight'])
-        kv = ops.linear(prev.view(B * Ltok, C), w[f'{p}.attn.to_kv.weight'])
+        q = ops.linear(c, w[f'{p}.attn.to_q.weight'], out_bf16=True)
+        kv = ops.linear(prev.view(B * Ltok, C), w[f'{p}.attn.to_kv.weight'], out_bf16=True)
         o = ops.empty((B * Ltok, inner), curr)
         ops.attention(q, kv, ops.offset(kv, inner), o, B=B, H=nh, Lq=Ltok, Lk=Ltok, D=dh, Dv=dh, scale=dh ** -0.5,
                       q_str=(Ltok * inner, inner, dh), k_str=(Ltok * 2 * inner, 2 * inner, dh),
@@ -264,7 +264,7 @@ class KeepNet:
             p = f'kalman_filter.uncertainty_estimator.{i}'
             # sparse-causal spatial attention (KA:686-748): keys = [frame 0 ; frame f-1]
             x1 = ops.layernorm(h, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'])
-            qkv = ops.linear(x1, w[f'{p}.attn1.to_qkv.weight'])
+            qkv = ops.linear(x1, w[f'{p}.attn1.to_qkv.weight'], out_bf16=True)
             o = ops.empty((BT * Ltok, inner), h)
             s3 = (Ltok * 3 * inner, 3 * inner, dh)
             ops.attention(qkv, ops.offset(qkv, inner), ops.offset(qkv, 2 * inner), o, B=BT, H=nh, Lq=Ltok,
@@ -277,7 +277,7 @@ class KeepNet:
             h = ops.linear(f, w[f'{p}.ff.net.2.weight'], w[f'{p}.ff.net.2.bias'], residual=h)
             # temporal attention over the T frames of each spatial token (KA:671-680): strided, no rearrange
             xt = ops.layernorm(h, w[f'{p}.norm_temp.weight'], w[f'{p}.norm_temp.bias'])
-            qkv = ops.linear(xt, w[f'{p}.attn_temp.to_qkv.weight'])
+            qkv = ops.linear(xt, w[f'{p}.attn_temp.to_qkv.weight'], out_bf16=True)
             o = ops.empty((BT * Ltok, inner), h)
             for b in range(B):
                 qb = ops.offset(qkv, b * T * Ltok * 3 * inner)
@@ -348,12 +348,12 @@ class KeepNet:
         wqkv = w[f'{p}.qkv.weight']
         o = torch.empty_like(src)
         if tgt is src:
-            qkv = ops.linear(src, wqkv)
+            qkv = ops.linear(src, wqkv, out_bf16=True)
             q, k, v = qkv, ops.offset(qkv, C), ops.offset(qkv, 2 * C)
             sq = skv = (Ltok * 3 * C, 3 * C, 0)
         else:
-            q = ops.linear(src, wqkv[:C])
-            kv = ops.linear(tgt, wqkv[C:])
+            q = ops.linear(src, wqkv[:C], out_bf16=True)
+            kv = ops.linear(tgt, wqkv[C:], out_bf16=True)
             k, v = kv, ops.offset(kv, C)
             sq, skv = (Ltok * C, C, 0), (Ltok * 2 * C, 2 * C, 0)
         ops.attention(q, k, v, o, B=n_img * 4, H=1, Lq=Ltok // 4, Lk=Ltok // 4, D=C, Dv=C, scale=1.0 / (C ** 0.5),

@@ -78,7 +78,7 @@ def pick_split_k(M, Cout, nsteps, bf16=False):
 
 def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=False, pro=None, pro_act=L.PRO_NONE,
          act=L.ACT_NONE, residual=None, aux=None, aux_w=1.0, cin=None, in_off=0, out=None, split_k=None, wb=None,
-         mma=None, stats=False):
+         mma=None, stats=False, out_bf16=False):
     """x [N,H,W,ld] -> [N,Ho,Wo,Cout].  ``w`` packed [Cout,KH,KW,Cin].  ``cin``/``in_off`` select a channel
     slice of a wider input buffer.  ``down`` = VQGAN Downsample geometry (pad right/bottom only, stride 2)."""
     N, H, W, ld = x.shape
@@ -94,14 +94,15 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
         pad_t = pad_l = pad
         Ho = (Hv + 2 * pad - KH) // stride + 1
         Wo = (Wv + 2 * pad - KW) // stride + 1
-    if out is None:
-        out = empty((N, Ho, Wo, Cout), x)
     M = N * Ho * Wo
     mma = MMA if mma is None else mma
+    out_bf16 = bool(out_bf16) and mma == L.MMA_BF16 and Cout % 4 == 0 and residual is None
+    if out is None:
+        out = torch.empty((N, Ho, Wo, Cout), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     if mma == L.MMA_BF16 and wb is None:
         wb = bf16_twin(w)
     in_dtype = L.F32
-    halo = (mma == L.MMA_BF16 and ksize == 3 and stride == 1 and not down and pad == 1 and Cin % 32 == 0
+    halo = (mma == L.MMA_BF16 and not out_bf16 and ksize == 3 and stride == 1 and not down and pad == 1 and Cin % 32 == 0
             and Cout % 64 == 0 and Ho % 8 == 0 and Wo % 32 == 0 and ld % 8 == 0 and in_off % 8 == 0)
     if halo and (pro is not None or pro_act != L.PRO_NONE):
         # 3x3 halo path: normalise + activate once per element into a bf16 tensor (instead of 9x inside the gather)
@@ -112,7 +113,9 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
         x, pro, pro_act, in_dtype = x16, None, L.PRO_NONE, L.BF16
     nsteps = KH * KW * math.ceil(Cin / (64 if mma == L.MMA_BF16 else 16))
     if split_k is None:
-        if halo:     # 8x32-pixel x 64-channel tiles; split over the 32-channel Cin chunks
+        if out_bf16:
+            split_k = 1
+        elif halo:     # 8x32-pixel x 64-channel tiles; split over the 32-channel Cin chunks
             waves = (M // 256) * (Cout // 64) * 4
             split_k = 1 if waves >= _TARGET_WAVES else max(1, min(_TARGET_WAVES // waves, Cin // 64, 16))
         else:
@@ -137,7 +140,8 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
              N=N, H=H, W=W, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=stride, pad_t=pad_t, pad_l=pad_l, Ho=Ho, Wo=Wo,
              in_ld=ld, out_ld=out.shape[-1], res_ld=0 if residual is None else residual.shape[-1],
              upsample=int(upsample), pro_act=pro_act, epi_act=act, aux_w=float(aux_w), split_k=split_k, dtype=in_dtype,
-             mma=mma, weight_bf16=wb if mma == L.MMA_BF16 else None, stats_out=part, stats_P=stats_P)
+             mma=mma, weight_bf16=wb if mma == L.MMA_BF16 else None, stats_out=part, stats_P=stats_P,
+             out_dtype=L.BF16 if out_bf16 else L.F32)
     if part is not None:
         out._keep_stats = (part, stats_P)
     if PROFILE is not None:
@@ -146,7 +150,7 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
 
 
 def linear(x, w, bias=None, *, act=L.ACT_NONE, residual=None, pro=None, pro_act=L.PRO_NONE, cin=None, in_off=0,
-           n_img=1):
+           n_img=1, out_bf16=False):
     """x [M,ld] (or any [...,ld]) @ w[Cout,Cin]^T.  ``n_img``>1 makes the prologue per-image: rows are n_img
     images of M/n_img pixels each (1x1 conv on a feature map)."""
     shp = x.shape
@@ -155,7 +159,7 @@ def linear(x, w, bias=None, *, act=L.ACT_NONE, residual=None, pro=None, pro_act=
     x4 = x.reshape(n_img, M // n_img, 1, ld)
     res4 = None if residual is None else residual.reshape(n_img, M // n_img, 1, residual.shape[-1])
     y = conv(x4, w, bias, stride=1, pad=0, ksize=1, pro=pro, pro_act=pro_act, act=act, residual=res4, cin=cin,
-             in_off=in_off)
+             in_off=in_off, out_bf16=out_bf16)
     return y.reshape(*shp[:-1], w.shape[0])
 
 
@@ -205,13 +209,17 @@ def attention(q, k, v, o, *, B, H, Lq, Lk, D, Dv, scale, q_str, k_str, v_str, o_
               img_h=0, img_w=0, ksplit=0, shift=0, kv_rot=0, n_img=0, mma=None):
     """Strides are (batch, token, head) element strides."""
     mma = ATTN_MMA if mma is None else mma
-    if mma == L.MMA_BF16 and (D % 16 or any(v % 4 for v in (*q_str, *k_str))):
+    in_dtype = L.F32
+    if q.dtype == torch.bfloat16:
+        assert k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16
+        in_dtype, mma = L.BF16, L.MMA_BF16
+    elif mma == L.MMA_BF16 and (D % 16 or any(v % 4 for v in (*q_str, *k_str))):
         mma = L.MMA_F32
     L.attention(q=q, k=k, v=v, o=o,
                 q_bs=q_str[0], q_ts=q_str[1], q_hs=q_str[2], k_bs=k_str[0], k_ts=k_str[1], k_hs=k_str[2],
                 v_bs=v_str[0], v_ts=v_str[1], v_hs=v_str[2], o_bs=o_str[0], o_ts=o_str[1], o_hs=o_str[2],
                 B=B, H=H, Lq=Lq, Lk=Lk, D=D, Dv=Dv, scale=float(scale), mode=mode, T=T, seg_len=seg_len,
-                img_h=img_h, img_w=img_w, ksplit=ksplit, shift=shift, kv_rot=kv_rot, n_img=n_img, mma=mma)
+                img_h=img_h, img_w=img_w, ksplit=ksplit, shift=shift, kv_rot=kv_rot, n_img=n_img, mma=mma, in_dtype=in_dtype)
     return o
 
 

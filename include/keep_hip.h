@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KEEP_ABI_VERSION 4
+#define KEEP_ABI_VERSION 5
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -100,6 +100,8 @@ typedef struct {
    * the 3x3 halo path, else 128, or 64 when Cout <= 64 or N*Ho*Wo <= 4096). */
   float* stats_out;
   int32_t stats_P;
+  int32_t out_dtype; /* KEEP_F32, or KEEP_BF16: `out` is a bf16 tensor (projections feeding keep_attention; needs
+                        Cout/out_ld %% 4 == 0, split_k == 1, no residual) */
 } keep_conv2d_args;
 int32_t keep_conv2d(const keep_conv2d_args* a, void* stream);
 
@@ -119,9 +121,9 @@ int32_t keep_conv2d(const keep_conv2d_args* a, void* stream);
  *           from image (image + kv_rot) % n_img  (the [f0;f1] vs [f1;f0] pairing, GM/transformer.py:301-314).
  */
 typedef struct {
-  const float* q;
-  const float* k;
-  const float* v;
+  const void* q;
+  const void* k;
+  const void* v;
   float* o;
   int64_t q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, o_bs, o_ts, o_hs;
   int32_t B, H, Lq, Lk, D, Dv;
@@ -130,6 +132,7 @@ typedef struct {
   int32_t T, seg_len;                           /* mode 1 */
   int32_t img_h, img_w, ksplit, shift, kv_rot, n_img; /* mode 2 */
   int32_t mma; /* KEEP_MMA_F32 | KEEP_MMA_BF16 (Q,K,V,P rounded to bf16; fp32 softmax + accumulate) */
+  int32_t in_dtype; /* KEEP_F32, or KEEP_BF16 (with KEEP_MMA_BF16): q, k, v are bf16 tensors, strides in elements */
 } keep_attention_args;
 int32_t keep_attention(const keep_attention_args* a, void* stream);
 

@@ -486,3 +486,57 @@ def test_conv_bf16_flat_k_small_cin():
     wp = pack(w)
     y = ops.conv(dev(nhwc(x)), wp, dev(b), mma=L.MMA_BF16, wb=wp.to(torch.bfloat16), stats=True)
     check(nchw(y), F.conv2d(bf16r(x), bf16r(w), b, padding=1), 2e-5, 'flat-K 3x3')
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,D,Dv", [(2, 8, 256, 256, 64, 64), (1, 1, 256, 256, 512, 512), (2, 4, 200, 200, 256, 256),
+                                            (3, 8, 50, 77, 48, 48), (2, 1, 1024, 1024, 128, 128), (4, 8, 20, 20, 48, 48)])
+def test_attention_bf16_inputs(B, H, Lq, Lk, D, Dv):
+    """q/k/v stored as bf16 (projection GEMMs write bf16): 64-key tiles, table-driven offsets, register prefetch."""
+    q, k, v = rnd('aq', (B, Lq, H, D)), rnd('ak', (B, Lk, H, D)), rnd('av', (B, Lk, H, Dv))
+    scale = D ** -0.5 * 3.0
+    o = torch.empty(B, Lq, H, Dv, device='cuda')
+    qb, kb, vb = (dev(t).to(torch.bfloat16) for t in (q, k, v))
+    ops.attention(qb, kb, vb, o, B=B, H=H, Lq=Lq, Lk=Lk, D=D, Dv=Dv, scale=scale,
+                  q_str=(Lq * H * D, H * D, D), k_str=(Lk * H * D, H * D, D), v_str=(Lk * H * Dv, H * Dv, Dv),
+                  o_str=(Lq * H * Dv, H * Dv, Dv))
+    ref = ref_attn(bf16r(q).permute(0, 2, 1, 3), bf16r(k).permute(0, 2, 1, 3), bf16r(v).permute(0, 2, 1, 3), scale)
+    check(o, ref.permute(0, 2, 1, 3), 6e-3, what=f'bf16-in attn {B, H, Lq, Lk, D, Dv}')
+
+
+def test_attention_bf16_inputs_window_sparse_and_linear_bf16_out():
+    P, h8, w8, C = 2, 16, 16, 128
+    n_img, Lt = 2 * P, h8 * w8
+    x = rnd('wx', (n_img * Lt, C))
+    wqkv = rnd('wqkv', (3 * C, C), 0.1)
+    qkv16 = ops.conv(dev(x).view(1, n_img * Lt, 1, C), dev(wqkv).view(3 * C, 1, 1, C), None, pad=0, ksize=1,
+                     mma=L.MMA_BF16, wb=dev(wqkv).to(torch.bfloat16), out_bf16=True).view(n_img * Lt, 3 * C)
+    assert qkv16.dtype == torch.bfloat16
+    check(qkv16.float(), F.linear(bf16r(x), bf16r(wqkv)), 8e-3, 'linear bf16 out')
+    o = torch.empty(n_img * Lt, C, device='cuda')
+    s3 = (Lt * 3 * C, 3 * C, 0)
+    ops.attention(qkv16, ops.offset(qkv16, C), ops.offset(qkv16, 2 * C), o, B=n_img * 4, H=1, Lq=Lt // 4, Lk=Lt // 4, D=C,
+                  Dv=C, scale=1 / C ** 0.5, q_str=s3, k_str=s3, v_str=s3, o_str=(Lt * C, C, 0), mode=2, img_h=h8, img_w=w8,
+                  ksplit=2, shift=4, kv_rot=P, n_img=n_img)
+    q, k, v = qkv16.float().cpu().view(n_img, Lt, 3 * C).chunk(3, dim=-1)
+    mask = O.shift_window_mask(h8, w8, h8 // 2, w8 // 2, h8 // 4, w8 // 4)
+    kr, vr = torch.cat([k[P:], k[:P]]), torch.cat([v[P:], v[:P]])
+    check(o.view(n_img, Lt, C), O._window_attention(q.contiguous(), kr, vr, 2, True, h8, w8, mask), 6e-3, 'bf16-in swin')
+    Bc, T, Lt2, H, D = 2, 3, 64, 8, 48
+    inner = H * D
+    qkv = rnd('sq', (Bc * T, Lt2, 3 * inner))
+    qd = dev(qkv).to(torch.bfloat16)
+    o = torch.empty(Bc * T, Lt2, inner, device='cuda')
+    s3 = (Lt2 * 3 * inner, 3 * inner, D)
+    ops.attention(qd, ops.offset(qd, inner), ops.offset(qd, 2 * inner), o, B=Bc * T, H=H, Lq=Lt2, Lk=2 * Lt2, D=D, Dv=D,
+                  scale=D ** -0.5, q_str=s3, k_str=s3, v_str=s3, o_str=(Lt2 * inner, inner, D), mode=1, T=T, seg_len=Lt2)
+    qq, kk, vv = bf16r(qkv).chunk(3, dim=-1)
+    former = torch.arange(T) - 1
+    former[0] = 0
+
+    def gather(t):
+        t = t.reshape(Bc, T, Lt2, inner)
+        return torch.cat([t[:, [0] * T], t[:, former]], dim=2).reshape(Bc * T, 2 * Lt2, inner)
+
+    hs = lambda t: t.reshape(t.shape[0], t.shape[1], H, D).permute(0, 2, 1, 3)  # noqa: E731
+    ref = ref_attn(hs(qq), hs(gather(kk)), hs(gather(vv)), D ** -0.5).permute(0, 2, 1, 3).reshape(Bc * T, Lt2, inner)
+    check(o, ref, 6e-3, 'bf16-in sparse causal')

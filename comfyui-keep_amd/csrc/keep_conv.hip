@@ -13,6 +13,8 @@
 // over the (tap, Cin-chunk) steps into a caller workspace + a reduce/epilogue kernel.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "keep_common.h"
 
 #define BK 16
@@ -446,8 +448,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
 // fragment (8 consecutive k per lane) is one ds_read_b128, conflict-free within each 16-lane service group, and the
 // staging ds_write_b128 of 8 lanes covers 8 distinct slots.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-#define BK16 64
-#define PITCH16 72  // bf16 elements per LDS row (144 B)
+#define BK16 64     // default K step; small-M / deep-K layers use BKT = 256 (see conv_bf16_kernel)
 
 __device__ __forceinline__ float pro_apply_fast(float v, int act) {
   if (act == KEEP_PRO_SWISH) return v * __frcp_rn(1.0f + __expf(-v));
@@ -455,20 +456,28 @@ __device__ __forceinline__ float pro_apply_fast(float v, int act) {
   return v;
 }
 
-template <int WGM, int WGN, int TM, int TN>
+// BKT = K step (channels of one tap per barrier pair).  64 with two LDS buffers is the default; layers with few
+// output tiles and a deep K (16x16 / 32x32 maps, token GEMMs) are latency-bound -- one global round trip per step with
+// only a handful of MFMAs to hide it -- so they run BKT = 256 with a single LDS buffer: 4x the bytes in flight per
+// round trip and 4x fewer barriers for the same registers a 4-deep prefetch ring would need.
+template <int WGM, int WGN, int TM, int TN, int BKT, int NS>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
   constexpr int BM = WGM * TM * 32;
   constexpr int BN = WGN * TN * 32;
-  constexpr int A_IT = BM * 8 / 256;  // 16-byte (8 x bf16) pieces per thread per K step
-  constexpr int B_IT = BN * 8 / 256;
+  constexpr int PITCH16 = BKT + 8;          // bf16 elements per LDS row: (BKT+8)*2 B is an odd number of 16-B slots
+  constexpr int GPR = BKT / 8;              // 8-channel groups per row
+  constexpr int RPI = 256 / GPR;            // rows covered per staging iteration
+  constexpr int NBUF = (BKT == 64) ? 2 : 1;
+  constexpr int A_IT = BM / RPI;            // 16-byte (8 x bf16) pieces per thread per K step
+  constexpr int B_IT = BN / RPI;
   static_assert(WGM * WGN == 4, "4 waves");
   static_assert(A_IT >= 1 && B_IT >= 1, "tile config");
 
-  constexpr int MAIN_B = 2 * (BM + BN) * PITCH16 * 2;              // bytes
+  constexpr int MAIN_B = NBUF * (BM + BN) * PITCH16 * 2;           // bytes
   constexpr int EPI_B = 4 * (TM * 32) * (TN * 32 + 4) * 4;         // bytes
   __shared__ __attribute__((aligned(16))) unsigned char smem_b[MAIN_B > EPI_B ? MAIN_B : EPI_B];
   __bf16(*As)[BM * PITCH16] = reinterpret_cast<__bf16(*)[BM * PITCH16]>(smem_b);
-  __bf16(*Bs)[BN * PITCH16] = reinterpret_cast<__bf16(*)[BN * PITCH16]>(smem_b + 2 * BM * PITCH16 * 2);
+  __bf16(*Bs)[BN * PITCH16] = reinterpret_cast<__bf16(*)[BN * PITCH16]>(smem_b + NBUF * BM * PITCH16 * 2);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -478,15 +487,15 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
   const long m0 = (long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int z = blockIdx.z;
-  const int cchunks = (p.Cin + BK16 - 1) / BK16;
-  const int nsteps = p.flatk ? (p.KH * p.KW * p.Cin + BK16 - 1) / BK16 : p.KH * p.KW * cchunks;
+  const int cchunks = (p.Cin + BKT - 1) / BKT;
+  const int nsteps = p.flatk ? (p.KH * p.KW * p.Cin + BKT - 1) / BKT : p.KH * p.KW * cchunks;
   const int per = (nsteps + p.split_k - 1) / p.split_k;
   const int s_begin = z * per;
   const int s_end = min(nsteps, s_begin + per);
 
-  // staging roles: piece = tid + it*256 -> row = piece >> 3, 8-channel group = piece & 7 (= tid & 7, constant)
-  const int grp = tid & 7;
-  const int row0 = tid >> 3;  // + it*32
+  // staging roles: piece = tid + it*256 -> row = piece / GPR, 8-channel group = piece % GPR (= tid % GPR, constant)
+  const int grp = tid % GPR;
+  const int row0 = tid / GPR;  // + it*RPI
   const int Hv = p.upsample ? 2 * p.H : p.H;
   const int Wv = p.upsample ? 2 * p.W : p.W;
   const int hw = p.Ho * p.Wo;
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
   bool a_mv[A_IT];
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
-    const long m = m0 + row0 + it * 32;
+    const long m = m0 + row0 + it * RPI;
     a_mv[it] = m < p.M;
     a_n[it] = 0; a_oy[it] = 0; a_ox[it] = 0;
     if (a_mv[it]) {
@@ -506,36 +515,42 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
   }
   const long wrow_stride = (long)p.KH * p.KW * p.Cin;
 
-  float a_raw[A_IT][8];
-  bool a_ok[A_IT];
-  uint4 b_raw[B_IT];
-  int a_c = 0;   // first channel of this thread's group in the pending step
+  // NS register slots of pending K steps.  NS = 3 is a ring (loads of step t+2 issued while step t is on the matrix
+  // cores, waited for when step t+1 is staged).  MEASURED (c512@16x16, B=4): the ring is 2x SLOWER than NS = 1 -- these
+  // layers are bound by operand bytes through the CU's L1 (64x64 tiles: 21 FLOP per L2 byte at ~12 B/clk/CU), not by
+  // load latency, and the ring's registers halve the resident blocks.  All dispatches use NS = 1; the fix for the
+  // small maps is operand reuse (the halo kernel), not deeper prefetch.
+  float a_raw[NS][A_IT][8];
+  bool a_ok[NS][A_IT];
+  uint4 b_raw[NS][B_IT];
+  int a_c[NS];   // first channel of this thread's group in the pending step
   // all rows of the tile in one image -> this thread's 8 scale/shift values are the same for all its pieces and
   // are prefetched with the operands (the common case: H*W is a multiple of the tile height)
   const long m_last = (m0 + BM - 1 < p.M) ? (m0 + BM - 1) : (long)p.M - 1;
   const bool uni_n = p.pro_scale && ((m0 / hw) == (m_last / hw));
   const long uni_off = (m0 / hw) * (long)p.Cin;
-  float u_sc[8], u_sh[8];
+  float u_sc[NS][8], u_sh[NS][8];
 
-  auto fetch = [&](int s) {
+  auto fetch = [&](auto slot_c, int s) {
+    constexpr int SL = decltype(slot_c)::value;
     const int tap = s / cchunks;
-    const int c0 = (s - tap * cchunks) * BK16;
+    const int c0 = (s - tap * cchunks) * BKT;
     const int kh = tap / p.KW;
     const int kw = tap - kh * p.KW;
     const int ca = c0 + grp * 8;
-    a_c = ca;
+    a_c[SL] = ca;
     if (p.flatk) {
       // K = (kh, kw, c) flattened (Cin = 3: 27 or 147 real k's instead of 9 / 49 nearly empty 64-wide chunks)
-      const int kbase = s * BK16 + grp * 8;
+      const int kbase = s * BKT + grp * 8;
       const int ktot = p.KH * p.KW * p.Cin;
 #pragma unroll
       for (int it = 0; it < A_IT; ++it) {
-        a_ok[it] = a_mv[it] && kbase < ktot;
+        a_ok[SL][it] = a_mv[it] && kbase < ktot;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int k = kbase + j;
           float v = 0.f;
-          if (a_ok[it] && k < ktot) {
+          if (a_ok[SL][it] && k < ktot) {
             const int tp = k / p.Cin, c = k - tp * p.Cin;
             const int kh2 = tp / p.KW, kw2 = tp - kh2 * p.KW;
             const int iy = a_oy[it] * p.stride - p.pad_t + kh2;
@@ -545,102 +560,103 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
               v = p.in[(((long)a_n[it] * p.H + sy) * p.W + sx) * p.in_ld + c];
             }
           }
-          a_raw[it][j] = v;
+          a_raw[SL][it][j] = v;
         }
       }
 #pragma unroll
       for (int it = 0; it < B_IT; ++it) {
-        const int co = n0 + row0 + it * 32;
+        const int co = n0 + row0 + it * RPI;
         unsigned short t[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           t[j] = (co < p.Cout && kbase + j < ktot) ? p.wb[(long)co * ktot + kbase + j] : (unsigned short)0;
-        b_raw[it] = make_uint4(t[0] | ((unsigned)t[1] << 16), t[2] | ((unsigned)t[3] << 16),
+        b_raw[SL][it] = make_uint4(t[0] | ((unsigned)t[1] << 16), t[2] | ((unsigned)t[3] << 16),
                                t[4] | ((unsigned)t[5] << 16), t[6] | ((unsigned)t[7] << 16));
       }
-      a_c = 0;     // stage(): every element already validated, no per-channel mask / affine (host forbids a prologue)
+      a_c[SL] = 0;     // stage(): every element already validated, no per-channel mask / affine (host forbids a prologue)
       return;
     }
     if (uni_n) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const bool cok = ca + j < p.Cin;
-        u_sc[j] = cok ? p.pro_scale[uni_off + ca + j] : 0.f;
-        u_sh[j] = cok ? p.pro_shift[uni_off + ca + j] : 0.f;
+        u_sc[SL][j] = cok ? p.pro_scale[uni_off + ca + j] : 0.f;
+        u_sh[SL][j] = cok ? p.pro_shift[uni_off + ca + j] : 0.f;
       }
     }
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int iy = a_oy[it] * p.stride - p.pad_t + kh;
       const int ix = a_ox[it] * p.stride - p.pad_l + kw;
-      a_ok[it] = a_mv[it] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv && ca < p.Cin;
-      if (a_ok[it]) {
+      a_ok[SL][it] = a_mv[it] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv && ca < p.Cin;
+      if (a_ok[SL][it]) {
         const int sy = p.upsample ? (iy >> 1) : iy;
         const int sx = p.upsample ? (ix >> 1) : ix;
         const float* src = p.in + (((long)a_n[it] * p.H + sy) * p.W + sx) * p.in_ld + ca;
         if (p.vec_ok && ca + 8 <= p.Cin) {
           const float4 v0 = *reinterpret_cast<const float4*>(src);
           const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
-          a_raw[it][0] = v0.x; a_raw[it][1] = v0.y; a_raw[it][2] = v0.z; a_raw[it][3] = v0.w;
-          a_raw[it][4] = v1.x; a_raw[it][5] = v1.y; a_raw[it][6] = v1.z; a_raw[it][7] = v1.w;
+          a_raw[SL][it][0] = v0.x; a_raw[SL][it][1] = v0.y; a_raw[SL][it][2] = v0.z; a_raw[SL][it][3] = v0.w;
+          a_raw[SL][it][4] = v1.x; a_raw[SL][it][5] = v1.y; a_raw[SL][it][6] = v1.z; a_raw[SL][it][7] = v1.w;
         } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) a_raw[it][j] = (ca + j < p.Cin) ? src[j] : 0.f;
+          for (int j = 0; j < 8; ++j) a_raw[SL][it][j] = (ca + j < p.Cin) ? src[j] : 0.f;
         }
       }
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const int co = n0 + row0 + it * 32;
-      b_raw[it] = make_uint4(0u, 0u, 0u, 0u);
+      const int co = n0 + row0 + it * RPI;
+      b_raw[SL][it] = make_uint4(0u, 0u, 0u, 0u);
       if (co < p.Cout && ca < p.Cin) {
         const unsigned short* src = p.wb + (long)co * wrow_stride + (long)tap * p.Cin + ca;
         if ((p.Cin & 7) == 0) {
-          b_raw[it] = *reinterpret_cast<const uint4*>(src);
+          b_raw[SL][it] = *reinterpret_cast<const uint4*>(src);
         } else {
           unsigned short t[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) t[j] = (ca + j < p.Cin) ? src[j] : (unsigned short)0;
-          b_raw[it] = make_uint4(t[0] | ((unsigned)t[1] << 16), t[2] | ((unsigned)t[3] << 16),
+          b_raw[SL][it] = make_uint4(t[0] | ((unsigned)t[1] << 16), t[2] | ((unsigned)t[3] << 16),
                                  t[4] | ((unsigned)t[5] << 16), t[6] | ((unsigned)t[7] << 16));
         }
       }
     }
   };
 
-  auto stage = [&](int buf) {
+  auto stage = [&](auto slot_c, int buf) {
+    constexpr int SL = decltype(slot_c)::value;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       bf16x8 h;
-      if (a_ok[it]) {
+      if (a_ok[SL][it]) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = a_raw[it][j];
+        for (int j = 0; j < 8; ++j) v[j] = a_raw[SL][it][j];
         if (uni_n) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = v[j] * u_sc[j] + u_sh[j];
+          for (int j = 0; j < 8; ++j) v[j] = v[j] * u_sc[SL][j] + u_sh[SL][j];
         } else if (p.pro_scale) {
-          const float* sc = p.pro_scale + (long)a_n[it] * p.Cin + a_c;
-          const float* sh = p.pro_shift + (long)a_n[it] * p.Cin + a_c;
+          const float* sc = p.pro_scale + (long)a_n[it] * p.Cin + a_c[SL];
+          const float* sh = p.pro_shift + (long)a_n[it] * p.Cin + a_c[SL];
 #pragma unroll
           for (int j = 0; j < 8; ++j)
-            if (a_c + j < p.Cin) v[j] = v[j] * sc[j] + sh[j];
+            if (a_c[SL] + j < p.Cin) v[j] = v[j] * sc[j] + sh[j];
         }
         if (p.pro_act != KEEP_PRO_NONE) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = pro_apply_fast(v[j], p.pro_act);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) h[j] = (__bf16)((p.flatk || a_c + j < p.Cin) ? v[j] : 0.f);
+        for (int j = 0; j < 8; ++j) h[j] = (__bf16)((p.flatk || a_c[SL] + j < p.Cin) ? v[j] : 0.f);
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) h[j] = (__bf16)0.f;
       }
-      *reinterpret_cast<bf16x8*>(&As[buf][(row0 + it * 32) * PITCH16 + grp * 8]) = h;
+      *reinterpret_cast<bf16x8*>(&As[buf][(row0 + it * RPI) * PITCH16 + grp * 8]) = h;
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it)
-      *reinterpret_cast<uint4*>(&Bs[buf][(row0 + it * 32) * PITCH16 + grp * 8]) = b_raw[it];
+      *reinterpret_cast<uint4*>(&Bs[buf][(row0 + it * RPI) * PITCH16 + grp * 8]) = b_raw[SL][it];
   };
 
   f32x16 acc[TM][TN];
@@ -656,32 +672,75 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
   const int a_f0 = (wm * TM * 32 + l31) * PITCH16 + lhi * 8;
   const int b_f0 = (wn * TN * 32 + l31) * PITCH16 + lhi * 8;
 
+  using IC0 = std::integral_constant<int, 0>;
+  using IC1 = std::integral_constant<int, (NS > 1 ? 1 : 0)>;
+  using IC2 = std::integral_constant<int, (NS > 2 ? 2 : 0)>;
+  auto mma_step = [&](int buf) {
+    const __bf16* Ab = As[buf];
+    const __bf16* Bb = Bs[buf];
+#pragma unroll
+    for (int ks = 0; ks < BKT / 16; ++ks) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + a_f0 + i * 32 * PITCH16 + ks * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + b_f0 + j * 32 * PITCH16 + ks * 16);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
   if (s_begin < s_end) {
-    fetch(s_begin);
-    stage(0);
-    __syncthreads();
-    int buf = 0;
-    for (int s = s_begin; s < s_end; ++s) {
-      const bool more = (s + 1 < s_end);
-      if (more) fetch(s + 1);
-      const __bf16* Ab = As[buf];
-      const __bf16* Bb = Bs[buf];
-#pragma unroll
-      for (int ks = 0; ks < BK16 / 16; ++ks) {
-        bf16x8 af[TM], bfr[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + a_f0 + i * 32 * PITCH16 + ks * 16);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + b_f0 + j * 32 * PITCH16 + ks * 16);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-      }
-      if (more) stage(buf ^ 1);
+    if (NS == 3) {
+      // ---- 3-slot ring, two LDS buffers
+      fetch(IC0{}, s_begin);
+      if (s_begin + 1 < s_end) fetch(IC1{}, s_begin + 1);
+      stage(IC0{}, 0);
       __syncthreads();
-      buf ^= 1;
+      int buf = 0;
+      for (int s = s_begin; s < s_end; s += 3) {
+        if (s + 2 < s_end) fetch(IC2{}, s + 2);
+        mma_step(buf);
+        if (s + 1 < s_end) stage(IC1{}, buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        if (s + 1 >= s_end) break;
+        if (s + 3 < s_end) fetch(IC0{}, s + 3);
+        mma_step(buf);
+        if (s + 2 < s_end) stage(IC2{}, buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        if (s + 2 >= s_end) break;
+        if (s + 4 < s_end) fetch(IC1{}, s + 4);
+        mma_step(buf);
+        if (s + 3 < s_end) stage(IC0{}, buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+      }
+    } else {
+      fetch(IC0{}, s_begin);
+      stage(IC0{}, 0);
+      __syncthreads();
+      int buf = 0;
+      for (int s = s_begin; s < s_end; ++s) {
+        const bool more = (s + 1 < s_end);
+        if (more) fetch(IC0{}, s + 1);
+        mma_step(buf);
+        if (NBUF == 2) {
+          if (more) stage(IC0{}, buf ^ 1);
+          __syncthreads();
+          buf ^= 1;
+        } else {
+          __syncthreads();           // single buffer: everyone is done reading before it is overwritten
+          if (more) {
+            stage(IC0{}, 0);
+            __syncthreads();
+          }
+        }
+      }
     }
   }
 
@@ -800,6 +859,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles
   const unsigned short* in16 = reinterpret_cast<const unsigned short*>(p.in) + img_off;
   const float* in32 = p.in + img_off;
 
+  // fp32 input may carry the previous normalisation: v = act(x*scale[n,c] + shift[n,c]) applied once per halo element
+  // while staging (n is block-uniform, the thread's 8 channels are fixed within a chunk)
+  const bool has_pro = !IN_BF16 && (p.pro_scale != nullptr || p.pro_act != KEEP_PRO_NONE);
+  float u_sc[8], u_sh[8];
   uint4 hreg[HALO_IT];                   // bf16 input: one 16-B piece each
   float4 hlo[IN_BF16 ? 1 : HALO_IT], hhi[IN_BF16 ? 1 : HALO_IT];   // fp32 input: 8 floats per piece
   uint4 wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7, wr8;   // named: a 9-element array is left in scratch by hipcc
@@ -807,6 +870,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles
 
   auto fetch = [&](int ch) {
     const int c0 = ch << 5;
+    if (!IN_BF16 && p.pro_scale) {
+      const float4 s0 = *reinterpret_cast<const float4*>(p.pro_scale + (long)n * p.Cin + c0 + g * 8);
+      const float4 s1 = *reinterpret_cast<const float4*>(p.pro_scale + (long)n * p.Cin + c0 + g * 8 + 4);
+      const float4 h0 = *reinterpret_cast<const float4*>(p.pro_shift + (long)n * p.Cin + c0 + g * 8);
+      const float4 h1 = *reinterpret_cast<const float4*>(p.pro_shift + (long)n * p.Cin + c0 + g * 8 + 4);
+      u_sc[0] = s0.x; u_sc[1] = s0.y; u_sc[2] = s0.z; u_sc[3] = s0.w; u_sc[4] = s1.x; u_sc[5] = s1.y; u_sc[6] = s1.z; u_sc[7] = s1.w;
+      u_sh[0] = h0.x; u_sh[1] = h0.y; u_sh[2] = h0.z; u_sh[3] = h0.w; u_sh[4] = h1.x; u_sh[5] = h1.y; u_sh[6] = h1.z; u_sh[7] = h1.w;
+    }
 #pragma unroll
     for (int it = 0; it < HALO_IT; ++it) {
       if (IN_BF16) {
@@ -836,9 +907,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles
           *reinterpret_cast<uint4*>(&Hs[hp * HPITCH + g * 8]) = hreg[it];
         } else {
           const float4 a = hlo[IN_BF16 ? 0 : it], b = hhi[IN_BF16 ? 0 : it];
+          float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+          if (has_pro && h_off[it] >= 0) {           // zero padding stays zero: it is applied AFTER the activation
+            if (p.pro_scale) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = v[j] * u_sc[j] + u_sh[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = pro_apply_fast(v[j], p.pro_act);
+          }
           bf16x8 h;
-          h[0] = (__bf16)a.x; h[1] = (__bf16)a.y; h[2] = (__bf16)a.z; h[3] = (__bf16)a.w;
-          h[4] = (__bf16)b.x; h[5] = (__bf16)b.y; h[6] = (__bf16)b.z; h[7] = (__bf16)b.w;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) h[j] = (__bf16)v[j];
           *reinterpret_cast<bf16x8*>(&Hs[hp * HPITCH + g * 8]) = h;
         }
       }
@@ -1068,7 +1148,9 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
   const bool halo_ok = a->mma == KEEP_MMA_BF16 && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 &&
                        a->pad_l == 1 && (a->Cin % 32 == 0) && (a->Cout % 64 == 0) && (a->Ho % HALO_TH == 0) &&
                        (a->Wo % HALO_TW == 0) && a->Ho == (a->upsample ? 2 * a->H : a->H) &&
-                       a->Wo == (a->upsample ? 2 * a->W : a->W) && !a->pro_scale && a->pro_act == KEEP_PRO_NONE &&
+                       a->Wo == (a->upsample ? 2 * a->W : a->W) &&
+                       (a->dtype == KEEP_F32 || (!a->pro_scale && a->pro_act == KEEP_PRO_NONE)) &&
+                       (!a->pro_scale || ((uintptr_t)a->pro_scale % 16 == 0 && (uintptr_t)a->pro_shift % 16 == 0)) &&
                        (a->out_dtype != KEEP_BF16) && (a->in_ld % 8 == 0) && ((uintptr_t)a->in % 16 == 0) && (a->out_ld % 4 == 0) &&
                        ((uintptr_t)a->out % 16 == 0) && (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&
                        (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0);
@@ -1100,13 +1182,20 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
     if (p.split_k > steps16) p.split_k = steps16;
     if (a->Cout <= 32) {
       dim3 grid(cdiv(M, 128), cdiv(a->Cout, 32), p.split_k);
-      hipLaunchKernelGGL((conv_bf16_kernel<4, 1, 1, 1>), grid, block, 0, st, p);
+      hipLaunchKernelGGL((conv_bf16_kernel<4, 1, 1, 1, 64, 1>), grid, block, 0, st, p);
     } else if (a->Cout <= 64 || M <= 4096) {
-      dim3 grid(cdiv(M, 64), cdiv(a->Cout, 64), p.split_k);
-      hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 1, 1>), grid, block, 0, st, p);
+      if (a->bk256 && !p.flatk) {
+        const int steps256 = a->KH * a->KW * ((a->Cin + 255) / 256);
+        if (p.split_k > steps256) p.split_k = steps256;
+        dim3 grid(cdiv(M, 64), cdiv(a->Cout, 64), p.split_k);
+        hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 1, 1, 256, 1>), grid, block, 0, st, p);
+      } else {
+        dim3 grid(cdiv(M, 64), cdiv(a->Cout, 64), p.split_k);
+        hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 1, 1, 64, 1>), grid, block, 0, st, p);
+      }
     } else {
       dim3 grid(cdiv(M, 128), cdiv(a->Cout, 128), p.split_k);
-      hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 2, 2>), grid, block, 0, st, p);
+      hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 2, 2, 64, 1>), grid, block, 0, st, p);
     }
   } else if (a->Cout <= 32) {
     dim3 grid(cdiv(M, 128), cdiv(a->Cout, 32), p.split_k);

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 F32, BF16 = 0, 1
 MMA_F32, MMA_BF16 = 0, 1
@@ -27,7 +27,7 @@ class ConvArgs(C.Structure):
                 ('residual', _vp), ('aux', _vp), ('workspace', _vp)] + \
                [(n, _i32) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad_t', 'pad_l', 'Ho', 'Wo',
                                     'in_ld', 'out_ld', 'res_ld', 'upsample', 'pro_act', 'epi_act')] + \
-               [('aux_w', _f32), ('split_k', _i32), ('dtype', _i32), ('mma', _i32), ('weight_bf16', _vp), ('stats_out', _vp), ('stats_P', _i32), ('out_dtype', _i32)]
+               [('aux_w', _f32), ('split_k', _i32), ('dtype', _i32), ('mma', _i32), ('weight_bf16', _vp), ('stats_out', _vp), ('stats_P', _i32), ('bk256', _i32), ('out_dtype', _i32)]
 
 
 class AttnArgs(C.Structure):

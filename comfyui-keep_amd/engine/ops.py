@@ -5,6 +5,7 @@ matrices ``[M,C]`` (same memory).  torch is used for allocation (caching allocat
 inside hipGraph capture) and views; every arithmetic op is a ``libkeep_hip.so`` kernel.
 """
 import math
+import os
 
 import torch
 
@@ -35,6 +36,9 @@ def bf16_twin(w):
         raise RuntimeError("weight view is not inside the packed blob; pass wb= explicitly")
     return _BLOB16[off:off + w.numel()]
 
+
+USE_BK256 = bool(int(os.environ.get('KEEP_BK256', '0')))   # measured slower than BK=64 + split-K at B<=4 (kept for A/B)
+HALO_PRENORM = bool(int(os.environ.get('KEEP_HALO_PRENORM', '0')))
 
 # bench.py's roofline leg: when a list, every keep_conv2d launch is bracketed by HIP events on the launch stream
 # and appended as (tile_config, algorithmic_flops, start_event, end_event)
@@ -104,14 +108,22 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
     in_dtype = L.F32
     halo = (mma == L.MMA_BF16 and not out_bf16 and ksize == 3 and stride == 1 and not down and pad == 1 and Cin % 32 == 0
             and Cout % 64 == 0 and Ho % 8 == 0 and Wo % 32 == 0 and ld % 8 == 0 and in_off % 8 == 0)
-    if halo and (pro is not None or pro_act != L.PRO_NONE):
-        # 3x3 halo path: normalise + activate once per element into a bf16 tensor (instead of 9x inside the gather)
+    if halo and (pro is not None or pro_act != L.PRO_NONE) and HALO_PRENORM:
+        # optional two-pass variant: normalise + activate once per element into a bf16 tensor in front of the halo conv
+        # (default: the halo kernel applies the affine + activation itself while staging its fp32 halo)
         assert in_off == 0 and Cin == ld
         x16 = torch.empty((N, H, W, ld), dtype=torch.bfloat16, device=x.device)
         L.call('keep_norm_act_bf16', x, None if pro is None else pro[0], None if pro is None else pro[1], x16,
                N, H * W, ld, pro_act)
         x, pro, pro_act, in_dtype = x16, None, L.PRO_NONE, L.BF16
     nsteps = KH * KW * math.ceil(Cin / (64 if mma == L.MMA_BF16 else 16))
+    # latency-bound gather layers (few 64x64 output tiles, deep K): 256-channel K steps, single LDS buffer
+    bk256 = (USE_BK256 and mma == L.MMA_BF16 and not halo and Cout > 32 and (Cout <= 64 or M <= 4096) and Cin >= 256 and nsteps >= 8)
+    if bk256:
+        nsteps = KH * KW * math.ceil(Cin / 256)
+        if split_k is None and not out_bf16:
+            tiles = math.ceil(M / 64) * math.ceil(Cout / 64)
+            split_k = max(1, min(512 // max(tiles, 1), nsteps // 2, 16))
     if split_k is None:
         if out_bf16:
             split_k = 1
@@ -131,7 +143,7 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
     xin = x if in_off == 0 else x.view(-1)[in_off:]
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        PROFILE.append(('conv3x3_halo_bf16' if halo else
+        PROFILE.append(('conv3x3_halo_bf16' if halo else 'conv_bf16<64x64,bk256>' if bk256 else
                         tile_config(M, Cout).replace('f32', 'bf16' if mma == L.MMA_BF16 else 'f32'),
                         2.0 * M * Cout * KH * KW * Cin, split_k, e0, e1))
         e0.record()
@@ -140,7 +152,7 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
              N=N, H=H, W=W, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=stride, pad_t=pad_t, pad_l=pad_l, Ho=Ho, Wo=Wo,
              in_ld=ld, out_ld=out.shape[-1], res_ld=0 if residual is None else residual.shape[-1],
              upsample=int(upsample), pro_act=pro_act, epi_act=act, aux_w=float(aux_w), split_k=split_k, dtype=in_dtype,
-             mma=mma, weight_bf16=wb if mma == L.MMA_BF16 else None, stats_out=part, stats_P=stats_P,
+             mma=mma, weight_bf16=wb if mma == L.MMA_BF16 else None, stats_out=part, stats_P=stats_P, bk256=int(bk256),
              out_dtype=L.BF16 if out_bf16 else L.F32)
     if part is not None:
         out._keep_stats = (part, stats_P)

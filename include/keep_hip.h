@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KEEP_ABI_VERSION 5
+#define KEEP_ABI_VERSION 6
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -100,6 +100,8 @@ typedef struct {
    * the 3x3 halo path, else 128, or 64 when Cout <= 64 or N*Ho*Wo <= 4096). */
   float* stats_out;
   int32_t stats_P;
+  int32_t bk256;     /* KEEP_MMA_BF16 gather path, 64x64 tiles: K step of 256 channels with a single LDS buffer
+                        (latency-bound small-M / deep-K layers); split_k then counts 256-channel steps */
   int32_t out_dtype; /* KEEP_F32, or KEEP_BF16: `out` is a bf16 tensor (projections feeding keep_attention; needs
                         Cout/out_ld %% 4 == 0, split_k == 1, no residual) */
 } keep_conv2d_args;

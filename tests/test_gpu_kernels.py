@@ -540,3 +540,16 @@ def test_attention_bf16_inputs_window_sparse_and_linear_bf16_out():
     hs = lambda t: t.reshape(t.shape[0], t.shape[1], H, D).permute(0, 2, 1, 3)  # noqa: E731
     ref = ref_attn(hs(qq), hs(gather(kk)), hs(gather(vv)), D ** -0.5).permute(0, 2, 1, 3).reshape(Bc * T, Lt2, inner)
     check(o, ref, 6e-3, 'bf16-in sparse causal')
+
+
+@pytest.mark.parametrize("cin,cout,hw,n,k,sk", [(512, 512, 16, 2, 3, None), (512, 512, 16, 1, 3, 3), (1024, 512, 16, 1, 1, 1),
+                                                (384, 256, 8, 3, 1, None), (256, 64, 32, 1, 3, None)])
+def test_conv_bf16_bk256_variant(cin, cout, hw, n, k, sk):
+    """latency-bound small-M / deep-K layers: 256-channel K steps (single LDS buffer) must equal the default path."""
+    x, w, b = rnd('kx', (n, cin, hw, hw)), rnd('kw', (cout, cin, k, k), 0.03), rnd('kb', (cout,))
+    wp = pack(w)
+    pro = ops.norm_affine(dev(nhwc(x)), None, None, cin, 1e-5)
+    y = ops.conv(dev(nhwc(x)), wp, dev(b), pad=k // 2, ksize=k, mma=L.MMA_BF16, wb=wp.to(torch.bfloat16), split_k=sk,
+                 pro=pro, pro_act=L.PRO_RELU)
+    ref = F.conv2d(bf16r(F.relu(F.instance_norm(x, eps=1e-5))), bf16r(w), b, padding=k // 2)
+    check(nchw(y), ref, 3e-3, f'bk256 {cin}->{cout} k{k} split {sk}')

@@ -22,6 +22,9 @@ LAYERS = {  # name: (N, H, W, Cin, Cout, ksize, upsample)
     'c256_64': (4, 64, 64, 256, 256, 3, False),
     'c512_16': (4, 16, 16, 512, 512, 3, False),
     'lin128': (1, 622592, 1, 128, 128, 1, False),
+    'c512_16_b8': (8, 16, 16, 512, 512, 3, False),
+    'lin512_1024': (1, 1024, 1, 512, 1024, 1, False),
+    'lin1024_512': (1, 1024, 1, 1024, 512, 1, False),
 }
 
 
@@ -35,6 +38,8 @@ def run(name, mma, in_bf16, iters=20):
     if in_bf16:
         pro = (torch.ones(N, Cin, device='cuda'), torch.zeros(N, Cin, device='cuda'))
     kw = dict(pad=k // 2, ksize=k, upsample=up, mma=mma, wb=wb, stats=True)
+    if os.environ.get('SPLITK'):
+        kw['split_k'] = int(os.environ['SPLITK'])
     if pro is not None:
         kw.update(pro=pro, pro_act=L.PRO_SWISH)
     for _ in range(3):

@@ -793,10 +793,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
 // The NEXT chunk's halo + weights are prefetched into registers while the current chunk is on the matrix cores;
 // 73 KB of LDS -> 2 blocks per CU so one block's staging overlaps the other's MFMA phase.
 // `upsample` folds nearest x2 into the halo addressing; split-K splits the Cin chunks (small maps at small batch).
-#define HALO_TH 8
-#define HALO_TW 32
-#define HALO_W (HALO_TW + 2)
-#define HALO_PIX ((HALO_TH + 2) * HALO_W)   // 340
+#define HALO_MAXPIX 340                      // 10 x 34 (8x32 tile) >= 18 x 18 (16x16 tile)
 #define HPITCH 40                            // bf16 elements per LDS pixel/weight row (80 B)
 #define HALO_IT 6                            // ceil(340*4 / 256) 16-byte pieces per thread
 
@@ -808,12 +805,15 @@ __device__ __forceinline__ int xcd_remap(int id, int total) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-template <bool IN_BF16>
+// TW = 32: 8 x 32 output tile (maps >= 32 wide); TW = 16: 16 x 16 tile (the 16x16 latent maps: a whole image per block).
+template <bool IN_BF16, int TW>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles_x, int tiles_y, int ncb) {
+  constexpr int HALO_TW = TW, HALO_TH = 256 / TW, HALO_W = TW + 2, HALO_PIX = (HALO_TH + 2) * HALO_W;
+  constexpr int RPT = 32 / TW;               // output rows covered by one 32-pixel MFMA block (1 or 2)
   // one LDS object: [halo | weights] during the main loop, [4 waves x 64 pixels x 68 floats] in the epilogue
-  __shared__ __attribute__((aligned(16))) __bf16 lds_all[HALO_PIX * HPITCH + 9 * 64 * HPITCH];
+  __shared__ __attribute__((aligned(16))) __bf16 lds_all[HALO_MAXPIX * HPITCH + 9 * 64 * HPITCH];
   __bf16* Hs = lds_all;
-  __bf16* Ws = lds_all + HALO_PIX * HPITCH;
+  __bf16* Ws = lds_all + HALO_MAXPIX * HPITCH;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -936,7 +936,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int a_base = ((2 * wave) * HALO_W + l31) * HPITCH + lhi * 8;   // + (i+kh)*HALO_W*HPITCH + kw*HPITCH + ks*16
+  // MFMA block i of this wave covers output rows (2*wave+i)*RPT .. +RPT-1; lane l31 -> (row l31/TW, column l31%TW)
+  const int a_base = (((2 * wave) * RPT + l31 / TW) * HALO_W + (l31 % TW)) * HPITCH + lhi * 8;
   const int b_base = l31 * HPITCH + lhi * 8;                           // + (tap*64 + j*32)*HPITCH + ks*16
 
   if (ch_begin < ch_end) {
@@ -955,7 +956,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles
             bf16x8 af[2], bfr[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-              af[i] = *reinterpret_cast<const bf16x8*>(&Hs[a_base + ((i + kh) * HALO_W + kw) * HPITCH + ks * 16]);
+              af[i] = *reinterpret_cast<const bf16x8*>(&Hs[a_base + ((i * RPT + kh) * HALO_W + kw) * HPITCH + ks * 16]);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
               bfr[j] = *reinterpret_cast<const bf16x8*>(&Ws[b_base + ((kh * 3 + kw) * 64 + j * 32) * HPITCH + ks * 16]);
@@ -1001,9 +1002,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles
   if (p.bias && p.split_k == 1) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
 #pragma unroll 4
   for (int it = 0; it < 16; ++it) {
-    const int px = it * 4 + prow;                          // 0..63 : row (px>>5), column (px&31)
-    const int oy = oy0 + 2 * wave + (px >> 5);
-    const long m = ((long)n * p.Ho + oy) * p.Wo + ox0 + (px & 31);
+    const int px = it * 4 + prow;                          // 0..63 : MFMA block px>>5, pixel px&31 inside it
+    const int oy = oy0 + (2 * wave + (px >> 5)) * RPT + (px & 31) / TW;
+    const long m = ((long)n * p.Ho + oy) * p.Wo + ox0 + (px & 31) % TW;
     float4 v = *reinterpret_cast<const float4*>(et + px * EP + c4);
     if (p.split_k > 1) {
       *reinterpret_cast<float4*>(p.ws + ((long)z * p.M + m) * p.Cout + co) = v;
@@ -1146,8 +1147,9 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
     KEEP_REQUIRE(a->stats_P > 0, "keep_conv2d: stats_out requires stats_P");
   }
   const bool halo_ok = a->mma == KEEP_MMA_BF16 && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 &&
-                       a->pad_l == 1 && (a->Cin % 32 == 0) && (a->Cout % 64 == 0) && (a->Ho % HALO_TH == 0) &&
-                       (a->Wo % HALO_TW == 0) && a->Ho == (a->upsample ? 2 * a->H : a->H) &&
+                       a->pad_l == 1 && (a->Cin % 32 == 0) && (a->Cout % 64 == 0) &&
+                       ((a->Ho % 8 == 0 && a->Wo % 32 == 0) || (a->Ho % 16 == 0 && a->Wo % 16 == 0)) &&
+                       a->Ho == (a->upsample ? 2 * a->H : a->H) &&
                        a->Wo == (a->upsample ? 2 * a->W : a->W) &&
                        (a->dtype == KEEP_F32 || (!a->pro_scale && a->pro_act == KEEP_PRO_NONE)) &&
                        (!a->pro_scale || ((uintptr_t)a->pro_scale % 16 == 0 && (uintptr_t)a->pro_shift % 16 == 0)) &&
@@ -1171,12 +1173,18 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
   if (halo_ok) {
     const int nchunks = a->Cin / 32;
     if (p.split_k > nchunks) p.split_k = nchunks;
-    const int tiles_x = a->Wo / HALO_TW, tiles_y = a->Ho / HALO_TH, ncb = a->Cout / 64;
+    const bool wide = (a->Ho % 8 == 0 && a->Wo % 32 == 0);
+    const int tw = wide ? 32 : 16, th = 256 / tw;
+    const int tiles_x = a->Wo / tw, tiles_y = a->Ho / th, ncb = a->Cout / 64;
     dim3 grid(a->N * tiles_x * tiles_y * ncb, 1, p.split_k);
-    if (p.in_bf16)
-      hipLaunchKernelGGL((conv3x3_halo_kernel<true>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
+    if (p.in_bf16 && wide)
+      hipLaunchKernelGGL((conv3x3_halo_kernel<true, 32>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
+    else if (p.in_bf16)
+      hipLaunchKernelGGL((conv3x3_halo_kernel<true, 16>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
+    else if (wide)
+      hipLaunchKernelGGL((conv3x3_halo_kernel<false, 32>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
     else
-      hipLaunchKernelGGL((conv3x3_halo_kernel<false>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
+      hipLaunchKernelGGL((conv3x3_halo_kernel<false, 16>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
   } else if (a->mma == KEEP_MMA_BF16) {
     const int steps16 = p.flatk ? (a->KH * a->KW * a->Cin + BK16 - 1) / BK16 : a->KH * a->KW * ((a->Cin + BK16 - 1) / BK16);
     if (p.split_k > steps16) p.split_k = steps16;

@@ -107,7 +107,8 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
         wb = bf16_twin(w)
     in_dtype = L.F32
     halo = (mma == L.MMA_BF16 and not out_bf16 and ksize == 3 and stride == 1 and not down and pad == 1 and Cin % 32 == 0
-            and Cout % 64 == 0 and Ho % 8 == 0 and Wo % 32 == 0 and ld % 8 == 0 and in_off % 8 == 0)
+            and Cout % 64 == 0 and ((Ho % 8 == 0 and Wo % 32 == 0) or (Ho % 16 == 0 and Wo % 16 == 0))
+            and ld % 8 == 0 and in_off % 8 == 0)
     if halo and (pro is not None or pro_act != L.PRO_NONE) and HALO_PRENORM:
         # optional two-pass variant: normalise + activate once per element into a bf16 tensor in front of the halo conv
         # (default: the halo kernel applies the affine + activation itself while staging its fp32 halo)

@@ -37,8 +37,11 @@ def bf16_twin(w):
     return _BLOB16[off:off + w.numel()]
 
 
+HALO_V1 = os.environ.get('KEEP_HALO_VER', '3') == '1'   # halo kernel generation (3 = persistent, default)
 USE_BK256 = bool(int(os.environ.get('KEEP_BK256', '0')))   # measured slower than BK=64 + split-K at B<=4 (kept for A/B)
-HALO_PRENORM = bool(int(os.environ.get('KEEP_HALO_PRENORM', '0')))
+# two-pass normalise+activate -> bf16 in front of the halo conv for inputs of at least this many pixels per launch
+# (N*H*W); below it the halo kernel applies the affine + activation itself while staging (measured crossover)
+HALO_PRENORM_MINPIX = int(os.environ.get('KEEP_HALO_PRENORM_MINPIX', '0'))
 
 # bench.py's roofline leg: when a list, every keep_conv2d launch is bracketed by HIP events on the launch stream
 # and appended as (tile_config, algorithmic_flops, start_event, end_event)
@@ -109,7 +112,7 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
     halo = (mma == L.MMA_BF16 and not out_bf16 and ksize == 3 and stride == 1 and not down and pad == 1 and Cin % 32 == 0
             and Cout % 64 == 0 and ((Ho % 8 == 0 and Wo % 32 == 0) or (Ho % 16 == 0 and Wo % 16 == 0))
             and ld % 8 == 0 and in_off % 8 == 0)
-    if halo and (pro is not None or pro_act != L.PRO_NONE) and HALO_PRENORM:
+    if halo and (pro is not None or pro_act != L.PRO_NONE) and N * H * W >= HALO_PRENORM_MINPIX:
         # optional two-pass variant: normalise + activate once per element into a bf16 tensor in front of the halo conv
         # (default: the halo kernel applies the affine + activation itself while staging its fp32 halo)
         assert in_off == 0 and Cin == ld
@@ -137,7 +140,8 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
     # per-tile channel statistics of the output for the next GroupNorm / InstanceNorm (epilogue-fused)
     part, stats_P = None, 0
     if stats and split_k == 1:
-        bm = 256 if halo else (128 if Cout <= 32 else (64 if (Cout <= 64 or M <= 4096) else 128))
+        halo_v2 = halo and pro is None and pro_act == L.PRO_NONE and not HALO_V1
+        bm = (64 if halo_v2 else 256) if halo else (128 if Cout <= 32 else (64 if (Cout <= 64 or M <= 4096) else 128))
         if (Ho * Wo) % bm == 0 and out.shape[-1] == Cout:
             stats_P = (Ho * Wo) // bm
             part = empty((N, stats_P, Cout, 2), x)

@@ -1371,6 +1371,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvP p, int tile
 
   int h_off[HALO_IT];
   long img_off = 0, w_base = 0;
+  bool w_ok = true;
   auto setup = [&](const HaloItem& it) {
 #pragma unroll
     for (int k = 0; k < HALO_IT; ++k) {
@@ -1386,7 +1387,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvP p, int tile
       }
     }
     img_off = (long)it.n * p.H * p.W * p.in_ld;
-    w_base = ((long)(it.n0 + (tid >> 2)) * 9) * p.Cin + g * 8;
+    w_ok = (it.n0 + (tid >> 2)) < p.Cout;             // Cout % 64 == 32: the last cout-block is half empty
+    w_base = w_ok ? ((long)(it.n0 + (tid >> 2)) * 9) * p.Cin + g * 8 : 0;
   };
 
   uint4 hreg[HALO_IT];
@@ -1410,7 +1412,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvP p, int tile
         }
       }
     }
-#define KEEP_WLOAD(TAP, R) R = *reinterpret_cast<const uint4*>(p.wb + w_base + (long)(TAP) * p.Cin + c0);
+#define KEEP_WLOAD(TAP, R) R = w_ok ? *reinterpret_cast<const uint4*>(p.wb + w_base + (long)(TAP) * p.Cin + c0) : make_uint4(0u, 0u, 0u, 0u);
     KEEP_TAPS(KEEP_WLOAD)
 #undef KEEP_WLOAD
   };
@@ -1474,11 +1476,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvP p, int tile
     __builtin_amdgcn_s_waitcnt(0xc07f);
     const int c4 = (lane & 15) * 4, prow = lane >> 4;
     const int co = it.n0 + c4;
+    const bool cok = co < p.Cout;
     float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && p.split_k == 1) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
+    if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
 #pragma unroll 4
     for (int q16 = 0; q16 < 16; ++q16) {
+      if (!cok) break;
       const int px = q16 * 4 + prow;
       const int oy = it.oy0 + (2 * wave + (px >> 5)) * RPT + (px & 31) / TW;
       const long m = ((long)it.n * p.Ho + oy) * p.Wo + it.ox0 + (px & 31) % TW;
@@ -1518,7 +1522,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvP p, int tile
         ss4[q] += __shfl_xor(ss4[q], 16);
         ss4[q] += __shfl_xor(ss4[q], 32);
       }
-      if (lane < 16) {
+      if (lane < 16 && cok) {
         float* dst = p.stats + (((long)it.n * p.stats_P + (it.ty * tiles_x + it.tx) * 4 + wave) * p.Cout + co) * 2;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1651,7 +1655,7 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
     KEEP_REQUIRE(a->stats_P > 0, "keep_conv2d: stats_out requires stats_P");
   }
   const bool halo_ok = a->mma == KEEP_MMA_BF16 && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 &&
-                       a->pad_l == 1 && (a->Cin % 32 == 0) && (a->Cout % 64 == 0) &&
+                       a->pad_l == 1 && (a->Cin % 32 == 0) && (a->Cout % 32 == 0) &&
                        ((a->Ho % 8 == 0 && a->Wo % 32 == 0) || (a->Ho % 16 == 0 && a->Wo % 16 == 0)) &&
                        a->Ho == (a->upsample ? 2 * a->H : a->H) &&
                        a->Wo == (a->upsample ? 2 * a->W : a->W) &&
@@ -1681,8 +1685,10 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
     if (p.split_k > nchunks) p.split_k = nchunks;
     const bool wide = (a->Ho % 8 == 0 && a->Wo % 32 == 0);
     const int tw = wide ? 32 : 16, th = 256 / tw;
-    const int tiles_x = a->Wo / tw, tiles_y = a->Ho / th, ncb = a->Cout / 64;
+    const int tiles_x = a->Wo / tw, tiles_y = a->Ho / th, ncb = (a->Cout + 63) / 64;
     static const int halo_ver = getenv("KEEP_HALO_VER") ? atoi(getenv("KEEP_HALO_VER")) : 3;
+    KEEP_REQUIRE(a->Cout % 64 == 0 || (halo_ver == 3 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE),
+                 "keep_conv2d: Cout %% 64 != 0 on the halo path needs the persistent kernel (no prologue)");
     if (halo_ver == 3 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE) {
       const int n_items = a->N * tiles_x * tiles_y * ncb * p.split_k;
       static int n_cu3 = 0;

@@ -67,29 +67,39 @@ extern "C" int32_t keep_chan_stats(const float* x, float* part, int32_t N, int32
   return KEEP_OK;
 }
 
-// grid (G, N), block 64: reduce P x (C/G) partials in double, write scale/shift for the group's channels.
-__global__ __launch_bounds__(64) void norm_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ scale,
-                                                           float* __restrict__ shift, int HW, int C, int G, int P,
-                                                           float eps) {
-  const int g = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+// grid (G, N), block 256: reduce P x (C/G) partials (float2 loads, fp64 accumulation), write scale/shift for the
+// group's channels.  P is up to 4096 per image with the per-wave partials of the persistent halo kernel.
+__global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ scale,
+                                                            float* __restrict__ shift, int HW, int C, int G, int P,
+                                                            float eps) {
+  __shared__ double red[2][4];
+  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const int cpg = C / G;
   const int total = P * cpg;
+  const float2* base = reinterpret_cast<const float2*>(part) + (long)n * P * C + g * cpg;
   double s = 0.0, ss = 0.0;
-  for (int i = lane; i < total; i += 64) {
+  for (int i = tid; i < total; i += 256) {
     const int pch = i / cpg, cc = i - pch * cpg;
-    const float* src = part + (((long)n * P + pch) * C + g * cpg + cc) * 2;
-    s += (double)src[0];
-    ss += (double)src[1];
+    const float2 v = base[(long)pch * C + cc];
+    s += (double)v.x;
+    ss += (double)v.y;
   }
   s = wave_sum_d(s);
   ss = wave_sum_d(ss);
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = s;
+    red[1][tid >> 6] = ss;
+  }
+  __syncthreads();
+  s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  ss = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   const double cnt = (double)HW * cpg;
   const double mean = s / cnt;
   double var = ss / cnt - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  for (int cc = lane; cc < cpg; cc += 64) {
+  for (int cc = tid; cc < cpg; cc += 256) {
     const int c = g * cpg + cc;
     const float ga = gamma ? gamma[c] : 1.f;
     const float be = beta ? beta[c] : 0.f;
@@ -104,7 +114,7 @@ extern "C" int32_t keep_norm_finalize(const float* part, const float* gamma, con
                                       void* stream) {
   KEEP_REQUIRE(part && scale && shift && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && P > 0,
                "keep_norm_finalize: bad args (C=%d G=%d)", C, G);
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3(G, N), dim3(64), 0, (hipStream_t)stream, part, gamma, beta, scale, shift,
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(G, N), dim3(256), 0, (hipStream_t)stream, part, gamma, beta, scale, shift,
                      HW, C, G, P, eps);
   KEEP_LAUNCH_CHECK("keep_norm_finalize");
   return KEEP_OK;

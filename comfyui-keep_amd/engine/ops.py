@@ -110,7 +110,7 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
         wb = bf16_twin(w)
     in_dtype = L.F32
     halo = (mma == L.MMA_BF16 and not out_bf16 and ksize == 3 and stride == 1 and not down and pad == 1 and Cin % 32 == 0
-            and Cout % 64 == 0 and ((Ho % 8 == 0 and Wo % 32 == 0) or (Ho % 16 == 0 and Wo % 16 == 0))
+            and (Cout % 64 == 0 or (Cout % 32 == 0 and not HALO_V1 and HALO_PRENORM_MINPIX == 0)) and ((Ho % 8 == 0 and Wo % 32 == 0) or (Ho % 16 == 0 and Wo % 16 == 0))
             and ld % 8 == 0 and in_off % 8 == 0)
     if halo and (pro is not None or pro_act != L.PRO_NONE) and N * H * W >= HALO_PRENORM_MINPIX:
         # optional two-pass variant: normalise + activate once per element into a bf16 tensor in front of the halo conv
@@ -132,7 +132,7 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
         if out_bf16:
             split_k = 1
         elif halo:     # 8x32-pixel x 64-channel tiles; split over the 32-channel Cin chunks
-            waves = (M // 256) * (Cout // 64) * 4
+            waves = (M // 256) * ((Cout + 63) // 64) * 4
             split_k = 1 if waves >= _TARGET_WAVES else max(1, min(_TARGET_WAVES // waves, Cin // 64, 16))
         else:
             split_k = pick_split_k(M, Cout, nsteps, mma == L.MMA_BF16)

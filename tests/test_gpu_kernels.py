@@ -331,7 +331,7 @@ def bf16r(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
-@pytest.mark.parametrize("cin,cout,hw,n,k", [(64, 64, 32, 2, 3), (128, 256, 16, 1, 3), (96, 128, 16, 2, 3),
+@pytest.mark.parametrize("cin,cout,hw,n,k", [(64, 64, 32, 2, 3), (128, 256, 16, 1, 3), (96, 128, 16, 2, 3), (96, 96, 32, 2, 3),
                                              (256, 128, 64, 1, 3), (512, 512, 16, 1, 1), (130, 256, 8, 1, 3),
                                              (3, 64, 32, 2, 3), (64, 3, 32, 1, 3)])
 def test_conv_bf16_operands_exact_products(cin, cout, hw, n, k):

@@ -9,9 +9,15 @@ B independent 20-frame 512x512 clips per GPU (config.workload), inputs already r
 weak scaling: every rank runs its own B clips; the only collective is the one-off RCCL broadcast of the packed
 weights (outside the timed region).  value = (N * B * 20 * K) / max-over-ranks wall time.
 
+BASELINE.json quotes the metric on configs[1] ("20-frame pre-aligned 512x512 clip, KEEP model, bf16, 1xMI355X"), so
+the default policy is bf16 (MFMA operands bf16, fp32 accumulate/storage); the fp32 policy -- the one the <=1e-3
+parity tests run on -- is timed in the same invocation and reported under "fp32_parity_policy", together with the
+live max-abs difference between the two policies on frame 0 of the same input.
+
 Also on the JSON line:
-  roofline      dominant kernel (conv_f32<128x128>, the 3x3 implicit-GEMM convolution): algorithmic FLOPs of its
-                launches in one clip-batch / their summed HIP-event durations, vs the fp32 MFMA peak (157.3 TF);
+  roofline      dominant kernel (bf16: conv3x3_halo3_kernel, the LDS-halo 3x3 implicit-GEMM convolution; fp32:
+                conv_f32_kernel<128x128>): algorithmic FLOPs of its launches in one clip-batch / their summed
+                HIP-event durations (events recorded on the launch stream), vs the dense MFMA peak of the operand type;
   cpu_baseline  the CPU oracle (a port of the reference algorithm, PyTorch-CPU fp32) timed on this box's host cores on
                 a bounded sample (one T=2 clip), rank 0 / N=1 only -- a reported baseline, not the target.
 """
@@ -72,17 +78,23 @@ def conv_roofline(net, x):
         d[0] += flops
         d[1] += e0.elapsed_time(e1) * 1e-3
         d[2] += 1
-    key = ('conv_f32<128x128>', False) if net.precision == 'fp32' else ('conv_bf16<128x128>', False)
+    key = ('conv_f32<128x128>', False) if net.precision == 'fp32' else ('conv3x3_halo_bf16', False)
     peak = PEAK_F32_MFMA_TFLOPS if net.precision == 'fp32' else PEAK_BF16_MFMA_TFLOPS
     flops, secs, n = by[key]
     tf = flops / secs / 1e12
+    tot_f = sum(v[0] for v in by.values())
+    tot_s = sum(v[1] for v in by.values())
     detail = {f"{k[0]}{'+splitK' if k[1] else ''}": {"launches": v[2], "gflop": round(v[0] / 1e9, 1),
                                                       "ms": round(v[1] * 1e3, 2),
                                                       "tflops": round(v[0] / v[1] / 1e12, 1)} for k, v in by.items()}
-    return {"bound": "mfma", "kernel": f"conv_{'f32' if net.precision == 'fp32' else 'bf16'}_kernel<2,2,2,2> (128x128 tile)",
+    kname = ("conv_f32_kernel<2,2,2,2> (128x128 tile, f32 MFMA 32x32x2)" if net.precision == 'fp32' else
+             "conv3x3_halo3_kernel (persistent LDS-halo 3x3, 256 px x 64 cout tiles, bf16 MFMA 32x32x16)")
+    return {"bound": "mfma", "kernel": kname,
             "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
             "traffic": None, "launches_per_step": n, "avg_launch_ms": round(secs / n * 1e3, 4),
-            "algorithmic_gflop_per_launch": round(flops / n / 1e9, 2), "all_conv_kernels": detail}
+            "algorithmic_gflop_per_launch": round(flops / n / 1e9, 2),
+            "conv_path_tflops": round(tot_f / tot_s / 1e12, 2), "conv_path_frac": round(tot_f / tot_s / 1e12 / peak, 4),
+            "conv_path_ms": round(tot_s * 1e3, 1), "all_conv_kernels": detail}
 
 
 def cpu_baseline():
@@ -90,7 +102,8 @@ def cpu_baseline():
     import keep_oracle as O
     W = synth.synth_state_dict(seed=0)
     x = synth.synth_clip(T=2, B=1, seed=1234)
-    threads = torch.get_num_threads()
+    threads = max(1, min(int(os.environ.get('KEEP_BENCH_CPU_THREADS', '32')), os.cpu_count() or 1))
+    torch.set_num_threads(threads)      # all 128+ hardware threads is slower than 32 (MIOpen-less CPU convs are memory-bound)
     t0 = time.time()
     O.keep_forward(x, W)
     dt = time.time() - t0
@@ -104,10 +117,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--clips', type=int, default=int(os.environ.get('KEEP_BENCH_CLIPS', '2')),
+    ap.add_argument('--clips', type=int, default=int(os.environ.get('KEEP_BENCH_CLIPS', '8')),
                     help='independent T=20 clips per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', default=os.environ.get('KEEP_BENCH_PRECISION', 'fp32'), choices=['fp32', 'bf16'],
+    ap.add_argument('--no-second-policy', action='store_true', help='skip timing the other precision policy')
+    ap.add_argument('--precision', default=os.environ.get('KEEP_BENCH_PRECISION', 'bf16'), choices=['fp32', 'bf16'],
                     help="MFMA operand policy: fp32 (parity <= 1e-3) or bf16 (conv/linear operands bf16, fp32 accumulate)")
     args = ap.parse_args()
 
@@ -125,19 +139,23 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        net(x)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = net(x)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
-    assert torch.isfinite(out).all()
+    def timed(xb, warmup, steps):
+        for _ in range(warmup):
+            net(xb)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            o = net(xb)
+        barrier()
+        d = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([d], dtype=torch.float64, device='cuda')
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            d = float(tmax.item())
+        assert torch.isfinite(o).all()
+        return d, o
+
+    dt, out = timed(x, args.warmup, args.steps)
 
     if rank == 0:
         frames = world * B * T_CLIP * args.steps
@@ -152,6 +170,29 @@ def main():
             "whole_net_tflops": round(fps * FLOP_PER_FRAME_T20 / 1e12, 2),
             "roofline": conv_roofline(net, x),
         }
+        if world == 1 and not args.no_second_policy:
+            other = 'fp32' if args.precision == 'bf16' else 'bf16'
+            B2 = min(B, 4)
+            x2 = x[:B2].contiguous()
+            net.set_precision(other)
+            d2, out2 = timed(x2, 1, 2)
+            _, aux2 = net(x2, return_aux=True)
+            net.set_precision(args.precision)
+            _, aux1 = net(x2, return_aux=True)
+            net.set_precision(other)
+            agree0 = float((aux1['indices'][:, 0] == aux2['indices'][:, 0]).float().mean())
+            d0 = (out2[:, 0] - out[:B2, 0]).abs()
+            key = "fp32_parity_policy" if other == 'fp32' else "bf16_policy"
+            line[key] = {"value": round(B2 * T_CLIP * 2 / d2, 3), "unit": "frames/s", "clips_per_gpu": B2,
+                         "ms_per_step": round(d2 / 2 * 1e3, 2), "roofline": conv_roofline(net, x2),
+                         "frame0_code_index_agreement_between_policies": round(agree0, 4),
+                         "frame0_median_abs_pixel_diff_between_policies": round(float(d0.median()), 5),
+                         "note": "fp32 policy = f32 MFMA everywhere, the policy the <=1e-3 parity tests run on.  bf16 operand "
+                                 "rounding flips low-margin code indices (argmax over 1024 logits of a random-weight "
+                                 "transformer), each flip replacing a 16x16-pixel codebook patch, so the policies are compared by "
+                                 "index agreement + median pixel difference on frame 0 (frames >= 1 of synthetic-weight clips "
+                                 "are chaotic: random GMFlow)"}
+            net.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -16,7 +16,7 @@ live max-abs difference between the two policies on frame 0 of the same input.
 
 Also on the JSON line:
   roofline      dominant kernel (bf16: conv3x3_halo3_kernel, the LDS-halo 3x3 implicit-GEMM convolution; fp32:
-                conv_f32_kernel<128x128>): algorithmic FLOPs of its launches in one clip-batch / their summed
+                conv3x3_halo_f32_kernel, the same design on f32 MFMA): algorithmic FLOPs of its launches in one clip-batch / their summed
                 HIP-event durations (events recorded on the launch stream), vs the dense MFMA peak of the operand type;
   cpu_baseline  the CPU oracle (a port of the reference algorithm, PyTorch-CPU fp32) timed on this box's host cores on
                 a bounded sample (one T=2 clip), rank 0 / N=1 only -- a reported baseline, not the target.
@@ -78,7 +78,7 @@ def conv_roofline(net, x):
         d[0] += flops
         d[1] += e0.elapsed_time(e1) * 1e-3
         d[2] += 1
-    key = ('conv_f32<128x128>', False) if net.precision == 'fp32' else ('conv3x3_halo_bf16', False)
+    key = ('conv3x3_halo_f32', False) if net.precision == 'fp32' else ('conv3x3_halo_bf16', False)
     peak = PEAK_F32_MFMA_TFLOPS if net.precision == 'fp32' else PEAK_BF16_MFMA_TFLOPS
     flops, secs, n = by[key]
     tf = flops / secs / 1e12
@@ -87,7 +87,7 @@ def conv_roofline(net, x):
     detail = {f"{k[0]}{'+splitK' if k[1] else ''}": {"launches": v[2], "gflop": round(v[0] / 1e9, 1),
                                                       "ms": round(v[1] * 1e3, 2),
                                                       "tflops": round(v[0] / v[1] / 1e12, 1)} for k, v in by.items()}
-    kname = ("conv_f32_kernel<2,2,2,2> (128x128 tile, f32 MFMA 32x32x2)" if net.precision == 'fp32' else
+    kname = ("conv3x3_halo_f32_kernel (persistent LDS-halo 3x3, 256 px x 64 cout tiles, f32 MFMA 32x32x2)" if net.precision == 'fp32' else
              "conv3x3_halo3_kernel (persistent LDS-halo 3x3, 256 px x 64 cout tiles, bf16 MFMA 32x32x16)")
     return {"bound": "mfma", "kernel": kname,
             "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),

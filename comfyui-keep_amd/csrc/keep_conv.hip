@@ -380,11 +380,11 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
     int buf = 0;
     for (int s = s_begin; s < s_end; ++s) {
       const bool more = (s + 1 < s_end);
-      if (more) fetch(s + 1);
+      if (more && !(p.exp & 1)) fetch(s + 1);
       const float* Ab = As[buf];
       const float* Bb = Bs[buf];
 #pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
+      for (int kk = 0; kk < ((p.exp & 4) ? 0 : BK / 2); ++kk) {
         float af[TM], bf[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[i] = Ab[(kk * 2 + lhi) * LDA + a_frag0 + i * 32];
@@ -396,13 +396,14 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
-      if (more) stage(buf ^ 1);
+      if (more && !(p.exp & 2)) stage(buf ^ 1);
       __syncthreads();
       buf ^= 1;
     }
   }
 
   // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (p.exp & 8) { if (acc[0][0][0] == 123.456f) p.out[0] = 1.f; return; }
   if (p.vec_epi) {
     staged_epilogue<WGM, WGN, TM, TN>(p, acc, smem_f, m0, n0, wm, wn, lane, wave, z);
     return;
@@ -1083,7 +1084,7 @@ struct HaloItem {
   int n, tx, ty, oy0, ox0, n0, z, ch_begin, ch_end;
 };
 
-template <int TW>
+template <int TW, int CSH = 5>
 __device__ __forceinline__ HaloItem halo_decode(const ConvP& p, int item, int items_per_z, int tiles_x, int tiles_y, int ncb) {
   HaloItem it;
   it.z = item / items_per_z;
@@ -1096,7 +1097,7 @@ __device__ __forceinline__ HaloItem halo_decode(const ConvP& p, int item, int it
   it.oy0 = it.ty * (256 / TW);
   it.ox0 = it.tx * TW;
   it.n0 = cb * 64;
-  const int nchunks = p.Cin >> 5;
+  const int nchunks = p.Cin >> CSH;
   const int per = (nchunks + p.split_k - 1) / p.split_k;
   it.ch_begin = it.z * per;
   it.ch_end = min(nchunks, it.ch_begin + per);
@@ -1574,6 +1575,248 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvP p, int tile
   }
 }
 
+// ------------------------------------------------------------------------------------------------ halo f32
+// The fp32-parity policy's 3x3 stride-1 convolution: the persistent halo kernel above with exact-f32 operands
+// (v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD).  The gather kernel (conv_f32_kernel) re-reads the A tile once per tap and
+// measured 72 TF of 157: with the loads ablated it ran 109 TF, with the MFMAs ablated the loads alone took half the
+// kernel time -- the L2->CU operand stream and the matrix pipe took turns instead of overlapping.  Here a block stages
+// the (8+2)x(32+2) (or 18x18) pixel halo of 16 channels ONCE and all 9 taps read it from LDS: 58 KB of operands per
+// 288 MFMAs (18.4 k matrix cycles) per wave, ~3 B/clk/CU, so the matrix pipe is the only busy resource.
+//   LDS rows (one pixel / one (tap, cout) weight row) are 16 floats at a 20-float pitch (80 B = 5 x 16-B slots, odd).
+//   The 32x32x2 MFMA takes k from lanes 0-31 and k+1 from lanes 32-63; WHICH channel plays k at step j is free as long
+//   as A and B agree, so lane-half h uses channel 8h + j at step j: each lane's 8 steps are 8 CONTIGUOUS floats = two
+//   ds_read_b128 per operand row per tap instead of eight ds_read_b32 (the wave issues 8 LDS reads per 32 MFMAs).
+//   GroupNorm affine + activation (exact expf) are applied when the raw fp32 halo registers are written to LDS: ~500
+//   VALU instructions per 16-channel chunk beside 18 k cycles of MFMA, so no separate normalisation pass is needed.
+#define FCSH 4                               // log2(channels per chunk)
+#define FPITCH 20
+
+template <int TW>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(ConvP p, int tiles_x, int tiles_y, int ncb, int n_items) {
+  constexpr int HALO_TH = 256 / TW, HALO_W = TW + 2, HALO_PIX = (HALO_TH + 2) * HALO_W;
+  constexpr int RPT = 32 / TW;
+  constexpr int MAIN_F = HALO_MAXPIX * FPITCH + 9 * 64 * FPITCH;
+  constexpr int EPI_F = 4 * 64 * 68;
+  __shared__ __attribute__((aligned(16))) float lds_f[MAIN_F > EPI_F ? MAIN_F : EPI_F];
+  float* Hs = lds_f;
+  float* Ws = lds_f + HALO_MAXPIX * FPITCH;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int items_per_z = n_items / p.split_k;
+  const int Hv = p.upsample ? 2 * p.H : p.H;
+  const int Wv = p.upsample ? 2 * p.W : p.W;
+  const int g = tid & 3;
+  const bool has_pro = p.pro_scale != nullptr || p.pro_act != KEEP_PRO_NONE;
+
+  int h_off[HALO_IT];
+  long img_off = 0, w_base = 0, sc_off = 0;
+  bool w_ok = true;
+  auto setup = [&](const HaloItem& it) {
+#pragma unroll
+    for (int k = 0; k < HALO_IT; ++k) {
+      const int hp = (tid >> 2) + k * 64;
+      h_off[k] = -1;
+      if (hp < HALO_PIX) {
+        const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+        const int iy = it.oy0 - 1 + hy, ix = it.ox0 - 1 + hx;
+        if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
+          const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+          h_off[k] = (sy * p.W + sx) * p.in_ld + g * 4;
+        }
+      }
+    }
+    img_off = (long)it.n * p.H * p.W * p.in_ld;
+    sc_off = (long)it.n * p.Cin + g * 4;
+    w_ok = (it.n0 + (tid >> 2)) < p.Cout;
+    w_base = w_ok ? ((long)(it.n0 + (tid >> 2)) * 9) * p.Cin + g * 4 : 0;
+  };
+
+  float4 hreg[HALO_IT];
+  float4 wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7, wr8;
+  float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch = [&](int ch) {
+    const int c0 = ch << FCSH;
+#pragma unroll
+    for (int k = 0; k < HALO_IT; ++k) {
+      hreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (h_off[k] >= 0) hreg[k] = *reinterpret_cast<const float4*>(p.in + img_off + h_off[k] + c0);
+    }
+#define KEEP_WLOADF(TAP, R) R = w_ok ? *reinterpret_cast<const float4*>(p.w + w_base + (long)(TAP) * p.Cin + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    KEEP_TAPS(KEEP_WLOADF)
+#undef KEEP_WLOADF
+    if (p.pro_scale) {
+      sc4 = *reinterpret_cast<const float4*>(p.pro_scale + sc_off + c0);
+      sh4 = *reinterpret_cast<const float4*>(p.pro_shift + sc_off + c0);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int k = 0; k < HALO_IT; ++k) {
+      const int hp = (tid >> 2) + k * 64;
+      if (hp < HALO_PIX) {
+        float4 v = hreg[k];
+        if (has_pro && h_off[k] >= 0) {      // zero padding applies to the normalised + activated tensor
+          v.x = pro_apply(v.x * sc4.x + sh4.x, p.pro_act);
+          v.y = pro_apply(v.y * sc4.y + sh4.y, p.pro_act);
+          v.z = pro_apply(v.z * sc4.z + sh4.z, p.pro_act);
+          v.w = pro_apply(v.w * sc4.w + sh4.w, p.pro_act);
+        }
+        *reinterpret_cast<float4*>(&Hs[hp * FPITCH + g * 4]) = v;
+      }
+    }
+#define KEEP_WSTOREF(TAP, R) *reinterpret_cast<float4*>(&Ws[((TAP) * 64 + (tid >> 2)) * FPITCH + g * 4]) = R;
+    KEEP_TAPS(KEEP_WSTOREF)
+#undef KEEP_WSTOREF
+  };
+
+  f32x16 acc[2][2];
+  const int a_base = (((2 * wave) * RPT + l31 / TW) * HALO_W + (l31 % TW)) * FPITCH + lhi * 8;
+  const int b_base = l31 * FPITCH + lhi * 8;
+  // (An explicit register double buffer of the fragments -- tap t+1 read while tap t multiplies, issue order pinned with
+  // sched_group_barrier -- measured the same: the second wave on the SIMD already covers the ds_read latency.)
+  auto mma = [&]() {
+#pragma unroll 1
+    for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        f32x4 af[2][2], bfr[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float* src = &Hs[a_base + ((i * RPT + kh) * HALO_W + kw) * FPITCH];
+          af[i][0] = *reinterpret_cast<const f32x4*>(src);
+          af[i][1] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float* src = &Ws[b_base + ((kh * 3 + kw) * 64 + j * 32) * FPITCH];
+          bfr[j][0] = *reinterpret_cast<const f32x4*>(src);
+          bfr[j][1] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][k2 >> 2][k2 & 3], bfr[j][k2 >> 2][k2 & 3], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  };
+  auto epilogue = [&](const HaloItem& it) {
+    constexpr int EP = 68;
+    float* et = lds_f + wave * 64 * EP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          et[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * EP + j * 32 + l31] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const int c4 = (lane & 15) * 4, prow = lane >> 4;
+    const int co = it.n0 + c4;
+    const bool cok = co < p.Cout;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
+#pragma unroll 4
+    for (int q16 = 0; q16 < 16; ++q16) {
+      if (!cok) break;
+      const int px = q16 * 4 + prow;
+      const int oy = it.oy0 + (2 * wave + (px >> 5)) * RPT + (px & 31) / TW;
+      const long m = ((long)it.n * p.Ho + oy) * p.Wo + it.ox0 + (px & 31) % TW;
+      const float4 v = *reinterpret_cast<const float4*>(et + px * EP + c4);
+      if (p.split_k > 1) {
+        *reinterpret_cast<float4*>(p.ws + ((long)it.z * p.M + m) * p.Cout + co) = v;
+        continue;
+      }
+      float e[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e[q] = act_apply(e[q], p.epi_act);
+      if (p.res) {
+        const float4 r4 = *reinterpret_cast<const float4*>(p.res + m * p.res_ld + co);
+        const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+        if (p.aux) {
+          const float4 a4 = *reinterpret_cast<const float4*>(p.aux + m * (long)p.Cout + co);
+          const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) e[q] = rr[q] + p.aux_w * (rr[q] * aa[q] + e[q]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) e[q] += rr[q];
+        }
+      }
+      *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s4[q] += e[q];
+        ss4[q] += e[q] * e[q];
+      }
+    }
+    if (p.stats) {          // per wave: stats_P = 4 * tiles, partial index = tile*4 + wave
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s4[q] += __shfl_xor(s4[q], 16);
+        s4[q] += __shfl_xor(s4[q], 32);
+        ss4[q] += __shfl_xor(ss4[q], 16);
+        ss4[q] += __shfl_xor(ss4[q], 32);
+      }
+      if (lane < 16 && cok) {
+        float* dst = p.stats + (((long)it.n * p.stats_P + (it.ty * tiles_x + it.tx) * 4 + wave) * p.Cout + co) * 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          dst[q * 2 + 0] = s4[q];
+          dst[q * 2 + 1] = ss4[q];
+        }
+      }
+    }
+  };
+
+  int item = blockIdx.x;
+  if (item >= n_items) return;
+  HaloItem cur = halo_decode<TW, FCSH>(p, item, items_per_z, tiles_x, tiles_y, ncb);
+  setup(cur);
+  if (cur.ch_begin < cur.ch_end) fetch(cur.ch_begin);
+  while (true) {
+    const bool valid = cur.ch_begin < cur.ch_end;
+    if (valid) stage();
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int ch = cur.ch_begin; ch < cur.ch_end; ++ch) {
+      const bool more = ch + 1 < cur.ch_end;
+      if (more && !(p.exp & 2)) fetch(ch + 1);
+      if (!(p.exp & 1)) mma();
+      __syncthreads();
+      if (more) {
+        if (!(p.exp & 8)) stage();
+        __syncthreads();
+      }
+    }
+    const int next_item = item + gridDim.x;
+    const bool has_next = next_item < n_items;
+    HaloItem nxt = cur;
+    if (has_next) {
+      nxt = halo_decode<TW, FCSH>(p, next_item, items_per_z, tiles_x, tiles_y, ncb);
+      setup(nxt);
+      if (nxt.ch_begin < nxt.ch_end) fetch(nxt.ch_begin);     // in flight during the epilogue below
+    }
+    if (!(p.exp & 4) || acc[0][0][0] == 123.456f) epilogue(cur);
+    if (!has_next) break;
+    __syncthreads();
+    item = next_item;
+    cur = nxt;
+  }
+}
+
 __global__ void conv_splitk_reduce_kernel(ConvP p) {
   const long total = (long)p.M * p.Cout;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -1664,6 +1907,16 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
                        (a->out_dtype != KEEP_BF16) && (a->in_ld % 8 == 0) && ((uintptr_t)a->in % 16 == 0) && (a->out_ld % 4 == 0) &&
                        ((uintptr_t)a->out % 16 == 0) && (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&
                        (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0);
+  const bool halo_f32_ok = a->mma != KEEP_MMA_BF16 && a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && a->KH == 3 && a->KW == 3 &&
+                           a->stride == 1 && a->pad_t == 1 && a->pad_l == 1 && (a->Cin % 16 == 0) && (a->Cout % 32 == 0) &&
+                           ((a->Ho % 8 == 0 && a->Wo % 32 == 0) || (a->Ho % 16 == 0 && a->Wo % 16 == 0)) &&
+                           a->Ho == (a->upsample ? 2 * a->H : a->H) && a->Wo == (a->upsample ? 2 * a->W : a->W) &&
+                           (!a->pro_scale || ((uintptr_t)a->pro_scale % 16 == 0 && (uintptr_t)a->pro_shift % 16 == 0)) &&
+                           (a->in_ld % 4 == 0) && ((uintptr_t)a->in % 16 == 0) && ((uintptr_t)a->weight % 16 == 0) &&
+                           (a->out_ld % 4 == 0) && ((uintptr_t)a->out % 16 == 0) &&
+                           (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&
+                           (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0) &&
+                           (!a->workspace || (uintptr_t)a->workspace % 16 == 0) && !getenv("KEEP_NO_HALO_F32");
   if (p.in_bf16 && !halo_ok) {
     keep_set_error("keep_conv2d: bf16 input tensors are only accepted by the 3x3 stride-1 halo path "
                    "(Cin%%32, Cout%%64, Ho%%8, Wo%%32, no prologue)");
@@ -1672,13 +1925,42 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
   if (p.stats) {
     const long hw_o = (long)a->Ho * a->Wo;
     const int hv = getenv("KEEP_HALO_VER") ? atoi(getenv("KEEP_HALO_VER")) : 3;
-    const bool halo_v2 = halo_ok && hv != 1 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE;   // v2/v3: per-wave partials
-    const int bm = halo_ok ? (halo_v2 ? 64 : 256) : ((a->Cout <= 32) ? 128 : ((a->Cout <= 64 || M <= 4096) ? 64 : 128));
+    const bool halo_v2 = halo_f32_ok || (halo_ok && hv != 1 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE);   // per-wave partials
+    const int bm = (halo_ok || halo_f32_ok) ? (halo_v2 ? 64 : 256) : ((a->Cout <= 32) ? 128 : ((a->Cout <= 64 || M <= 4096) ? 64 : 128));
     KEEP_REQUIRE(hw_o % bm == 0 && a->stats_P == hw_o / bm, "keep_conv2d: stats_P=%d must equal Ho*Wo/%d", a->stats_P, bm);
   }
   if (p.out_bf16) {
     KEEP_REQUIRE(p.vec_epi && p.split_k == 1 && !a->residual,
                  "keep_conv2d: bf16 output needs Cout/out_ld %% 4 == 0, aligned pointers, split_k == 1, no residual");
+  }
+  if (halo_f32_ok) {
+    const int nchunks = a->Cin / 16;
+    if (p.split_k > nchunks) p.split_k = nchunks;
+    const bool wide = (a->Ho % 8 == 0 && a->Wo % 32 == 0);
+    const int tw = wide ? 32 : 16, th = 256 / tw;
+    const int tiles_x = a->Wo / tw, tiles_y = a->Ho / th, ncb = (a->Cout + 63) / 64;
+    const int n_items = a->N * tiles_x * tiles_y * ncb * p.split_k;
+    static int n_cuf = 0;
+    if (n_cuf == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cuf = prop.multiProcessorCount;
+      if (n_cuf <= 0) n_cuf = 256;
+    }
+    dim3 gridf(n_items < 2 * n_cuf ? n_items : 2 * n_cuf);
+    if (wide)
+      hipLaunchKernelGGL((conv3x3_halo_f32_kernel<32>), gridf, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);
+    else
+      hipLaunchKernelGGL((conv3x3_halo_f32_kernel<16>), gridf, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);
+    KEEP_LAUNCH_CHECK("keep_conv2d(halo f32)");
+    if (p.split_k > 1) {
+      const long total = M * a->Cout;
+      int blocks = cdiv(total, 256);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+      KEEP_LAUNCH_CHECK("keep_conv2d(split-K reduce)");
+    }
+    return KEEP_OK;
   }
   if (halo_ok) {
     const int nchunks = a->Cin / 32;

@@ -37,6 +37,7 @@ def bf16_twin(w):
     return _BLOB16[off:off + w.numel()]
 
 
+HALO_F32 = os.environ.get('KEEP_NO_HALO_F32') is None     # dev switch: fall back to the gather kernel
 HALO_V1 = os.environ.get('KEEP_HALO_VER', '3') == '1'   # halo kernel generation (3 = persistent, default)
 USE_BK256 = bool(int(os.environ.get('KEEP_BK256', '0')))   # measured slower than BK=64 + split-K at B<=4 (kept for A/B)
 # two-pass normalise+activate -> bf16 in front of the halo conv for inputs of at least this many pixels per launch
@@ -112,6 +113,10 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
     halo = (mma == L.MMA_BF16 and not out_bf16 and ksize == 3 and stride == 1 and not down and pad == 1 and Cin % 32 == 0
             and (Cout % 64 == 0 or (Cout % 32 == 0 and not HALO_V1 and HALO_PRENORM_MINPIX == 0)) and ((Ho % 8 == 0 and Wo % 32 == 0) or (Ho % 16 == 0 and Wo % 16 == 0))
             and ld % 8 == 0 and in_off % 8 == 0)
+    # fp32 policy: persistent LDS-halo kernel on f32 MFMA (16-channel chunks, GroupNorm affine + activation fused in staging)
+    halo_f32 = (mma != L.MMA_BF16 and HALO_F32 and x.dtype == torch.float32 and ksize == 3 and stride == 1 and not down
+                and pad == 1 and Cin % 16 == 0 and Cout % 32 == 0
+                and ((Ho % 8 == 0 and Wo % 32 == 0) or (Ho % 16 == 0 and Wo % 16 == 0)) and ld % 4 == 0 and in_off % 4 == 0)
     if halo and (pro is not None or pro_act != L.PRO_NONE) and N * H * W >= HALO_PRENORM_MINPIX:
         # optional two-pass variant: normalise + activate once per element into a bf16 tensor in front of the halo conv
         # (default: the halo kernel applies the affine + activation itself while staging its fp32 halo)
@@ -131,6 +136,9 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
     if split_k is None:
         if out_bf16:
             split_k = 1
+        elif halo_f32:  # 256-pixel x 64-channel work items on a persistent grid of 2 blocks per CU; split over 16-channel chunks
+            items = (M // 256) * ((Cout + 63) // 64)
+            split_k = 1 if items >= 256 else max(1, min(512 // items, Cin // 32, 16))
         elif halo:     # 8x32-pixel x 64-channel tiles; split over the 32-channel Cin chunks
             waves = (M // 256) * ((Cout + 63) // 64) * 4
             split_k = 1 if waves >= _TARGET_WAVES else max(1, min(_TARGET_WAVES // waves, Cin // 64, 16))
@@ -140,15 +148,15 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
     # per-tile channel statistics of the output for the next GroupNorm / InstanceNorm (epilogue-fused)
     part, stats_P = None, 0
     if stats and split_k == 1:
-        halo_v2 = halo and pro is None and pro_act == L.PRO_NONE and not HALO_V1
-        bm = (64 if halo_v2 else 256) if halo else (128 if Cout <= 32 else (64 if (Cout <= 64 or M <= 4096) else 128))
+        halo_v2 = halo_f32 or (halo and pro is None and pro_act == L.PRO_NONE and not HALO_V1)
+        bm = (64 if halo_v2 else 256) if (halo or halo_f32) else (128 if Cout <= 32 else (64 if (Cout <= 64 or M <= 4096) else 128))
         if (Ho * Wo) % bm == 0 and out.shape[-1] == Cout:
             stats_P = (Ho * Wo) // bm
             part = empty((N, stats_P, Cout, 2), x)
     xin = x if in_off == 0 else x.view(-1)[in_off:]
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        PROFILE.append(('conv3x3_halo_bf16' if halo else 'conv_bf16<64x64,bk256>' if bk256 else
+        PROFILE.append(('conv3x3_halo_f32' if halo_f32 else 'conv3x3_halo_bf16' if halo else 'conv_bf16<64x64,bk256>' if bk256 else
                         tile_config(M, Cout).replace('f32', 'bf16' if mma == L.MMA_BF16 else 'f32'),
                         2.0 * M * Cout * KH * KW * Cin, split_k, e0, e1))
         e0.record()

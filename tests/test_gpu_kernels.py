@@ -57,6 +57,34 @@ def test_conv3x3_plain(cin, cout, hw, n):
     check(nchw(y), F.conv2d(x, w, b, padding=1), what='conv3x3')
 
 
+def test_conv3x3_f32_halo_kernel_vs_gather_kernel(monkeypatch):
+    """fp32 policy: the persistent LDS-halo kernel (default for 3x3 stride-1) against the implicit-GEMM gather kernel
+    and against F.conv2d -- wide (8x32) and square (16x16) tiles, masked half cout-block, fused GN+swish, upsample."""
+    for (n, cin, cout, h, wd, up) in [(2, 64, 64, 64, 64, False), (1, 128, 96, 16, 48, False), (2, 32, 128, 16, 16, True)]:
+        x, w, b = rnd('hfx', (n, cin, h, wd), 2.0) + 0.3, rnd('hfw', (cout, cin, 3, 3), 0.05), rnd('hfb', (cout,))
+        gamma, beta = rnd('hfg', (cin,)) * 0.2 + 1, rnd('hfbt', (cin,)) * 0.2
+        xd = dev(nhwc(x))
+        pro = ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6)
+        kw = dict(pro=pro, pro_act=L.PRO_SWISH, upsample=up, stats=True, split_k=1)
+        y = ops.conv(xd, pack(w), dev(b), **kw)
+        assert hasattr(y, '_keep_stats') and y._keep_stats[1] == (y.shape[1] * y.shape[2]) // 64
+        monkeypatch.setattr(ops, 'HALO_F32', False)
+        monkeypatch.setenv('KEEP_NO_HALO_F32', '1')
+        y_g = ops.conv(xd, pack(w), dev(b), **kw)
+        monkeypatch.setattr(ops, 'HALO_F32', True)
+        monkeypatch.delenv('KEEP_NO_HALO_F32')
+        hn = F.group_norm(x, 32, gamma, beta, eps=1e-6)
+        hn = hn * torch.sigmoid(hn)
+        if up:
+            hn = F.interpolate(hn, scale_factor=2.0, mode='nearest')
+        ref = F.conv2d(hn, w, b, padding=1)
+        check(nchw(y), ref, what='halo f32 vs torch')
+        check(y, y_g, 2e-5, what='halo f32 vs gather kernel')
+        sc, sh = ops.norm_affine(y, None, None, cout, 1e-5)
+        sc2, sh2 = ops.norm_affine(y.clone(), None, None, cout, 1e-5)
+        check(sc, sc2, 1e-5, 'halo f32 fused stats scale'); check(sh, sh2, 1e-5, 'halo f32 fused stats shift')
+
+
 def test_conv3x3_splitk_matches():
     x, w, b = rnd('sx', (1, 512, 16, 16)), rnd('sw', (512, 512, 3, 3), 0.02), rnd('sb', (512,))
     ref = F.conv2d(x, w, b, padding=1)

@@ -59,6 +59,10 @@ def run(name, mma, in_bf16, iters=20):
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(LAYERS)
+    if os.environ.get('F32'):
+        for n in names:
+            run(n, L.MMA_F32, False)
+        sys.exit(0)
     for n in names:
         run(n, L.MMA_BF16, False)
         if LAYERS[n][5] == 3:

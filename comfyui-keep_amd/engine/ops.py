@@ -45,17 +45,16 @@ USE_BK256 = bool(int(os.environ.get('KEEP_BK256', '0')))   # measured slower tha
 HALO_PRENORM_MINPIX = int(os.environ.get('KEEP_HALO_PRENORM_MINPIX', '0'))
 
 # bench.py's roofline leg: when a list, every keep_conv2d launch is bracketed by HIP events on the launch stream
-# and appended as (tile_config, algorithmic_flops, start_event, end_event)
+# and appended as (kernel instantiation, algorithmic_flops, split_k, start_event, end_event)
 PROFILE = None
 
 
-def tile_config(M, Cout):
-    """Name of the kernel instantiation keep_conv.hip selects (keep in sync)."""
-    if Cout <= 32:
-        return 'conv_f32<128x32>'
-    if Cout <= 64 or M <= 4096:
-        return 'conv_f32<64x64>'
-    return 'conv_f32<128x128>'
+def tile_config(M, Cout, bf16=False, bk256=False):
+    """Name of the gather-kernel instantiation keep_conv.hip selects, as rocprofv3 prints it (keep in sync)."""
+    t = '4, 1, 1, 1' if Cout <= 32 else ('2, 2, 1, 1' if (Cout <= 64 or M <= 4096) else '2, 2, 2, 2')
+    if bf16:
+        return f"conv_bf16_kernel<{t}, {'256, 1' if bk256 else '64, 1'}>"
+    return f'conv_f32_kernel<{t}>'
 
 
 def empty(shape, like):
@@ -156,9 +155,11 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
     xin = x if in_off == 0 else x.view(-1)[in_off:]
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        PROFILE.append(('conv3x3_halo_f32' if halo_f32 else 'conv3x3_halo_bf16' if halo else 'conv_bf16<64x64,bk256>' if bk256 else
-                        tile_config(M, Cout).replace('f32', 'bf16' if mma == L.MMA_BF16 else 'f32'),
-                        2.0 * M * Cout * KH * KW * Cin, split_k, e0, e1))
+        tw = 32 if (Ho % 8 == 0 and Wo % 32 == 0) else 16
+        kname = (f'conv3x3_halo_f32_kernel<{tw}>' if halo_f32 else
+                 f"conv3x3_halo3_kernel<{'true' if in_dtype == L.BF16 else 'false'}, {tw}>" if halo else
+                 tile_config(M, Cout, mma == L.MMA_BF16, bk256))
+        PROFILE.append((kname, 2.0 * M * Cout * KH * KW * Cin, split_k, e0, e1))
         e0.record()
     L.conv2d(inp=xin, weight=w, bias=bias, out=out, pro_scale=None if pro is None else pro[0],
              pro_shift=None if pro is None else pro[1], residual=residual, aux=aux, workspace=ws,

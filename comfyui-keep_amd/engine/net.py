@@ -523,3 +523,34 @@ class KeepNet:
                 for k, n in enumerate(grp):
                     outs[n] = res[k:k + 1]
         return outs
+
+    # ------------------------------------------------------------------ device-side pre/post
+    def run_clips_u8(self, clips_u8):
+        """list of uint8 BGR crops [T_i,H,W,3] (host or device) -> list of restored uint8 BGR [T_i,H,W,3] on the host.
+
+        Replaces the per-frame host conversions either side of the clip loop -- ``img2tensor(face/255., bgr2rgb) +
+        normalize(0.5, 0.5)`` (keep_processor.py:258-259) and ``tensor2img(rgb2bgr, min_max=(-1,1))``
+        (keep_processor.py:272-273, img_util.py:66-90) -- with ``keep_img2tensor`` / ``keep_tensor2img`` on the GPU, so
+        only uint8 crosses PCIe (4x fewer bytes each way).  Bit-identical to the host converters."""
+        if self.w is None:
+            raise RuntimeError("KeepNet: weights are not on a device (load_state_dict + .to('cuda') first)")
+        clips = []
+        with torch.cuda.device(self.device):
+            for c in clips_u8:
+                if c.dim() != 4 or c.shape[-1] != 3 or c.dtype != torch.uint8:
+                    raise ValueError(f"expected uint8 [T,H,W,3], got {c.dtype} {tuple(c.shape)}")
+                u8 = c.to(self.device, non_blocking=True).contiguous()
+                T, H, Wd, _ = u8.shape
+                f = torch.empty((T, H, Wd, 3), dtype=torch.float32, device=self.device)
+                L.call('keep_img2tensor', u8, f, T * H * Wd)
+                clips.append(ops.nhwc_to_nchw(f).unsqueeze(0))
+            outs = self.run_clips(clips)
+            res = []
+            for o in outs:
+                _, T, _, H, Wd = o.shape
+                y = ops.nchw_to_nhwc(o.view(T, 3, H, Wd))
+                u8 = torch.empty((T, H, Wd, 3), dtype=torch.uint8, device=self.device)
+                L.call('keep_tensor2img', y, u8, T * H * Wd)
+                res.append(u8)
+            return [r.cpu() for r in res]
+

@@ -95,6 +95,31 @@ class KEEPFaceProcessor:
             kept.append(o[:, 0:1] if e - s == 1 else o)
         return torch.cat(kept, dim=1).squeeze(0)
 
+    def _restore_crops_u8(self, crops, max_clip_length):
+        """list of uint8 BGR [512,512,3] crops -> list of restored uint8 BGR crops (same order).
+
+        Same chunking as ``_restore_clips`` (keep_processor.py:263-270); when the net offers ``run_clips_u8`` the
+        uint8<->fp32 conversions of keep_processor.py:258-259,272-273 run on the GPU and only uint8 crosses PCIe,
+        otherwise the host converters are used (reference behaviour)."""
+        run_u8 = getattr(self.keep_net, 'run_clips_u8', None)
+        if run_u8 is None:
+            x = crops_to_net_input(crops).unsqueeze(0).to(self.device)
+            return [net_output_to_bgr_u8(f) for f in self._restore_clips(x, max_clip_length)]
+        arr = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(c) for c in crops], axis=0)))
+        spans = split_clips(arr.shape[0], max_clip_length)
+        clips = []
+        for s, e in spans:
+            clip = arr[s:e]
+            if e - s == 1:                               # net needs T>=2 in the reference (KP:173-178)
+                clip = torch.cat([clip, clip], dim=0)
+            clips.append(clip)
+        outs = run_u8(clips)
+        faces = []
+        for (s, e), o in zip(spans, outs):
+            o = o.numpy()
+            faces.extend(o[k] for k in range(e - s))
+        return [np.ascontiguousarray(f) for f in faces]
+
     def _run_upscaler(self, model, cv2_image):
         if model is None:
             return cv2_image
@@ -132,10 +157,8 @@ class KEEPFaceProcessor:
             if not crops:
                 return bg_img_final
 
-        x = crops_to_net_input(crops).unsqueeze(0).to(self.device)
         # one face -> T=2 duplicate, keep frame 0; several faces -> one "clip" of T=#faces (KP:173-178)
-        restored = self._restore_clips(x, max_clip_length=max(x.shape[1], 1))
-        faces = [net_output_to_bgr_u8(f) for f in restored]
+        faces = self._restore_crops_u8(crops, max_clip_length=max(len(crops), 1))
         self.last_restored_faces = faces
         helper.restored_faces = [f.astype('uint8') for f in faces]
 
@@ -205,10 +228,7 @@ class KEEPFaceProcessor:
         # -- 3. restore: the hot path
         restored_faces = []
         if crops:
-            x = crops_to_net_input(crops).unsqueeze(0).to(self.device)
-            restored = self._restore_clips(x, max_clip_length)
-            restored_faces = [net_output_to_bgr_u8(f) for f in restored]
-            del x, restored
+            restored_faces = self._restore_crops_u8(crops, max_clip_length)
         self.last_restored_faces = restored_faces
         pbar.update(n_frames)
 

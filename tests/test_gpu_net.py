@@ -203,6 +203,36 @@ def test_processor_runs_on_engine(gpu_net):
     assert np.array_equal(out, U.net_output_to_bgr_u8(ref[0]))
 
 
+def test_processor_device_side_u8_path_equals_host_converters(gpu_net):
+    """crops go to the GPU as uint8 and come back as uint8 (keep_img2tensor / keep_tensor2img either side
+    of the clip loop); the result must be bit-identical to the reference's host converters around the same net, for a
+    ragged chunking (3 crops, max_clip_length 2 -> clips of T=2 and T=1 -> duplicated)."""
+    import test_host_logic as H   # installs the ComfyUI stubs
+    from comfyui_keep_amd.modules.keep_processor import KEEPFaceProcessor
+    from comfyui_keep_amd.modules.keep_model_loader import KEEPModelPack
+    from comfyui_keep_amd.modules import utils as U
+    pack = KEEPModelPack(gpu_net, H._Helper(), None, None, 'KEEP')
+    pack.device = torch.device('cuda')
+    proc = KEEPFaceProcessor(pack)
+    base = synth.ramp_image()
+    crops = [np.ascontiguousarray(np.roll(base, 17 * k, axis=1)) for k in range(3)]
+    dev_faces = proc._restore_crops_u8(crops, 2)
+
+    class HostOnly:                      # same net, without the device-side converters
+        def __init__(self, net):
+            self.net = net
+
+        def run_clips(self, clips, need_upscale=False):
+            return self.net.run_clips(clips, need_upscale=need_upscale)
+
+    proc.keep_net = HostOnly(gpu_net)
+    host_faces = proc._restore_crops_u8(crops, 2)
+    assert len(dev_faces) == len(host_faces) == 3
+    for a, b in zip(dev_faces, host_faces):
+        assert a.shape == (512, 512, 3) and a.dtype == np.uint8
+        assert np.array_equal(a, b)
+
+
 def test_bf16_policy_quality_report(gpu_net):
     """bf16-MFMA policy (conv / linear operands rounded to bf16, fp32 accumulate and storage): measured against the
     reference golden -- index agreement and max-abs pixel error with the reference indices injected.  Code indices

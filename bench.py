@@ -75,23 +75,35 @@ def conv_roofline(net, x):
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
     by = {}
-    for cfg, flops, split_k, e0, e1 in rec:
-        d = by.setdefault(cfg, [0.0, 0.0, 0])
+    for cfg, flops, split_k, e0, e1, nbytes in rec:
+        d = by.setdefault(cfg, [0.0, 0.0, 0, 0.0])
         d[0] += flops
         d[1] += e0.elapsed_time(e1) * 1e-3          # split-K launches include their reduce kernel
         d[2] += 1
+        d[3] += nbytes
     key = max(by, key=lambda k: by[k][1])
     peak = PEAK_F32_MFMA_TFLOPS if net.precision == 'fp32' else PEAK_BF16_MFMA_TFLOPS
-    flops, secs, n = by[key]
+    flops, secs, n, nbytes = by[key]
     tf = flops / secs / 1e12
+    # HBM bytes per launch of this kernel from the committed PMC passes of the same step (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE cannot run inside this process): only reported when policy, clips per GPU and kernel match
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))[net.precision]
+        if pmc['clips_per_gpu'] == x.shape[0] and key in pmc['kernels']:
+            traffic = pmc['kernels'][key]['hbm_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        pass
     tot_f = sum(v[0] for v in by.values())
     tot_s = sum(v[1] for v in by.values())
     detail = {k: {"launches": v[2], "gflop": round(v[0] / 1e9, 1), "ms": round(v[1] * 1e3, 2),
-                  "tflops": round(v[0] / v[1] / 1e12, 1)} for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
+                  "tflops": round(v[0] / v[1] / 1e12, 1), "algorithmic_gb_per_s": round(v[3] / v[1] / 1e9, 1)}
+              for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
     return {"bound": "mfma", "kernel": key,
             "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-            "traffic": None, "launches_per_step": n, "avg_launch_ms": round(secs / n * 1e3, 4),
-            "algorithmic_gflop_per_launch": round(flops / n / 1e9, 2),
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+            "algorithmic_bytes_per_launch": round(nbytes / n), "launches_per_step": n,
+            "avg_launch_ms": round(secs / n * 1e3, 4), "algorithmic_gflop_per_launch": round(flops / n / 1e9, 2),
             "conv_path_tflops": round(tot_f / tot_s / 1e12, 2), "conv_path_frac": round(tot_f / tot_s / 1e12 / peak, 4),
             "conv_path_ms": round(tot_s * 1e3, 1), "all_conv_kernels": detail}
 

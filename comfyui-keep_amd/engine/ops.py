@@ -45,7 +45,7 @@ USE_BK256 = bool(int(os.environ.get('KEEP_BK256', '0')))   # measured slower tha
 HALO_PRENORM_MINPIX = int(os.environ.get('KEEP_HALO_PRENORM_MINPIX', '0'))
 
 # bench.py's roofline leg: when a list, every keep_conv2d launch is bracketed by HIP events on the launch stream
-# and appended as (kernel instantiation, algorithmic_flops, split_k, start_event, end_event)
+# and appended as (kernel instantiation, algorithmic_flops, split_k, start_event, end_event, algorithmic_bytes)
 PROFILE = None
 
 
@@ -159,7 +159,10 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
         kname = (f'conv3x3_halo_f32_kernel<{tw}>' if halo_f32 else
                  f"conv3x3_halo3_kernel<{'true' if in_dtype == L.BF16 else 'false'}, {tw}>" if halo else
                  tile_config(M, Cout, mma == L.MMA_BF16, bk256))
-        PROFILE.append((kname, 2.0 * M * Cout * KH * KW * Cin, split_k, e0, e1))
+        # algorithmic bytes: one read of the input window at its storage type, the weights, one write of the output
+        alg_bytes = (N * H * W * Cin * x.element_size() + Cout * KH * KW * Cin * (2 if mma == L.MMA_BF16 else 4)
+                     + M * Cout * out.element_size() + (0 if residual is None else M * Cout * 4))
+        PROFILE.append((kname, 2.0 * M * Cout * KH * KW * Cin, split_k, e0, e1, alg_bytes))
         e0.record()
     L.conv2d(inp=xin, weight=w, bias=bias, out=out, pro_scale=None if pro is None else pro[0],
              pro_shift=None if pro is None else pro[1], residual=residual, aux=aux, workspace=ws,

@@ -50,7 +50,7 @@ def run(name, mma, in_bf16, iters=20):
         y = ops.conv(x, w, b, **kw)
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
-    ms = sum(e0.elapsed_time(e1) for *_, e0, e1 in rec) / len(rec)
+    ms = sum(r[3].elapsed_time(r[4]) for r in rec) / len(rec)
     fl = rec[0][1]
     print(f"{name:10s} mma={'bf16' if mma else 'f32 '} pre-activated-bf16-input={in_bf16!s:5s} kernel={rec[0][0]:22s} "
           f"{ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s (incl. the norm_act pass when present)")

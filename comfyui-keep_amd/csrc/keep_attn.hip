@@ -30,6 +30,7 @@ struct AttnP {
   int mode, T, seg_len;
   int img_h, img_w, ksplit, shift, kv_rot, n_img;
   int nslices;  // dv slices per head
+  int exp;      // dev-only ablation switch (KEEP_ATTN_EXP), 0 in production
 };
 
 // window-mode: token t of window-batch bw -> (image, pixel index)
@@ -131,7 +132,7 @@ __device__ __forceinline__ void load_tile_direct(const AttnP& p, const float* ba
 // With a single chunk (D <= 128) and 4 waves, the NEXT key tile's K and V are prefetched into registers while the
 // current tile is on the matrix cores.
 template <int WAVES, int DVT>
-__global__ __launch_bounds__(64 * WAVES) void attn_f32_kernel(AttnP p) {
+__global__ __launch_bounds__(64 * WAVES, 2) void attn_f32_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int DVS = DVT * 32;    // dv slice handled by this block
   constexpr int NT = 64 * WAVES;
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(256) void attn_bf16in_kernel(AttnP p) {
       if (kt + 1 < ntiles) {
         fill_tables(kt + 1);
       }
-      for (int d = 0; d < DC; d += 16) {
+      for (int d = 0; d < ((p.exp & 1) ? 0 : DC); d += 16) {
         const abf16x8 qf = *reinterpret_cast<const abf16x8*>(qp + d);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -679,8 +680,10 @@ __global__ __launch_bounds__(256) void attn_bf16in_kernel(AttnP p) {
       }
       if (kt + 1 < ntiles) {
         __syncthreads();                 // tables of tile kt+1 visible
-        k_issue(0);                      // next tile's loads fly during softmax + PV
-        v_issue();
+        if (!(p.exp & 8)) {
+          k_issue(0);                    // next tile's loads fly during softmax + PV
+          v_issue();
+        }
       }
     } else {
       for (int ch = 0; ch < nch; ++ch) {
@@ -710,6 +713,7 @@ __global__ __launch_bounds__(256) void attn_bf16in_kernel(AttnP p) {
     }
 
     float mloc = -INFINITY;
+    if (!(p.exp & 2)) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -744,8 +748,9 @@ __global__ __launch_bounds__(256) void attn_bf16in_kernel(AttnP p) {
 #pragma unroll
       for (int j = 0; j < DVT; ++j) o[j][r] *= ar;
     }
+    }
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
+    for (int st = 0; st < ((p.exp & 4) ? 0 : 4); ++st) {
       abf16x8 pa;
 #pragma unroll
       for (int j = 0; j < 8; ++j) pa[j] = (__bf16)s[st >> 1][(st & 1) * 8 + j];
@@ -758,8 +763,8 @@ __global__ __launch_bounds__(256) void attn_bf16in_kernel(AttnP p) {
     }
     if (prefetch && kt + 1 < ntiles) {
       __syncthreads();                   // every wave is done reading K / V^T of tile kt
-      k_commit();
-      v_commit();
+      if (!(p.exp & 16)) k_commit();
+      if (!(p.exp & 32)) v_commit();
     }
   }
 
@@ -830,6 +835,7 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
   p.scale = a->scale; p.mode = a->mode; p.T = a->T; p.seg_len = a->seg_len;
   p.img_h = a->img_h; p.img_w = a->img_w; p.ksplit = a->ksplit; p.shift = a->shift; p.kv_rot = a->kv_rot;
   p.n_img = a->n_img;
+  { const char* e = getenv("KEEP_ATTN_EXP"); p.exp = e ? atoi(e) : 0; }
   hipStream_t st = (hipStream_t)stream;
   // dv slice per block: 32 / 64 / 128 columns
   const int dvt = a->Dv <= 32 ? 1 : (a->Dv <= 64 ? 2 : 4);

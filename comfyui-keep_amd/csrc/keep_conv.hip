@@ -46,6 +46,7 @@ struct ConvP {
   int out_bf16; // write the output tensor as bf16 (gather kernels' staged epilogue only)
   int vec_epi;  // Cout/out_ld/res_ld %% 4 == 0 and aligned pointers -> LDS-staged float4 epilogue
   int exp;      // dev-only ablation switch (KEEP_HALO_EXP), 0 in production
+  int stagger;  // persistent halo kernels: spread of the per-block start delay, in shader cycles (0 = none)
   int flatk;    // Cin < 8: K = KH*KW*Cin flattened (element-wise gather) instead of tap-major chunks
 };
 
@@ -1080,6 +1081,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles
 //     and the per-block launch / geometry cost is paid once per CU instead of once per tile.
 //   * normalisation partial sums are per consumer wave (stats_P = 4 x tiles): no cross-wave reduction, no barrier
 //     that the producers would have to join.
+// Blocks of a persistent launch start together and do identical work, so they reach their epilogues together: the output
+// stores of the whole GPU arrive as one burst while every matrix pipe idles, then everybody computes again.  A
+// per-block start delay (golden-ratio sequence over blockIdx, uniform in [0, spread)) de-phases the blocks.
+__device__ __forceinline__ void halo_stagger(int spread) {
+  if (spread <= 0) return;
+  const float ph = (float)blockIdx.x * 0.6180339887f;
+  const long wait = (long)((ph - floorf(ph)) * (float)spread);
+  const long t0 = __builtin_readcyclecounter();
+  while ((long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+}
+
 struct HaloItem {
   int n, tx, ty, oy0, ox0, n0, z, ch_begin, ch_end;
 };
@@ -1401,7 +1413,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvP p, int tile
     for (int k = 0; k < HALO_IT; ++k) {
       if (IN_BF16) {
         hreg[k] = make_uint4(0u, 0u, 0u, 0u);
-        if (h_off[k] >= 0)
+        if (h_off[k] >= 0 && !(p.exp & 32))
           hreg[k] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.in) + img_off + h_off[k] + c0);
       } else {
         hlo[IN_BF16 ? 0 : k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1413,7 +1425,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvP p, int tile
         }
       }
     }
-#define KEEP_WLOAD(TAP, R) R = w_ok ? *reinterpret_cast<const uint4*>(p.wb + w_base + (long)(TAP) * p.Cin + c0) : make_uint4(0u, 0u, 0u, 0u);
+#define KEEP_WLOAD(TAP, R) R = (w_ok && !(p.exp & 16)) ? *reinterpret_cast<const uint4*>(p.wb + w_base + (long)(TAP) * p.Cin + c0) : make_uint4(0u, 0u, 0u, 0u);
     KEEP_TAPS(KEEP_WLOAD)
 #undef KEEP_WLOAD
   };
@@ -1536,6 +1548,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvP p, int tile
 
   int item = blockIdx.x;
   if (item >= n_items) return;
+  halo_stagger(p.stagger);
   HaloItem cur = halo_decode<TW>(p, item, items_per_z, tiles_x, tiles_y, ncb);
   setup(cur);
   if (cur.ch_begin < cur.ch_end) fetch(cur.ch_begin);
@@ -1551,11 +1564,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvP p, int tile
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     for (int ch = cur.ch_begin; ch < cur.ch_end; ++ch) {
       const bool more = ch + 1 < cur.ch_end;
-      if (more) fetch(ch + 1);
-      mma();
+      if (more && !(p.exp & 2)) fetch(ch + 1);
+      if (!(p.exp & 1)) mma();
       __syncthreads();
       if (more) {
-        stage();
+        if (!(p.exp & 8)) stage();
         __syncthreads();
       }
     }
@@ -1567,7 +1580,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvP p, int tile
       setup(nxt);
       if (nxt.ch_begin < nxt.ch_end) fetch(nxt.ch_begin);     // in flight during the epilogue below
     }
-    epilogue(cur);
+    if (!(p.exp & 4) || acc[0][0][0] == 123.456f) epilogue(cur);
     if (!has_next) break;
     __syncthreads();                                            // every wave is done with its staged tile
     item = next_item;
@@ -1817,6 +1830,82 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(ConvP p, int t
   }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3, Cout <= 4
+// The generator's output convolution (64 -> 3 channels at 512x512, VQ:241): on a 32-wide MFMA tile 29 of 32 output
+// columns are padding (the 128x32 gather tile measured 6.7 TF, 1 ms per 8 frames).  With <= 4 output channels the op
+// is 9*Cin FMAs per pixel per channel -- plain fp32 VALU work on an LDS halo: one thread per output pixel, 8x32-pixel
+// tile per block, 16-channel chunks of the (8+2)x(32+2) halo staged once (GroupNorm affine + activation applied
+// while staging), weights read through the scalar cache (uniform addresses), exact fp32 in both precision policies.
+#define SC_TH 8
+#define SC_TW 32
+#define SC_CH 16
+#define SC_PITCH 20
+
+__global__ __launch_bounds__(256) void conv3x3_cout4_kernel(ConvP p) {
+  constexpr int HW_ = SC_TW + 2, HPIX = (SC_TH + 2) * HW_;
+  __shared__ __attribute__((aligned(16))) float Hs[HPIX * SC_PITCH];
+  const int tid = threadIdx.x;
+  const int tiles_x = p.Wo / SC_TW;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, n = blockIdx.y;
+  const int oy0 = ty * SC_TH, ox0 = tx * SC_TW;
+  const int py = tid >> 5, px = tid & 31;
+  const int g = tid & 3;
+  const float* in = p.in + (long)n * p.H * p.W * p.in_ld;
+  const bool has_pro = p.pro_scale != nullptr || p.pro_act != KEEP_PRO_NONE;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < p.Cin; c0 += SC_CH) {
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.pro_scale) {
+      sc4 = *reinterpret_cast<const float4*>(p.pro_scale + (long)n * p.Cin + c0 + g * 4);
+      sh4 = *reinterpret_cast<const float4*>(p.pro_shift + (long)n * p.Cin + c0 + g * 4);
+    }
+    __syncthreads();                                  // previous chunk fully consumed
+    for (int hp = tid >> 2; hp < HPIX; hp += 64) {
+      const int hy = hp / HW_, hx = hp - hy * HW_;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+        v = *reinterpret_cast<const float4*>(in + ((long)iy * p.W + ix) * p.in_ld + c0 + g * 4);
+        if (has_pro) {                                // zero padding applies to the normalised tensor
+          v.x = pro_apply(v.x * sc4.x + sh4.x, p.pro_act);
+          v.y = pro_apply(v.y * sc4.y + sh4.y, p.pro_act);
+          v.z = pro_apply(v.z * sc4.z + sh4.z, p.pro_act);
+          v.w = pro_apply(v.w * sc4.w + sh4.w, p.pro_act);
+        }
+      }
+      *reinterpret_cast<float4*>(&Hs[hp * SC_PITCH + g * 4]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const float* hrow = &Hs[((py + kh) * HW_ + px + kw) * SC_PITCH];
+      float x[SC_CH];
+#pragma unroll
+      for (int q = 0; q < SC_CH / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(hrow + q * 4);
+        x[q * 4 + 0] = v.x; x[q * 4 + 1] = v.y; x[q * 4 + 2] = v.z; x[q * 4 + 3] = v.w;
+      }
+#pragma unroll
+      for (int co = 0; co < 4; ++co) {
+        if (co < p.Cout) {                            // uniform branch; weight addresses are uniform -> scalar loads
+          const float* wrow = p.w + ((long)co * 9 + tap) * p.Cin + c0;
+#pragma unroll
+          for (int c = 0; c < SC_CH; ++c) acc[co] = fmaf(x[c], wrow[c], acc[co]);
+        }
+      }
+    }
+  }
+  const long m = ((long)n * p.Ho + oy0 + py) * p.Wo + ox0 + px;
+#pragma unroll
+  for (int co = 0; co < 4; ++co) {
+    if (co < p.Cout) {
+      float v = acc[co] + (p.bias ? p.bias[co] : 0.f);
+      p.out[m * p.out_ld + co] = act_apply(v, p.epi_act);
+    }
+  }
+}
+
 __global__ void conv_splitk_reduce_kernel(ConvP p) {
   const long total = (long)p.M * p.Cout;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -1890,6 +1979,7 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
                (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0) &&
                (!a->workspace || (uintptr_t)a->workspace % 16 == 0)) ? 1 : 0;
   { const char* e = getenv("KEEP_HALO_EXP"); p.exp = e ? atoi(e) : 0; }
+  { const char* e = getenv("KEEP_HALO_STAGGER"); p.stagger = e ? atoi(e) : 0; }
   p.flatk = (a->mma == KEEP_MMA_BF16 && a->Cin < 8 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE) ? 1 : 0;
   p.stats = a->stats_out;
   p.stats_P = a->stats_P;
@@ -1907,6 +1997,18 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
                        (a->out_dtype != KEEP_BF16) && (a->in_ld % 8 == 0) && ((uintptr_t)a->in % 16 == 0) && (a->out_ld % 4 == 0) &&
                        ((uintptr_t)a->out % 16 == 0) && (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&
                        (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0);
+  // <= 4 output channels: VALU kernel (both precision policies compute it in exact fp32)
+  if (a->Cout <= 4 && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 && a->pad_l == 1 && !a->upsample &&
+      a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && a->Cin % SC_CH == 0 && a->in_ld % 4 == 0 &&
+      (uintptr_t)a->in % 16 == 0 && a->Ho == a->H && a->Wo == a->W && a->Ho % SC_TH == 0 && a->Wo % SC_TW == 0 &&
+      !a->residual && !a->aux && !a->stats_out && p.split_k == 1 &&
+      (!a->pro_scale || ((uintptr_t)a->pro_scale % 16 == 0 && (uintptr_t)a->pro_shift % 16 == 0)) &&
+      !getenv("KEEP_NO_COUT4")) {
+    dim3 grid((a->Ho / SC_TH) * (a->Wo / SC_TW), a->N);
+    hipLaunchKernelGGL(conv3x3_cout4_kernel, grid, block, 0, st, p);
+    KEEP_LAUNCH_CHECK("keep_conv2d(cout<=4)");
+    return KEEP_OK;
+  }
   const bool halo_f32_ok = a->mma != KEEP_MMA_BF16 && a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && a->KH == 3 && a->KW == 3 &&
                            a->stride == 1 && a->pad_t == 1 && a->pad_l == 1 && (a->Cin % 16 == 0) && (a->Cout % 32 == 0) &&
                            ((a->Ho % 8 == 0 && a->Wo % 32 == 0) || (a->Ho % 16 == 0 && a->Wo % 16 == 0)) &&

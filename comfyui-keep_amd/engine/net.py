@@ -367,12 +367,12 @@ class KeepNet:
         m2 = ops.linear(hmid, w[f'{p}.mlp.2.weight'])
         return ops.layernorm(m2, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], res=src)
 
-    def _gmflow(self, im1, im2):
-        """im1, im2 [P,3,H,W] NCHW in [-1,1] -> backward flow [P,H,W,2] (channels-last: (dx, dy))."""
+    def _gm_backbone(self, img_nchw):
+        """GMFlow CNN encoder (GM/backbone.py) on [N,3,H,W] frames in [-1,1] -> 1/8-resolution features [N,h8,w8,C].
+        Per-image arithmetic only (InstanceNorm, convolutions), so a frame's features do not depend on its pair."""
         w = self.w
         pfx = 'flownet.model'
-        P, _, H, Wd = im1.shape
-        img = ops.nchw_to_nhwc(torch.cat([im1, im2], dim=0), mode=1)                      # [2P,H,W,3] normalised
+        img = ops.nchw_to_nhwc(img_nchw, mode=1)                                           # [N,H,W,3] normalised
         f = ops.conv(img, w[f'{pfx}.backbone.conv1.weight'], None, stride=2, pad=3, ksize=7, stats=True)
         s, hh = self._inorm(f)
         x = torch.empty_like(f)
@@ -380,7 +380,29 @@ class KeepNet:
         for li, stride in ((1, 1), (2, 2), (3, 2)):
             x = self._gm_resblock(x, f'{pfx}.backbone.layer{li}.0', stride)
             x = self._gm_resblock(x, f'{pfx}.backbone.layer{li}.1', 1)
-        feat = ops.linear(x, w[f'{pfx}.backbone.conv2.weight'], w[f'{pfx}.backbone.conv2.bias'])   # [2P,h8,w8,C]
+        return ops.linear(x, w[f'{pfx}.backbone.conv2.weight'], w[f'{pfx}.backbone.conv2.bias'])
+
+    def _gmflow(self, im1, im2):
+        """im1, im2 [P,3,H,W] NCHW in [-1,1] -> backward flow [P,H,W,2] (channels-last: (dx, dy))."""
+        P = im1.shape[0]
+        return self._gmflow_pairs(self._gm_backbone(torch.cat([im1, im2], dim=0)), P)
+
+    def _gmflow_clip(self, x):
+        """K1 for a batch of clips x [B,T,3,H,W]: flownet(x[:,1:], x[:,:-1]) (KA:976-986) -> [B*(T-1),H,W,2].
+        The reference pushes every interior frame through the CNN encoder twice (once as the first image of pair t,
+        once as the second image of pair t+1); here the encoder runs once per frame and the pair batch
+        [x[:,1:] ; x[:,:-1]] is assembled from the B*T feature maps (same values, 47 % less encoder work at T=20)."""
+        B, T = x.shape[:2]
+        feat = self._gm_backbone(x.reshape(B * T, *x.shape[2:]))
+        first = [b * T + t + 1 for b in range(B) for t in range(T - 1)]
+        second = [b * T + t for b in range(B) for t in range(T - 1)]
+        idx = torch.tensor(first + second, device=feat.device, dtype=torch.long)
+        return self._gmflow_pairs(feat.index_select(0, idx), B * (T - 1))
+
+    def _gmflow_pairs(self, feat, P):
+        """feat [2P,h8,w8,C]: features of the P first images followed by the P second images -> flow [P,H,W,2]."""
+        w = self.w
+        pfx = 'flownet.model'
         n_img, h8, w8, C = feat.shape
         Ltok = h8 * w8
         table, grid = self._gm_consts(h8, w8, feat.device)
@@ -449,7 +471,7 @@ class KeepNet:
         if force_flows is not None:      # parity tests: inject the oracle's flows [B,T-1,2,H,W] (isolates GMFlow drift)
             flows = force_flows.to(device=self.device, dtype=torch.float32).permute(0, 1, 3, 4, 2).contiguous()
         elif T > 1:
-            flows = self._gmflow(x[:, 1:].reshape(-1, 3, H, Wd), x[:, :-1].reshape(-1, 3, H, Wd))
+            flows = self._gmflow_clip(x)
             flows = flows.view(B, T - 1, H, Wd, 2)
         # K2: LQ encoder over all B*T frames, stash CFT taps
         xn = ops.nchw_to_nhwc(x.view(B * T, 3, H, Wd))

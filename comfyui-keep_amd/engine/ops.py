@@ -37,6 +37,7 @@ def bf16_twin(w):
     return _BLOB16[off:off + w.numel()]
 
 
+COUT4 = os.environ.get('KEEP_NO_COUT4') is None            # dev switch: Cout <= 4 3x3 convs on the gather kernel
 HALO_F32 = os.environ.get('KEEP_NO_HALO_F32') is None     # dev switch: fall back to the gather kernel
 HALO_V1 = os.environ.get('KEEP_HALO_VER', '3') == '1'   # halo kernel generation (3 = persistent, default)
 USE_BK256 = bool(int(os.environ.get('KEEP_BK256', '0')))   # measured slower than BK=64 + split-K at B<=4 (kept for A/B)
@@ -106,8 +107,6 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
     out_bf16 = bool(out_bf16) and mma == L.MMA_BF16 and Cout % 4 == 0 and residual is None
     if out is None:
         out = torch.empty((N, Ho, Wo, Cout), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
-    if mma == L.MMA_BF16 and wb is None:
-        wb = bf16_twin(w)
     in_dtype = L.F32
     halo = (mma == L.MMA_BF16 and not out_bf16 and ksize == 3 and stride == 1 and not down and pad == 1 and Cin % 32 == 0
             and (Cout % 64 == 0 or (Cout % 32 == 0 and not HALO_V1 and HALO_PRENORM_MINPIX == 0)) and ((Ho % 8 == 0 and Wo % 32 == 0) or (Ho % 16 == 0 and Wo % 16 == 0))
@@ -124,6 +123,14 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
         L.call('keep_norm_act_bf16', x, None if pro is None else pro[0], None if pro is None else pro[1], x16,
                N, H * W, ld, pro_act)
         x, pro, pro_act, in_dtype = x16, None, L.PRO_NONE, L.BF16
+    # <= 4 output channels (the generator's 64 -> 3 output conv): exact-fp32 VALU kernel on an LDS halo, both policies
+    cout4 = (COUT4 and Cout <= 4 and ksize == 3 and stride == 1 and not down and pad == 1 and not upsample
+             and x.dtype == torch.float32 and not out_bf16 and Cin % 16 == 0 and ld % 4 == 0 and in_off % 4 == 0
+             and Ho % 8 == 0 and Wo % 32 == 0 and residual is None and aux is None)
+    if cout4:
+        split_k, halo, halo_f32, stats, mma = 1, False, False, False, L.MMA_F32
+    elif mma == L.MMA_BF16 and wb is None:
+        wb = bf16_twin(w)
     nsteps = KH * KW * math.ceil(Cin / (64 if mma == L.MMA_BF16 else 16))
     # latency-bound gather layers (few 64x64 output tiles, deep K): 256-channel K steps, single LDS buffer
     bk256 = (USE_BK256 and mma == L.MMA_BF16 and not halo and Cout > 32 and (Cout <= 64 or M <= 4096) and Cin >= 256 and nsteps >= 8)
@@ -156,7 +163,7 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         tw = 32 if (Ho % 8 == 0 and Wo % 32 == 0) else 16
-        kname = (f'conv3x3_halo_f32_kernel<{tw}>' if halo_f32 else
+        kname = ('conv3x3_cout4_kernel' if cout4 else f'conv3x3_halo_f32_kernel<{tw}>' if halo_f32 else
                  f"conv3x3_halo3_kernel<{'true' if in_dtype == L.BF16 else 'false'}, {tw}>" if halo else
                  tile_config(M, Cout, mma == L.MMA_BF16, bk256))
         # algorithmic bytes: one read of the input window at its storage type, the weights, one write of the output

@@ -85,6 +85,28 @@ def test_conv3x3_f32_halo_kernel_vs_gather_kernel(monkeypatch):
         check(sc, sc2, 1e-5, 'halo f32 fused stats scale'); check(sh, sh2, 1e-5, 'halo f32 fused stats shift')
 
 
+def test_conv3x3_small_cout_valu_kernel(monkeypatch):
+    """VQ:241 output conv (GroupNorm -> conv 64 -> 3): the Cout <= 4 fp32 VALU kernel vs torch and vs the gather kernel."""
+    for cout in (3, 1, 4):
+        x, w, b = rnd('scx', (2, 64, 16, 64), 2.0) - 0.4, rnd('scw', (cout, 64, 3, 3), 0.05), rnd('scb', (cout,))
+        gamma, beta = rnd('scg', (64,)) * 0.2 + 1, rnd('scbt', (64,)) * 0.2
+        xd = dev(nhwc(x))
+        pro = ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6)
+        y = ops.conv(xd, pack(w), dev(b), pro=pro)
+        monkeypatch.setattr(ops, 'COUT4', False)
+        monkeypatch.setenv('KEEP_NO_COUT4', '1')
+        y_g = ops.conv(xd, pack(w), dev(b), pro=pro)
+        monkeypatch.setattr(ops, 'COUT4', True)
+        monkeypatch.delenv('KEEP_NO_COUT4')
+        ref = F.conv2d(F.group_norm(x, 32, gamma, beta, eps=1e-6), w, b, padding=1)
+        check(nchw(y), ref, what=f'cout{cout} valu vs torch')
+        check(y, y_g, 2e-5, what=f'cout{cout} valu vs gather kernel')
+    # swish prologue + sigmoid epilogue, no bias, bf16 policy routes here too (exact fp32)
+    x, w = rnd('scx2', (1, 32, 8, 32)), rnd('scw2', (2, 32, 3, 3), 0.1)
+    y = ops.conv(dev(nhwc(x)), pack(w), None, pro_act=L.PRO_SWISH, act=L.ACT_SIGMOID, mma=L.MMA_BF16)
+    check(nchw(y), torch.sigmoid(F.conv2d(x * torch.sigmoid(x), w, None, padding=1)), what='cout2 swish/sigmoid')
+
+
 def test_conv3x3_splitk_matches():
     x, w, b = rnd('sx', (1, 512, 16, 16)), rnd('sw', (512, 512, 3, 3), 0.02), rnd('sb', (512,))
     ref = F.conv2d(x, w, b, padding=1)
@@ -361,7 +383,7 @@ def bf16r(t):
 
 @pytest.mark.parametrize("cin,cout,hw,n,k", [(64, 64, 32, 2, 3), (128, 256, 16, 1, 3), (96, 128, 16, 2, 3), (96, 96, 32, 2, 3),
                                              (256, 128, 64, 1, 3), (512, 512, 16, 1, 1), (130, 256, 8, 1, 3),
-                                             (3, 64, 32, 2, 3), (64, 3, 32, 1, 3)])
+                                             (3, 64, 32, 2, 3), (64, 3, 24, 1, 3)])
 def test_conv_bf16_operands_exact_products(cin, cout, hw, n, k):
     """bf16 policy: operands are RNE-rounded to bf16 when staged, products accumulate in fp32 -> equals an fp32 conv of
     the rounded operands up to accumulation order."""

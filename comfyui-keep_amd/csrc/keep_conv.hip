@@ -43,7 +43,7 @@ struct ConvP {
   int fast;     // bf16 policy: fast-math epilogue activations
   float* stats; // optional [N][P][Cout][2] per-tile (sum, sumsq) of the epilogue output, P = stats_P tiles per image
   int stats_P;
-  int out_bf16; // write the output tensor as bf16 (gather kernels' staged epilogue only)
+  int out_bf16; // write the output tensor as bf16 (gather kernels' staged epilogue, persistent bf16 halo kernel)
   int vec_epi;  // Cout/out_ld/res_ld %% 4 == 0 and aligned pointers -> LDS-staged float4 epilogue
   int exp;      // dev-only ablation switch (KEEP_HALO_EXP), 0 in production
   int stagger;  // persistent halo kernels: spread of the per-block start delay, in shader cycles (0 = none)
@@ -1520,7 +1520,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvP p, int tile
           for (int q = 0; q < 4; ++q) e[q] += rr[q];
         }
       }
-      *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
+      if (p.out_bf16) {          // ResBlock conv1 -> GroupNorm -> conv2: the only reader is the normalise pass
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+        bf16x4_t h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = (__bf16)e[q];
+        *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(p.out) + m * p.out_ld + co) = h;
+      } else {
+        *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         s4[q] += e[q];
@@ -1994,7 +2002,9 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
                        a->Wo == (a->upsample ? 2 * a->W : a->W) &&
                        (a->dtype == KEEP_F32 || (!a->pro_scale && a->pro_act == KEEP_PRO_NONE)) &&
                        (!a->pro_scale || ((uintptr_t)a->pro_scale % 16 == 0 && (uintptr_t)a->pro_shift % 16 == 0)) &&
-                       (a->out_dtype != KEEP_BF16) && (a->in_ld % 8 == 0) && ((uintptr_t)a->in % 16 == 0) && (a->out_ld % 4 == 0) &&
+                       (a->out_dtype != KEEP_BF16 || (!a->pro_scale && a->pro_act == KEEP_PRO_NONE && !a->residual && a->split_k == 1 &&
+                                                      a->Cout % 64 == 0 && !(getenv("KEEP_HALO_VER") && atoi(getenv("KEEP_HALO_VER")) != 3))) &&
+                       (a->in_ld % 8 == 0) && ((uintptr_t)a->in % 16 == 0) && (a->out_ld % 4 == 0) &&
                        ((uintptr_t)a->out % 16 == 0) && (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&
                        (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0);
   // <= 4 output channels: VALU kernel (both precision policies compute it in exact fp32)
@@ -2020,8 +2030,10 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
                            (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0) &&
                            (!a->workspace || (uintptr_t)a->workspace % 16 == 0) && !getenv("KEEP_NO_HALO_F32");
   if (p.in_bf16 && !halo_ok) {
+    // (a bf16-input branch in the gather kernel was measured: +7 % on every 128x128 launch for the extra registers, and the
+    //  GMFlow MLP it was meant for is epilogue-bound, not byte-bound -- bf16 tensors feed the halo path only)
     keep_set_error("keep_conv2d: bf16 input tensors are only accepted by the 3x3 stride-1 halo path "
-                   "(Cin%%32, Cout%%64, Ho%%8, Wo%%32, no prologue)");
+                   "(Cin%%32, Cout%%32, tileable map, no prologue)");
     return KEEP_EUNSUP;
   }
   if (p.stats) {

@@ -207,13 +207,21 @@ extern "C" int32_t keep_affine_act(const float* x, const float* scale, const flo
 // out_bf16 = bf16( act_pro( x*scale[n,c] + shift[n,c] ) ): the normalise+activate pass that feeds the 3x3 halo
 // convolution (8 channels per thread: two float4 loads, one 16-byte store; RNE via v_cvt_pk_bf16_f32).
 typedef __attribute__((ext_vector_type(8))) __bf16 ops_bf16x8;
-__global__ void norm_act_bf16_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+template <bool IN_BF16>
+__global__ void norm_act_bf16_kernel(const void* __restrict__ xin, const float* __restrict__ scale,
                                      const float* __restrict__ shift, ops_bf16x8* __restrict__ out, long total8,
                                      long per_n8, int C8, int act) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
-    const float4 a = reinterpret_cast<const float4*>(x)[2 * i];
-    const float4 b = reinterpret_cast<const float4*>(x)[2 * i + 1];
-    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float v[8];
+    if (IN_BF16) {
+      const ops_bf16x8 h = reinterpret_cast<const ops_bf16x8*>(xin)[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+    } else {
+      const float4 a = reinterpret_cast<const float4*>(xin)[2 * i];
+      const float4 b = reinterpret_cast<const float4*>(xin)[2 * i + 1];
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
     if (scale) {
       const long n = i / per_n8;
       const int c = (int)(i % C8) * 8;
@@ -238,16 +246,21 @@ __global__ void norm_act_bf16_kernel(const float* __restrict__ x, const float* _
   }
 }
 
-extern "C" int32_t keep_norm_act_bf16(const float* x, const float* scale, const float* shift, void* out, int32_t N,
-                                      int32_t HW, int32_t C, int32_t act, void* stream) {
+extern "C" int32_t keep_norm_act_bf16(const void* x, const float* scale, const float* shift, void* out, int32_t N,
+                                      int32_t HW, int32_t C, int32_t act, int32_t in_dtype, void* stream) {
   KEEP_REQUIRE(x && out && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "keep_norm_act_bf16: bad args (C=%d)", C);
   KEEP_REQUIRE((scale == nullptr) == (shift == nullptr), "keep_norm_act_bf16: scale/shift must pair");
   KEEP_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0, "keep_norm_act_bf16: 16-byte alignment");
+  KEEP_REQUIRE(in_dtype == KEEP_F32 || in_dtype == KEEP_BF16, "keep_norm_act_bf16: bad in_dtype %d", in_dtype);
   const long total8 = (long)N * HW * C / 8;
   int blocks = cdiv(total8, 256);
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(norm_act_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
-                     (ops_bf16x8*)out, total8, (long)HW * C / 8, C / 8, act);
+  if (in_dtype == KEEP_BF16)
+    hipLaunchKernelGGL(norm_act_bf16_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+                       (ops_bf16x8*)out, total8, (long)HW * C / 8, C / 8, act);
+  else
+    hipLaunchKernelGGL(norm_act_bf16_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+                       (ops_bf16x8*)out, total8, (long)HW * C / 8, C / 8, act);
   KEEP_LAUNCH_CHECK("keep_norm_act_bf16");
   return KEEP_OK;
 }

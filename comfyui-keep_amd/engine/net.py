@@ -136,8 +136,15 @@ class KeepNet:
     def _resblock(self, x, p):
         """VQ:170-181."""
         w = self.w
+        # bf16 policy: h is read once, by the normalise+swish pass in front of conv2's halo kernel -> store it as bf16
+        # (its GroupNorm statistics come from conv1's epilogue, taken on the fp32 values)
+        N, H, Wd, _ = x.shape
+        cmid = w[f'{p}.conv1.weight'].shape[0]
+        h16 = (ops.MMA == L.MMA_BF16 and cmid % 64 == 0 and ops.halo_bf16_eligible(x.shape[-1], cmid, H, Wd)
+               and ops.halo_bf16_eligible(cmid, w[f'{p}.conv2.weight'].shape[0], H, Wd)
+               and (N * H * Wd // 256) * (cmid // 64) * 4 >= ops._TARGET_WAVES)     # small maps keep fp32 + split-K
         h = ops.conv(x, w[f'{p}.conv1.weight'], w[f'{p}.conv1.bias'], pro=self._gn(x, f'{p}.norm1'),
-                     pro_act=L.PRO_SWISH, stats=True)
+                     pro_act=L.PRO_SWISH, stats=True, out_bf16=h16)
         sc = x
         if f'{p}.conv_out.weight' in w:
             sc = ops.linear(x, w[f'{p}.conv_out.weight'], w[f'{p}.conv_out.bias'])

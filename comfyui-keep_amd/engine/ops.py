@@ -84,6 +84,13 @@ def pick_split_k(M, Cout, nsteps, bf16=False):
     return max(1, s)
 
 
+def halo_bf16_eligible(Cin, Cout, Ho, Wo, ld=None, in_off=0):
+    """Geometry accepted by the persistent bf16 LDS-halo kernel (3x3, stride 1, pad 1 checked by the caller)."""
+    ld = Cin if ld is None else ld
+    return (Cin % 32 == 0 and (Cout % 64 == 0 or (Cout % 32 == 0 and not HALO_V1 and HALO_PRENORM_MINPIX == 0))
+            and ((Ho % 8 == 0 and Wo % 32 == 0) or (Ho % 16 == 0 and Wo % 16 == 0)) and ld % 8 == 0 and in_off % 8 == 0)
+
+
 def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=False, pro=None, pro_act=L.PRO_NONE,
          act=L.ACT_NONE, residual=None, aux=None, aux_w=1.0, cin=None, in_off=0, out=None, split_k=None, wb=None,
          mma=None, stats=False, out_bf16=False):
@@ -107,10 +114,13 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
     out_bf16 = bool(out_bf16) and mma == L.MMA_BF16 and Cout % 4 == 0 and residual is None
     if out is None:
         out = torch.empty((N, Ho, Wo, Cout), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
-    in_dtype = L.F32
-    halo = (mma == L.MMA_BF16 and not out_bf16 and ksize == 3 and stride == 1 and not down and pad == 1 and Cin % 32 == 0
-            and (Cout % 64 == 0 or (Cout % 32 == 0 and not HALO_V1 and HALO_PRENORM_MINPIX == 0)) and ((Ho % 8 == 0 and Wo % 32 == 0) or (Ho % 16 == 0 and Wo % 16 == 0))
-            and ld % 8 == 0 and in_off % 8 == 0)
+    in_dtype = L.BF16 if x.dtype == torch.bfloat16 else L.F32
+    halo = (mma == L.MMA_BF16 and ksize == 3 and stride == 1 and not down and pad == 1
+            and halo_bf16_eligible(Cin, Cout, Ho, Wo, ld, in_off)
+            and (not out_bf16 or (Cout % 64 == 0 and not HALO_V1 and HALO_PRENORM_MINPIX == 0 and split_k in (None, 1))))
+    assert in_dtype == L.F32 or halo, "bf16 activation tensors only feed the 3x3 halo convolution (via the normalise pass)"
+    if halo and out_bf16:
+        split_k = 1
     # fp32 policy: persistent LDS-halo kernel on f32 MFMA (16-channel chunks, GroupNorm affine + activation fused in staging)
     halo_f32 = (mma != L.MMA_BF16 and HALO_F32 and x.dtype == torch.float32 and ksize == 3 and stride == 1 and not down
                 and pad == 1 and Cin % 16 == 0 and Cout % 32 == 0
@@ -121,7 +131,7 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
         assert in_off == 0 and Cin == ld
         x16 = torch.empty((N, H, W, ld), dtype=torch.bfloat16, device=x.device)
         L.call('keep_norm_act_bf16', x, None if pro is None else pro[0], None if pro is None else pro[1], x16,
-               N, H * W, ld, pro_act)
+               N, H * W, ld, pro_act, in_dtype)
         x, pro, pro_act, in_dtype = x16, None, L.PRO_NONE, L.BF16
     # <= 4 output channels (the generator's 64 -> 3 output conv): exact-fp32 VALU kernel on an LDS halo, both policies
     cout4 = (COUT4 and Cout <= 4 and ksize == 3 and stride == 1 and not down and pad == 1 and not upsample
@@ -211,6 +221,7 @@ def norm_affine(x, gamma, beta, groups, eps):
         part, P = fused
         L.call('keep_norm_finalize', part, gamma, beta, scale, shift, N, HW, C, groups, P, float(eps))
         return scale, shift
+    assert x.dtype == torch.float32, "bf16 activations carry their statistics from the producing conv's epilogue"
     cpg = C // groups
     if ((cpg % 4 == 0 and HW * cpg <= 32768) or HW <= 1024) and C % 4 == 0 and groups * N >= 16:
         # small maps: one block per (image, group), one launch

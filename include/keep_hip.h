@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KEEP_ABI_VERSION 6
+#define KEEP_ABI_VERSION 7
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -157,8 +157,8 @@ int32_t keep_affine_act(const float* x, const float* scale, const float* shift, 
                         int32_t C, int32_t act, void* stream);
 /* out (bf16 [N,HW,C]) = bf16( act_pro(x*scale[n,c]+shift[n,c]) ); scale/shift NULL = plain cast.  The normalise +
  * activate pass in front of the 3x3 halo convolution under KEEP_MMA_BF16 (keep_conv2d with dtype = KEEP_BF16). */
-int32_t keep_norm_act_bf16(const float* x, const float* scale, const float* shift, void* out, int32_t N, int32_t HW,
-                           int32_t C, int32_t act, void* stream);
+int32_t keep_norm_act_bf16(const void* x, const float* scale, const float* shift, void* out, int32_t N, int32_t HW,
+                           int32_t C, int32_t act, int32_t in_dtype /* KEEP_F32 | KEEP_BF16 */, void* stream);
 /* GM/backbone.py:36: out = relu( (a*sa+ha) + relu(b*sb+hb) ); sa/ha may be NULL (identity shortcut) */
 int32_t keep_gm_join(const float* a, const float* sa, const float* ha, const float* b, const float* sb,
                      const float* hb, float* out, int32_t N, int32_t HW, int32_t C, void* stream);

@@ -527,6 +527,29 @@ def test_conv_epilogue_stats_match_standalone(mma):
     check(sc, sc2, 1e-5, 'in scale'); check(sh, sh2, 1e-5, 'in shift')
 
 
+def test_conv_bf16_halo_bf16_output_and_bf16_inputs():
+    """bf16 policy storage: (a) the halo kernel writes a bf16 tensor + fp32-accurate GroupNorm partials (ResBlock conv1),
+    (b) the normalise pass reads that bf16 tensor and feeds the second halo conv."""
+    x, w, b = rnd('hbx', (2, 64, 32, 32)), rnd('hbw', (128, 64, 3, 3), 0.05), rnd('hbb', (128,))
+    wp = pack(w)
+    wb = wp.to(torch.bfloat16)
+    xd = dev(nhwc(x))
+    y32 = ops.conv(xd, wp, dev(b), mma=L.MMA_BF16, wb=wb, stats=True, split_k=1)
+    y16 = ops.conv(xd, wp, dev(b), mma=L.MMA_BF16, wb=wb, stats=True, out_bf16=True)
+    assert y16.dtype == torch.bfloat16 and hasattr(y16, '_keep_stats')
+    check(y16.float(), bf16r(y32.cpu()), 1e-6, 'halo bf16 output == RNE(fp32 output)')
+    check(y16._keep_stats[0], y32._keep_stats[0], 1e-6, 'stats taken before rounding')
+    # (b) GN + swish pass from the bf16 tensor, then the second halo conv
+    gamma, beta = rnd('hbg', (128,)) * 0.2 + 1, rnd('hbbt', (128,)) * 0.2
+    w2 = rnd('hbw2', (64, 128, 3, 3), 0.05)
+    pro = ops.norm_affine(y16, dev(gamma), dev(beta), 32, 1e-6)
+    z = ops.conv(y16, pack(w2), None, pro=pro, pro_act=L.PRO_SWISH, mma=L.MMA_BF16, wb=pack(w2).to(torch.bfloat16))
+    sc, sh = pro[0].cpu(), pro[1].cpu()
+    hn = y16.float().cpu() * sc[:, None, None, :] + sh[:, None, None, :]
+    hn = bf16r(hn * torch.sigmoid(hn))
+    check(nchw(z), F.conv2d(nchw(hn), bf16r(w2), None, padding=1), 3e-4, 'bf16 tensor -> norm pass -> halo conv')
+
+
 def test_conv_bf16_flat_k_small_cin():
     x, w = rnd('7x', (2, 3, 64, 64)), rnd('7w', (64, 3, 7, 7), 0.1)
     wp = pack(w)

@@ -61,7 +61,7 @@ def build_net(rank, world):
         if rank != 0:
             net.adopt_packed(index, blob)
         if rank == 0:
-            print(f"[bench] RCCL weight broadcast: {blob.numel() * 4 / 1e6:.0f} MB in {time.time() - t0:.3f}s",
+            print(f"[bench] weight broadcast ({torch.distributed.get_backend()}): {blob.numel() * 4 / 1e6:.0f} MB in {time.time() - t0:.3f}s",
                   file=sys.stderr)
     return net.eval()
 
@@ -160,7 +160,8 @@ def main():
         barrier()
         d = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([d], dtype=torch.float64, device='cuda')
+            tmax = torch.tensor([d], dtype=torch.float64,
+                                device='cuda' if torch.distributed.get_backend() == 'nccl' else 'cpu')
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
             d = float(tmax.item())
         assert torch.isfinite(o).all()
@@ -204,6 +205,20 @@ def main():
                                  "index agreement + median pixel difference on frame 0 (frames >= 1 of synthetic-weight clips "
                                  "are chaotic: random GMFlow)"}
             net.set_precision(args.precision)
+        if world == 1:
+            # the same step entered from host memory the way the processor does: uint8 crops in pinned host
+            # memory -> H2D -> keep_img2tensor -> net -> keep_tensor2img -> D2H uint8.  Reported beside `value`, never as it.
+            u8 = [torch.randint(0, 256, (T_CLIP, 512, 512, 3), dtype=torch.uint8).pin_memory() for _ in range(B)]
+            net.run_clips_u8(u8, max_b=B)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = net.run_clips_u8(u8, max_b=B)
+            torch.cuda.synchronize()
+            d3 = time.perf_counter() - t0
+            assert len(res) == B and res[0].shape == (T_CLIP, 512, 512, 3)
+            line["pcie_inclusive"] = {"value": round(B * T_CLIP / d3, 3), "unit": "frames/s",
+                                      "what": "uint8 BGR crops in pinned host memory -> restored uint8 BGR crops in host memory "
+                                              "(H2D + device-side converters + net + D2H), one step"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

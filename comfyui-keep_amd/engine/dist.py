@@ -19,9 +19,11 @@ def init_from_env(backend=None):
         return 0, 1, 0
     rank = int(os.environ['RANK'])
     local = int(os.environ.get('LOCAL_RANK', rank))
+    if os.environ.get('KEEP_DIST_DEVICE') is not None:      # single-GPU smoke runs of the N > 1 path: every rank on one device
+        local = int(os.environ['KEEP_DIST_DEVICE'])
     if not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('KEEP_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -40,14 +42,17 @@ def broadcast_packed_weights(index, blob, src=0):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return index, blob
     rank = dist.get_rank()
-    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    nccl = dist.get_backend() == 'nccl'
+    dev = torch.device('cuda', torch.cuda.current_device()) if nccl else torch.device('cpu')
+    target = dev if (nccl or not torch.cuda.is_available()) else torch.device('cuda', torch.cuda.current_device())
     meta = [index, None if blob is None else int(blob.numel())] if rank == src else [None, None]
     dist.broadcast_object_list(meta, src=src)
     index, numel = meta
     if rank != src:
         blob = torch.empty(numel, dtype=torch.float32, device=dev)
-    dist.broadcast(blob, src=src)
-    return index, blob
+    wire = blob if blob.device.type == dev.type else blob.to(dev)     # gloo moves host memory
+    dist.broadcast(wire, src=src)
+    return index, (blob if rank == src else wire.to(target))
 
 
 def gather_by_clip(local_results, n_clips, rank, world):

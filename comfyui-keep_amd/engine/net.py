@@ -537,14 +537,13 @@ class KeepNet:
         return out
 
     # ------------------------------------------------------------------ independent clips (hot loop #1)
-    def run_clips(self, clips, need_upscale=False):
+    def run_clips(self, clips, need_upscale=False, max_b=4):
         """list of [1,T_i,3,H,W] -> list of restored clips.  Clips share no state (KA:1050,1064,1113), so
         equal-length clips are stacked on the batch axis; results equal the sequential loop."""
         order = {}
         for n, c in enumerate(clips):
             order.setdefault((c.shape[1], c.shape[3], c.shape[4]), []).append(n)
         outs = [None] * len(clips)
-        max_b = 4
         for _, ids in order.items():
             for s in range(0, len(ids), max_b):
                 grp = ids[s:s + max_b]
@@ -554,7 +553,7 @@ class KeepNet:
         return outs
 
     # ------------------------------------------------------------------ device-side pre/post
-    def run_clips_u8(self, clips_u8):
+    def run_clips_u8(self, clips_u8, max_b=4):
         """list of uint8 BGR crops [T_i,H,W,3] (host or device) -> list of restored uint8 BGR [T_i,H,W,3] on the host.
 
         Replaces the per-frame host conversions either side of the clip loop -- ``img2tensor(face/255., bgr2rgb) +
@@ -573,7 +572,7 @@ class KeepNet:
                 f = torch.empty((T, H, Wd, 3), dtype=torch.float32, device=self.device)
                 L.call('keep_img2tensor', u8, f, T * H * Wd)
                 clips.append(ops.nhwc_to_nchw(f).unsqueeze(0))
-            outs = self.run_clips(clips)
+            outs = self.run_clips(clips, max_b=max_b)
             res = []
             for o in outs:
                 _, T, _, H, Wd = o.shape

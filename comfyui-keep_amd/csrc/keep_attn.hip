@@ -66,6 +66,42 @@ __device__ __forceinline__ int win_region(const AttnP& p, int bw, int t) {
   return ih * 3 + iw;
 }
 
+// Block-uniform part of the window index math (mode 2): every token of a block lives in one window of one image, so the
+// divisions by ksplit happen once per block; per token only t / ww remains (exact float reciprocal for t < 65536).
+struct WinCtx {
+  int img, img_kv, y0, x0, wh, ww;
+  float inv_ww;
+};
+__device__ __forceinline__ WinCtx win_ctx(const AttnP& p, int bw) {
+  WinCtx c;
+  const int k2 = p.ksplit * p.ksplit;
+  c.img = bw / k2;
+  const int widx = bw - c.img * k2;
+  const int wy = widx / p.ksplit, wx = widx - wy * p.ksplit;
+  c.wh = p.img_h / p.ksplit;
+  c.ww = p.img_w / p.ksplit;
+  c.y0 = wy * c.wh;
+  c.x0 = wx * c.ww;
+  c.img_kv = c.img + p.kv_rot;
+  if (c.img_kv >= p.n_img) c.img_kv -= p.n_img;
+  c.inv_ww = 1.0f / (float)c.ww;
+  return c;
+}
+// token t of the window -> pixel index in the un-rolled image and region id in the rolled frame (GM/transformer.py:24-35)
+__device__ __forceinline__ void win_token(const AttnP& p, const WinCtx& c, int t, int& pix, int& region) {
+  const int ty = (int)(((float)t + 0.5f) * c.inv_ww);
+  const int tx = t - ty * c.ww;
+  const int yr = c.y0 + ty, xr = c.x0 + tx;
+  int y = yr + p.shift, x = xr + p.shift;
+  if (y >= p.img_h) y -= p.img_h;
+  if (x >= p.img_w) x -= p.img_w;
+  pix = y * p.img_w + x;
+  const int sh = c.wh / 2, sw = c.ww / 2;
+  const int ih = yr < p.img_h - c.wh ? 0 : (yr < p.img_h - sh ? 1 : 2);
+  const int iw = xr < p.img_w - c.ww ? 0 : (xr < p.img_w - sw ? 1 : 2);
+  region = ih * 3 + iw;
+}
+
 __device__ __forceinline__ long q_offset(const AttnP& p, int b, int t, long bs, long ts) {
   if (p.mode == 2) {
     int img, pix;
@@ -525,29 +561,38 @@ static int launch_attn_bf16(const AttnP& p, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------------ bf16-input variant
 // Q, K, V already live in HBM as bf16 (the projection GEMMs write bf16, halving the K/V traffic that every q-tile
-// block re-reads).  128 queries per block (4 waves), 64 keys per iteration (two 32x32 score tiles per wave) so each
-// barrier pair covers twice the MFMA work, token offsets / window region ids are computed once per tile into LDS
-// tables instead of per element, and with a single D chunk the next tile's K and V pieces are prefetched into
-// registers while the current tile is on the matrix cores.  V^T is staged key-permuted exactly like attn_bf16_kernel.
+// block re-reads).  128 queries per block (4 waves), 64 keys per iteration (two 32x32 score tiles per wave).
+// Single D chunk (D <= 128, every caller but the VQGAN AttnBlock) -- the pipelined path:
+//   * token offsets and the shifted-window region masks of a key tile are computed THREE tiles ahead by a rotating wave
+//     into a 3-deep LDS ring (off the critical path; the masks are 64-bit ballots per region id, so a lane tests one
+//     bit per score instead of reading 32 region ids);
+//   * the K / V pieces of tile kt+2 are issued right after tile kt+1 was committed to LDS, so they have a whole
+//     iteration (QK^T, softmax, PV of tile kt+1) to land; two barriers per tile;
+//   * Q fragments stay in registers; softmax runs in the exp2 domain (scale * log2 e folded into one multiply).
+// An ablation of the previous schedule on the GMFlow window shape (981 us) had shown 383 us of pure skeleton (four
+// barriers + serial table math per tile), 160 us of exposed load latency and 205 us of softmax VALU.
+// D > 128 (AttnBlock, D = 512): the chunked path -- tables per tile, Q/K re-staged per 128-wide chunk.
+// V^T is staged key-permuted exactly like attn_bf16_kernel.
 template <int DVT>
-__global__ __launch_bounds__(256) void attn_bf16in_kernel(AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_bf16in_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int DVS = DVT * 32;
   constexpr int NT = 256, KT = 64;
   constexpr int VP = KT + 8;             // V^T row pitch (bf16): 144 B = 9 slots
   constexpr int KPF = 4;                 // prefetched 16-byte K pieces per thread (64 rows x 16 groups / 256)
   constexpr int VPF = (DVS / 8 + 3) / 4; // prefetched 16-byte V pieces per thread (lane = key, 4 waves share dv groups)
+  constexpr int NTAB = 3;                // table ring depth
   const int DC = p.D < 128 ? p.D : 128;
   const int nch = p.D / DC;
   const int QP = DC + 8;
   const int g8n = DC >> 3;
-  long* qoff = reinterpret_cast<long*>(smem_raw);            // [128]
-  long* koff = qoff + 128;                                   // [64]
-  long* voff = koff + KT;                                    // [64]
-  int* kreg_tab = reinterpret_cast<int*>(voff + KT);         // [64] window region ids (mode 2, shift > 0)
-  __bf16* Qs = reinterpret_cast<__bf16*>(kreg_tab + KT);     // [128][QP]
-  __bf16* Ks = Qs + 128 * QP;                                // [64][QP]
-  __bf16* Vt = Ks + KT * QP;                                 // [DVS][VP]
+  long* qoff = reinterpret_cast<long*>(smem_raw);                                  // [128]
+  long* koff = qoff + 128;                                                         // [NTAB][64]
+  long* voff = koff + NTAB * KT;                                                   // [NTAB][64]
+  unsigned long long* kmask = reinterpret_cast<unsigned long long*>(voff + NTAB * KT);   // [NTAB][16] region ballots
+  __bf16* Qs = reinterpret_cast<__bf16*>(kmask + NTAB * 16);                       // [128][QP]
+  __bf16* Ks = Qs + 128 * QP;                                                      // [64][QP]
+  __bf16* Vt = Ks + KT * QP;                                                       // [DVS][VP]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -559,18 +604,43 @@ __global__ __launch_bounds__(256) void attn_bf16in_kernel(AttnP p) {
   const int q0 = blockIdx.x * 128;
   const long qh = (long)head * p.q_hs, kh = (long)head * p.k_hs, vh = (long)head * p.v_hs;
   const bool use_mask = (p.mode == 2 && p.shift > 0);
+  WinCtx wc = {};
+  if (p.mode == 2) wc = win_ctx(p, b);
+  // element offset of query / key / value / output token t (window, sparse-causal or plain addressing) + region id
+  auto tok_q = [&](int t, long bs, long ts) -> long {
+    if (p.mode == 2) {
+      int pix, reg;
+      win_token(p, wc, t, pix, reg);
+      return (long)wc.img * bs + (long)pix * ts;
+    }
+    return (long)b * bs + (long)t * ts;
+  };
 
   if (tid < 128) {
     const int t = q0 + tid;
-    qoff[tid] = (t < p.Lq) ? q_offset(p, b, t, p.q_bs, p.q_ts) + qh : -1;
+    qoff[tid] = (t < p.Lq) ? tok_q(t, p.q_bs, p.q_ts) + qh : -1;
   }
-  auto fill_tables = [&](int kt) {
-    if (tid < KT) {
-      const int t = kt * KT + tid;
-      const bool ok = t < p.Lk;
-      koff[tid] = ok ? kv_offset(p, b, t, p.k_bs, p.k_ts) + kh : -1;
-      voff[tid] = ok ? kv_offset(p, b, t, p.v_bs, p.v_ts) + vh : -1;
-      kreg_tab[tid] = (ok && use_mask) ? win_region(p, b, t) : 0;
+  // executed by ONE wave (all 64 lanes, lane <-> key of the tile)
+  auto fill_tables = [&](int kt, int slot) {
+    const int t = kt * KT + lane;
+    const bool ok = t < p.Lk;
+    int reg = 0;
+    if (p.mode == 2) {
+      int pix;
+      win_token(p, wc, t, pix, reg);
+      koff[slot * KT + lane] = ok ? (long)wc.img_kv * p.k_bs + (long)pix * p.k_ts + kh : -1;
+      voff[slot * KT + lane] = ok ? (long)wc.img_kv * p.v_bs + (long)pix * p.v_ts + vh : -1;
+    } else {
+      koff[slot * KT + lane] = ok ? kv_offset(p, b, t, p.k_bs, p.k_ts) + kh : -1;
+      voff[slot * KT + lane] = ok ? kv_offset(p, b, t, p.v_bs, p.v_ts) + vh : -1;
+    }
+    if (use_mask) {
+      if (!ok) reg = 0;
+#pragma unroll
+      for (int R = 0; R < 9; ++R) {
+        const unsigned long long m = __ballot(reg != R);
+        if (lane == R) kmask[slot * 16 + R] = m;
+      }
     }
   };
   auto stage_q = [&](int ch) {
@@ -582,14 +652,15 @@ __global__ __launch_bounds__(256) void attn_bf16in_kernel(AttnP p) {
     }
   };
   uint4 kpf[KPF], vpf[VPF];
-  auto k_issue = [&](int ch) {
+  auto k_issue = [&](int ch, int slot) {
 #pragma unroll
     for (int u = 0; u < KPF; ++u) {
       const int i = tid + u * NT;
       kpf[u] = make_uint4(0u, 0u, 0u, 0u);
       if (i < KT * g8n) {
         const int row = i / g8n, c = (i - row * g8n) << 3;
-        if (koff[row] >= 0) kpf[u] = *reinterpret_cast<const uint4*>(p.k16 + koff[row] + ch * DC + c);
+        const long off = koff[slot * KT + row];
+        if (off >= 0) kpf[u] = *reinterpret_cast<const uint4*>(p.k16 + off + ch * DC + c);
       }
     }
   };
@@ -603,13 +674,14 @@ __global__ __launch_bounds__(256) void attn_bf16in_kernel(AttnP p) {
       }
     }
   };
-  auto v_issue = [&]() {    // lane <-> key, waves share the 8-column dv groups
+  auto v_issue = [&](int slot) {    // lane <-> key, waves share the 8-column dv groups
+    const long off = voff[slot * KT + lane];
 #pragma unroll
     for (int u = 0; u < VPF; ++u) {
       const int dg = wave + u * 4;
       vpf[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (dg * 8 < DVS && dv0 + dg * 8 < p.Dv && voff[lane] >= 0)
-        vpf[u] = *reinterpret_cast<const uint4*>(p.v16 + voff[lane] + dv0 + dg * 8);
+      if (dg * 8 < DVS && dv0 + dg * 8 < p.Dv && off >= 0)
+        vpf[u] = *reinterpret_cast<const uint4*>(p.v16 + off + dv0 + dg * 8);
     }
   };
   auto v_commit = [&]() {
@@ -628,8 +700,14 @@ __global__ __launch_bounds__(256) void attn_bf16in_kernel(AttnP p) {
 
   const int my_q = q0 + wave * 32 + l31;
   int my_region = 0;
-  if (use_mask && my_q < p.Lq) my_region = win_region(p, b, my_q);
+  if (use_mask && my_q < p.Lq) {
+    int pix;
+    win_token(p, wc, my_q, pix, my_region);
+  }
 
+  // scores live in the exp2 domain: s2 = s * scale * log2(e); the -100 of the window mask scales along
+  const float scale2 = p.scale * 1.4426950408889634f;
+  const float mask2 = -100.0f * 1.4426950408889634f;
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 o[DVT];
 #pragma unroll
@@ -640,107 +718,39 @@ __global__ __launch_bounds__(256) void attn_bf16in_kernel(AttnP p) {
   const __bf16* kp = Ks + l31 * QP + lhi * 8;
   const __bf16* qp = Qs + (wave * 32 + l31) * QP + lhi * 8;
   const int ntiles = (p.Lk + KT - 1) / KT;
-  const bool prefetch = (nch == 1);
+  const bool pipelined = (nch == 1);
 
-  fill_tables(0);
-  __syncthreads();                       // qoff + tables of tile 0 visible
-  if (prefetch) {
-    stage_q(0);
-    k_issue(0);
-    v_issue();
-    k_commit();
-    v_commit();
-  }
-
-  for (int kt = 0; kt < ntiles; ++kt) {
-    f32x16 s[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-    int kreg_l[2][16];
-    if (prefetch) {
-      __syncthreads();                   // LDS image of tile kt complete (K, V^T, region table); tables free to refill
-      if (use_mask) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) kreg_l[t][r] = kreg_tab[t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
-      }
-      __syncthreads();                   // everyone has read the region table of tile kt
-      if (kt + 1 < ntiles) {
-        fill_tables(kt + 1);
-      }
-      for (int d = 0; d < ((p.exp & 1) ? 0 : DC); d += 16) {
-        const abf16x8 qf = *reinterpret_cast<const abf16x8*>(qp + d);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(kp + t * 32 * QP + d), qf,
-                                                         s[t], 0, 0, 0);
-      }
-      if (kt + 1 < ntiles) {
-        __syncthreads();                 // tables of tile kt+1 visible
-        if (!(p.exp & 8)) {
-          k_issue(0);                    // next tile's loads fly during softmax + PV
-          v_issue();
-        }
-      }
-    } else {
-      for (int ch = 0; ch < nch; ++ch) {
-        __syncthreads();
-        if (ch == 0 && kt > 0) fill_tables(kt);
-        if (ch == 0) __syncthreads();
-        stage_q(ch);
-        k_issue(ch);
-        if (ch == 0) v_issue();
-        k_commit();
-        if (ch == 0) v_commit();
-        __syncthreads();
-        if (ch == 0 && use_mask) {
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) kreg_l[t][r] = kreg_tab[t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
-        }
-        for (int d = 0; d < DC; d += 16) {
-          const abf16x8 qf = *reinterpret_cast<const abf16x8*>(qp + d);
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-            s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(kp + t * 32 * QP + d),
-                                                           qf, s[t], 0, 0, 0);
-        }
-      }
-    }
-
+  // online softmax + P.V of one 64-key tile; `mbits`: bit (t*32 + (r&3) + 8*(r>>2)) set = key outside the lane's region
+  // (already shifted right by 4*lhi)
+  auto softmax_pv = [&](int kt, f32x16 (&s)[2], unsigned long long mbits) {
+    const bool full = (kt + 1) * KT <= p.Lk;
+    const unsigned mlo = (unsigned)mbits, mhi = (unsigned)(mbits >> 32);
     float mloc = -INFINITY;
-    if (!(p.exp & 2)) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kt * KT + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        float val = s[t][r] * p.scale;
-        if (use_mask && kreg_l[t][r] != my_region) val += -100.0f;
-        if (key >= p.Lk) val = -INFINITY;
+        float val = s[t][r] * scale2;
+        if (use_mask && (((t ? mhi : mlo) >> ((r & 3) + 8 * (r >> 2))) & 1u)) val += mask2;
+        if (!full && kt * KT + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi >= p.Lk) val = -INFINITY;
         s[t][r] = val;
         mloc = fmaxf(mloc, val);
       }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
     const float m_new = fmaxf(m_run, mloc);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float lsum = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __expf(s[t][r] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(s[t][r] - m_new);
         s[t][r] = pv;
         lsum += pv;
       }
     lsum += __shfl_xor(lsum, 32);
     l_run = l_run * alpha + lsum;
     m_run = m_new;
-
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -748,9 +758,8 @@ __global__ __launch_bounds__(256) void attn_bf16in_kernel(AttnP p) {
 #pragma unroll
       for (int j = 0; j < DVT; ++j) o[j][r] *= ar;
     }
-    }
 #pragma unroll
-    for (int st = 0; st < ((p.exp & 4) ? 0 : 4); ++st) {
+    for (int st = 0; st < 4; ++st) {
       abf16x8 pa;
 #pragma unroll
       for (int j = 0; j < 8; ++j) pa[j] = (__bf16)s[st >> 1][(st & 1) * 8 + j];
@@ -761,21 +770,121 @@ __global__ __launch_bounds__(256) void attn_bf16in_kernel(AttnP p) {
         o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vb, o[j], 0, 0, 0);
       }
     }
-    if (prefetch && kt + 1 < ntiles) {
-      __syncthreads();                   // every wave is done reading K / V^T of tile kt
-      if (!(p.exp & 16)) k_commit();
-      if (!(p.exp & 32)) v_commit();
+  };
+
+  if (pipelined) {
+    if (wave < NTAB && wave < ntiles) fill_tables(wave, wave);
+    __syncthreads();                       // qoff + tables of tiles 0..2 visible
+    stage_q(0);
+    k_issue(0, 0);
+    v_issue(0);
+    k_commit();
+    v_commit();
+    __syncthreads();                       // Q + tile 0 in LDS
+    if (ntiles > 1) {
+      k_issue(0, 1);
+      v_issue(1);
+    }
+    for (int kt = 0; kt < ntiles; ++kt) {
+      f32x16 s[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+      unsigned long long mbits = 0ull;
+      if (use_mask) mbits = kmask[(kt % NTAB) * 16 + my_region] >> (4 * lhi);
+#pragma unroll
+      for (int d8 = 0; d8 < 8; ++d8) {
+        if (d8 * 16 < DC) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(kp + t * 32 * QP + d8 * 16),
+                                                           *reinterpret_cast<const abf16x8*>(qp + d8 * 16), s[t], 0, 0, 0);
+        }
+      }
+      softmax_pv(kt, s, mbits);
+      __syncthreads();                     // every wave is done with the LDS image (and the tables) of tile kt
+      if (kt + 1 < ntiles) {
+        k_commit();                        // tile kt+1: issued one iteration ago
+        v_commit();
+        if (kt + 2 < ntiles) {
+          k_issue(0, (kt + 2) % NTAB);     // lands during the whole next iteration
+          v_issue((kt + 2) % NTAB);
+        }
+        if (kt + 3 < ntiles && wave == (kt & 3)) fill_tables(kt + 3, kt % NTAB);
+        __syncthreads();                   // image of tile kt+1 complete; tables of tile kt+3 visible before their use
+      }
+    }
+  } else {
+    for (int kt = 0; kt < ntiles; ++kt) {
+      f32x16 s[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+      unsigned long long mbits = 0ull;
+      for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();
+        if (ch == 0 && wave == 0) fill_tables(kt, 0);
+        if (ch == 0) __syncthreads();
+        stage_q(ch);
+        k_issue(ch, 0);
+        if (ch == 0) v_issue(0);
+        k_commit();
+        if (ch == 0) v_commit();
+        __syncthreads();
+        if (ch == 0 && use_mask) mbits = kmask[my_region] >> (4 * lhi);
+        for (int d = 0; d < DC; d += 16) {
+          const abf16x8 qf = *reinterpret_cast<const abf16x8*>(qp + d);
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(kp + t * 32 * QP + d),
+                                                           qf, s[t], 0, 0, 0);
+        }
+      }
+      softmax_pv(kt, s, mbits);
     }
   }
 
+  // Output: the 32 x DVS tile of each wave goes through LDS so that global stores are 16 bytes per lane along dv
+  // (4-byte stores straight from the MFMA layout are issue-bound: 64 store instructions per lane per block).
   const float inv_l = 1.0f / l_run;
+  const bool vec_o = (p.Dv % 4 == 0) && (p.o_ts % 4 == 0) && (p.o_bs % 4 == 0) && (p.o_hs % 4 == 0) &&
+                     ((uintptr_t)p.o % 16 == 0);
+  if (vec_o) {
+    constexpr int OP = DVS + 4;
+    __syncthreads();                       // every wave is done with Q / K / V^T: the operand area becomes the staging area
+    float* ost = reinterpret_cast<float*>(Qs) + wave * 32 * OP;
+    long* ooff = qoff;                     // reuse: output row offsets of this block's 128 queries
+    if (tid < 128) {
+      const int t = q0 + tid;
+      ooff[tid] = (t < p.Lq) ? tok_q(t, p.o_bs, p.o_ts) + (long)head * p.o_hs : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const float il = __shfl(inv_l, qrow);
+#pragma unroll
+      for (int j = 0; j < DVT; ++j) ost[qrow * OP + j * 32 + l31] = o[j][r] * il;
+    }
+    __syncthreads();                       // staged tiles + ooff visible
+    constexpr int C4 = DVS / 4;
+#pragma unroll 4
+    for (int i = lane; i < 32 * C4; i += 64) {
+      const int row = i / C4, c4 = (i - row * C4) * 4;
+      const long base = ooff[wave * 32 + row];
+      if (base >= 0 && dv0 + c4 < p.Dv)
+        *reinterpret_cast<float4*>(p.o + base + dv0 + c4) = *reinterpret_cast<const float4*>(ost + row * OP + c4);
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
     const float il = __shfl(inv_l, qrow);
     const int t = q0 + wave * 32 + qrow;
     if (t < p.Lq) {
-      const long base = q_offset(p, b, t, p.o_bs, p.o_ts) + (long)head * p.o_hs;
+      const long base = tok_q(t, p.o_bs, p.o_ts) + (long)head * p.o_hs;
 #pragma unroll
       for (int j = 0; j < DVT; ++j) {
         const int dv = dv0 + j * 32 + l31;
@@ -788,8 +897,10 @@ __global__ __launch_bounds__(256) void attn_bf16in_kernel(AttnP p) {
 template <int DVT>
 static int launch_attn_bf16in(const AttnP& p, hipStream_t st) {
   const int DC = p.D < 128 ? p.D : 128;
-  const size_t lds = (128 + 64 + 64) * sizeof(long) + 64 * sizeof(int) +
-                     (size_t)((128 + 64) * (DC + 8) + DVT * 32 * 72) * 2;
+  const size_t operands = (size_t)((128 + 64) * (DC + 8) + DVT * 32 * 72) * 2;
+  const size_t staging = (size_t)4 * 32 * (DVT * 32 + 4) * 4;          // the output tiles reuse the operand area
+  const size_t lds = (128 + 3 * 64 + 3 * 64) * sizeof(long) + 3 * 16 * sizeof(unsigned long long) +
+                     (operands > staging ? operands : staging);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_bf16in_kernel<DVT>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -823,6 +934,7 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
     KEEP_REQUIRE(a->n_img > 0 && a->B == a->n_img * a->ksplit * a->ksplit, "keep_attention: B != n_img*ksplit^2");
     KEEP_REQUIRE(a->shift >= 0 && a->shift < wh && a->shift < ww, "keep_attention: bad shift");
     KEEP_REQUIRE(a->kv_rot >= 0 && a->kv_rot < a->n_img, "keep_attention: bad kv_rot");
+    KEEP_REQUIRE((long)a->img_h * a->img_w <= 65536, "keep_attention: window mode supports maps of at most 65536 tokens");
   }
   AttnP p;
   p.q = (const float*)a->q; p.k = (const float*)a->k; p.v = (const float*)a->v; p.o = a->o;

@@ -562,7 +562,8 @@ def test_conv_bf16_flat_k_small_cin():
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,D,Dv", [(2, 8, 256, 256, 64, 64), (1, 1, 256, 256, 512, 512), (2, 4, 200, 200, 256, 256),
-                                            (3, 8, 50, 77, 48, 48), (2, 1, 1024, 1024, 128, 128), (4, 8, 20, 20, 48, 48)])
+                                            (3, 8, 50, 77, 48, 48), (2, 1, 1024, 1024, 128, 128), (4, 8, 20, 20, 48, 48),
+                                            (2, 8, 256, 512, 48, 48), (1, 2, 130, 70, 32, 128)])
 def test_attention_bf16_inputs(B, H, Lq, Lk, D, Dv):
     """q/k/v stored as bf16 (projection GEMMs write bf16): 64-key tiles, table-driven offsets, register prefetch."""
     q, k, v = rnd('aq', (B, Lq, H, D)), rnd('ak', (B, Lk, H, D)), rnd('av', (B, Lk, H, Dv))

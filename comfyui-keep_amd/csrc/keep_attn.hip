@@ -987,3 +987,148 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
   if (dvt == 2) return launch_attn<4, 2>(p, st);
   return launch_attn<4, 4>(p, st);
 }
+
+// ------------------------------------------------------------------------------------------------ fused GMFlow FFN
+// GM/transformer.py:139-142,182: message = Linear(8C -> C)( GELU( Linear(2C -> 8C)( cat[source, message] ) ) ), no biases,
+// C = 128.  As two GEMM launches the [M, 8C] intermediate costs 5 GB written + 5 GB read per layer at M = 1.2 M tokens
+// (bench: 4.7 ms + 1.6 ms per layer, six layers).  Fused, the intermediate never leaves the CU -- same structure as
+// the attention kernel above with W0 in the role of K and W2 in the role of V:
+//   per 64-wide chunk of the hidden dimension   H^T (hidden x tokens) = W0c . X^T        (X fragments live in registers)
+//                                               out (tokens x C)     += gelu(H) . W2c^T  (H feeds the MFMA from the
+//   lane's own registers; W2c is staged with its hidden columns permuted into that order, vt_pos)
+// Block = 128 tokens (4 waves x 32), W0c / W2c chunks in LDS (52 KB), next chunk prefetched into registers while the
+// current one is on the matrix cores, 2 blocks per CU; fp32 in / fp32 out, bf16 MFMA operands, exact-erf-class GELU
+// (erf_fast, 1.5e-7) in fp32.
+#define MLP_C 128
+__global__ __launch_bounds__(256, 2) void gm_mlp_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
+                                                        const unsigned short* __restrict__ w0,
+                                                        const unsigned short* __restrict__ w2, float* __restrict__ out,
+                                                        long M) {
+  constexpr int K1 = 2 * MLP_C, HID = 8 * MLP_C, HC = 64;
+  constexpr int P0 = K1 + 8;               // W0c row pitch (bf16): 528 B = 33 slots
+  constexpr int P2 = HC + 8;               // W2c row pitch (bf16): 144 B = 9 slots
+  constexpr int OP = MLP_C + 4;            // output staging pitch (floats)
+  constexpr int OPER_B = (HC * P0 + MLP_C * P2) * 2;
+  constexpr int STAGE_B = 4 * 32 * OP * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[OPER_B > STAGE_B ? OPER_B : STAGE_B];
+  __bf16* W0s = reinterpret_cast<__bf16*>(lds_raw);            // [64][P0]
+  __bf16* W2s = W0s + HC * P0;                                 // [128][P2], hidden columns permuted (vt_pos)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const long m0 = (long)blockIdx.x * 128;
+  const long my_tok = m0 + wave * 32 + l31;
+
+  // ---- X fragments: token my_tok, channels ks*16 + lhi*8 .. +8 of cat[xa | xb], ks = 0..15
+  abf16x8 xf[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const int c = ks * 16 + lhi * 8;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (my_tok < M) {
+      const float* src = (c < MLP_C ? xa + my_tok * MLP_C + c : xb + my_tok * MLP_C + (c - MLP_C));
+      v0 = *reinterpret_cast<const float4*>(src);
+      v1 = *reinterpret_cast<const float4*>(src + 4);
+    }
+    xf[ks][0] = (__bf16)v0.x; xf[ks][1] = (__bf16)v0.y; xf[ks][2] = (__bf16)v0.z; xf[ks][3] = (__bf16)v0.w;
+    xf[ks][4] = (__bf16)v1.x; xf[ks][5] = (__bf16)v1.y; xf[ks][6] = (__bf16)v1.z; xf[ks][7] = (__bf16)v1.w;
+  }
+
+  // ---- weight chunk staging: W0c = rows hc*64..+64 of w0 [HID][K1]; W2c = columns hc*64..+64 of w2 [C][HID]
+  // (named registers: hipcc keeps small arrays that are captured by a lambda in scratch memory)
+  uint4 p00, p01, p02, p03, p04, p05, p06, p07, p20, p21, p22, p23;
+#define MLP_P0(X) X(0, p00) X(1, p01) X(2, p02) X(3, p03) X(4, p04) X(5, p05) X(6, p06) X(7, p07)
+#define MLP_P2(X) X(0, p20) X(1, p21) X(2, p22) X(3, p23)
+#define MLP_LD0(U, R) R = *reinterpret_cast<const uint4*>(w0 + (long)(hc_n * HC + ((tid + (U) * 256) >> 5)) * K1 + (((tid + (U) * 256) & 31) << 3));
+#define MLP_LD2(U, R) R = *reinterpret_cast<const uint4*>(w2 + (long)((tid + (U) * 256) >> 3) * HID + hc_n * HC + (((tid + (U) * 256) & 7) << 3));
+#define MLP_ST0(U, R) *reinterpret_cast<uint4*>(W0s + ((tid + (U) * 256) >> 5) * P0 + (((tid + (U) * 256) & 31) << 3)) = R;
+  // hidden h8 .. h8+7 of a W2 row: the first four land at vt_pos(h8), the last four 8 positions further (other lane half)
+#define MLP_ST2(U, R)                                                                                   \
+  {                                                                                                     \
+    const int h8 = ((tid + (U) * 256) & 7) << 3;                                                        \
+    uint2* d = reinterpret_cast<uint2*>(W2s + ((tid + (U) * 256) >> 3) * P2 + (h8 >> 5) * 32 + vt_pos(h8 & 31)); \
+    d[0] = make_uint2(R.x, R.y);                                                                        \
+    d[2] = make_uint2(R.z, R.w);                                                                        \
+  }
+
+  f32x16 o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+
+  const __bf16* a0 = W0s + l31 * P0 + lhi * 8;
+  {
+    const int hc_n = 0;
+    MLP_P0(MLP_LD0)
+    MLP_P2(MLP_LD2)
+  }
+  for (int hc = 0; hc < HID / HC; ++hc) {
+    MLP_P0(MLP_ST0)
+    MLP_P2(MLP_ST2)
+    __syncthreads();                               // chunk hc in LDS
+    if (hc + 1 < HID / HC) {                       // next chunk flies during the MFMAs below
+      const int hc_n = hc + 1;
+      MLP_P0(MLP_LD0)
+      MLP_P2(MLP_LD2)
+    }
+    f32x16 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a0 + t * 32 * P0 + ks * 16), xf[ks],
+                                                       s[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      abf16x8 pa;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = s[st >> 1][(st & 1) * 8 + j];
+        pa[j] = (__bf16)(0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f)));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const abf16x8 wb = *reinterpret_cast<const abf16x8*>(W2s + (j * 32 + l31) * P2 + (st >> 1) * 32 + ((st & 1) * 2 + lhi) * 8);
+        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, wb, o[j], 0, 0, 0);
+      }
+    }
+    __syncthreads();                               // every wave is done with chunk hc
+  }
+
+  // ---- output through LDS: 16-byte stores along the channel axis
+  float* ost = reinterpret_cast<float*>(lds_raw) + wave * 32 * OP;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ost[row * OP + j * 32 + l31] = o[j][r];
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);              // wave-private tile: LDS writes of this wave landed
+#pragma unroll 4
+  for (int i = lane; i < 32 * (MLP_C / 4); i += 64) {
+    const int row = i >> 5, c4 = (i & 31) << 2;
+    const long tok = m0 + wave * 32 + row;
+    if (tok < M) *reinterpret_cast<float4*>(out + tok * MLP_C + c4) = *reinterpret_cast<const float4*>(ost + row * OP + c4);
+  }
+}
+
+extern "C" int32_t keep_gm_mlp(const float* a, const float* b, const void* w0_bf16, const void* w2_bf16, float* out,
+                               int64_t M, int32_t C, void* stream) {
+  KEEP_REQUIRE(a && b && w0_bf16 && w2_bf16 && out && M > 0, "keep_gm_mlp: bad args");
+  KEEP_REQUIRE(C == MLP_C, "keep_gm_mlp: built for C = %d (got %d)", MLP_C, C);
+  KEEP_REQUIRE((uintptr_t)a % 16 == 0 && (uintptr_t)b % 16 == 0 && (uintptr_t)w0_bf16 % 16 == 0 &&
+                   (uintptr_t)w2_bf16 % 16 == 0 && (uintptr_t)out % 16 == 0,
+               "keep_gm_mlp: 16-byte alignment");
+  hipLaunchKernelGGL(gm_mlp_kernel, dim3(cdiv(M, 128)), dim3(256), 0, (hipStream_t)stream, a, b,
+                     (const unsigned short*)w0_bf16, (const unsigned short*)w2_bf16, out, (long)M);
+  KEEP_LAUNCH_CHECK("keep_gm_mlp");
+  return KEEP_OK;
+}

@@ -28,6 +28,9 @@ _KNOWN_KW = set(DEFAULT_ARCH) | {
     'cross_residual', 'mask_ratio'}
 
 
+FUSED_GM_MLP = os.environ.get('KEEP_NO_FUSED_MLP') is None     # dev switch
+
+
 class KeepNet:
     def __init__(self, **arch):
         unknown = set(arch) - _KNOWN_KW
@@ -370,8 +373,11 @@ class KeepNet:
         if not ffn:
             return ops.layernorm(m, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], res=src)
         m = ops.layernorm(m, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'])
-        hmid = ops.linear(ops.concat2(src, m), w[f'{p}.mlp.0.weight'], act=L.ACT_GELU)
-        m2 = ops.linear(hmid, w[f'{p}.mlp.2.weight'])
+        if ops.MMA == L.MMA_BF16 and C == 128 and FUSED_GM_MLP:
+            m2 = ops.gm_mlp(src, m, w[f'{p}.mlp.0.weight'], w[f'{p}.mlp.2.weight'])      # [M,8C] never leaves the CU
+        else:
+            hmid = ops.linear(ops.concat2(src, m), w[f'{p}.mlp.0.weight'], act=L.ACT_GELU)
+            m2 = ops.linear(hmid, w[f'{p}.mlp.2.weight'])
         return ops.layernorm(m2, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], res=src)
 
     def _gm_backbone(self, img_nchw):

@@ -270,6 +270,16 @@ def attention(q, k, v, o, *, B, H, Lq, Lk, D, Dv, scale, q_str, k_str, v_str, o_
     return o
 
 
+def gm_mlp(a, b, w0, w2):
+    """GMFlow FFN fused (bf16 policy): W2 . gelu(W0 . cat[a | b]); a, b [M,C] fp32, w0 [8C,2C], w2 [C,8C] fp32 views of
+    the packed blob (their bf16 twins are used)."""
+    C = a.shape[-1]
+    M = a.numel() // C
+    out = empty((M, C), a)
+    L.call('keep_gm_mlp', a, b, bf16_twin(w0), bf16_twin(w2), out, M, C)
+    return out
+
+
 def offset(t, off):
     """Flat view of ``t`` starting ``off`` elements in (channel-slice pointer for strided kernels)."""
     return t.view(-1)[off:] if off else t

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KEEP_ABI_VERSION 7
+#define KEEP_ABI_VERSION 8
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -159,6 +159,10 @@ int32_t keep_affine_act(const float* x, const float* scale, const float* shift, 
  * activate pass in front of the 3x3 halo convolution under KEEP_MMA_BF16 (keep_conv2d with dtype = KEEP_BF16). */
 int32_t keep_norm_act_bf16(const void* x, const float* scale, const float* shift, void* out, int32_t N, int32_t HW,
                            int32_t C, int32_t act, int32_t in_dtype /* KEEP_F32 | KEEP_BF16 */, void* stream);
+/* GM/transformer.py:139-142,182 (bf16 policy): out[M,C] = W2 . gelu( W0 . cat[a[M,C] | b[M,C]] ), W0 bf16 [8C,2C],
+ * W2 bf16 [C,8C], no biases, C = 128; the [M,8C] intermediate stays on the CU. */
+int32_t keep_gm_mlp(const float* a, const float* b, const void* w0_bf16, const void* w2_bf16, float* out, int64_t M,
+                    int32_t C, void* stream);
 /* GM/backbone.py:36: out = relu( (a*sa+ha) + relu(b*sb+hb) ); sa/ha may be NULL (identity shortcut) */
 int32_t keep_gm_join(const float* a, const float* sa, const float* ha, const float* b, const float* sb,
                      const float* hb, float* out, int32_t N, int32_t HW, int32_t C, void* stream);

@@ -550,6 +550,22 @@ def test_conv_bf16_halo_bf16_output_and_bf16_inputs():
     check(nchw(z), F.conv2d(nchw(hn), bf16r(w2), None, padding=1), 3e-4, 'bf16 tensor -> norm pass -> halo conv')
 
 
+def test_gm_mlp_fused_matches_two_gemms():
+    """keep_gm_mlp (GM/transformer.py:139-142,182 fused): vs torch on the bf16-rounded operands with the GELU output
+    rounded to bf16 (what the second MFMA consumes), ragged M."""
+    C, M = 128, 300
+    a, b = rnd('ma', (M, C)), rnd('mb', (M, C))
+    w0, w2 = rnd('mw0', (8 * C, 2 * C), 0.06), rnd('mw2', (C, 8 * C), 0.03)
+    out = torch.empty(M, C, device='cuda')
+    L.call('keep_gm_mlp', dev(a), dev(b), dev(w0).to(torch.bfloat16), dev(w2).to(torch.bfloat16), out, M, C)
+    h = F.gelu(F.linear(bf16r(torch.cat([a, b], -1)), bf16r(w0)))
+    ref = F.linear(bf16r(h), bf16r(w2))
+    check(out, ref, 2e-3, 'fused GMFlow FFN')
+    # and against the unfused engine path (fp32 intermediate): difference = one bf16 rounding of the hidden activations
+    hm = ops.linear(ops.concat2(dev(a), dev(b)), dev(w0), act=L.ACT_GELU, )
+    check(out, ops.linear(hm, dev(w2)), 2e-2, 'fused vs two fp32-policy GEMMs')
+
+
 def test_conv_bf16_flat_k_small_cin():
     x, w = rnd('7x', (2, 3, 64, 64)), rnd('7w', (64, 3, 7, 7), 0.1)
     wp = pack(w)

@@ -184,7 +184,7 @@ def main():
         }
         if world == 1 and not args.no_second_policy:
             other = 'fp32' if args.precision == 'bf16' else 'bf16'
-            B2 = min(B, 4)
+            B2 = B
             x2 = x[:B2].contiguous()
             net.set_precision(other)
             d2, out2 = timed(x2, 1, 2)

@@ -38,6 +38,9 @@ def run(name, mma, in_bf16, iters=20):
     if in_bf16:
         pro = (torch.ones(N, Cin, device='cuda'), torch.zeros(N, Cin, device='cuda'))
     kw = dict(pad=k // 2, ksize=k, upsample=up, mma=mma, wb=wb, stats=True)
+    if os.environ.get('RES'):
+        Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+        kw['residual'] = torch.randn(N, Ho, Wo, Cout, device='cuda')
     if os.environ.get('SPLITK'):
         kw['split_k'] = int(os.environ['SPLITK'])
     if pro is not None:

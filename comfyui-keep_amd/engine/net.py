@@ -80,9 +80,14 @@ class KeepNet:
             raise NotImplementedError("KeepNet is an inference engine (the reference trains with BasicSR)")
         return self.eval()
 
+    # frame 0 of a clip depends on no other frame (no flow, no Kalman update, no CFA for i == 0), so a lone crop can be
+    # restored as a T = 1 clip instead of the reference's T = 2 duplicate (keep_processor.py:173-178) with the same result
+    supports_single_frame = True
+
     def set_precision(self, precision):
         """'fp32': f32 MFMA everywhere (the <=1e-3 parity policy).  'bf16': convolutions / linear layers round their
         MFMA operands to bf16 (fp32 accumulate, fp32 activations in HBM); attention, norms, softmax stay fp32."""
+
         if precision not in ('fp32', 'bf16'):
             raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
         self.precision = precision
@@ -492,8 +497,9 @@ class KeepNet:
         z, feats = self._vq_stack(xn, 'encoder', encoder_blocks(cfg), taps)
         enc_feat = {k: v.view(B, T, *v.shape[1:]) for k, v in feats.items()}
         zc = z.view(B, T, *z.shape[1:])
-        # K3: Kalman gains over the whole clip
-        gains = self._kalman_gain(z, B, T).view(B, T, -1)
+        # K3: Kalman gains over the whole clip.  They only enter frames i >= 1 (KA:1067-1070), so a T = 1 "clip" (the
+        # single-image fast path: frame 0 depends on neither the flows nor the gains nor the other frames) skips them.
+        gains = self._kalman_gain(z, B, T).view(B, T, -1) if T > 1 else None
         cft_at = {FUSE_GENERATOR_BLOCK[s]: s for s in cfg['cft_list']}
         cfa_at = {FUSE_GENERATOR_BLOCK[s]: s for s in cfg['cfa_list']}
         gblocks = generator_blocks(cfg)

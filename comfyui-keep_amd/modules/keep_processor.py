@@ -81,8 +81,8 @@ class KEEPFaceProcessor:
         clips = []
         for s, e in split_clips(n, max_clip_length):
             clip = crops_tensor[:, s:e]
-            if clip.shape[1] == 1:                       # net needs T>=2 in the reference
-                clip = torch.cat([clip, clip], dim=1)
+            if clip.shape[1] == 1 and not getattr(self.keep_net, 'supports_single_frame', False):
+                clip = torch.cat([clip, clip], dim=1)    # the reference net needs T>=2 (KP:173-178); frame 0 is kept
             clips.append(clip)
         run_clips = getattr(self.keep_net, 'run_clips', None)
         if run_clips is not None:                        # engine: batch / shard independent clips
@@ -108,10 +108,11 @@ class KEEPFaceProcessor:
         arr = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(c) for c in crops], axis=0)))
         spans = split_clips(arr.shape[0], max_clip_length)
         clips = []
+        t1_ok = getattr(self.keep_net, 'supports_single_frame', False)
         for s, e in spans:
             clip = arr[s:e]
-            if e - s == 1:                               # net needs T>=2 in the reference (KP:173-178)
-                clip = torch.cat([clip, clip], dim=0)
+            if e - s == 1 and not t1_ok:                 # the reference net needs T>=2 (KP:173-178): duplicate, keep frame 0
+                clip = torch.cat([clip, clip], dim=0)    # (the engine restores a lone frame as T=1: same frame 0, half the work)
             clips.append(clip)
         outs = run_u8(clips)
         faces = []

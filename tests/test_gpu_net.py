@@ -188,7 +188,8 @@ def test_batched_clips_equal_sequential(gpu_net):
 
 
 def test_processor_runs_on_engine(gpu_net):
-    """Config 1 (BASELINE.json configs[0]) through the drop-in processor: aligned 512x512 face, T=2 duplicate."""
+    """Config 1 (BASELINE.json configs[0]) through the drop-in processor: one aligned 512x512 face (restored as a T=1
+    clip by the engine; the reference's T=2 duplicate gives the same frame 0, see the single-frame test below)."""
     import test_host_logic as H   # installs the ComfyUI stubs
     from comfyui_keep_amd.modules.keep_processor import KEEPFaceProcessor
     from comfyui_keep_amd.modules.keep_model_loader import KEEPModelPack
@@ -199,7 +200,7 @@ def test_processor_runs_on_engine(gpu_net):
     out = KEEPFaceProcessor(pack).process_image(img, 1.0, True, True, False)
     assert out.shape == (512, 512, 3) and out.dtype == np.uint8
     x = U.crops_to_net_input([img]).unsqueeze(0).cuda()
-    ref = gpu_net(torch.cat([x, x], 1))[:, 0]
+    ref = gpu_net(x)[:, 0]
     assert np.array_equal(out, U.net_output_to_bgr_u8(ref[0]))
 
 
@@ -219,6 +220,8 @@ def test_processor_device_side_u8_path_equals_host_converters(gpu_net):
     dev_faces = proc._restore_crops_u8(crops, 2)
 
     class HostOnly:                      # same net, without the device-side converters
+        supports_single_frame = True
+
         def __init__(self, net):
             self.net = net
 
@@ -231,6 +234,34 @@ def test_processor_device_side_u8_path_equals_host_converters(gpu_net):
     for a, b in zip(dev_faces, host_faces):
         assert a.shape == (512, 512, 3) and a.dtype == np.uint8
         assert np.array_equal(a, b)
+
+
+def test_single_frame_fast_path_equals_frame0_of_duplicate(gpu_net):
+    """Frame 0 of a clip depends on no other frame (no flow, no Kalman update, no CFA at i == 0): the engine restores a
+    lone crop as T = 1 and must reproduce frame 0 of the reference's T = 2 duplicate (keep_processor.py:173-178)."""
+    x = synth.synth_clip(T=1, B=2, seed=77).cuda()
+    one = gpu_net(x)
+    two = gpu_net(torch.cat([x, x], dim=1))
+    assert one.shape == (2, 1, 3, 512, 512)
+    assert (one[:, 0] - two[:, 0]).abs().max().item() <= 5e-4      # split-K factors depend on the batch size
+    import test_host_logic as H   # installs the ComfyUI stubs
+    from comfyui_keep_amd.modules.keep_processor import KEEPFaceProcessor
+    from comfyui_keep_amd.modules.keep_model_loader import KEEPModelPack
+    pack = KEEPModelPack(gpu_net, H._Helper(), None, None, 'KEEP')
+    pack.device = torch.device('cuda')
+    proc = KEEPFaceProcessor(pack)
+    crop = [synth.ramp_image()]
+    fast = proc._restore_crops_u8(crop, 20)
+
+    class NoT1:
+        supports_single_frame = False
+
+        def __init__(self, net):
+            self.run_clips_u8 = net.run_clips_u8
+
+    proc.keep_net = NoT1(gpu_net)
+    dup = proc._restore_crops_u8(crop, 20)
+    assert np.abs(fast[0].astype(np.int16) - dup[0].astype(np.int16)).max() <= 1     # uint8 rounding of <=5e-4 differences
 
 
 def test_bf16_policy_quality_report(gpu_net):

@@ -40,7 +40,9 @@ __device__ __forceinline__ void win_decode(const AttnP& p, int bw, int t, int ro
   const int widx = bw - img * k2;
   const int wy = widx / p.ksplit, wx = widx - wy * p.ksplit;
   const int wh = p.img_h / p.ksplit, ww = p.img_w / p.ksplit;
-  const int ty = t / ww, tx = t - ty * ww;
+  // t / ww without the ~40-instruction integer division (exact for t < 65536, enforced on the host): everything else in
+  // this function is block-uniform and lands on the scalar unit
+  const int ty = (int)(((float)t + 0.5f) * (1.0f / (float)ww)), tx = t - ty * ww;
   int y = wy * wh + ty + p.shift;
   int x = wx * ww + tx + p.shift;
   if (y >= p.img_h) y -= p.img_h;
@@ -58,7 +60,7 @@ __device__ __forceinline__ int win_region(const AttnP& p, int bw, int t) {
   const int widx = bw % k2;
   const int wy = widx / p.ksplit, wx = widx - wy * p.ksplit;
   const int wh = p.img_h / p.ksplit, ww = p.img_w / p.ksplit;
-  const int ty = t / ww, tx = t - ty * ww;
+  const int ty = (int)(((float)t + 0.5f) * (1.0f / (float)ww)), tx = t - ty * ww;
   const int yr = wy * wh + ty, xr = wx * ww + tx;
   const int sh = wh / 2, sw = ww / 2;
   const int ih = yr < p.img_h - wh ? 0 : (yr < p.img_h - sh ? 1 : 2);

@@ -25,6 +25,8 @@ LAYERS = {  # name: (N, H, W, Cin, Cout, ksize, upsample)
     'c512_16_b8': (8, 16, 16, 512, 512, 3, False),
     'lin512_1024': (1, 1024, 1, 512, 1024, 1, False),
     'lin1024_512': (1, 1024, 1, 1024, 512, 1, False),
+    'lin512_b8': (1, 2048, 1, 512, 512, 1, False),
+    'lin1024_b8': (1, 2048, 1, 1024, 512, 1, False),
 }
 
 

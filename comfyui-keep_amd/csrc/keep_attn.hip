@@ -1134,3 +1134,167 @@ extern "C" int32_t keep_gm_mlp(const float* a, const float* b, const void* w0_bf
   KEEP_LAUNCH_CHECK("keep_gm_mlp");
   return KEEP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ streaming token GEMM
+// out[M, N] = X[M, 128] . W[N, 128]^T (+ bias): the GMFlow projections (qkv / q / kv / merge, GM/transformer.py:148-176) at
+// M = 1.2 M tokens are pure streaming: 2 K steps of work per 128x128 output tile, so the generic tile kernel spends its
+// time in per-tile prologue / epilogue (650 us for 1.27 GB = 1.9 TB/s).  Here W (<= 384 x 128 bf16) is staged in LDS ONCE
+// per persistent block; the block then walks token tiles of 128 rows: the next tile's X rows are in flight (registers)
+// while the current one is multiplied, outputs leave through a wave-private LDS tile as 16-byte stores (fp32 or bf16).
+#define TL_K 128
+template <int NT>                                   // N = NT * 128
+__global__ __launch_bounds__(256, (NT == 1 ? 2 : 1)) void token_linear_kernel(const float* __restrict__ x,
+                                                                               const unsigned short* __restrict__ w,
+                                                                               const float* __restrict__ bias, void* __restrict__ out,
+                                                                               long M, int out_bf16, int n_tiles) {
+  constexpr int N = NT * 128;
+  constexpr int XP = TL_K + 8;                      // bf16 pitch: 272 B = 17 slots
+  constexpr int OP = 64 + 4;                        // staging pitch (floats): 64 output columns at a time
+  extern __shared__ __attribute__((aligned(16))) unsigned char tl_raw[];
+  __bf16* Wsh = reinterpret_cast<__bf16*>(tl_raw);                 // [N][XP]
+  __bf16* Xs = Wsh + N * XP;                                       // [128][XP]
+  float* Ost = reinterpret_cast<float*>(Xs);                       // [4 waves][32][OP]: aliases the X tile (same size)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  for (int i = tid; i < N * (TL_K / 8); i += 256) {                // W -> LDS, once
+    const int row = i >> 4, c8 = (i & 15) << 3;
+    *reinterpret_cast<uint4*>(Wsh + row * XP + c8) = *reinterpret_cast<const uint4*>(w + (long)row * TL_K + c8);
+  }
+
+  // X tile 128 x 128 fp32 = 4096 float4: 16 per thread, row = (tid >> 5) + 8*u, float4 column = tid & 31
+  float4 x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15;
+#define TL_XR(X) X(0, x0) X(1, x1) X(2, x2) X(3, x3) X(4, x4) X(5, x5) X(6, x6) X(7, x7) X(8, x8) X(9, x9) X(10, x10) \
+                 X(11, x11) X(12, x12) X(13, x13) X(14, x14) X(15, x15)
+#define TL_LD(U, R)                                                                                         \
+  {                                                                                                         \
+    const long row = m_n + (tid >> 5) + 8 * (U);                                                            \
+    R = row < M ? *reinterpret_cast<const float4*>(x + row * TL_K + ((tid & 31) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f); \
+  }
+#define TL_ST(U, R)                                                                                         \
+  {                                                                                                         \
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;                                            \
+    bf16x4_t h;                                                                                             \
+    h[0] = (__bf16)R.x; h[1] = (__bf16)R.y; h[2] = (__bf16)R.z; h[3] = (__bf16)R.w;                         \
+    *reinterpret_cast<bf16x4_t*>(Xs + ((tid >> 5) + 8 * (U)) * XP + ((tid & 31) << 2)) = h;                 \
+  }
+
+  int tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  {
+    const long m_n = (long)tile * 128;
+    TL_XR(TL_LD)
+  }
+  const __bf16* ap = Xs + (wave * 32 + l31) * XP + lhi * 8;
+  const __bf16* bp = Wsh + l31 * XP + lhi * 8;
+  float* ost = Ost + wave * 32 * OP;
+  while (true) {
+    const long m0 = (long)tile * 128;
+    __syncthreads();                                 // previous tile's fragment reads are done (and W is staged)
+    TL_XR(TL_ST)
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < n_tiles) {
+      const long m_n = (long)next * 128;
+      TL_XR(TL_LD)
+    }
+    abf16x8 af[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const abf16x8*>(ap + ks * 16);
+    __syncthreads();                                 // every wave holds its X fragments: the tile becomes the output staging area
+#pragma unroll
+    for (int nh = 0; nh < NT * 2; ++nh) {            // 64 output columns at a time
+      f32x16 o[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], *reinterpret_cast<const abf16x8*>(bp + ((nh * 2 + j) * 32) * XP + ks * 16),
+                                                         o[j], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ost[row * OP + j * 32 + l31] = o[j][r];
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);            // wave-private tile
+#pragma unroll 4
+      for (int i = lane; i < 32 * 16; i += 64) {
+        const int row = i >> 4, c4 = (i & 15) << 2;
+        const long tok = m0 + wave * 32 + row;
+        if (tok < M) {
+          float4 v = *reinterpret_cast<const float4*>(ost + row * OP + c4);
+          if (bias) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + nh * 64 + c4);
+            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          }
+          if (out_bf16) {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+            bf16x4_t h;
+            h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+            *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(out) + tok * N + nh * 64 + c4) = h;
+          } else {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + tok * N + nh * 64 + c4) = v;
+          }
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);            // staging tile read before the next 64 columns overwrite it
+    }
+    if (next >= n_tiles) break;
+    tile = next;
+  }
+#undef TL_XR
+#undef TL_LD
+#undef TL_ST
+}
+
+template <int NT>
+static int launch_token_linear(const float* x, const void* w, const float* bias, void* out, long M, int out_bf16,
+                               hipStream_t st) {
+  const size_t lds = (size_t)(NT * 128 + 128) * (TL_K + 8) * 2;     // W + X tile (the output staging aliases the X tile)
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)token_linear_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      keep_set_error("keep_token_linear: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return KEEP_EHIP;
+    }
+    attr_set = true;
+  }
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const int n_tiles = cdiv(M, 128);
+  const int per_cu = (NT == 1) ? 2 : 1;
+  const int blocks = n_tiles < per_cu * n_cu ? n_tiles : per_cu * n_cu;
+  hipLaunchKernelGGL(token_linear_kernel<NT>, dim3(blocks), dim3(256), lds, st, x, (const unsigned short*)w, bias, out, M,
+                     out_bf16, n_tiles);
+  KEEP_LAUNCH_CHECK("keep_token_linear");
+  return KEEP_OK;
+}
+
+extern "C" int32_t keep_token_linear(const float* x, const void* w_bf16, const float* bias, void* out, int64_t M, int32_t K,
+                                     int32_t N, int32_t out_dtype, void* stream) {
+  KEEP_REQUIRE(x && w_bf16 && out && M > 0, "keep_token_linear: bad args");
+  KEEP_REQUIRE(K == TL_K && (N == 128 || N == 256 || N == 384), "keep_token_linear: built for K = 128, N in {128,256,384} (got K=%d N=%d)", K, N);
+  KEEP_REQUIRE(out_dtype == KEEP_F32 || out_dtype == KEEP_BF16, "keep_token_linear: bad out_dtype");
+  KEEP_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w_bf16 % 16 == 0 && (uintptr_t)out % 16 == 0 &&
+                   (!bias || (uintptr_t)bias % 16 == 0),
+               "keep_token_linear: 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  const int ob = out_dtype == KEEP_BF16 ? 1 : 0;
+  if (N == 128) return launch_token_linear<1>(x, w_bf16, bias, out, (long)M, ob, st);
+  if (N == 256) return launch_token_linear<2>(x, w_bf16, bias, out, (long)M, ob, st);
+  return launch_token_linear<3>(x, w_bf16, bias, out, (long)M, ob, st);
+}

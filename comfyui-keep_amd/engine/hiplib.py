@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 F32, BF16 = 0, 1
 MMA_F32, MMA_BF16 = 0, 1
@@ -47,6 +47,7 @@ _SIGNATURES = {
     'keep_group_stats': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     'keep_affine_act': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     'keep_gm_mlp': [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    'keep_token_linear': [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
     'keep_norm_act_bf16': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     'keep_gm_join': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     'keep_layernorm': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp],

@@ -38,6 +38,7 @@ def bf16_twin(w):
 
 
 COUT4 = os.environ.get('KEEP_NO_COUT4') is None            # dev switch: Cout <= 4 3x3 convs on the gather kernel
+TOKEN_LINEAR = os.environ.get('KEEP_NO_TOKEN_LINEAR') is None   # dev switch: streaming GEMM for the GMFlow projections
 HALO_F32 = os.environ.get('KEEP_NO_HALO_F32') is None     # dev switch: fall back to the gather kernel
 HALO_V1 = os.environ.get('KEEP_HALO_VER', '3') == '1'   # halo kernel generation (3 = persistent, default)
 USE_BK256 = bool(int(os.environ.get('KEEP_BK256', '0')))   # measured slower than BK=64 + split-K at B<=4 (kept for A/B)
@@ -202,6 +203,10 @@ def linear(x, w, bias=None, *, act=L.ACT_NONE, residual=None, pro=None, pro_act=
     shp = x.shape
     ld = shp[-1]
     M = x.numel() // ld
+    if (TOKEN_LINEAR and MMA == L.MMA_BF16 and ld == 128 and w.shape[0] in (128, 256, 384) and w.shape[-1] == 128 and M >= 65536
+            and act == L.ACT_NONE and residual is None and pro is None and pro_act == L.PRO_NONE and cin is None and in_off == 0
+            and x.dtype == torch.float32 and x.is_contiguous()):
+        return token_linear(x.view(M, ld), w.view(w.shape[0], 128), bias, out_bf16).reshape(*shp[:-1], w.shape[0])
     x4 = x.reshape(n_img, M // n_img, 1, ld)
     res4 = None if residual is None else residual.reshape(n_img, M // n_img, 1, residual.shape[-1])
     y = conv(x4, w, bias, stride=1, pad=0, ksize=1, pro=pro, pro_act=pro_act, act=act, residual=res4, cin=cin,
@@ -268,6 +273,16 @@ def attention(q, k, v, o, *, B, H, Lq, Lk, D, Dv, scale, q_str, k_str, v_str, o_
                 B=B, H=H, Lq=Lq, Lk=Lk, D=D, Dv=Dv, scale=float(scale), mode=mode, T=T, seg_len=seg_len,
                 img_h=img_h, img_w=img_w, ksplit=ksplit, shift=shift, kv_rot=kv_rot, n_img=n_img, mma=mma, in_dtype=in_dtype)
     return o
+
+
+def token_linear(x, w, bias=None, out_bf16=False):
+    """Streaming GEMM for the GMFlow projections (bf16 policy): x [M,128] fp32 @ w[N,128]^T, N in {128,256,384}."""
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    L.call('keep_token_linear', x, bf16_twin(w), bias, out, M, K, N, L.BF16 if out_bf16 else L.F32)
+    return out
 
 
 def gm_mlp(a, b, w0, w2):

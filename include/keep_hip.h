@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KEEP_ABI_VERSION 8
+#define KEEP_ABI_VERSION 9
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -163,6 +163,10 @@ int32_t keep_norm_act_bf16(const void* x, const float* scale, const float* shift
  * W2 bf16 [C,8C], no biases, C = 128; the [M,8C] intermediate stays on the CU. */
 int32_t keep_gm_mlp(const float* a, const float* b, const void* w0_bf16, const void* w2_bf16, float* out, int64_t M,
                     int32_t C, void* stream);
+/* GM/transformer.py:148-176 projections at M ~ 1e6 tokens (bf16 policy): out[M,N] = x[M,128] . W[N,128]^T (+ bias),
+ * W bf16, N in {128,256,384}, out fp32 or bf16 (out_dtype); persistent blocks keep W in LDS and stream the token rows. */
+int32_t keep_token_linear(const float* x, const void* w_bf16, const float* bias, void* out, int64_t M, int32_t K, int32_t N,
+                          int32_t out_dtype, void* stream);
 /* GM/backbone.py:36: out = relu( (a*sa+ha) + relu(b*sb+hb) ); sa/ha may be NULL (identity shortcut) */
 int32_t keep_gm_join(const float* a, const float* sa, const float* ha, const float* b, const float* sb,
                      const float* hb, float* out, int32_t N, int32_t HW, int32_t C, void* stream);

@@ -550,6 +550,22 @@ def test_conv_bf16_halo_bf16_output_and_bf16_inputs():
     check(nchw(z), F.conv2d(nchw(hn), bf16r(w2), None, padding=1), 3e-4, 'bf16 tensor -> norm pass -> halo conv')
 
 
+@pytest.mark.parametrize("N,out_bf16,with_bias", [(128, False, False), (384, True, False), (256, True, True), (128, False, True)])
+def test_token_linear_streaming_gemm(N, out_bf16, with_bias):
+    """keep_token_linear (GMFlow projections): persistent blocks, W resident in LDS, ragged M, fp32 / bf16 output."""
+    M = 128 * 5 + 37
+    x, w = rnd('tlx', (M, 128)), rnd('tlw', (N, 128), 0.08)
+    b = rnd('tlb', (N,)) if with_bias else None
+    out = torch.empty(M, N, device='cuda', dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    L.call('keep_token_linear', dev(x), dev(w).to(torch.bfloat16), None if b is None else dev(b), out, M, 128, N,
+           L.BF16 if out_bf16 else L.F32)
+    ref = F.linear(bf16r(x), bf16r(w), b)
+    if out_bf16:
+        check(out.float(), bf16r(ref), 1e-2, f'token linear N={N} bf16 out')
+    else:
+        check(out, ref, 2e-5, f'token linear N={N}')
+
+
 def test_gm_mlp_fused_matches_two_gemms():
     """keep_gm_mlp (GM/transformer.py:139-142,182 fused): vs torch on the bf16-rounded operands with the GELU output
     rounded to bf16 (what the second MFMA consumes), ragged M."""

@@ -173,6 +173,36 @@ def test_single_image_aligned_duplicates_to_T2():
     assert net.calls == [2] and out.shape == (512, 512, 3) and out.dtype == np.uint8
 
 
+class _U8Net(_RecordingNet):
+    """engine stand-in offering the device-side uint8 entry point: output clip = 255 - input, records clip lengths."""
+
+    def __init__(self, single_frame):
+        super().__init__()
+        self.supports_single_frame = single_frame
+
+    def run_clips_u8(self, clips, max_b=4):
+        for c in clips:
+            assert c.dtype == torch.uint8 and c.dim() == 4 and c.shape[1:] == (512, 512, 3)
+            self.calls.append(c.shape[0])
+        return [255 - c for c in clips]
+
+
+@pytest.mark.parametrize("single_frame", [True, False])
+def test_uint8_entry_point_chunking_and_lone_crops(single_frame):
+    """SURVEY 8f-1 host logic: crops are handed over as uint8 clips chunked like keep_processor.py:263-270; a lone crop goes
+    as T=1 when the engine supports it, else as the reference's T=2 duplicate with frame 0 kept -- same restored faces."""
+    net = _U8Net(single_frame)
+    proc = KEEPFaceProcessor(_pack(net))
+    base = synth.ramp_image()
+    crops = [np.ascontiguousarray(np.roll(base, k, axis=0)) for k in range(5)]
+    faces = proc._restore_crops_u8(crops, 2)
+    assert net.calls == ([2, 2, 1] if single_frame else [2, 2, 2])
+    assert len(faces) == 5 and all(f.dtype == np.uint8 and f.shape == (512, 512, 3) for f in faces)
+    assert all(np.array_equal(f, 255 - c) for f, c in zip(faces, crops))
+    out = proc.process_image(base, 1.0, True, True, False)           # single-image node, aligned input
+    assert net.calls[-1] == (1 if single_frame else 2) and np.array_equal(out, 255 - base)
+
+
 def test_legacy_key_conversion_and_param_selection():
     sd = {'cross_fuse.16.norm1.weight': 1, 'fuse_convs_dict.32.scale.0.bias': 2, 'encoder.blocks.0.weight': 3}
     out = convert_legacy_keys(sd)

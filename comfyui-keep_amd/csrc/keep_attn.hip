@@ -30,7 +30,6 @@ struct AttnP {
   int mode, T, seg_len;
   int img_h, img_w, ksplit, shift, kv_rot, n_img;
   int nslices;  // dv slices per head
-  int exp;      // dev-only ablation switch (KEEP_ATTN_EXP), 0 in production
 };
 
 // window-mode: token t of window-batch bw -> (image, pixel index)
@@ -949,7 +948,6 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
   p.scale = a->scale; p.mode = a->mode; p.T = a->T; p.seg_len = a->seg_len;
   p.img_h = a->img_h; p.img_w = a->img_w; p.ksplit = a->ksplit; p.shift = a->shift; p.kv_rot = a->kv_rot;
   p.n_img = a->n_img;
-  { const char* e = getenv("KEEP_ATTN_EXP"); p.exp = e ? atoi(e) : 0; }
   hipStream_t st = (hipStream_t)stream;
   // dv slice per block: 32 / 64 / 128 columns
   const int dvt = a->Dv <= 32 ? 1 : (a->Dv <= 64 ? 2 : 4);

@@ -46,7 +46,6 @@ struct ConvP {
   int out_bf16; // write the output tensor as bf16 (gather kernels' staged epilogue, persistent bf16 halo kernel)
   int vec_epi;  // Cout/out_ld/res_ld %% 4 == 0 and aligned pointers -> LDS-staged float4 epilogue
   int exp;      // dev-only ablation switch (KEEP_HALO_EXP), 0 in production
-  int stagger;  // persistent halo kernels: spread of the per-block start delay, in shader cycles (0 = none)
   int flatk;    // Cin < 8: K = KH*KW*Cin flattened (element-wise gather) instead of tap-major chunks
 };
 
@@ -1081,17 +1080,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles
 //     and the per-block launch / geometry cost is paid once per CU instead of once per tile.
 //   * normalisation partial sums are per consumer wave (stats_P = 4 x tiles): no cross-wave reduction, no barrier
 //     that the producers would have to join.
-// Blocks of a persistent launch start together and do identical work, so they reach their epilogues together: the output
-// stores of the whole GPU arrive as one burst while every matrix pipe idles, then everybody computes again.  A
-// per-block start delay (golden-ratio sequence over blockIdx, uniform in [0, spread)) de-phases the blocks.
-__device__ __forceinline__ void halo_stagger(int spread) {
-  if (spread <= 0) return;
-  const float ph = (float)blockIdx.x * 0.6180339887f;
-  const long wait = (long)((ph - floorf(ph)) * (float)spread);
-  const long t0 = __builtin_readcyclecounter();
-  while ((long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-}
-
 struct HaloItem {
   int n, tx, ty, oy0, ox0, n0, z, ch_begin, ch_end;
 };
@@ -1556,7 +1544,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvP p, int tile
 
   int item = blockIdx.x;
   if (item >= n_items) return;
-  halo_stagger(p.stagger);
   HaloItem cur = halo_decode<TW>(p, item, items_per_z, tiles_x, tiles_y, ncb);
   setup(cur);
   if (cur.ch_begin < cur.ch_end) fetch(cur.ch_begin);
@@ -1987,7 +1974,6 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
                (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0) &&
                (!a->workspace || (uintptr_t)a->workspace % 16 == 0)) ? 1 : 0;
   { const char* e = getenv("KEEP_HALO_EXP"); p.exp = e ? atoi(e) : 0; }
-  { const char* e = getenv("KEEP_HALO_STAGGER"); p.stagger = e ? atoi(e) : 0; }
   p.flatk = (a->mma == KEEP_MMA_BF16 && a->Cin < 8 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE) ? 1 : 0;
   p.stats = a->stats_out;
   p.stats_P = a->stats_P;

@@ -128,7 +128,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--clips', type=int, default=int(os.environ.get('KEEP_BENCH_CLIPS', '8')),
+    ap.add_argument('--clips', type=int, default=int(os.environ.get('KEEP_BENCH_CLIPS', '16')),
                     help='independent T=20 clips per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-second-policy', action='store_true', help='skip timing the other precision policy')
@@ -180,6 +180,7 @@ def main():
                                    f"{args.precision} MFMA-operand policy, fp32 accumulate + storage), KEEP config, synthetic weights seed 0",
                        "clips_per_gpu": B, "clip_length": T_CLIP, "parallelism": f"dp{world} over clips"},
             "whole_net_tflops": round(fps * FLOP_PER_FRAME_T20 / 1e12, 2),
+            "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
             "roofline": conv_roofline(net, x),
         }
         if world == 1 and not args.no_second_policy:

@@ -4,11 +4,11 @@
 set -e
 cd "$(dirname "$0")/.."
 BF=$1; FP=$2; PMCB=$3; PMCF=$4; BJ=$5
-{ echo "# rocprofv3 --kernel-trace --stats -- python tools/run_step.py bf16 8 2   (bf16 policy, 8 clips x T=20 per pass, 2 passes; the first pass includes first-touch allocation)";
-  python profiles/summarize_rocpd.py $BF 2; } > profiles/r01_bf16_b8_kernel_stats.txt
-{ echo "# rocprofv3 --kernel-trace --stats -- python tools/run_step.py fp32 8 2   (fp32 parity policy, 8 clips x T=20 per pass, 2 passes)";
-  python profiles/summarize_rocpd.py $FP 2; } > profiles/r01_fp32_b8_kernel_stats.txt
-for p in bf16 fp32; do B=8; PMC=$PMCB; [ $p = fp32 ] && PMC=$PMCF
+{ echo "# rocprofv3 --kernel-trace --stats -- python tools/run_step.py bf16 16 2   (bf16 policy, 16 clips x T=20 per pass, 2 passes; the first pass includes first-touch allocation)";
+  python profiles/summarize_rocpd.py $BF 2; } > profiles/r01_bf16_b16_kernel_stats.txt
+{ echo "# rocprofv3 --kernel-trace --stats -- python tools/run_step.py fp32 16 2   (fp32 parity policy, 16 clips x T=20 per pass, 2 passes)";
+  python profiles/summarize_rocpd.py $FP 2; } > profiles/r01_fp32_b16_kernel_stats.txt
+for p in bf16 fp32; do B=16; PMC=$PMCB; [ $p = fp32 ] && PMC=$PMCF
   { echo "# rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace --output-format csv -- python tools/run_step.py $p $B 1   (one step = $B clips x T=20)";
     echo "# KiB per launch as reported; FETCH_SIZE must be doubled on gfx950 (MI355X_MICROARCH.md; calibrated on norm_act_bf16 in profiles/r01_pmc_halo_traffic.txt)";
     python profiles/summarize_pmc.py $PMC/${p}_*_counter_collection.csv | head -40; } > profiles/r01_pmc_step_${p}_b$B.txt
@@ -18,7 +18,7 @@ import csv, collections, json, sys
 csv.field_size_limit(1 << 30)
 pmcs = {'bf16': sys.argv[1], 'fp32': sys.argv[2]}
 out = {}
-for pol, B in (('bf16', 8), ('fp32', 8)):
+for pol, B in (('bf16', 16), ('fp32', 16)):
     pmc = pmcs[pol]
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):

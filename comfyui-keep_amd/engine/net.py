@@ -549,7 +549,7 @@ class KeepNet:
         return out
 
     # ------------------------------------------------------------------ independent clips (hot loop #1)
-    def run_clips(self, clips, need_upscale=False, max_b=4):
+    def run_clips(self, clips, need_upscale=False, max_b=8):
         """list of [1,T_i,3,H,W] -> list of restored clips.  Clips share no state (KA:1050,1064,1113), so
         equal-length clips are stacked on the batch axis; results equal the sequential loop."""
         order = {}
@@ -565,7 +565,7 @@ class KeepNet:
         return outs
 
     # ------------------------------------------------------------------ device-side pre/post
-    def run_clips_u8(self, clips_u8, max_b=4):
+    def run_clips_u8(self, clips_u8, max_b=8):
         """list of uint8 BGR crops [T_i,H,W,3] (host or device) -> list of restored uint8 BGR [T_i,H,W,3] on the host.
 
         Replaces the per-frame host conversions either side of the clip loop -- ``img2tensor(face/255., bgr2rgb) +

@@ -150,7 +150,7 @@ class KeepNet:
         cmid = w[f'{p}.conv1.weight'].shape[0]
         h16 = (ops.MMA == L.MMA_BF16 and cmid % 64 == 0 and ops.halo_bf16_eligible(x.shape[-1], cmid, H, Wd)
                and ops.halo_bf16_eligible(cmid, w[f'{p}.conv2.weight'].shape[0], H, Wd)
-               and (N * H * Wd // 256) * (cmid // 64) * 4 >= ops._TARGET_WAVES)     # small maps keep fp32 + split-K
+               and H * Wd >= 16384)     # maps below 128x128 keep fp32 + split-K; per-image rule: results do not depend on B
         h = ops.conv(x, w[f'{p}.conv1.weight'], w[f'{p}.conv1.bias'], pro=self._gn(x, f'{p}.norm1'),
                      pro_act=L.PRO_SWISH, stats=True, out_bf16=h16)
         sc = x

@@ -1825,6 +1825,159 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(ConvP p, int t
   }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3, Cin <= 4
+// The first convolutions (RGB -> 64 channels at 512x512: VQ conv_in of the LQ encoder over all B*T frames and of the HQ
+// encoder every frame).  K = 27: on the generic tile kernel a block is one K step wrapped in prologue + epilogue
+// (731 us for 16 frames, 1.5 TB/s on an op that only has to write 1.07 GB).  Here: persistent blocks (2 per CU), the
+// weights [Cout_blk 64][K 32] stay in LDS, per 8x32-pixel item the 10x34x3 fp32 halo is loaded once (coalesced 4-byte
+// loads of contiguous rows), every thread expands ITS pixel into one 32-wide bf16 im2col row in LDS, and the wave runs
+// 8 MFMAs (64 pixels x 64 couts, K = 32) before the same LDS-staged float4 epilogue + GroupNorm partials as the halo kernel.
+#define C3_K 32
+#define C3_PITCH 40                          // bf16 per im2col / weight row (80 B: conflict-free ds_read_b128)
+
+__global__ __launch_bounds__(256, 2) void conv3x3_c3_kernel(ConvP p, int tiles_x, int tiles_y, int ncb, int n_items) {
+  constexpr int HW_ = 34, HROWS = 10;
+  constexpr int EPI_B = 4 * 64 * 68 * 4;                                    // staging tile; the im2col rows alias it
+  constexpr int A_B = 256 * C3_PITCH * 2;
+  static_assert(A_B <= EPI_B, "im2col rows fit the staging area");
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[EPI_B + 64 * C3_PITCH * 2 + HROWS * HW_ * 4 * 4];
+  float* et_base = reinterpret_cast<float*>(lds_raw);
+  __bf16* As = reinterpret_cast<__bf16*>(lds_raw);                          // [256 px][C3_PITCH]
+  __bf16* Ws = reinterpret_cast<__bf16*>(lds_raw + EPI_B);                  // [64][C3_PITCH], resident across items
+  float* Hs = reinterpret_cast<float*>(lds_raw + EPI_B + 64 * C3_PITCH * 2);   // [10][34 * Cin]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int Cin = p.Cin, K = 9 * Cin;                                        // K <= 36 > 32 only for Cin = 4: host limits Cin <= 3
+  const int rowf = HW_ * Cin;                                                // floats per halo row
+
+  int cur_cb = -1;
+  auto load_weights = [&](int cb) {                                          // [64 couts][K] bf16, zero padded to 32
+    for (int i = tid; i < 64 * C3_K; i += 256) {
+      const int co = i >> 5, k = i & 31;
+      unsigned short v = 0;
+      if (k < K && cb * 64 + co < p.Cout) v = p.wb[(long)(cb * 64 + co) * K + k];
+      reinterpret_cast<unsigned short*>(Ws)[co * C3_PITCH + k] = v;
+    }
+  };
+
+  f32x16 acc[2][2];
+  const int py = tid >> 5, px = tid & 31;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int lid = xcd_remap(item, n_items);
+    const int cb = lid % ncb;
+    int t = lid / ncb;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int n = t / tiles_y;
+    const int oy0 = ty * 8, ox0 = tx * 32, n0 = cb * 64;
+    __syncthreads();                                                         // previous item's staging tile fully stored
+    if (cb != cur_cb) {
+      load_weights(cb);
+      cur_cb = cb;
+    }
+    // ---- halo rows: (oy0-1 .. oy0+8) x (ox0-1 .. ox0+32) x Cin, contiguous in memory per row
+    const float* img = p.in + (long)n * p.H * p.W * p.in_ld;
+    for (int i = tid; i < HROWS * rowf; i += 256) {
+      const int hy = i / rowf, r = i - hy * rowf;
+      const int hx = r / Cin, c = r - hx * Cin;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      float v = 0.f;
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = img[((long)iy * p.W + ix) * p.in_ld + c];
+      Hs[i] = v;
+    }
+    __syncthreads();
+    // ---- im2col row of this thread's pixel: k = (kh*3 + kw)*Cin + c
+    {
+      float vals[C3_K];
+#pragma unroll
+      for (int k = 0; k < C3_K; ++k) vals[k] = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kwc = 0; kwc < 9; ++kwc)                                    // (kw, c) run is contiguous in the halo row for Cin = 3
+          if (kwc < 3 * Cin && kh * 3 * Cin + kwc < C3_K) vals[kh * 3 * Cin + kwc] = Hs[(py + kh) * rowf + px * Cin + kwc];
+      bf16x8 h[4];
+#pragma unroll
+      for (int k = 0; k < C3_K; ++k) h[k >> 3][k & 7] = (__bf16)vals[k];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x8*>(&As[tid * C3_PITCH + q * 8]) = h[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[(wave * 64 + i * 32 + l31) * C3_PITCH + ks * 16 + lhi * 8]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(&Ws[(j * 32 + l31) * C3_PITCH + ks * 16 + lhi * 8]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();                                                         // A reads done: the area becomes the staging tile
+    // ---- epilogue: wave tile = rows 2*wave, 2*wave+1 of the item (64 pixels) x 64 couts
+    constexpr int EP = 68;
+    float* et = et_base + wave * 64 * EP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) et[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * EP + j * 32 + l31] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const int c4 = (lane & 15) * 4, prow = lane >> 4;
+    const int co = n0 + c4;
+    const bool cok = co < p.Cout;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
+#pragma unroll 4
+    for (int q16 = 0; q16 < 16; ++q16) {
+      if (!cok) break;
+      const int pxl = q16 * 4 + prow;
+      const int oy = oy0 + 2 * wave + (pxl >> 5);
+      const long m = ((long)n * p.Ho + oy) * p.Wo + ox0 + (pxl & 31);
+      const float4 v = *reinterpret_cast<const float4*>(et + pxl * EP + c4);
+      float e[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e[q] = act_apply_fast(e[q], p.epi_act);
+      *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s4[q] += e[q];
+        ss4[q] += e[q] * e[q];
+      }
+    }
+    if (p.stats) {          // per wave: stats_P = Ho*Wo/64, partial index = tile*4 + wave
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s4[q] += __shfl_xor(s4[q], 16);
+        s4[q] += __shfl_xor(s4[q], 32);
+        ss4[q] += __shfl_xor(ss4[q], 16);
+        ss4[q] += __shfl_xor(ss4[q], 32);
+      }
+      if (lane < 16 && cok) {
+        float* dst = p.stats + (((long)n * p.stats_P + (ty * tiles_x + tx) * 4 + wave) * p.Cout + co) * 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          dst[q * 2 + 0] = s4[q];
+          dst[q * 2 + 1] = ss4[q];
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ 3x3, Cout <= 4
 // The generator's output convolution (64 -> 3 channels at 512x512, VQ:241): on a 32-wide MFMA tile 29 of 32 output
 // columns are padding (the 128x32 gather tile measured 6.7 TF, 1 ms per 8 frames).  With <= 4 output channels the op
@@ -2003,6 +2156,32 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
     dim3 grid((a->Ho / SC_TH) * (a->Wo / SC_TW), a->N);
     hipLaunchKernelGGL(conv3x3_cout4_kernel, grid, block, 0, st, p);
     KEEP_LAUNCH_CHECK("keep_conv2d(cout<=4)");
+    return KEEP_OK;
+  }
+  // RGB first convolutions, bf16 policy: persistent im2col-in-LDS kernel
+  const bool c3_ok = a->mma == KEEP_MMA_BF16 && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 && a->pad_l == 1 &&
+                     !a->upsample && a->Cin <= 3 && a->Cout % 4 == 0 && a->Cout >= 32 && a->dtype == KEEP_F32 &&
+                     a->out_dtype != KEEP_BF16 && a->Ho == a->H && a->Wo == a->W && a->Ho % 8 == 0 && a->Wo % 32 == 0 &&
+                     !a->pro_scale && a->pro_act == KEEP_PRO_NONE && !a->residual && !a->aux && p.split_k == 1 &&
+                     a->out_ld % 4 == 0 && (uintptr_t)a->out % 16 == 0 && (!a->bias || (uintptr_t)a->bias % 16 == 0) &&
+                     !getenv("KEEP_NO_C3");
+  if (p.stats && c3_ok) {
+    const long hw_o = (long)a->Ho * a->Wo;
+    KEEP_REQUIRE(a->stats_P == hw_o / 64, "keep_conv2d: stats_P=%d must equal Ho*Wo/64", a->stats_P);
+  }
+  if (c3_ok) {
+    const int tiles_x = a->Wo / 32, tiles_y = a->Ho / 8, ncb = (a->Cout + 63) / 64;
+    const int n_items = a->N * tiles_x * tiles_y * ncb;
+    static int n_cu_c3 = 0;
+    if (n_cu_c3 == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu_c3 = prop.multiProcessorCount;
+      if (n_cu_c3 <= 0) n_cu_c3 = 256;
+    }
+    hipLaunchKernelGGL(conv3x3_c3_kernel, dim3(n_items < 2 * n_cu_c3 ? n_items : 2 * n_cu_c3), block, 0, st, p, tiles_x, tiles_y, ncb,
+                       n_items);
+    KEEP_LAUNCH_CHECK("keep_conv2d(Cin<=3)");
     return KEEP_OK;
   }
   const bool halo_f32_ok = a->mma != KEEP_MMA_BF16 && a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && a->KH == 3 && a->KW == 3 &&

@@ -37,6 +37,7 @@ def bf16_twin(w):
     return _BLOB16[off:off + w.numel()]
 
 
+C3 = os.environ.get('KEEP_NO_C3') is None                  # dev switch: Cin <= 3 first convs on the gather kernel
 COUT4 = os.environ.get('KEEP_NO_COUT4') is None            # dev switch: Cout <= 4 3x3 convs on the gather kernel
 TOKEN_LINEAR = os.environ.get('KEEP_NO_TOKEN_LINEAR') is None   # dev switch: streaming GEMM for the GMFlow projections
 HALO_F32 = os.environ.get('KEEP_NO_HALO_F32') is None     # dev switch: fall back to the gather kernel
@@ -138,6 +139,13 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
     cout4 = (COUT4 and Cout <= 4 and ksize == 3 and stride == 1 and not down and pad == 1 and not upsample
              and x.dtype == torch.float32 and not out_bf16 and Cin % 16 == 0 and ld % 4 == 0 and in_off % 4 == 0
              and Ho % 8 == 0 and Wo % 32 == 0 and residual is None and aux is None)
+    # RGB first convolutions (Cin <= 3), bf16 policy: persistent im2col-in-LDS kernel
+    c3 = (C3 and not cout4 and mma == L.MMA_BF16 and ksize == 3 and stride == 1 and not down and pad == 1 and not upsample
+          and Cin <= 3 and Cout % 4 == 0 and Cout >= 32 and x.dtype == torch.float32 and not out_bf16 and Ho % 8 == 0
+          and Wo % 32 == 0 and pro is None and pro_act == L.PRO_NONE and residual is None and aux is None
+          and split_k in (None, 1))
+    if c3:
+        split_k = 1
     if cout4:
         split_k, halo, halo_f32, stats, mma = 1, False, False, False, L.MMA_F32
     elif mma == L.MMA_BF16 and wb is None:
@@ -166,7 +174,7 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
     part, stats_P = None, 0
     if stats and split_k == 1:
         halo_v2 = halo_f32 or (halo and pro is None and pro_act == L.PRO_NONE and not HALO_V1)
-        bm = (64 if halo_v2 else 256) if (halo or halo_f32) else (128 if Cout <= 32 else (64 if (Cout <= 64 or M <= 4096) else 128))
+        bm = 64 if c3 else (64 if halo_v2 else 256) if (halo or halo_f32) else (128 if Cout <= 32 else (64 if (Cout <= 64 or M <= 4096) else 128))
         if (Ho * Wo) % bm == 0 and out.shape[-1] == Cout:
             stats_P = (Ho * Wo) // bm
             part = empty((N, stats_P, Cout, 2), x)
@@ -174,7 +182,7 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         tw = 32 if (Ho % 8 == 0 and Wo % 32 == 0) else 16
-        kname = ('conv3x3_cout4_kernel' if cout4 else f'conv3x3_halo_f32_kernel<{tw}>' if halo_f32 else
+        kname = ('conv3x3_cout4_kernel' if cout4 else 'conv3x3_c3_kernel' if c3 else f'conv3x3_halo_f32_kernel<{tw}>' if halo_f32 else
                  f"conv3x3_halo3_kernel<{'true' if in_dtype == L.BF16 else 'false'}, {tw}>" if halo else
                  tile_config(M, Cout, mma == L.MMA_BF16, bk256))
         # algorithmic bytes: one read of the input window at its storage type, the weights, one write of the output

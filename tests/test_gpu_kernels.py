@@ -582,6 +582,29 @@ def test_gm_mlp_fused_matches_two_gemms():
     check(out, ops.linear(hm, dev(w2)), 2e-2, 'fused vs two fp32-policy GEMMs')
 
 
+def test_conv_bf16_rgb_first_conv_kernel(monkeypatch):
+    """VQ conv_in (3 -> 64, 3x3): the persistent im2col-in-LDS kernel vs torch on the rounded operands, vs the flat-K
+    gather kernel, and its fused GroupNorm partials; also Cout = 96 (masked half cout-block) and Cin = 1."""
+    for (n, cin, cout, h, wd) in [(2, 3, 64, 32, 64), (1, 3, 96, 8, 32), (3, 1, 32, 16, 32)]:
+        x, w, b = rnd('c3x', (n, cin, h, wd)), rnd('c3w', (cout, cin, 3, 3), 0.2), rnd('c3b', (cout,))
+        wp = pack(w)
+        wb = wp.to(torch.bfloat16)
+        ops.PROFILE = []
+        y = ops.conv(dev(nhwc(x)), wp, dev(b), mma=L.MMA_BF16, wb=wb, stats=True)
+        assert ops.PROFILE[-1][0] == 'conv3x3_c3_kernel'
+        ops.PROFILE = None
+        monkeypatch.setattr(ops, 'C3', False)
+        monkeypatch.setenv('KEEP_NO_C3', '1')
+        y_g = ops.conv(dev(nhwc(x)), wp, dev(b), mma=L.MMA_BF16, wb=wb, stats=True)
+        monkeypatch.setattr(ops, 'C3', True)
+        monkeypatch.delenv('KEEP_NO_C3')
+        check(nchw(y), F.conv2d(bf16r(x), bf16r(w), b, padding=1), 2e-5, f'rgb conv {cin}->{cout}')
+        check(y, y_g, 2e-5, 'rgb conv vs flat-K gather kernel')
+        sc, sh = ops.norm_affine(y, None, None, cout, 1e-5)
+        sc2, sh2 = ops.norm_affine(y.clone(), None, None, cout, 1e-5)
+        check(sc, sc2, 1e-5, 'rgb conv fused stats scale'); check(sh, sh2, 1e-5, 'rgb conv fused stats shift')
+
+
 def test_conv_bf16_flat_k_small_cin():
     x, w = rnd('7x', (2, 3, 64, 64)), rnd('7w', (64, 3, 7, 7), 0.1)
     wp = pack(w)

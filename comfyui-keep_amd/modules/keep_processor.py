@@ -16,6 +16,8 @@ What this build adds: independent clips are handed to the engine in one call
 (``keep_net.run_clips``) so it can batch equal-length clips per GPU and shard them across
 GPUs; results are identical to the sequential loop because clips share no state.
 """
+import os
+
 import numpy as np
 import torch
 from tqdm import tqdm
@@ -73,6 +75,10 @@ class KEEPFaceProcessor:
         # restored 512x512 faces of the last call, uint8 BGR (the reference discards them on the
         # aligned-sequence path; exposed so callers / tests can read what the net produced)
         self.last_restored_faces = []
+        # reference quirk P2: `KEEP Image Sequence` with has_aligned=True restores every frame
+        # and then returns the *input* frames.  Default: bug-compatible.  KEEP_AMD_RETURN_RESTORED_ALIGNED=1 (or setting
+        # the attribute) returns the restored faces instead.
+        self.return_restored_aligned = os.environ.get('KEEP_AMD_RETURN_RESTORED_ALIGNED', '0') == '1'
 
     # ------------------------------------------------------------------ net invocation
     def _restore_clips(self, crops_tensor, max_clip_length):
@@ -239,6 +245,16 @@ class KEEPFaceProcessor:
         for i in tqdm(range(n_frames), desc="Pasting faces and finalizing frames"):
             bg = self._final_background(frames_bgr[i], final_upscale_factor)
             k = faces_per_frame[i]
+            if has_aligned_frames and self.return_restored_aligned and k:
+                # opt-in fix of reference quirk P2: an aligned sequence returns its restored faces, resized the way the
+                # single-image node does (keep_processor.py:190-197), instead of the upscaled input
+                face = restored_faces[face_ptr]
+                face_ptr += k
+                if self.face_upscale_model:
+                    face = self._run_upscaler(self.face_upscale_model, face)
+                side = int(512 * final_upscale_factor)
+                out_frames.append(_resize(face, side, side, 'INTER_LANCZOS4'))
+                continue
             if k == 0 or has_aligned_frames:            # aligned: restored faces unused (reference quirk P2)
                 out_frames.append(bg)
                 continue

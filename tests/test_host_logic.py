@@ -165,6 +165,21 @@ def test_sequence_clip_loop_aligned():
     assert ProgressBar.last.current == 41 * 3          # no paste ticks on the aligned path (Appendix A.2)
 
 
+def test_sequence_aligned_fix_flag_returns_restored_faces():
+    """Opt-in fix of reference quirk P2: with return_restored_aligned the aligned-sequence node returns the restored
+    faces (here 255 - crop through the uint8 entry point) instead of its input; default stays bug-compatible."""
+    net = _U8Net(True)
+    proc = KEEPFaceProcessor(_pack(net))
+    frames = torch.rand(3, 512, 512, 3)
+    u8 = (frames * 255).to(torch.uint8)
+    out_default = proc.process_image_sequence(frames, 1.0, True, True, False, max_clip_length=2)
+    assert torch.equal(out_default, u8.float() / 255.0)
+    proc.return_restored_aligned = True
+    out_fixed = proc.process_image_sequence(frames, 1.0, True, True, False, max_clip_length=2)
+    assert out_fixed.shape == (3, 512, 512, 3)
+    assert torch.equal(out_fixed, (255 - u8).float() / 255.0)
+
+
 def test_single_image_aligned_duplicates_to_T2():
     net = _RecordingNet()
     proc = KEEPFaceProcessor(_pack(net))

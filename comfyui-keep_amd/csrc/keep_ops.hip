@@ -347,11 +347,54 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// C == 128 (the GMFlow token stream, 2.5 M rows per call at 16 clips): 16 lanes per row, two float4 per lane -- the generic
+// kernel spends a whole wave and 16 predicated iterations on 512 bytes.  Same two-pass arithmetic.
+__global__ __launch_bounds__(256) void layernorm128_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ res,
+                                                           float* __restrict__ out, long M, float eps) {
+  const int sub = threadIdx.x & 15;                       // float4 columns sub and sub + 16
+  const float4 g0 = *reinterpret_cast<const float4*>(gamma + sub * 4), g1 = *reinterpret_cast<const float4*>(gamma + 64 + sub * 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(beta + sub * 4), b1 = *reinterpret_cast<const float4*>(beta + 64 + sub * 4);
+  for (long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4); row < M; row += (long)gridDim.x * 16) {
+    const float* xr = x + row * 128;
+    const float4 a = *reinterpret_cast<const float4*>(xr + sub * 4), b = *reinterpret_cast<const float4*>(xr + 64 + sub * 4);
+    float s = (a.x + a.y) + (a.z + a.w) + (b.x + b.y) + (b.z + b.w);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / 128.0f);
+    const float d[8] = {a.x - mean, a.y - mean, a.z - mean, a.w - mean, b.x - mean, b.y - mean, b.z - mean, b.w - mean};
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q += d[j] * d[j];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 128.0f) + eps);
+    float4 y0 = make_float4(d[0] * rstd * g0.x + b0.x, d[1] * rstd * g0.y + b0.y, d[2] * rstd * g0.z + b0.z, d[3] * rstd * g0.w + b0.w);
+    float4 y1 = make_float4(d[4] * rstd * g1.x + b1.x, d[5] * rstd * g1.y + b1.y, d[6] * rstd * g1.z + b1.z, d[7] * rstd * g1.w + b1.w);
+    if (res) {
+      const float4 r0 = *reinterpret_cast<const float4*>(res + row * 128 + sub * 4);
+      const float4 r1 = *reinterpret_cast<const float4*>(res + row * 128 + 64 + sub * 4);
+      y0.x += r0.x; y0.y += r0.y; y0.z += r0.z; y0.w += r0.w;
+      y1.x += r1.x; y1.y += r1.y; y1.z += r1.z; y1.w += r1.w;
+    }
+    *reinterpret_cast<float4*>(out + row * 128 + sub * 4) = y0;
+    *reinterpret_cast<float4*>(out + row * 128 + 64 + sub * 4) = y1;
+  }
+}
+
 extern "C" int32_t keep_layernorm(const float* x, const float* gamma, const float* beta, const float* res, float* out,
                                   const float* pos, int32_t pos_rows, float* out2, int32_t M, int32_t C, float eps,
                                   void* stream) {
   KEEP_REQUIRE(x && gamma && beta && out && M > 0 && C > 0 && C <= 1024, "keep_layernorm: bad args (C=%d)", C);
   KEEP_REQUIRE(!out2 || (pos && pos_rows > 0), "keep_layernorm: out2 requires pos");
+  if (C == 128 && !out2 && M >= 4096 && (uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)gamma % 16 == 0 &&
+      (uintptr_t)beta % 16 == 0 && (!res || (uintptr_t)res % 16 == 0)) {
+    int blocks = cdiv(M, 16);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(layernorm128_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, res, out, (long)M, eps);
+    KEEP_LAUNCH_CHECK("keep_layernorm(C=128)");
+    return KEEP_OK;
+  }
   hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, res, out, pos,
                      pos_rows > 0 ? pos_rows : 1, out2, M, C, eps);
   KEEP_LAUNCH_CHECK("keep_layernorm");

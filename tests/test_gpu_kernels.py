@@ -566,6 +566,17 @@ def test_token_linear_streaming_gemm(N, out_bf16, with_bias):
         check(out, ref, 2e-5, f'token linear N={N}')
 
 
+def test_layernorm_c128_streaming_variant():
+    """keep_layernorm, C = 128 and M >= 4096 (GMFlow token stream): the 16-lanes-per-row kernel vs torch, with and
+    without the residual, ragged M."""
+    M = 4096 + 37
+    x, res = rnd('l1x', (M, 128), 3.0) + 0.7, rnd('l1r', (M, 128))
+    g, b = rnd('l1g', (128,)) * 0.3 + 1, rnd('l1b', (128,)) * 0.3
+    ref = F.layer_norm(x, (128,), g, b, eps=1e-5)
+    check(ops.layernorm(dev(x), dev(g), dev(b)), ref, 2e-5, 'LN C=128')
+    check(ops.layernorm(dev(x), dev(g), dev(b), res=dev(res)), ref + res, 2e-5, 'LN C=128 + res')
+
+
 def test_gm_mlp_fused_matches_two_gemms():
     """keep_gm_mlp (GM/transformer.py:139-142,182 fused): vs torch on the bf16-rounded operands with the GELU output
     rounded to bf16 (what the second MFMA consumes), ragged M."""

@@ -192,10 +192,33 @@ __global__ void affine_act_kernel(const float* __restrict__ x, const float* __re
   }
 }
 
+// C % 4 == 0 and 16-byte aligned tensors: one float4 per lane (the scalar form above moves 4 bytes per lane and access)
+__global__ __launch_bounds__(256) void affine_act4_kernel(const float4* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, float4* __restrict__ out, long total4,
+                                                          long per_n4, int C4, int act) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / per_n4;
+    const int c = (int)(i % C4) * 4;
+    const float4 v = x[i];
+    const float4 sc = *reinterpret_cast<const float4*>(scale + n * C4 * 4 + c);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + n * C4 * 4 + c);
+    out[i] = make_float4(act_apply(v.x * sc.x + sh.x, act), act_apply(v.y * sc.y + sh.y, act), act_apply(v.z * sc.z + sh.z, act),
+                         act_apply(v.w * sc.w + sh.w, act));
+  }
+}
+
 extern "C" int32_t keep_affine_act(const float* x, const float* scale, const float* shift, float* out, int32_t N,
                                    int32_t HW, int32_t C, int32_t act, void* stream) {
   KEEP_REQUIRE(x && scale && shift && out && N > 0 && HW > 0 && C > 0, "keep_affine_act: bad args");
   const long total = (long)N * HW * C;
+  if (C % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)scale % 16 == 0 && (uintptr_t)shift % 16 == 0) {
+    int blocks4 = cdiv(total / 4, 256);
+    if (blocks4 > 16384) blocks4 = 16384;
+    hipLaunchKernelGGL(affine_act4_kernel, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, (const float4*)x, scale, shift,
+                       (float4*)out, total / 4, (long)HW * C / 4, C / 4, act);
+    KEEP_LAUNCH_CHECK("keep_affine_act");
+    return KEEP_OK;
+  }
   int blocks = cdiv(total, 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(affine_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out, total,
@@ -295,11 +318,41 @@ __global__ void gm_join_kernel(const float* __restrict__ a, const float* __restr
   }
 }
 
+__global__ __launch_bounds__(256) void gm_join4_kernel(const float4* __restrict__ a, const float* __restrict__ sa,
+                                                       const float* __restrict__ ha, const float4* __restrict__ b,
+                                                       const float* __restrict__ sb, const float* __restrict__ hb,
+                                                       float4* __restrict__ out, long total4, long per_n4, int C4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / per_n4;
+    const long o = n * C4 * 4 + (i % C4) * 4;
+    float4 xa = a[i];
+    if (sa) {
+      const float4 s = *reinterpret_cast<const float4*>(sa + o), h = *reinterpret_cast<const float4*>(ha + o);
+      xa = make_float4(xa.x * s.x + h.x, xa.y * s.y + h.y, xa.z * s.z + h.z, xa.w * s.w + h.w);
+    }
+    const float4 yb = b[i];
+    const float4 s = *reinterpret_cast<const float4*>(sb + o), h = *reinterpret_cast<const float4*>(hb + o);
+    const float r0 = fmaxf(yb.x * s.x + h.x, 0.f), r1 = fmaxf(yb.y * s.y + h.y, 0.f);
+    const float r2 = fmaxf(yb.z * s.z + h.z, 0.f), r3 = fmaxf(yb.w * s.w + h.w, 0.f);
+    out[i] = make_float4(fmaxf(xa.x + r0, 0.f), fmaxf(xa.y + r1, 0.f), fmaxf(xa.z + r2, 0.f), fmaxf(xa.w + r3, 0.f));
+  }
+}
+
 extern "C" int32_t keep_gm_join(const float* a, const float* sa, const float* ha, const float* b, const float* sb,
                                 const float* hb, float* out, int32_t N, int32_t HW, int32_t C, void* stream) {
   KEEP_REQUIRE(a && b && sb && hb && out && N > 0 && HW > 0 && C > 0, "keep_gm_join: bad args");
   KEEP_REQUIRE((sa == nullptr) == (ha == nullptr), "keep_gm_join: sa/ha must pair");
   const long total = (long)N * HW * C;
+  const bool al = (uintptr_t)a % 16 == 0 && (uintptr_t)b % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)sb % 16 == 0 &&
+                  (uintptr_t)hb % 16 == 0 && (!sa || ((uintptr_t)sa % 16 == 0 && (uintptr_t)ha % 16 == 0));
+  if (C % 4 == 0 && al) {
+    int blocks4 = cdiv(total / 4, 256);
+    if (blocks4 > 16384) blocks4 = 16384;
+    hipLaunchKernelGGL(gm_join4_kernel, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, (const float4*)a, sa, ha,
+                       (const float4*)b, sb, hb, (float4*)out, total / 4, (long)HW * C / 4, C / 4);
+    KEEP_LAUNCH_CHECK("keep_gm_join");
+    return KEEP_OK;
+  }
   int blocks = cdiv(total, 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(gm_join_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, sa, ha, b, sb, hb, out, total,

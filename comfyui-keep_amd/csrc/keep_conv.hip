@@ -1068,18 +1068,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles
   }
 }
 
-// ------------------------------------------------------------------------------------------------ halo v2
-// Persistent, wave-specialised version of the 3x3 halo convolution.  Ablation of v1 (c128@256x256): load+stage 46 us,
-// MFMA 42 us, epilogue 45 us -- and the full kernel takes their SUM (136 us): co-resident blocks run in lock-step,
-// so the three phases never overlap.  v2 makes the overlap structural:
-//   * 8 waves per block, one block per CU: waves 0-3 are CONSUMERS (MFMA + epilogue), waves 4-7 are PRODUCERS (global
-//     loads, fp32->bf16 conversion, LDS writes).  Two LDS images (2 x 73 KB): while the consumers run the 72 MFMAs of
-//     chunk g out of image g&1, the producers fill image (g+1)&1 with chunk g+1.  One barrier per chunk.
-//   * persistent: 256 blocks walk the (tile, cout-block, k-split) work items, so the producers fetch the first
-//     chunk of the NEXT item while the consumers are still in the epilogue of the current one (stores overlap loads),
-//     and the per-block launch / geometry cost is paid once per CU instead of once per tile.
-//   * normalisation partial sums are per consumer wave (stats_P = 4 x tiles): no cross-wave reduction, no barrier
-//     that the producers would have to join.
+// ------------------------------------------------------------------------------------------------ persistent work items
+// (A wave-specialised producer/consumer version of the halo kernel -- 4 loader waves + 4 MFMA waves, one block per CU -- was
+// measured SLOWER than v1: only 256 threads issue loads, halving the bytes in flight per CU, and the kernel is bound by the
+// L2->CU operand stream.  It was removed; v3 below keeps every wave loading, staging and computing.)
 struct HaloItem {
   int n, tx, ty, oy0, ox0, n0, z, ch_begin, ch_end;
 };
@@ -1104,251 +1096,8 @@ __device__ __forceinline__ HaloItem halo_decode(const ConvP& p, int item, int it
   return it;
 }
 
-template <bool IN_BF16, int TW>
-__global__ __launch_bounds__(512) void conv3x3_halo2_kernel(ConvP p, int tiles_x, int tiles_y, int ncb, int n_items) {
-  constexpr int HALO_TH = 256 / TW, HALO_W = TW + 2, HALO_PIX = (HALO_TH + 2) * HALO_W;
-  constexpr int RPT = 32 / TW;
-  constexpr int IMG = HALO_MAXPIX * HPITCH + 9 * 64 * HPITCH;       // bf16 elements per LDS image
-  __shared__ __attribute__((aligned(16))) __bf16 lds2[2 * IMG];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const bool producer = wave >= 4;
-  const int l31 = lane & 31, lhi = lane >> 5;
-  const int items_per_z = n_items / p.split_k;
-  const int Hv = p.upsample ? 2 * p.H : p.H;
-  const int Wv = p.upsample ? 2 * p.W : p.W;
-
-  // ------------------------------------------------------------------ producer side
-  const int ptid = tid & 255;
-  const int pg = ptid & 3;
-  int h_off[HALO_IT];
-  long img_off = 0, w_base = 0;
-  auto producer_setup = [&](const HaloItem& it) {
-#pragma unroll
-    for (int k = 0; k < HALO_IT; ++k) {
-      const int hp = (ptid >> 2) + k * 64;
-      h_off[k] = -1;
-      if (hp < HALO_PIX) {
-        const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-        const int iy = it.oy0 - 1 + hy, ix = it.ox0 - 1 + hx;
-        if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
-          const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
-          h_off[k] = (sy * p.W + sx) * p.in_ld + pg * 8;
-        }
-      }
-    }
-    img_off = (long)it.n * p.H * p.W * p.in_ld;
-    w_base = ((long)(it.n0 + (ptid >> 2)) * 9) * p.Cin + pg * 8;
-  };
-  auto producer_fill = [&](int ch, int buf) {
-    const int c0 = ch << 5;
-    __bf16* Hs = lds2 + buf * IMG;
-    __bf16* Ws = Hs + HALO_MAXPIX * HPITCH;
-    uint4 wr[9];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) wr[tap] = *reinterpret_cast<const uint4*>(p.wb + w_base + (long)tap * p.Cin + c0);
-    if (IN_BF16) {
-      const unsigned short* in16 = reinterpret_cast<const unsigned short*>(p.in) + img_off;
-      uint4 hr[HALO_IT];
-#pragma unroll
-      for (int k = 0; k < HALO_IT; ++k) {
-        hr[k] = make_uint4(0u, 0u, 0u, 0u);
-        if (h_off[k] >= 0) hr[k] = *reinterpret_cast<const uint4*>(in16 + h_off[k] + c0);
-      }
-#pragma unroll
-      for (int k = 0; k < HALO_IT; ++k) {
-        const int hp = (ptid >> 2) + k * 64;
-        if (hp < HALO_PIX) *reinterpret_cast<uint4*>(&Hs[hp * HPITCH + pg * 8]) = hr[k];
-      }
-    } else {
-      const float* in32 = p.in + img_off;
-      float4 lo[HALO_IT], hi[HALO_IT];
-#pragma unroll
-      for (int k = 0; k < HALO_IT; ++k) {
-        lo[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        hi[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h_off[k] >= 0) {
-          lo[k] = *reinterpret_cast<const float4*>(in32 + h_off[k] + c0);
-          hi[k] = *reinterpret_cast<const float4*>(in32 + h_off[k] + c0 + 4);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < HALO_IT; ++k) {
-        const int hp = (ptid >> 2) + k * 64;
-        if (hp < HALO_PIX) {
-          bf16x8 h;
-          h[0] = (__bf16)lo[k].x; h[1] = (__bf16)lo[k].y; h[2] = (__bf16)lo[k].z; h[3] = (__bf16)lo[k].w;
-          h[4] = (__bf16)hi[k].x; h[5] = (__bf16)hi[k].y; h[6] = (__bf16)hi[k].z; h[7] = (__bf16)hi[k].w;
-          *reinterpret_cast<bf16x8*>(&Hs[hp * HPITCH + pg * 8]) = h;
-        }
-      }
-    }
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) *reinterpret_cast<uint4*>(&Ws[(tap * 64 + (ptid >> 2)) * HPITCH + pg * 8]) = wr[tap];
-  };
-
-  // ------------------------------------------------------------------ consumer side
-  f32x16 acc[2][2];
-  const int a_base = (((2 * wave) * RPT + l31 / TW) * HALO_W + (l31 % TW)) * HPITCH + lhi * 8;   // wave < 4 only
-  const int b_base = l31 * HPITCH + lhi * 8;
-  auto consumer_zero = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  };
-  auto consumer_mma = [&](int buf) {
-    const __bf16* Hs = lds2 + buf * IMG;
-    const __bf16* Ws = Hs + HALO_MAXPIX * HPITCH;
-#pragma unroll 1
-    for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          bf16x8 af[2], bfr[2];
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            af[i] = *reinterpret_cast<const bf16x8*>(&Hs[a_base + ((i * RPT + kh) * HALO_W + kw) * HPITCH + ks * 16]);
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            bfr[j] = *reinterpret_cast<const bf16x8*>(&Ws[b_base + ((kh * 3 + kw) * 64 + j * 32) * HPITCH + ks * 16]);
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-      }
-    }
-  };
-  auto consumer_epilogue = [&](const HaloItem& it, int buf) {
-    // the image just consumed is free until the barrier after the NEXT chunk: park the wave tile there
-    constexpr int EP = 68;
-    float* et = reinterpret_cast<float*>(lds2 + buf * IMG) + wave * 64 * EP;
-    // all 4 consumer waves must be done reading this image before any of them overwrites it: they are, each wave
-    // only overwrites after ITS OWN MFMAs, but other waves may still read rows of the weight slab / halo ->
-    // wave-private regions overlap the shared image, so rendezvous the consumers through an LDS-free trick:
-    // the staging region of wave w lies inside [w*17408, (w+1)*17408) bytes of the image; consumer waves read the
-    // whole image during consumer_mma, hence a consumer-only barrier is required (s_barrier counts all 8 waves, so
-    // the producers execute the matching barrier in their branch).
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          et[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * EP + j * 32 + l31] = acc[i][j][r];
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    const int c4 = (lane & 15) * 4, prow = lane >> 4;
-    const int co = it.n0 + c4;
-    float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && p.split_k == 1) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
-#pragma unroll 4
-    for (int q16 = 0; q16 < 16; ++q16) {
-      const int px = q16 * 4 + prow;
-      const int oy = it.oy0 + (2 * wave + (px >> 5)) * RPT + (px & 31) / TW;
-      const long m = ((long)it.n * p.Ho + oy) * p.Wo + it.ox0 + (px & 31) % TW;
-      const float4 v = *reinterpret_cast<const float4*>(et + px * EP + c4);
-      if (p.split_k > 1) {
-        *reinterpret_cast<float4*>(p.ws + ((long)it.z * p.M + m) * p.Cout + co) = v;
-        continue;
-      }
-      float e[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) e[q] = act_apply_fast(e[q], p.epi_act);
-      if (p.res) {
-        const float4 r4 = *reinterpret_cast<const float4*>(p.res + m * p.res_ld + co);
-        const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
-        if (p.aux) {
-          const float4 a4 = *reinterpret_cast<const float4*>(p.aux + m * (long)p.Cout + co);
-          const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) e[q] = rr[q] + p.aux_w * (rr[q] * aa[q] + e[q]);
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) e[q] += rr[q];
-        }
-      }
-      *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        s4[q] += e[q];
-        ss4[q] += e[q] * e[q];
-      }
-    }
-    if (p.stats) {          // per consumer wave: stats_P = 4 * tiles, partial index = tile*4 + wave
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        s4[q] += __shfl_xor(s4[q], 16);
-        s4[q] += __shfl_xor(s4[q], 32);
-        ss4[q] += __shfl_xor(ss4[q], 16);
-        ss4[q] += __shfl_xor(ss4[q], 32);
-      }
-      if (lane < 16) {
-        float* dst = p.stats + (((long)it.n * p.stats_P + (it.ty * tiles_x + it.tx) * 4 + wave) * p.Cout + co) * 2;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          dst[q * 2 + 0] = s4[q];
-          dst[q * 2 + 1] = ss4[q];
-        }
-      }
-    }
-  };
-
-  // ------------------------------------------------------------------ persistent pipeline
-  int item = blockIdx.x;
-  if (item >= n_items) return;
-  HaloItem cur = halo_decode<TW>(p, item, items_per_z, tiles_x, tiles_y, ncb);
-  // skip empty k-ranges (split_k not dividing the chunk count): still a valid item, produces zeros
-  int buf = 0;
-  if (producer) {
-    producer_setup(cur);
-    if (cur.ch_begin < cur.ch_end) producer_fill(cur.ch_begin, 0);
-  }
-  __syncthreads();
-  while (true) {
-    if (!producer) consumer_zero();
-    const int next_item = item + gridDim.x;
-    const bool has_next = next_item < n_items;
-    HaloItem nxt = cur;
-    if (has_next) nxt = halo_decode<TW>(p, next_item, items_per_z, tiles_x, tiles_y, ncb);
-    const int nch = max(cur.ch_end - cur.ch_begin, 1);          // an empty range still runs one (zero) iteration
-    for (int c = 0; c < nch; ++c) {
-      const int ch = cur.ch_begin + c;
-      const bool last = (c + 1 == nch);
-      if (producer) {
-        if (!last) {
-          producer_fill(ch + 1, buf ^ 1);
-        } else if (has_next) {
-          producer_setup(nxt);
-          if (nxt.ch_begin < nxt.ch_end) producer_fill(nxt.ch_begin, buf ^ 1);
-        }
-        if (last) __builtin_amdgcn_s_barrier();                 // matches the consumers' pre-epilogue barrier
-      } else {
-        if (ch < cur.ch_end) consumer_mma(buf);
-        if (last) {
-          __builtin_amdgcn_s_barrier();                         // every consumer wave is done reading image `buf`
-          consumer_epilogue(cur, buf);
-        }
-      }
-      __syncthreads();
-      buf ^= 1;
-    }
-    if (!has_next) break;
-    item = next_item;
-    cur = nxt;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ halo v3
-// v1 made persistent.  (v2's wave specialisation measured SLOWER than v1: with one block per CU only 256 threads issue
-// loads, halving the bytes in flight per CU, and the kernel is bound by the L2->CU operand stream.)  v3 keeps v1's
+// v1 made persistent: v3 keeps v1's
 // two 4-wave blocks per CU -- every wave loads, converts, stages and computes -- but each block walks the work items
 // (tile, cout-block, k-split) itself: the geometry / launch cost is paid once per block instead of once per tile, and
 // the first chunk of the NEXT item is already in flight (in registers) while the epilogue of the current item runs,
@@ -2270,35 +2019,6 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
       else
         hipLaunchKernelGGL((conv3x3_halo3_kernel<false, 16>), grid3, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);
       KEEP_LAUNCH_CHECK("keep_conv2d(halo v3)");
-      if (p.split_k > 1) {
-        const long total = M * a->Cout;
-        int blocks = cdiv(total, 256);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
-        KEEP_LAUNCH_CHECK("keep_conv2d(split-K reduce)");
-      }
-      return KEEP_OK;
-    }
-    if (halo_ver == 2 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE) {
-      const int n_items = a->N * tiles_x * tiles_y * ncb * p.split_k;
-      static int n_cu = 0;
-      if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-      }
-      const int nblk = n_items < n_cu ? n_items : n_cu;
-      dim3 grid2(nblk), block2(512);
-      if (p.in_bf16 && wide)
-        hipLaunchKernelGGL((conv3x3_halo2_kernel<true, 32>), grid2, block2, 0, st, p, tiles_x, tiles_y, ncb, n_items);
-      else if (p.in_bf16)
-        hipLaunchKernelGGL((conv3x3_halo2_kernel<true, 16>), grid2, block2, 0, st, p, tiles_x, tiles_y, ncb, n_items);
-      else if (wide)
-        hipLaunchKernelGGL((conv3x3_halo2_kernel<false, 32>), grid2, block2, 0, st, p, tiles_x, tiles_y, ncb, n_items);
-      else
-        hipLaunchKernelGGL((conv3x3_halo2_kernel<false, 16>), grid2, block2, 0, st, p, tiles_x, tiles_y, ncb, n_items);
-      KEEP_LAUNCH_CHECK("keep_conv2d(halo v2)");
       if (p.split_k > 1) {
         const long total = M * a->Cout;
         int blocks = cdiv(total, 256);

@@ -616,6 +616,26 @@ def test_conv_bf16_rgb_first_conv_kernel(monkeypatch):
         check(sc, sc2, 1e-5, 'rgb conv fused stats scale'); check(sh, sh2, 1e-5, 'rgb conv fused stats shift')
 
 
+def test_conv_bf16_halo_fused_prologue_variant(monkeypatch):
+    """The C-ABI also accepts the GroupNorm affine + swish directly on the bf16 halo path (conv3x3_halo_kernel, applied
+    while the fp32 halo is staged) -- the engine prefers the separate normalise pass, so exercise the fused form here."""
+    monkeypatch.setattr(ops, 'HALO_PRENORM_MINPIX', 1 << 40)
+    x, w, b = rnd('fpx', (2, 64, 32, 32), 2.0) + 0.5, rnd('fpw', (128, 64, 3, 3), 0.05), rnd('fpb', (128,))
+    gamma, beta = rnd('fpg', (64,)) * 0.2 + 1, rnd('fpbt', (64,)) * 0.2
+    res = rnd('fpr', (2, 128, 32, 32))
+    xd = dev(nhwc(x))
+    wp = pack(w)
+    pro = ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6)
+    y = ops.conv(xd, wp, dev(b), pro=pro, pro_act=L.PRO_SWISH, residual=dev(nhwc(res)), mma=L.MMA_BF16,
+                 wb=wp.to(torch.bfloat16), stats=True, split_k=1)
+    hn = F.group_norm(x, 32, gamma, beta, eps=1e-6)
+    hn = bf16r(hn * torch.sigmoid(hn))
+    check(nchw(y), F.conv2d(hn, bf16r(w), b, padding=1) + res, 3e-4, 'halo with fused GN+swish prologue')
+    sc, sh = ops.norm_affine(y, None, None, 128, 1e-5)
+    sc2, sh2 = ops.norm_affine(y.clone(), None, None, 128, 1e-5)
+    check(sc, sc2, 1e-5, 'fused-prologue halo stats scale'); check(sh, sh2, 1e-5, 'fused-prologue halo stats shift')
+
+
 def test_conv_bf16_flat_k_small_cin():
     x, w = rnd('7x', (2, 3, 64, 64)), rnd('7w', (64, 3, 7, 7), 0.1)
     wp = pack(w)

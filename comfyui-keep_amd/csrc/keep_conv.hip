@@ -472,7 +472,9 @@ __device__ __forceinline__ float pro_apply_fast(float v, int act) {
 // output tiles and a deep K (16x16 / 32x32 maps, token GEMMs) are latency-bound -- one global round trip per step with
 // only a handful of MFMAs to hide it -- so they run BKT = 256 with a single LDS buffer: 4x the bytes in flight per
 // round trip and 4x fewer barriers for the same registers a 4-deep prefetch ring would need.
-template <int WGM, int WGN, int TM, int TN, int BKT, int NS>
+// PLAIN (host-checked): no flattened K, no prologue, no upsample, Cin % 8 == 0 and 16-byte aligned rows -- the fetch /
+// stage code of every K step then carries none of those uniform branches (token GEMMs, 1x1 convs, plain strided convs).
+template <int WGM, int WGN, int TM, int TN, int BKT, int NS, bool PLAIN = false>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
   constexpr int BM = WGM * TM * 32;
   constexpr int BN = WGN * TN * 32;
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
     const int kw = tap - kh * p.KW;
     const int ca = c0 + grp * 8;
     a_c[SL] = ca;
-    if (p.flatk) {
+    if (!PLAIN && p.flatk) {
       // K = (kh, kw, c) flattened (Cin = 3: 27 or 147 real k's instead of 9 / 49 nearly empty 64-wide chunks)
       const int kbase = s * BKT + grp * 8;
       const int ktot = p.KH * p.KW * p.Cin;
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
       a_c[SL] = 0;     // stage(): every element already validated, no per-channel mask / affine (host forbids a prologue)
       return;
     }
-    if (uni_n) {
+    if (!PLAIN && uni_n) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const bool cok = ca + j < p.Cin;
@@ -602,10 +604,10 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
       const int ix = a_ox[it] * p.stride - p.pad_l + kw;
       a_ok[SL][it] = a_mv[it] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv && ca < p.Cin;
       if (a_ok[SL][it]) {
-        const int sy = p.upsample ? (iy >> 1) : iy;
-        const int sx = p.upsample ? (ix >> 1) : ix;
+        const int sy = (!PLAIN && p.upsample) ? (iy >> 1) : iy;
+        const int sx = (!PLAIN && p.upsample) ? (ix >> 1) : ix;
         const float* src = p.in + (((long)a_n[it] * p.H + sy) * p.W + sx) * p.in_ld + ca;
-        if (p.vec_ok && ca + 8 <= p.Cin) {
+        if (PLAIN || (p.vec_ok && ca + 8 <= p.Cin)) {
           const float4 v0 = *reinterpret_cast<const float4*>(src);
           const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
           a_raw[SL][it][0] = v0.x; a_raw[SL][it][1] = v0.y; a_raw[SL][it][2] = v0.z; a_raw[SL][it][3] = v0.w;
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
       b_raw[SL][it] = make_uint4(0u, 0u, 0u, 0u);
       if (co < p.Cout && ca < p.Cin) {
         const unsigned short* src = p.wb + (long)co * wrow_stride + (long)tap * p.Cin + ca;
-        if ((p.Cin & 7) == 0) {
+        if (PLAIN || (p.Cin & 7) == 0) {
           b_raw[SL][it] = *reinterpret_cast<const uint4*>(src);
         } else {
           unsigned short t[8];
@@ -644,7 +646,8 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = a_raw[SL][it][j];
-        if (uni_n) {
+        if (PLAIN) {
+        } else if (uni_n) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = v[j] * u_sc[SL][j] + u_sh[SL][j];
         } else if (p.pro_scale) {
@@ -654,12 +657,12 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
           for (int j = 0; j < 8; ++j)
             if (a_c[SL] + j < p.Cin) v[j] = v[j] * sc[j] + sh[j];
         }
-        if (p.pro_act != KEEP_PRO_NONE) {
+        if (!PLAIN && p.pro_act != KEEP_PRO_NONE) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = pro_apply_fast(v[j], p.pro_act);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) h[j] = (__bf16)((p.flatk || a_c[SL] + j < p.Cin) ? v[j] : 0.f);
+        for (int j = 0; j < 8; ++j) h[j] = (__bf16)((PLAIN || p.flatk || a_c[SL] + j < p.Cin) ? v[j] : 0.f);
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) h[j] = (__bf16)0.f;
@@ -2074,6 +2077,8 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
     else
       hipLaunchKernelGGL((conv3x3_halo_kernel<false, 16>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
   } else if (a->mma == KEEP_MMA_BF16) {
+    const bool plain = !p.flatk && p.vec_ok && !a->pro_scale && a->pro_act == KEEP_PRO_NONE && !a->upsample && (a->Cin % 8 == 0) &&
+                       !getenv("KEEP_NO_PLAIN");
     const int steps16 = p.flatk ? (a->KH * a->KW * a->Cin + BK16 - 1) / BK16 : a->KH * a->KW * ((a->Cin + BK16 - 1) / BK16);
     if (p.split_k > steps16) p.split_k = steps16;
     if (a->Cout <= 32) {
@@ -2087,11 +2092,17 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
         hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 1, 1, 256, 1>), grid, block, 0, st, p);
       } else {
         dim3 grid(cdiv(M, 64), cdiv(a->Cout, 64), p.split_k);
-        hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 1, 1, 64, 1>), grid, block, 0, st, p);
+        if (plain)
+          hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 1, 1, 64, 1, true>), grid, block, 0, st, p);
+        else
+          hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 1, 1, 64, 1>), grid, block, 0, st, p);
       }
     } else {
       dim3 grid(cdiv(M, 128), cdiv(a->Cout, 128), p.split_k);
-      hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 2, 2, 64, 1>), grid, block, 0, st, p);
+      if (plain)
+        hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 2, 2, 64, 1, true>), grid, block, 0, st, p);
+      else
+        hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 2, 2, 64, 1>), grid, block, 0, st, p);
     }
   } else if (a->Cout <= 32) {
     dim3 grid(cdiv(M, 128), cdiv(a->Cout, 32), p.split_k);

@@ -52,11 +52,12 @@ HALO_PRENORM_MINPIX = int(os.environ.get('KEEP_HALO_PRENORM_MINPIX', '0'))
 PROFILE = None
 
 
-def tile_config(M, Cout, bf16=False, bk256=False):
+def tile_config(M, Cout, bf16=False, bk256=False, plain=False):
     """Name of the gather-kernel instantiation keep_conv.hip selects, as rocprofv3 prints it (keep in sync)."""
     t = '4, 1, 1, 1' if Cout <= 32 else ('2, 2, 1, 1' if (Cout <= 64 or M <= 4096) else '2, 2, 2, 2')
     if bf16:
-        return f"conv_bf16_kernel<{t}, {'256, 1' if bk256 else '64, 1'}>"
+        plain = plain and not bk256 and t != '4, 1, 1, 1'
+        return f"conv_bf16_kernel<{t}, {'256, 1' if bk256 else '64, 1'}, {'true' if plain else 'false'}>"
     return f'conv_f32_kernel<{t}>'
 
 
@@ -184,7 +185,8 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
         tw = 32 if (Ho % 8 == 0 and Wo % 32 == 0) else 16
         kname = ('conv3x3_cout4_kernel' if cout4 else 'conv3x3_c3_kernel' if c3 else f'conv3x3_halo_f32_kernel<{tw}>' if halo_f32 else
                  f"conv3x3_halo3_kernel<{'true' if in_dtype == L.BF16 else 'false'}, {tw}>" if halo else
-                 tile_config(M, Cout, mma == L.MMA_BF16, bk256))
+                 tile_config(M, Cout, mma == L.MMA_BF16, bk256,
+                             plain=(Cin % 8 == 0 and ld % 4 == 0 and pro is None and pro_act == L.PRO_NONE and not upsample)))
         # algorithmic bytes: one read of the input window at its storage type, the weights, one write of the output
         alg_bytes = (N * H * W * Cin * x.element_size() + Cout * KH * KW * Cin * (2 if mma == L.MMA_BF16 else 4)
                      + M * Cout * out.element_size() + (0 if residual is None else M * Cout * 4))

@@ -219,7 +219,9 @@ __device__ __forceinline__ void staged_epilogue(const ConvP& p, f32x16 (&acc)[TM
     staged_epilogue_impl<WGM, WGN, TM, TN, false>(p, acc, lds, m0, n0, wm, wn, lane, wave, z);
 }
 
-template <int WGM, int WGN, int TM, int TN>
+// PLAIN (host-checked): no prologue, no upsample, Cin % 16 == 0 and 16-byte aligned rows: the K loop carries none of
+// those uniform branches (token GEMMs, 1x1 convs, plain strided convs).
+template <int WGM, int WGN, int TM, int TN, bool PLAIN = false>
 __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
   constexpr int BM = WGM * TM * 32;
   constexpr int BN = WGN * TN * 32;
@@ -296,13 +298,13 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
     const int iy = a_oy * p.stride - p.pad_t + kh;
     const int ix = a_ox * p.stride - p.pad_l + kw;
     a_ok = a_mvalid && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-    const int sy = p.upsample ? (iy >> 1) : iy;
-    const int sx = p.upsample ? (ix >> 1) : ix;
+    const int sy = (!PLAIN && p.upsample) ? (iy >> 1) : iy;
+    const int sx = (!PLAIN && p.upsample) ? (ix >> 1) : ix;
     const int ca = c0 + a_kq;
     a_ca = ca;
     if (a_ok) {
       const float* src = p.in + (((long)a_n * p.H + sy) * p.W + sx) * p.in_ld + ca;
-      if (p.vec_ok && (A_CPT % 4 == 0) && ca + A_CPT <= p.Cin) {
+      if ((PLAIN || p.vec_ok) && (A_CPT % 4 == 0) && (PLAIN || ca + A_CPT <= p.Cin)) {
 #pragma unroll
         for (int j = 0; j < A_CPT; j += 4) {
           float4 v = *reinterpret_cast<const float4*>(src + j);
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
           if (j + 2 < A_CPT) a_reg[j + 2] = v.z;
           if (j + 3 < A_CPT) a_reg[j + 3] = v.w;
         }
-        if (a_scale) {
+        if (!PLAIN && a_scale) {
 #pragma unroll
           for (int j = 0; j < A_CPT; j += 4) {
             float4 sc = *reinterpret_cast<const float4*>(a_scale + ca + j);
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
     const int cb = c0 + b_kq;
     if (b_valid) {
       const float* src = p.w + w_rowoff + (long)tap * p.Cin + cb;
-      if ((p.Cin % 4 == 0) && (B_CPT % 4 == 0) && cb + B_CPT <= p.Cin) {
+      if ((PLAIN || p.Cin % 4 == 0) && (B_CPT % 4 == 0) && (PLAIN || cb + B_CPT <= p.Cin)) {
 #pragma unroll
         for (int j = 0; j < B_CPT; j += 4) {
           float4 v = *reinterpret_cast<const float4*>(src + j);
@@ -361,10 +363,12 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
 #pragma unroll
     for (int j = 0; j < A_CPT; ++j) {
       float v = 0.f;
-      if (a_ok && a_ca + j < p.Cin) {
+      if (a_ok && (PLAIN || a_ca + j < p.Cin)) {
         v = a_reg[j];
-        if (a_scale) v = v * a_sc[j] + a_sh[j];
-        v = pro_apply(v, p.pro_act);
+        if (!PLAIN) {
+          if (a_scale) v = v * a_sc[j] + a_sh[j];
+          v = pro_apply(v, p.pro_act);
+        }
       }
       As[buf][(a_kq + j) * LDA + a_row] = v;
     }
@@ -1894,6 +1898,8 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
   p.nsteps = a->KH * a->KW * p.cchunks;
   if (p.split_k > p.nsteps) p.split_k = p.nsteps;
   p.vec_ok = (a->Cin % 4 == 0 && a->in_ld % 4 == 0 && ((uintptr_t)a->in % 16 == 0)) ? 1 : 0;
+  const bool plain_f32 = a->mma != KEEP_MMA_BF16 && p.vec_ok && a->Cin % 16 == 0 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE &&
+                         !a->upsample && !getenv("KEEP_NO_PLAIN");
   KEEP_REQUIRE((uintptr_t)a->weight % 16 == 0, "keep_conv2d: weight pointer must be 16-byte aligned");
   KEEP_REQUIRE(!a->pro_scale || ((uintptr_t)a->pro_scale % 16 == 0 && (uintptr_t)a->pro_shift % 16 == 0),
                "keep_conv2d: pro_scale/pro_shift must be 16-byte aligned");
@@ -2109,10 +2115,16 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
     hipLaunchKernelGGL((conv_f32_kernel<4, 1, 1, 1>), grid, block, 0, st, p);
   } else if (a->Cout <= 64 || M <= 4096) {
     dim3 grid(cdiv(M, 64), cdiv(a->Cout, 64), p.split_k);
-    hipLaunchKernelGGL((conv_f32_kernel<2, 2, 1, 1>), grid, block, 0, st, p);
+    if (plain_f32)
+      hipLaunchKernelGGL((conv_f32_kernel<2, 2, 1, 1, true>), grid, block, 0, st, p);
+    else
+      hipLaunchKernelGGL((conv_f32_kernel<2, 2, 1, 1>), grid, block, 0, st, p);
   } else {
     dim3 grid(cdiv(M, 128), cdiv(a->Cout, 128), p.split_k);
-    hipLaunchKernelGGL((conv_f32_kernel<2, 2, 2, 2>), grid, block, 0, st, p);
+    if (plain_f32)
+      hipLaunchKernelGGL((conv_f32_kernel<2, 2, 2, 2, true>), grid, block, 0, st, p);
+    else
+      hipLaunchKernelGGL((conv_f32_kernel<2, 2, 2, 2>), grid, block, 0, st, p);
   }
   KEEP_LAUNCH_CHECK("keep_conv2d");
   if (p.split_k > 1) {

@@ -230,10 +230,10 @@ extern "C" int32_t keep_affine_act(const float* x, const float* scale, const flo
 // out_bf16 = bf16( act_pro( x*scale[n,c] + shift[n,c] ) ): the normalise+activate pass that feeds the 3x3 halo
 // convolution (8 channels per thread: two float4 loads, one 16-byte store; RNE via v_cvt_pk_bf16_f32).
 typedef __attribute__((ext_vector_type(8))) __bf16 ops_bf16x8;
-template <bool IN_BF16>
+template <bool IN_BF16, int ACT>
 __global__ __launch_bounds__(256) void norm_act_bf16_kernel(const void* __restrict__ xin, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, ops_bf16x8* __restrict__ out,
-                                                            long total8, long per_n8, int C8, int act) {
+                                                            long total8, long per_n8, int C8) {
   // two independent 8-element groups per thread and iteration: twice the bytes in flight per wave (the kernel is a pure
   // HBM stream: 4 or 2 bytes in, 2 bytes out per element)
   const long stride = (long)gridDim.x * blockDim.x;
@@ -275,8 +275,8 @@ __global__ __launch_bounds__(256) void norm_act_bf16_kernel(const void* __restri
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float t = v[u][j];
-        if (act == KEEP_PRO_SWISH) t = t * __frcp_rn(1.0f + __expf(-t));
-        else if (act == KEEP_PRO_RELU) t = t > 0.f ? t : 0.f;
+        if (ACT == KEEP_PRO_SWISH) t = t * __frcp_rn(1.0f + __expf(-t));
+        else if (ACT == KEEP_PRO_RELU) t = t > 0.f ? t : 0.f;
         h[j] = (__bf16)t;
       }
       out[i] = h;
@@ -293,12 +293,20 @@ extern "C" int32_t keep_norm_act_bf16(const void* x, const float* scale, const f
   const long total8 = (long)N * HW * C / 8;
   int blocks = cdiv(total8, 256);
   if (blocks > 16384) blocks = 16384;
-  if (in_dtype == KEEP_BF16)
-    hipLaunchKernelGGL(norm_act_bf16_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
-                       (ops_bf16x8*)out, total8, (long)HW * C / 8, C / 8, act);
-  else
-    hipLaunchKernelGGL(norm_act_bf16_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
-                       (ops_bf16x8*)out, total8, (long)HW * C / 8, C / 8, act);
+#define KEEP_NA_LAUNCH(INB, ACTV)                                                                                       \
+  hipLaunchKernelGGL((norm_act_bf16_kernel<INB, ACTV>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scale, shift, \
+                     (ops_bf16x8*)out, total8, (long)HW * C / 8, C / 8)
+  KEEP_REQUIRE(act == KEEP_PRO_NONE || act == KEEP_PRO_SWISH || act == KEEP_PRO_RELU, "keep_norm_act_bf16: bad act %d", act);
+  if (in_dtype == KEEP_BF16) {
+    if (act == KEEP_PRO_SWISH) KEEP_NA_LAUNCH(true, KEEP_PRO_SWISH);
+    else if (act == KEEP_PRO_RELU) KEEP_NA_LAUNCH(true, KEEP_PRO_RELU);
+    else KEEP_NA_LAUNCH(true, KEEP_PRO_NONE);
+  } else {
+    if (act == KEEP_PRO_SWISH) KEEP_NA_LAUNCH(false, KEEP_PRO_SWISH);
+    else if (act == KEEP_PRO_RELU) KEEP_NA_LAUNCH(false, KEEP_PRO_RELU);
+    else KEEP_NA_LAUNCH(false, KEEP_PRO_NONE);
+  }
+#undef KEEP_NA_LAUNCH
   KEEP_LAUNCH_CHECK("keep_norm_act_bf16");
   return KEEP_OK;
 }

@@ -574,7 +574,7 @@ static int launch_attn_bf16(const AttnP& p, hipStream_t st) {
 // barriers + serial table math per tile), 160 us of exposed load latency and 205 us of softmax VALU.
 // D > 128 (AttnBlock, D = 512): the chunked path -- tables per tile, Q/K re-staged per 128-wide chunk.
 // V^T is staged key-permuted exactly like attn_bf16_kernel.
-template <int DVT>
+template <int DVT, bool MASKED>       // MASKED: shifted windows (mode 2, shift > 0) -- the only caller of the region mask
 __global__ __launch_bounds__(256, 2) void attn_bf16in_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int DVS = DVT * 32;
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16in_kernel(AttnP p) {
   const int dv0 = (blockIdx.y - head * p.nslices) * DVS;
   const int q0 = blockIdx.x * 128;
   const long qh = (long)head * p.q_hs, kh = (long)head * p.k_hs, vh = (long)head * p.v_hs;
-  const bool use_mask = (p.mode == 2 && p.shift > 0);
+  constexpr bool use_mask = MASKED;
   WinCtx wc = {};
   if (p.mode == 2) wc = win_ctx(p, b);
   // element offset of query / key / value / output token t (window, sparse-causal or plain addressing) + region id
@@ -904,8 +904,10 @@ static int launch_attn_bf16in(const AttnP& p, hipStream_t st) {
                      (operands > staging ? operands : staging);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bf16in_kernel<DVT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bf16in_kernel<DVT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)attn_bf16in_kernel<DVT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       keep_set_error("keep_attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return KEEP_EHIP;
@@ -913,7 +915,10 @@ static int launch_attn_bf16in(const AttnP& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(cdiv(p.Lq, 128), p.H * p.nslices, p.B);
-  hipLaunchKernelGGL((attn_bf16in_kernel<DVT>), grid, dim3(256), lds, st, p);
+  if (p.mode == 2 && p.shift > 0)
+    hipLaunchKernelGGL((attn_bf16in_kernel<DVT, true>), grid, dim3(256), lds, st, p);
+  else
+    hipLaunchKernelGGL((attn_bf16in_kernel<DVT, false>), grid, dim3(256), lds, st, p);
   KEEP_LAUNCH_CHECK("keep_attention(bf16 inputs)");
   return KEEP_OK;
 }

@@ -1377,7 +1377,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvP p, int tile
 #define FCSH 4                               // log2(channels per chunk)
 #define FPITCH 20
 
-template <int TW>
+// PRO: the prologue activation (KEEP_PRO_*) compiled in -- the staging step applies it to 24 values per thread and chunk.
+template <int TW, int PRO>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(ConvP p, int tiles_x, int tiles_y, int ncb, int n_items) {
   constexpr int HALO_TH = 256 / TW, HALO_W = TW + 2, HALO_PIX = (HALO_TH + 2) * HALO_W;
   constexpr int RPT = 32 / TW;
@@ -1395,7 +1396,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(ConvP p, int t
   const int Hv = p.upsample ? 2 * p.H : p.H;
   const int Wv = p.upsample ? 2 * p.W : p.W;
   const int g = tid & 3;
-  const bool has_pro = p.pro_scale != nullptr || p.pro_act != KEEP_PRO_NONE;
+  const bool has_pro = p.pro_scale != nullptr || PRO != KEEP_PRO_NONE;
 
   int h_off[HALO_IT];
   long img_off = 0, w_base = 0, sc_off = 0;
@@ -1445,10 +1446,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(ConvP p, int t
       if (hp < HALO_PIX) {
         float4 v = hreg[k];
         if (has_pro && h_off[k] >= 0) {      // zero padding applies to the normalised + activated tensor
-          v.x = pro_apply(v.x * sc4.x + sh4.x, p.pro_act);
-          v.y = pro_apply(v.y * sc4.y + sh4.y, p.pro_act);
-          v.z = pro_apply(v.z * sc4.z + sh4.z, p.pro_act);
-          v.w = pro_apply(v.w * sc4.w + sh4.w, p.pro_act);
+          v.x = pro_apply(v.x * sc4.x + sh4.x, PRO);
+          v.y = pro_apply(v.y * sc4.y + sh4.y, PRO);
+          v.z = pro_apply(v.z * sc4.z + sh4.z, PRO);
+          v.w = pro_apply(v.w * sc4.w + sh4.w, PRO);
         }
         *reinterpret_cast<float4*>(&Hs[hp * FPITCH + g * 4]) = v;
       }
@@ -2013,10 +2014,19 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
       if (n_cuf <= 0) n_cuf = 256;
     }
     dim3 gridf(n_items < 2 * n_cuf ? n_items : 2 * n_cuf);
-    if (wide)
-      hipLaunchKernelGGL((conv3x3_halo_f32_kernel<32>), gridf, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);
-    else
-      hipLaunchKernelGGL((conv3x3_halo_f32_kernel<16>), gridf, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);
+#define KEEP_LAUNCH_HF(TWV)                                                                                                  \
+  if (a->pro_act == KEEP_PRO_SWISH)                                                                                          \
+    hipLaunchKernelGGL((conv3x3_halo_f32_kernel<TWV, KEEP_PRO_SWISH>), gridf, block, 0, st, p, tiles_x, tiles_y, ncb, n_items); \
+  else if (a->pro_act == KEEP_PRO_RELU)                                                                                      \
+    hipLaunchKernelGGL((conv3x3_halo_f32_kernel<TWV, KEEP_PRO_RELU>), gridf, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);  \
+  else                                                                                                                       \
+    hipLaunchKernelGGL((conv3x3_halo_f32_kernel<TWV, KEEP_PRO_NONE>), gridf, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);
+    if (wide) {
+      KEEP_LAUNCH_HF(32)
+    } else {
+      KEEP_LAUNCH_HF(16)
+    }
+#undef KEEP_LAUNCH_HF
     KEEP_LAUNCH_CHECK("keep_conv2d(halo f32)");
     if (p.split_k > 1) {
       const long total = M * a->Cout;

@@ -1650,6 +1650,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_kernel(ConvP p, int tiles_x
   };
 
   f32x16 acc[2][2];
+  const bool has_act = p.epi_act != KEEP_ACT_NONE;
   const int py = tid >> 5, px = tid & 31;
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int lid = xcd_remap(item, n_items);
@@ -1727,7 +1728,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_kernel(ConvP p, int tiles_x
     float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
-#pragma unroll 4
+#pragma unroll 8
     for (int q16 = 0; q16 < 16; ++q16) {
       if (!cok) break;
       const int pxl = q16 * 4 + prow;
@@ -1735,8 +1736,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_kernel(ConvP p, int tiles_x
       const long m = ((long)n * p.Ho + oy) * p.Wo + ox0 + (pxl & 31);
       const float4 v = *reinterpret_cast<const float4*>(et + pxl * EP + c4);
       float e[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
+      if (has_act) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) e[q] = act_apply_fast(e[q], p.epi_act);
+        for (int q = 0; q < 4; ++q) e[q] = act_apply_fast(e[q], p.epi_act);
+      }
       *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {

@@ -46,6 +46,7 @@ struct ConvP {
   int out_bf16; // write the output tensor as bf16 (gather kernels' staged epilogue, persistent bf16 halo kernel)
   int vec_epi;  // Cout/out_ld/res_ld %% 4 == 0 and aligned pointers -> LDS-staged float4 epilogue
   int flatk;    // Cin < 8: K = KH*KW*Cin flattened (element-wise gather) instead of tap-major chunks
+  int flatk_f32;  // the same for the f32 gather kernel (16-wide K steps)
 };
 
 __device__ __forceinline__ float epilogue_one(const ConvP& p, float v, long m, int co) {
@@ -290,6 +291,34 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
   int a_ca = 0;
 
   auto fetch = [&](int s) {
+    if (!PLAIN && p.flatk_f32) {
+      // K = (kh, kw, c) flattened: the RGB first convolutions (Cin = 3) take ceil(9*3/16) = 2 K steps instead of 9 (7x7:
+      // 10 instead of 49) that are 13/16 padding.  Host guarantees no prologue.
+      const int ktot = p.KH * p.KW * p.Cin;
+      const int ka = s * BK + a_kq;
+      a_ok = a_mvalid;
+      a_ca = 0;
+#pragma unroll
+      for (int j = 0; j < A_CPT; ++j) {
+        const int kk = ka + j;
+        float v = 0.f;
+        if (a_mvalid && kk < ktot) {
+          const int tp = kk / p.Cin, c = kk - tp * p.Cin;
+          const int kh2 = tp / p.KW, kw2 = tp - kh2 * p.KW;
+          const int iy = a_oy * p.stride - p.pad_t + kh2;
+          const int ix = a_ox * p.stride - p.pad_l + kw2;
+          if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
+            const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+            v = p.in[(((long)a_n * p.H + sy) * p.W + sx) * p.in_ld + c];
+          }
+        }
+        a_reg[j] = v;
+      }
+      const int kb = s * BK + b_kq;
+#pragma unroll
+      for (int j = 0; j < B_CPT; ++j) b_reg[j] = (b_valid && kb + j < ktot) ? p.w[w_rowoff + kb + j] : 0.f;
+      return;
+    }
     const int tap = s / p.cchunks;
     const int c0 = (s - tap * p.cchunks) * BK;
     const int kh = tap / p.KW;
@@ -363,9 +392,9 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
 #pragma unroll
     for (int j = 0; j < A_CPT; ++j) {
       float v = 0.f;
-      if (a_ok && (PLAIN || a_ca + j < p.Cin)) {
+      if (a_ok && (PLAIN || p.flatk_f32 || a_ca + j < p.Cin)) {
         v = a_reg[j];
-        if (!PLAIN) {
+        if (!PLAIN && !p.flatk_f32) {
           if (a_scale) v = v * a_sc[j] + a_sh[j];
           v = pro_apply(v, p.pro_act);
         }
@@ -1900,6 +1929,9 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
   p.M = (int)M;
   p.cchunks = (a->Cin + BK - 1) / BK;
   p.nsteps = a->KH * a->KW * p.cchunks;
+  p.flatk_f32 = (a->mma != KEEP_MMA_BF16 && a->Cin < 8 && a->dtype == KEEP_F32 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE &&
+                 !getenv("KEEP_NO_FLATK_F32")) ? 1 : 0;
+  if (p.flatk_f32) p.nsteps = (a->KH * a->KW * a->Cin + BK - 1) / BK;
   if (p.split_k > p.nsteps) p.split_k = p.nsteps;
   p.vec_ok = (a->Cin % 4 == 0 && a->in_ld % 4 == 0 && ((uintptr_t)a->in % 16 == 0)) ? 1 : 0;
   const bool plain_f32 = a->mma != KEEP_MMA_BF16 && p.vec_ok && a->Cin % 16 == 0 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE &&

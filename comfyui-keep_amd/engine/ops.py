@@ -152,6 +152,8 @@ def conv(x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=Fals
     elif mma == L.MMA_BF16 and wb is None:
         wb = bf16_twin(w)
     nsteps = KH * KW * math.ceil(Cin / (64 if mma == L.MMA_BF16 else 16))
+    if mma != L.MMA_BF16 and Cin < 8 and pro is None and pro_act == L.PRO_NONE:      # f32 gather kernel: flattened K
+        nsteps = math.ceil(KH * KW * Cin / 16)
     # latency-bound gather layers (few 64x64 output tiles, deep K): 256-channel K steps, single LDS buffer
     bk256 = (USE_BK256 and mma == L.MMA_BF16 and not halo and Cout > 32 and (Cout <= 64 or M <= 4096) and Cin >= 256 and nsteps >= 8)
     if bk256:

@@ -90,8 +90,12 @@ def conv_roofline(net, x):
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))[net.precision]
-        if pmc['clips_per_gpu'] == x.shape[0] and key in pmc['kernels']:
-            traffic = pmc['kernels'][key]['hbm_bytes_per_launch']
+        if pmc['clips_per_gpu'] == x.shape[0]:
+            # `key` names the kernel family; rocprofv3 may list its template instantiations separately (epilogue variants)
+            fam = [v for k, v in pmc['kernels'].items() if k == key or k.startswith(key[:-1] + ',')]
+            n_l = sum(v['launches'] for v in fam)
+            if n_l:
+                traffic = round(sum(v['hbm_bytes_per_launch'] * v['launches'] for v in fam) / n_l)
     except (OSError, KeyError, ValueError):
         pass
     tot_f = sum(v[0] for v in by.values())

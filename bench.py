@@ -70,10 +70,10 @@ def conv_roofline(net, x):
     """One instrumented clip-batch: every keep_conv2d launch bracketed by HIP events on the launch stream.  Launches are
     grouped by the exact kernel instantiation (the name rocprofv3 prints); the dominant kernel is the one with the
     largest summed duration, and `achieved` = its algorithmic FLOPs / its summed event durations."""
-    ops.PROFILE = []
+    net.o.profile = []
     net(x)
     torch.cuda.synchronize()
-    rec, ops.PROFILE = ops.PROFILE, None
+    rec, net.o.profile = net.o.profile, None
     by = {}
     for cfg, flops, split_k, e0, e1, nbytes in rec:
         d = by.setdefault(cfg, [0.0, 0.0, 0, 0.0])
@@ -137,7 +137,7 @@ def main():
                     help='independent T=20 clips per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-second-policy', action='store_true', help='skip timing the other precision policy')
-    ap.add_argument('--precision', default=os.environ.get('KEEP_BENCH_PRECISION', 'bf16'), choices=['fp32', 'bf16'],
+    ap.add_argument('--precision', default=os.environ.get('KEEP_BENCH_PRECISION', 'bf16'), choices=['fp32', 'x3', 'bf16'],
                     help="MFMA operand policy: fp32 (parity <= 1e-3) or bf16 (conv/linear operands bf16, fp32 accumulate)")
     args = ap.parse_args()
 

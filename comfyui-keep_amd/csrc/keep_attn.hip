@@ -13,6 +13,7 @@
 // Token addressing modes (plain / sparse-causal keys / shifted windows with region mask) are pure index math at
 // tile-load time, so the window partition, roll, key concatenation and batch swap of the reference cost no HBM pass.
 #include <math.h>
+#include <stdlib.h>
 
 #include "keep_common.h"
 
@@ -560,6 +561,343 @@ static int launch_attn_bf16(const AttnP& p, hipStream_t st) {
   return KEEP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ split fp16 (x3) variant
+// KEEP_MMA_X3 (see keep_conv_x3.hip): Q, K, V and P are each split into two fp16 halves (x = hi + lo) and every product
+// runs as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 -- fp32-grade scores and outputs at 3 MFMAs per 32x32x16 step
+// instead of 8 f32 MFMAs (32x32x2) at 1/16 of the rate.  Same algorithm as attn_bf16_kernel (S^T = K.Q^T so the softmax
+// reduction is in-lane; P feeds P.V from the lane's own registers against a key-permuted V^T); softmax in exact fp32 (expf).
+//   LDS rows: Q / K  [hi x DC | lo x DC | pad x 8] fp16 (pitch 2*DC+8: an odd number of 16-byte slots for DC % 8 == 0),
+//             V^T    [32 keys hi (permuted) | 32 keys lo | pad x 8] per dv column (pitch 72).
+//   The next key tile's K and V are fetched into registers while the current tile is on the matrix cores (single D chunk).
+typedef _Float16 af16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 af16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 af16x2 __attribute__((ext_vector_type(2)));
+
+// PF: register prefetch of the next key tile (4-wave blocks); QREG: D <= 128, the wave's Q fragments (hi + lo, 8 x 16-d
+// steps) live in registers for the whole kernel -- loaded straight from global, never staged -- so a block's LDS is one
+// K tile + one V^T tile (<= 35 KB) and two blocks share a CU.  D > 128 (VQGAN AttnBlock D = 512, CFA D = 256; 16x16 / 32x32
+// token maps): Q and K are re-staged through LDS per 128-wide chunk.
+template <int WAVES, int DVT, bool QREG>
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_x3_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 smemx[];
+  constexpr int DVS = DVT * 32;
+  constexpr int NT = 64 * WAVES;
+  constexpr int VP = 72;
+  constexpr bool PF = (WAVES == 4) && QREG;
+  constexpr int KPF = PF ? (32 * 32 + NT - 1) / NT : 1;        // float4 pieces of a 32 x 128 K tile per thread
+  constexpr int VPF = PF ? (16 * DVS + NT - 1) / NT : 1;       // (key pair, dv) items of a 32 x DVS V tile per thread
+  const int DC = p.D < 128 ? p.D : 128;
+  const int nch = p.D / DC;
+  const int QP = 2 * DC + 8;
+  _Float16* Ks = smemx;                               // [32][QP]
+  _Float16* Vt = Ks + 32 * QP;                        // [DVS][VP]
+  _Float16* Qs = Vt + DVS * VP;                       // [WAVES*32][QP], chunked path only
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int b = blockIdx.z;
+  const int head = blockIdx.y / p.nslices;
+  const int dv0 = (blockIdx.y - head * p.nslices) * DVS;
+  const int q0 = blockIdx.x * (WAVES * 32);
+  const long qh = (long)head * p.q_hs, kh = (long)head * p.k_hs, vh = (long)head * p.v_hs;
+  const int g4n = DC >> 2;
+
+  auto split8 = [&](const float4 a, const float4 c, af16x8& hi, af16x8& lo) {
+    const float f[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const _Float16 h = (_Float16)f[j];
+      hi[j] = h;
+      lo[j] = (_Float16)(f[j] - (float)h);
+    }
+  };
+  auto split_store4 = [&](const float4 v, _Float16* dst) {      // dst -> hi; lo lives DC elements further
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    af16x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const _Float16 h = (_Float16)f[j];
+      hi[j] = h;
+      lo[j] = (_Float16)(f[j] - (float)h);
+    }
+    *reinterpret_cast<af16x4*>(dst) = hi;
+    *reinterpret_cast<af16x4*>(dst + DC) = lo;
+  };
+  auto stage_rows = [&](const float* base, long bs, long ts, long hoff, bool is_q, int t0, int tmax, int nrows, int c0,
+                        _Float16* dst) {
+    for (int i = tid; i < nrows * g4n; i += NT) {
+      const int row = i / g4n, c = (i - row * g4n) << 2;
+      const int t = t0 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < tmax)
+        v = *reinterpret_cast<const float4*>(base + (is_q ? q_offset(p, b, t, bs, ts) : kv_offset(p, b, t, bs, ts)) + hoff + c0 + c);
+      split_store4(v, dst + row * QP + c);
+    }
+  };
+  auto stage_vt = [&](int kt) {      // lane <-> dv column (coalesced 4-byte reads), two consecutive keys per item
+    for (int i = tid; i < 16 * DVS; i += NT) {
+      const int pair = i / DVS, dv = i - pair * DVS;
+      const int t = kt * 32 + pair * 2;
+      float v[2] = {0.f, 0.f};
+      if (dv0 + dv < p.Dv) {
+        if (t < p.Lk) v[0] = p.v[kv_offset(p, b, t, p.v_bs, p.v_ts) + vh + dv0 + dv];
+        if (t + 1 < p.Lk) v[1] = p.v[kv_offset(p, b, t + 1, p.v_bs, p.v_ts) + vh + dv0 + dv];
+      }
+      af16x2 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const _Float16 h = (_Float16)v[j];
+        hi[j] = h;
+        lo[j] = (_Float16)(v[j] - (float)h);
+      }
+      _Float16* d = Vt + dv * VP + vt_pos(pair * 2);          // vt_pos(k0+1) = vt_pos(k0) + 1 for even k0
+      *reinterpret_cast<af16x2*>(d) = hi;
+      *reinterpret_cast<af16x2*>(d + 32) = lo;
+    }
+  };
+  // ---- register prefetch of the next key tile
+  float4 kreg[KPF];
+  float vreg[VPF][2];
+  auto k_issue = [&](int kt) {
+#pragma unroll
+    for (int u = 0; u < KPF; ++u) {
+      const int i = tid + u * NT;
+      kreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < 32 * g4n) {
+        const int row = i / g4n, c = (i - row * g4n) << 2;
+        const int t = kt * 32 + row;
+        if (t < p.Lk) kreg[u] = *reinterpret_cast<const float4*>(p.k + kv_offset(p, b, t, p.k_bs, p.k_ts) + kh + c);
+      }
+    }
+  };
+  auto k_commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < KPF; ++u) {
+      const int i = tid + u * NT;
+      if (i < 32 * g4n) {
+        const int row = i / g4n, c = (i - row * g4n) << 2;
+        split_store4(kreg[u], Ks + row * QP + c);
+      }
+    }
+  };
+  auto v_issue = [&](int kt) {
+#pragma unroll
+    for (int u = 0; u < VPF; ++u) {
+      const int i = tid + u * NT;
+      vreg[u][0] = 0.f;
+      vreg[u][1] = 0.f;
+      if (i < 16 * DVS) {
+        const int pair = i / DVS, dv = i - pair * DVS;
+        const int t = kt * 32 + pair * 2;
+        if (dv0 + dv < p.Dv) {
+          if (t < p.Lk) vreg[u][0] = p.v[kv_offset(p, b, t, p.v_bs, p.v_ts) + vh + dv0 + dv];
+          if (t + 1 < p.Lk) vreg[u][1] = p.v[kv_offset(p, b, t + 1, p.v_bs, p.v_ts) + vh + dv0 + dv];
+        }
+      }
+    }
+  };
+  auto v_commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < VPF; ++u) {
+      const int i = tid + u * NT;
+      if (i < 16 * DVS) {
+        const int pair = i / DVS, dv = i - pair * DVS;
+        af16x2 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const _Float16 h = (_Float16)vreg[u][j];
+          hi[j] = h;
+          lo[j] = (_Float16)(vreg[u][j] - (float)h);
+        }
+        _Float16* d = Vt + dv * VP + vt_pos(pair * 2);
+        *reinterpret_cast<af16x2*>(d) = hi;
+        *reinterpret_cast<af16x2*>(d + 32) = lo;
+      }
+    }
+  };
+
+  const int my_q = q0 + wave * 32 + l31;
+  // ---- Q fragments of this lane: row my_q, d in [16*step + 8*lhi, +8), split once
+  af16x8 qfh[QREG ? 8 : 1], qfl[QREG ? 8 : 1];
+  if (QREG) {
+    const bool qok = my_q < p.Lq;
+    const float* qrow = p.q + (qok ? q_offset(p, b, my_q, p.q_bs, p.q_ts) + qh : 0) + lhi * 8;
+#pragma unroll
+    for (int d8 = 0; d8 < 8; ++d8) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+      if (qok && d8 * 16 < DC) {
+        a = *reinterpret_cast<const float4*>(qrow + d8 * 16);
+        c = *reinterpret_cast<const float4*>(qrow + d8 * 16 + 4);
+      }
+      split8(a, c, qfh[QREG ? d8 : 0], qfl[QREG ? d8 : 0]);
+    }
+  }
+  if (PF) {
+    k_issue(0);
+    v_issue(0);
+    k_commit();
+    v_commit();
+  }
+
+  int my_region = 0;
+  if (p.mode == 2 && p.shift > 0 && my_q < p.Lq) my_region = win_region(p, b, my_q);
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 o[DVT];
+#pragma unroll
+  for (int j = 0; j < DVT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+
+  const _Float16* kp = Ks + l31 * QP + lhi * 8;
+  const _Float16* qp = Qs + (wave * 32 + l31) * QP + lhi * 8;
+  const int ntiles = (p.Lk + 31) / 32;
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    if (QREG) {
+      if (!PF) {
+        __syncthreads();                             // previous tile fully consumed
+        stage_rows(p.k, p.k_bs, p.k_ts, kh, false, kt * 32, p.Lk, 32, 0, Ks);
+        stage_vt(kt);
+      }
+      __syncthreads();                               // tile kt visible in LDS
+      if (PF && kt + 1 < ntiles) {
+        k_issue(kt + 1);                             // next tile's loads fly during the MFMAs below
+        v_issue(kt + 1);
+      }
+#pragma unroll
+      for (int d8 = 0; d8 < 8; ++d8) {
+        if (d8 * 16 < DC) {
+          const af16x8 kh8 = *reinterpret_cast<const af16x8*>(kp + d8 * 16);
+          const af16x8 kl8 = *reinterpret_cast<const af16x8*>(kp + DC + d8 * 16);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qfh[QREG ? d8 : 0], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qfl[QREG ? d8 : 0], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qfh[QREG ? d8 : 0], s, 0, 0, 0);
+        }
+      }
+    } else {
+      for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();
+        stage_rows(p.q, p.q_bs, p.q_ts, qh, true, q0, p.Lq, WAVES * 32, ch * DC, Qs);
+        stage_rows(p.k, p.k_bs, p.k_ts, kh, false, kt * 32, p.Lk, 32, ch * DC, Ks);
+        if (ch == 0) stage_vt(kt);
+        __syncthreads();
+        for (int d = 0; d < DC; d += 16) {
+          const af16x8 kh8 = *reinterpret_cast<const af16x8*>(kp + d), kl8 = *reinterpret_cast<const af16x8*>(kp + DC + d);
+          const af16x8 qh8 = *reinterpret_cast<const af16x8*>(qp + d), ql8 = *reinterpret_cast<const af16x8*>(qp + DC + d);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh8, s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, ql8, s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qh8, s, 0, 0, 0);
+        }
+      }
+    }
+
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      float val = s[r] * p.scale;
+      if (p.mode == 2 && p.shift > 0 && key < p.Lk) {
+        if (win_region(p, b, key) != my_region) val += -100.0f;
+      }
+      if (key >= p.Lk) val = -INFINITY;
+      s[r] = val;
+      mloc = fmaxf(mloc, val);
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = expf(m_run - m_new);
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = expf(s[r] - m_new);
+      s[r] = pv;
+      lsum += pv;
+    }
+    lsum += __shfl_xor(lsum, 32);
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const float ar = __shfl(alpha, qrow);
+#pragma unroll
+      for (int j = 0; j < DVT; ++j) o[j][r] *= ar;
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      af16x8 ph, pl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const _Float16 h = (_Float16)s[st * 8 + j];
+        ph[j] = h;
+        pl[j] = (_Float16)(s[st * 8 + j] - (float)h);
+      }
+#pragma unroll
+      for (int j = 0; j < DVT; ++j) {
+        const _Float16* vrow = Vt + (j * 32 + l31) * VP + (st * 2 + lhi) * 8;
+        const af16x8 vh8 = *reinterpret_cast<const af16x8*>(vrow), vl8 = *reinterpret_cast<const af16x8*>(vrow + 32);
+        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh8, o[j], 0, 0, 0);
+        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl8, o[j], 0, 0, 0);
+        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh8, o[j], 0, 0, 0);
+      }
+    }
+    if (PF && kt + 1 < ntiles) {
+      __syncthreads();                               // every wave is done reading tile kt
+      k_commit();
+      v_commit();
+    }
+  }
+
+  const float inv_l = 1.0f / l_run;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    const float il = __shfl(inv_l, qrow);
+    const int t = q0 + wave * 32 + qrow;
+    if (t < p.Lq) {
+      const long base = q_offset(p, b, t, p.o_bs, p.o_ts) + (long)head * p.o_hs;
+#pragma unroll
+      for (int j = 0; j < DVT; ++j) {
+        const int dv = dv0 + j * 32 + l31;
+        if (dv < p.Dv) p.o[base + dv] = o[j][r] * il;
+      }
+    }
+  }
+}
+
+template <int WAVES, int DVT, bool QREG>
+static int launch_attn_x3_t(const AttnP& p, hipStream_t st) {
+  const int DC = p.D < 128 ? p.D : 128;
+  const size_t lds = (size_t)(((QREG ? 0 : WAVES * 32) + 32) * (2 * DC + 8) + DVT * 32 * 72) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_x3_kernel<WAVES, DVT, QREG>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      keep_set_error("keep_attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return KEEP_EHIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid(cdiv(p.Lq, WAVES * 32), p.H * p.nslices, p.B);
+  hipLaunchKernelGGL((attn_x3_kernel<WAVES, DVT, QREG>), grid, dim3(64 * WAVES), lds, st, p);
+  KEEP_LAUNCH_CHECK("keep_attention(x3)");
+  return KEEP_OK;
+}
+
+template <int WAVES, int DVT>
+static int launch_attn_x3(const AttnP& p, hipStream_t st) {
+  if (p.D <= 128) return launch_attn_x3_t<WAVES, DVT, true>(p, st);
+  return launch_attn_x3_t<4, DVT, false>(p, st);
+}
+
 // ------------------------------------------------------------------------------------------------ bf16-input variant
 // Q, K, V already live in HBM as bf16 (the projection GEMMs write bf16, halving the K/V traffic that every q-tile
 // block re-reads).  128 queries per block (4 waves), 64 keys per iteration (two 32x32 score tiles per wave).
@@ -929,7 +1267,7 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
   KEEP_REQUIRE(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0 && a->D > 0 && a->Dv > 0, "keep_attention: bad dims");
   KEEP_REQUIRE(a->D % 2 == 0 && (a->D <= 128 || a->D % 128 == 0), "keep_attention: D=%d must be even and (<= 128 or a multiple of 128)", a->D);
   KEEP_REQUIRE(a->mode >= 0 && a->mode <= 2, "keep_attention: bad mode %d", a->mode);
-  KEEP_REQUIRE(a->mma == KEEP_MMA_F32 || a->mma == KEEP_MMA_BF16, "keep_attention: bad mma %d", a->mma);
+  KEEP_REQUIRE(a->mma == KEEP_MMA_F32 || a->mma == KEEP_MMA_BF16 || a->mma == KEEP_MMA_X3, "keep_attention: bad mma %d", a->mma);
   if (a->mode == 1)
     KEEP_REQUIRE(a->T > 0 && a->seg_len > 0 && a->Lk == 2 * a->seg_len && a->B % a->T == 0,
                  "keep_attention: sparse-causal mode needs Lk == 2*seg_len and B %% T == 0");
@@ -981,6 +1319,19 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
     if (dvt == 1) return launch_attn_bf16<4, 1>(p, st);
     if (dvt == 2) return launch_attn_bf16<4, 2>(p, st);
     return launch_attn_bf16<4, 4>(p, st);
+  }
+  // split fp16: fp32 tensors with 16-byte aligned rows, D a multiple of 16; everything else runs on the exact-f32 kernel
+  if (a->mma == KEEP_MMA_X3 && (a->D % 16 == 0) && (a->q_ts % 4 == 0) && (a->q_bs % 4 == 0) && (a->q_hs % 4 == 0) &&
+      (a->k_ts % 4 == 0) && (a->k_bs % 4 == 0) && (a->k_hs % 4 == 0) && ((uintptr_t)a->q % 16 == 0) &&
+      ((uintptr_t)a->k % 16 == 0) && !getenv("KEEP_NO_ATTN_X3")) {
+    if (a->Lq <= 32) {
+      if (dvt == 1) return launch_attn_x3<1, 1>(p, st);
+      if (dvt == 2) return launch_attn_x3<1, 2>(p, st);
+      return launch_attn_x3<1, 4>(p, st);
+    }
+    if (dvt == 1) return launch_attn_x3<4, 1>(p, st);
+    if (dvt == 2) return launch_attn_x3<4, 2>(p, st);
+    return launch_attn_x3<4, 4>(p, st);
   }
   // one wave per block for tiny query counts (temporal attention over T frames), else 4 (one per SIMD)
   if (a->Lq <= 32) {

@@ -13,212 +13,7 @@
 // over the (tap, Cin-chunk) steps into a caller workspace + a reduce/epilogue kernel.
 #include <stdlib.h>
 
-#include <type_traits>
-
-#include "keep_common.h"
-
-#define BK 16
-
-struct ConvP {
-  const float* in;
-  const float* w;
-  const unsigned short* wb;  // bf16 copy of w (same layout), KEEP_MMA_BF16 only
-  const float* bias;
-  float* out;
-  const float* pro_scale;
-  const float* pro_shift;
-  const float* res;
-  const float* aux;
-  float* ws;
-  int N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo;
-  int in_ld, out_ld, res_ld;
-  int upsample, pro_act, epi_act;
-  float aux_w;
-  int split_k;
-  int M;        // N*Ho*Wo
-  int cchunks;  // ceil(Cin/BK)
-  int nsteps;   // KH*KW*cchunks
-  int vec_ok;   // Cin%4==0 && in_ld%4==0 -> float4 loads
-  int in_bf16;  // input tensor is bf16 (halo kernel only)
-  int fast;     // bf16 policy: fast-math epilogue activations
-  float* stats; // optional [N][P][Cout][2] per-tile (sum, sumsq) of the epilogue output, P = stats_P tiles per image
-  int stats_P;
-  int out_bf16; // write the output tensor as bf16 (gather kernels' staged epilogue, persistent bf16 halo kernel)
-  int vec_epi;  // Cout/out_ld/res_ld %% 4 == 0 and aligned pointers -> LDS-staged float4 epilogue
-  int flatk;    // Cin < 8: K = KH*KW*Cin flattened (element-wise gather) instead of tap-major chunks
-  int flatk_f32;  // the same for the f32 gather kernel (16-wide K steps)
-};
-
-__device__ __forceinline__ float epilogue_one(const ConvP& p, float v, long m, int co) {
-  if (p.bias) v += p.bias[co];
-  v = p.fast ? act_apply_fast(v, p.epi_act) : act_apply(v, p.epi_act);
-  if (p.res) {
-    float r = p.res[m * p.res_ld + co];
-    if (p.aux) {
-      float a = p.aux[m * (long)p.Cout + co];
-      v = r + p.aux_w * (r * a + v);
-    } else {
-      v = v + r;
-    }
-  }
-  return v;
-}
-
-// Epilogue statistics for the NEXT normalisation (GroupNorm / InstanceNorm): every lane owns one output channel
-// (column) of its wave tile; (sum, sumsq) over the tile's rows are combined across the two half-waves by a shuffle
-// and across the waves that share the columns through `red` (LDS), then written as one partial per (tile, channel).
-template <int WGM, int WGN, int TN>
-__device__ __forceinline__ void emit_tile_stats(const ConvP& p, float (*red)[2], const float (&cs)[TN], const float (&css)[TN],
-                                                int wm, int wn, int lane, int n_img, int p_idx, int n0) {
-  const int l31 = lane & 31;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    float s = cs[j] + __shfl_xor(cs[j], 32);
-    float ss = css[j] + __shfl_xor(css[j], 32);
-    if (lane < 32) {
-      red[(wm * WGN + wn) * TN * 32 + j * 32 + l31][0] = s;
-      red[(wm * WGN + wn) * TN * 32 + j * 32 + l31][1] = ss;
-    }
-  }
-  __syncthreads();
-  constexpr int BNc = WGN * TN * 32;
-  for (int c = threadIdx.x; c < BNc; c += 256) {
-    const int wn_c = c / (TN * 32), rem = c - wn_c * (TN * 32);
-    float s = 0.f, ss = 0.f;
-#pragma unroll
-    for (int m = 0; m < WGM; ++m) {
-      s += red[(m * WGN + wn_c) * TN * 32 + rem][0];
-      ss += red[(m * WGN + wn_c) * TN * 32 + rem][1];
-    }
-    const int co = n0 + c;
-    if (co < p.Cout) {
-      float* dst = p.stats + (((long)n_img * p.stats_P + p_idx) * p.Cout + co) * 2;
-      dst[0] = s;
-      dst[1] = ss;
-    }
-  }
-}
-
-// Epilogue through LDS (shared by the gather kernels): the MFMA C/D layout gives a lane one output channel x 16
-// rows -> 4-byte strided stores, issue-bound at ~2 TB/s.  Each wave parks its (TM*32 x TN*32) tile in LDS and reads it
-// back channel-contiguous: 16 bytes per lane, full rows per store instruction, float4 bias / residual / aux, and the
-// normalisation partial sums are lane-local (4 fixed channels per lane).  Needs Cout, out_ld, res_ld multiples of 4 and
-// 16-byte aligned pointers (p.vec_epi); otherwise the scalar path below is used.
-// SIMPLE (chosen once per call, uniform): split_k == 1, no aux tensor, no activation -- the row loop then carries neither
-// those branches nor the activation switch (worth 10 % on the halo kernel, whose epilogue has the same shape).
-template <int WGM, int WGN, int TM, int TN, bool SIMPLE>
-__device__ __forceinline__ void staged_epilogue_impl(const ConvP& p, f32x16 (&acc)[TM][TN], float* lds, long m0, int n0,
-                                                     int wm, int wn, int lane, int wave, int z) {
-  constexpr int WR = TM * 32, WC = TN * 32, EP = WC + 4;
-  constexpr int LPR = WC / 4;          // lanes per row (float4 each)
-  constexpr int RPI = 64 / LPR;        // rows per wave-instruction
-  const int l31 = lane & 31, lhi = lane >> 5;
-  float* et = lds + wave * WR * EP;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        et[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * EP + j * 32 + l31] = acc[i][j][r];
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): wave-local hand-off, LDS ops of one wave retire in order
-  const int c4 = (lane % LPR) * 4;
-  const int prow = lane / LPR;
-  const int co = n0 + wn * WC + c4;
-  const bool cok = co < p.Cout;
-  float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
-  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
-#pragma unroll 4
-  for (int it = 0; it < WR / RPI; ++it) {
-    const int px = it * RPI + prow;
-    const long m = m0 + wm * WR + px;
-    if (m >= p.M || !cok) continue;
-    const float4 v = *reinterpret_cast<const float4*>(et + px * EP + c4);
-    if (!SIMPLE && p.split_k > 1) {
-      *reinterpret_cast<float4*>(p.ws + ((long)z * p.M + m) * p.Cout + co) = v;
-      continue;
-    }
-    float e[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
-    if (!SIMPLE) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) e[q] = p.fast ? act_apply_fast(e[q], p.epi_act) : act_apply(e[q], p.epi_act);
-    }
-    if (p.res) {
-      const float4 r4 = *reinterpret_cast<const float4*>(p.res + m * p.res_ld + co);
-      const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
-      if (!SIMPLE && p.aux) {
-        const float4 a4 = *reinterpret_cast<const float4*>(p.aux + m * (long)p.Cout + co);
-        const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) e[q] = rr[q] + p.aux_w * (rr[q] * aa[q] + e[q]);
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) e[q] += rr[q];
-      }
-    }
-    if (p.out_bf16) {
-      typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-      bf16x4_t h;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) h[q] = (__bf16)e[q];
-      *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(p.out) + m * p.out_ld + co) = h;
-    } else {
-      *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      s4[q] += e[q];
-      ss4[q] += e[q] * e[q];
-    }
-  }
-  if (p.stats) {   // host guarantees split_k == 1 and H*W % BM == 0 (a tile never straddles two images)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-      for (int o = LPR; o < 64; o <<= 1) {
-        s4[q] += __shfl_xor(s4[q], o);
-        ss4[q] += __shfl_xor(ss4[q], o);
-      }
-    }
-    __syncthreads();                     // all waves finished reading their staged tiles
-    float* red = lds;                    // [4 waves][WC][2]
-    if (lane < LPR) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        red[(wave * WC + c4 + q) * 2 + 0] = s4[q];
-        red[(wave * WC + c4 + q) * 2 + 1] = ss4[q];
-      }
-    }
-    __syncthreads();
-    constexpr int BNc = WGN * WC;
-    const int hw_o = p.Ho * p.Wo;
-    const int n_img = (int)(m0 / hw_o), p_idx = (int)((m0 % hw_o) / (WGM * WR));
-    for (int c = threadIdx.x; c < BNc; c += 256) {
-      const int wn_c = c / WC, rem = c - wn_c * WC;
-      float a = 0.f, b2 = 0.f;
-#pragma unroll
-      for (int mm = 0; mm < WGM; ++mm) {
-        a += red[((mm * WGN + wn_c) * WC + rem) * 2 + 0];
-        b2 += red[((mm * WGN + wn_c) * WC + rem) * 2 + 1];
-      }
-      if (n0 + c < p.Cout) {
-        float* dst = p.stats + (((long)n_img * p.stats_P + p_idx) * p.Cout + n0 + c) * 2;
-        dst[0] = a;
-        dst[1] = b2;
-      }
-    }
-  }
-}
-
-template <int WGM, int WGN, int TM, int TN>
-__device__ __forceinline__ void staged_epilogue(const ConvP& p, f32x16 (&acc)[TM][TN], float* lds, long m0, int n0,
-                                                int wm, int wn, int lane, int wave, int z) {
-  if (p.split_k == 1 && !p.aux && p.epi_act == KEEP_ACT_NONE)
-    staged_epilogue_impl<WGM, WGN, TM, TN, true>(p, acc, lds, m0, n0, wm, wn, lane, wave, z);
-  else
-    staged_epilogue_impl<WGM, WGN, TM, TN, false>(p, acc, lds, m0, n0, wm, wn, lane, wave, z);
-}
+#include "keep_conv_common.h"
 
 // PLAIN (host-checked): no prologue, no upsample, Cin % 16 == 0 and 16-byte aligned rows: the K loop carries none of
 // those uniform branches (token GEMMs, 1x1 convs, plain strided convs).
@@ -841,18 +636,6 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvP p) {
 // The NEXT chunk's halo + weights are prefetched into registers while the current chunk is on the matrix cores;
 // 73 KB of LDS -> 2 blocks per CU so one block's staging overlaps the other's MFMA phase.
 // `upsample` folds nearest x2 into the halo addressing; split-K splits the Cin chunks (small maps at small batch).
-#define HALO_MAXPIX 340                      // 10 x 34 (8x32 tile) >= 18 x 18 (16x16 tile)
-#define HPITCH 40                            // bf16 elements per LDS pixel/weight row (80 B)
-#define HALO_IT 6                            // ceil(340*4 / 256) 16-byte pieces per thread
-
-__device__ __forceinline__ int xcd_remap(int id, int total) {
-  // blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of logical ids so that neighbouring
-  // tiles (shared halo rows, shared weight slab) meet in one L2.  Bijective for any total (guide T1).
-  const int q = total >> 3, r = total & 7;
-  const int xcd = id & 7, slot = id >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-}
-
 // TW = 32: 8 x 32 output tile (maps >= 32 wide); TW = 16: 16 x 16 tile (the 16x16 latent maps: a whole image per block).
 template <bool IN_BF16, int TW>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles_x, int tiles_y, int ncb) {
@@ -914,7 +697,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles
   uint4 hreg[HALO_IT];                   // bf16 input: one 16-B piece each
   float4 hlo[IN_BF16 ? 1 : HALO_IT], hhi[IN_BF16 ? 1 : HALO_IT];   // fp32 input: 8 floats per piece
   uint4 wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7, wr8;   // named: a 9-element array is left in scratch by hipcc
-#define KEEP_TAPS(X) X(0, wr0) X(1, wr1) X(2, wr2) X(3, wr3) X(4, wr4) X(5, wr5) X(6, wr6) X(7, wr7) X(8, wr8)
 
   auto fetch = [&](int ch) {
     const int c0 = ch << 5;
@@ -1117,30 +899,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, int tiles
 // (A wave-specialised producer/consumer version of the halo kernel -- 4 loader waves + 4 MFMA waves, one block per CU -- was
 // measured SLOWER than v1: only 256 threads issue loads, halving the bytes in flight per CU, and the kernel is bound by the
 // L2->CU operand stream.  It was removed; v3 below keeps every wave loading, staging and computing.)
-struct HaloItem {
-  int n, tx, ty, oy0, ox0, n0, z, ch_begin, ch_end;
-};
-
-template <int TW, int CSH = 5>
-__device__ __forceinline__ HaloItem halo_decode(const ConvP& p, int item, int items_per_z, int tiles_x, int tiles_y, int ncb) {
-  HaloItem it;
-  it.z = item / items_per_z;
-  const int lid = xcd_remap(item - it.z * items_per_z, items_per_z);
-  const int cb = lid % ncb;
-  int t = lid / ncb;
-  it.tx = t % tiles_x; t /= tiles_x;
-  it.ty = t % tiles_y;
-  it.n = t / tiles_y;
-  it.oy0 = it.ty * (256 / TW);
-  it.ox0 = it.tx * TW;
-  it.n0 = cb * 64;
-  const int nchunks = p.Cin >> CSH;
-  const int per = (nchunks + p.split_k - 1) / p.split_k;
-  it.ch_begin = it.z * per;
-  it.ch_end = min(nchunks, it.ch_begin + per);
-  return it;
-}
-
 // ------------------------------------------------------------------------------------------------ halo v3
 // v1 made persistent: v3 keeps v1's
 // two 4-wave blocks per CU -- every wave loads, converts, stages and computes -- but each block walks the work items
@@ -1883,13 +1641,49 @@ __global__ void conv_splitk_reduce_kernel(ConvP p) {
   }
 }
 
-extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
+// ------------------------------------------------------------------------------------------------ plan + dispatch
+// ONE place decides which kernel a keep_conv2d call runs on, its tile, the split-K factor and the layout of the epilogue
+// statistics: plan_conv().  keep_conv2d_plan() exposes that decision to the host, which sizes the workspace / statistics
+// buffers from it and never re-derives kernel internals (a retune here cannot silently corrupt a caller).
+int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
+int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
+bool keep_conv_x3_halo_ok(const keep_conv2d_args* a);
+bool keep_conv_x3_gather_ok(const keep_conv2d_args* a, const ConvP& p);
+
+enum ConvPath {
+  PATH_COUT4 = 0, PATH_C3, PATH_HALO_F32, PATH_HALO_BF16, PATH_HALO_BF16_V1, PATH_GATHER_BF16, PATH_GATHER_F32, PATH_HALO_X3,
+  PATH_GATHER_X3
+};
+
+struct ConvPlan {
+  ConvPath path;
+  int tile;            // gather kernels: 0 = 128x32 (4,1,1,1), 1 = 64x64 (2,2,1,1), 2 = 128x128 (2,2,2,2)
+  bool plain, wide, bk256;
+  int split_k;
+  int stats_rows;      // output pixels per statistics partial; 0 = this call cannot emit statistics
+  int wants_bf16_input, out_bf16_ok;
+  char kernel[64];
+};
+
+static int n_cu_cached() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  return n_cu;
+}
+
+static const int kTargetWaves = 1024;   // below this many matrix-core waves a launch cannot fill 256 CUs x 4 SIMDs -> split K
+
+static int validate_conv(const keep_conv2d_args* a) {
   KEEP_REQUIRE(a != nullptr, "keep_conv2d: null args");
   if (a->dtype != KEEP_F32 && !(a->dtype == KEEP_BF16 && a->mma == KEEP_MMA_BF16)) {
     keep_set_error("keep_conv2d: dtype %d not supported (fp32 input, or bf16 input with KEEP_MMA_BF16)", a->dtype);
     return KEEP_EUNSUP;
   }
-  KEEP_REQUIRE(a->in && a->weight && a->out, "keep_conv2d: null tensor pointer");
   KEEP_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->KH > 0 && a->KW > 0 &&
                    a->stride > 0 && a->Ho > 0 && a->Wo > 0,
                "keep_conv2d: non-positive dimension");
@@ -1897,21 +1691,27 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
   KEEP_REQUIRE((a->pro_scale == nullptr) == (a->pro_shift == nullptr), "keep_conv2d: pro_scale/pro_shift must pair");
   KEEP_REQUIRE(!a->aux || a->residual, "keep_conv2d: aux epilogue requires residual");
   KEEP_REQUIRE(!a->residual || a->res_ld >= a->Cout, "keep_conv2d: res_ld smaller than Cout");
-  KEEP_REQUIRE(a->split_k >= 1, "keep_conv2d: split_k must be >= 1");
-  KEEP_REQUIRE(a->split_k == 1 || a->workspace, "keep_conv2d: split_k>1 requires a workspace");
+  KEEP_REQUIRE(a->split_k >= 0, "keep_conv2d: split_k must be >= 0 (0 = let the library choose)");
   {
     const int Hv = a->upsample ? 2 * a->H : a->H, Wv = a->upsample ? 2 * a->W : a->W;
-    // the last tap of the last output must not start beyond one row/col of padding logic: (Ho-1)*s - pt < Hv
     KEEP_REQUIRE((long)(a->Ho - 1) * a->stride - a->pad_t < Hv && (long)(a->Wo - 1) * a->stride - a->pad_l < Wv,
                  "keep_conv2d: output extent %dx%d inconsistent with input %dx%d", a->Ho, a->Wo, Hv, Wv);
   }
-  KEEP_REQUIRE(a->mma == KEEP_MMA_F32 || a->mma == KEEP_MMA_BF16, "keep_conv2d: bad mma %d", a->mma);
-  KEEP_REQUIRE(a->mma == KEEP_MMA_F32 || (a->weight_bf16 && (uintptr_t)a->weight_bf16 % 16 == 0),
-               "keep_conv2d: KEEP_MMA_BF16 needs a 16-byte aligned weight_bf16");
-  ConvP p;
+  KEEP_REQUIRE(a->mma == KEEP_MMA_F32 || a->mma == KEEP_MMA_BF16 || a->mma == KEEP_MMA_X3, "keep_conv2d: bad mma %d", a->mma);
+  KEEP_REQUIRE((long)a->N * a->Ho * a->Wo < (1L << 31), "keep_conv2d: M too large");
+  return KEEP_OK;
+}
+
+// Pointer-independent geometry checks use the pointers only for their alignment; the plan query passes the same struct
+// the launch will see (NULL optional tensors stay NULL), so plan and launch always agree.
+static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
+  memset(&pl, 0, sizeof(pl));
+  const long M = (long)a->N * a->Ho * a->Wo;
   p.in = (const float*)a->in;
   p.w = a->weight;
   p.wb = (const unsigned short*)a->weight_bf16;
+  p.wx3 = (const unsigned short*)a->weight_x3;
+  p.acc_scale = a->x3_acc_scale;
   p.bias = a->bias;
   p.out = (float*)a->out;
   p.pro_scale = a->pro_scale;
@@ -1923,132 +1723,243 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
   p.stride = a->stride; p.pad_t = a->pad_t; p.pad_l = a->pad_l; p.Ho = a->Ho; p.Wo = a->Wo;
   p.in_ld = a->in_ld; p.out_ld = a->out_ld; p.res_ld = a->res_ld;
   p.upsample = a->upsample; p.pro_act = a->pro_act; p.epi_act = a->epi_act; p.aux_w = a->aux_w;
-  p.split_k = a->split_k;
-  const long M = (long)a->N * a->Ho * a->Wo;
-  KEEP_REQUIRE(M < (1L << 31), "keep_conv2d: M too large");
   p.M = (int)M;
   p.cchunks = (a->Cin + BK - 1) / BK;
   p.nsteps = a->KH * a->KW * p.cchunks;
-  p.flatk_f32 = (a->mma != KEEP_MMA_BF16 && a->Cin < 8 && a->dtype == KEEP_F32 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE &&
-                 !getenv("KEEP_NO_FLATK_F32")) ? 1 : 0;
-  if (p.flatk_f32) p.nsteps = (a->KH * a->KW * a->Cin + BK - 1) / BK;
-  if (p.split_k > p.nsteps) p.split_k = p.nsteps;
-  p.vec_ok = (a->Cin % 4 == 0 && a->in_ld % 4 == 0 && ((uintptr_t)a->in % 16 == 0)) ? 1 : 0;
-  const bool plain_f32 = a->mma != KEEP_MMA_BF16 && p.vec_ok && a->Cin % 16 == 0 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE &&
-                         !a->upsample && !getenv("KEEP_NO_PLAIN");
-  KEEP_REQUIRE((uintptr_t)a->weight % 16 == 0, "keep_conv2d: weight pointer must be 16-byte aligned");
-  KEEP_REQUIRE(!a->pro_scale || ((uintptr_t)a->pro_scale % 16 == 0 && (uintptr_t)a->pro_shift % 16 == 0),
-               "keep_conv2d: pro_scale/pro_shift must be 16-byte aligned");
-
-  hipStream_t st = (hipStream_t)stream;
-  dim3 block(256);
   p.in_bf16 = (a->dtype == KEEP_BF16) ? 1 : 0;
   p.fast = (a->mma == KEEP_MMA_BF16) ? 1 : 0;
   p.out_bf16 = (a->out_dtype == KEEP_BF16) ? 1 : 0;
+  p.vec_ok = (a->Cin % 4 == 0 && a->in_ld % 4 == 0 && ((uintptr_t)a->in % 16 == 0)) ? 1 : 0;
   p.vec_epi = (a->Cout % 4 == 0 && a->out_ld % 4 == 0 && (uintptr_t)a->out % 16 == 0 &&
                (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&
                (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0) &&
                (!a->workspace || (uintptr_t)a->workspace % 16 == 0)) ? 1 : 0;
-  p.flatk = (a->mma == KEEP_MMA_BF16 && a->Cin < 8 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE) ? 1 : 0;
+  p.flatk = 0;
+  p.flatk_f32 = 0;
   p.stats = a->stats_out;
   p.stats_P = a->stats_P;
-  if (p.stats) {
-    KEEP_REQUIRE(a->split_k == 1, "keep_conv2d: stats_out requires split_k == 1");
-    KEEP_REQUIRE(a->stats_P > 0, "keep_conv2d: stats_out requires stats_P");
-  }
-  const bool halo_ok = a->mma == KEEP_MMA_BF16 && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 &&
-                       a->pad_l == 1 && (a->Cin % 32 == 0) && (a->Cout % 32 == 0) &&
-                       ((a->Ho % 8 == 0 && a->Wo % 32 == 0) || (a->Ho % 16 == 0 && a->Wo % 16 == 0)) &&
-                       a->Ho == (a->upsample ? 2 * a->H : a->H) &&
-                       a->Wo == (a->upsample ? 2 * a->W : a->W) &&
-                       (a->dtype == KEEP_F32 || (!a->pro_scale && a->pro_act == KEEP_PRO_NONE)) &&
-                       (!a->pro_scale || ((uintptr_t)a->pro_scale % 16 == 0 && (uintptr_t)a->pro_shift % 16 == 0)) &&
-                       (a->out_dtype != KEEP_BF16 || (!a->pro_scale && a->pro_act == KEEP_PRO_NONE && !a->residual && a->split_k == 1 &&
-                                                      a->Cout % 64 == 0 && !(getenv("KEEP_HALO_VER") && atoi(getenv("KEEP_HALO_VER")) != 3))) &&
-                       (a->in_ld % 8 == 0) && ((uintptr_t)a->in % 16 == 0) && (a->out_ld % 4 == 0) &&
-                       ((uintptr_t)a->out % 16 == 0) && (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&
-                       (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0);
-  // <= 4 output channels: VALU kernel (both precision policies compute it in exact fp32)
-  if (a->Cout <= 4 && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 && a->pad_l == 1 && !a->upsample &&
-      a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && a->Cin % SC_CH == 0 && a->in_ld % 4 == 0 &&
-      (uintptr_t)a->in % 16 == 0 && a->Ho == a->H && a->Wo == a->W && a->Ho % SC_TH == 0 && a->Wo % SC_TW == 0 &&
-      !a->residual && !a->aux && !a->stats_out && p.split_k == 1 &&
-      (!a->pro_scale || ((uintptr_t)a->pro_scale % 16 == 0 && (uintptr_t)a->pro_shift % 16 == 0)) &&
-      !getenv("KEEP_NO_COUT4")) {
-    dim3 grid((a->Ho / SC_TH) * (a->Wo / SC_TW), a->N);
-    hipLaunchKernelGGL(conv3x3_cout4_kernel, grid, block, 0, st, p);
-    KEEP_LAUNCH_CHECK("keep_conv2d(cout<=4)");
+  const bool no_pro = !a->pro_scale && a->pro_act == KEEP_PRO_NONE;
+  const bool is33s1 = a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 && a->pad_l == 1;
+  const bool same_size = a->Ho == (a->upsample ? 2 * a->H : a->H) && a->Wo == (a->upsample ? 2 * a->W : a->W);
+  const bool tileable = (a->Ho % 8 == 0 && a->Wo % 32 == 0) || (a->Ho % 16 == 0 && a->Wo % 16 == 0);
+  const bool pro_al = !a->pro_scale || ((uintptr_t)a->pro_scale % 16 == 0 && (uintptr_t)a->pro_shift % 16 == 0);
+  const bool epi_al = (a->out_ld % 4 == 0) && ((uintptr_t)a->out % 16 == 0) &&
+                      (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&
+                      (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0);
+  pl.wide = (a->Ho % 8 == 0 && a->Wo % 32 == 0);
+  const int ncb = (a->Cout + 63) / 64;
+  int mma = a->mma;
+  int auto_split = 1;
+
+  // ---- <= 4 output channels: exact-fp32 VALU kernel in every precision policy
+  if (a->Cout <= 4 && is33s1 && !a->upsample && a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && a->Cin % SC_CH == 0 &&
+      a->in_ld % 4 == 0 && (uintptr_t)a->in % 16 == 0 && a->Ho == a->H && a->Wo == a->W && a->Ho % SC_TH == 0 &&
+      a->Wo % SC_TW == 0 && !a->residual && !a->aux && a->split_k <= 1 && pro_al && !getenv("KEEP_NO_COUT4")) {
+    pl.path = PATH_COUT4;
+    pl.split_k = 1;
+    snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_cout4_kernel");
     return KEEP_OK;
   }
-  // RGB first convolutions, bf16 policy: persistent im2col-in-LDS kernel
-  const bool c3_ok = a->mma == KEEP_MMA_BF16 && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 && a->pad_l == 1 &&
-                     !a->upsample && a->Cin <= 3 && a->Cout % 4 == 0 && a->Cout >= 32 && a->dtype == KEEP_F32 &&
-                     a->out_dtype != KEEP_BF16 && a->Ho == a->H && a->Wo == a->W && a->Ho % 8 == 0 && a->Wo % 32 == 0 &&
-                     !a->pro_scale && a->pro_act == KEEP_PRO_NONE && !a->residual && !a->aux && p.split_k == 1 &&
-                     a->out_ld % 4 == 0 && (uintptr_t)a->out % 16 == 0 && (!a->bias || (uintptr_t)a->bias % 16 == 0) &&
-                     !getenv("KEEP_NO_C3");
-  if (p.stats && c3_ok) {
-    const long hw_o = (long)a->Ho * a->Wo;
-    KEEP_REQUIRE(a->stats_P == hw_o / 64, "keep_conv2d: stats_P=%d must equal Ho*Wo/64", a->stats_P);
+  // ---- RGB first convolutions, bf16 policy: persistent im2col-in-LDS kernel
+  if (mma == KEEP_MMA_BF16 && is33s1 && !a->upsample && a->Cin <= 3 && a->Cout % 4 == 0 && a->Cout >= 32 && a->dtype == KEEP_F32 &&
+      a->out_dtype != KEEP_BF16 && a->Ho == a->H && a->Wo == a->W && a->Ho % 8 == 0 && a->Wo % 32 == 0 && no_pro && !a->residual &&
+      !a->aux && a->split_k <= 1 && a->out_ld % 4 == 0 && (uintptr_t)a->out % 16 == 0 && (!a->bias || (uintptr_t)a->bias % 16 == 0) &&
+      !getenv("KEEP_NO_C3")) {
+    pl.path = PATH_C3;
+    pl.split_k = 1;
+    pl.stats_rows = 64;
+    snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_c3_kernel");
+    return KEEP_OK;
   }
-  if (c3_ok) {
-    const int tiles_x = a->Wo / 32, tiles_y = a->Ho / 8, ncb = (a->Cout + 63) / 64;
-    const int n_items = a->N * tiles_x * tiles_y * ncb;
-    static int n_cu_c3 = 0;
-    if (n_cu_c3 == 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu_c3 = prop.multiProcessorCount;
-      if (n_cu_c3 <= 0) n_cu_c3 = 256;
+  // ---- split fp16: halo / gather kernels where the geometry fits, the exact-f32 kernels otherwise (same parity grade)
+  if (mma == KEEP_MMA_X3) {
+    KEEP_REQUIRE(a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16, "keep_conv2d: KEEP_MMA_X3 takes and writes fp32 tensors");
+    const bool have_w = a->weight_x3 != nullptr && (uintptr_t)a->weight_x3 % 16 == 0 && a->x3_acc_scale > 0.f;
+    if (have_w && is33s1 && keep_conv_x3_halo_ok(a) && !getenv("KEEP_NO_HALO_X3")) {
+      pl.path = PATH_HALO_X3;
+      const long items = (M / 256) * ncb;
+      auto_split = items >= 256 ? 1 : (int)max(1L, min(min(512L / items, (long)a->Cin / 32), 16L));
+      pl.split_k = a->split_k > 0 ? a->split_k : auto_split;
+      if (pl.split_k > a->Cin / 16) pl.split_k = a->Cin / 16;
+      pl.stats_rows = 64;
+      snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3_kernel<%d>", pl.wide ? 32 : 16);
+      return KEEP_OK;
     }
-    hipLaunchKernelGGL(conv3x3_c3_kernel, dim3(n_items < 2 * n_cu_c3 ? n_items : 2 * n_cu_c3), block, 0, st, p, tiles_x, tiles_y, ncb,
-                       n_items);
-    KEEP_LAUNCH_CHECK("keep_conv2d(Cin<=3)");
+    if (have_w && keep_conv_x3_gather_ok(a, p) && !getenv("KEEP_NO_GATHER_X3")) {
+      pl.path = PATH_GATHER_X3;
+      pl.tile = (a->Cout <= 64 || M <= 4096) ? 1 : 2;
+      pl.plain = no_pro;
+      const int steps = a->KH * a->KW * ((a->Cin + 31) / 32);
+      const long blocks = pl.tile == 1 ? (long)cdiv(M, 64) * cdiv(a->Cout, 64) : (long)cdiv(M, 128) * cdiv(a->Cout, 128);
+      const long waves = blocks * 4;
+      auto_split = (waves >= kTargetWaves || steps < 8) ? 1 : (int)max(1L, min(min(4L * kTargetWaves / waves, (long)steps / 2), 32L));
+      pl.split_k = a->split_k > 0 ? a->split_k : auto_split;
+      if (pl.split_k > steps) pl.split_k = steps;
+      pl.stats_rows = pl.tile == 1 ? 64 : 128;
+      snprintf(pl.kernel, sizeof(pl.kernel), "conv_x3_kernel<%s, %s>", pl.tile == 1 ? "2, 2, 1, 1" : "2, 2, 2, 2",
+               pl.plain ? "true" : "false");
+      return KEEP_OK;
+    }
+    mma = KEEP_MMA_F32;
+  }
+  KEEP_REQUIRE(mma == KEEP_MMA_F32 || (a->weight_bf16 && (uintptr_t)a->weight_bf16 % 16 == 0) || a->weight == nullptr,
+               "keep_conv2d: KEEP_MMA_BF16 needs a 16-byte aligned weight_bf16");
+  // ---- fp32 policy: persistent LDS-halo kernel on f32 MFMA
+  if (mma == KEEP_MMA_F32 && a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && is33s1 && (a->Cin % 16 == 0) &&
+      (a->Cout % 32 == 0) && tileable && same_size && pro_al && (a->in_ld % 4 == 0) && ((uintptr_t)a->in % 16 == 0) &&
+      ((uintptr_t)a->weight % 16 == 0) && epi_al && (!a->workspace || (uintptr_t)a->workspace % 16 == 0) &&
+      !getenv("KEEP_NO_HALO_F32")) {
+    pl.path = PATH_HALO_F32;
+    const long items = (M / 256) * ncb;
+    auto_split = items >= 256 ? 1 : (int)max(1L, min(min(512L / items, (long)a->Cin / 32), 16L));
+    pl.split_k = a->split_k > 0 ? a->split_k : auto_split;
+    if (pl.split_k > a->Cin / 16) pl.split_k = a->Cin / 16;
+    pl.stats_rows = 64;
+    snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_f32_kernel<%d>", pl.wide ? 32 : 16);
     return KEEP_OK;
   }
-  const bool halo_f32_ok = a->mma != KEEP_MMA_BF16 && a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && a->KH == 3 && a->KW == 3 &&
-                           a->stride == 1 && a->pad_t == 1 && a->pad_l == 1 && (a->Cin % 16 == 0) && (a->Cout % 32 == 0) &&
-                           ((a->Ho % 8 == 0 && a->Wo % 32 == 0) || (a->Ho % 16 == 0 && a->Wo % 16 == 0)) &&
-                           a->Ho == (a->upsample ? 2 * a->H : a->H) && a->Wo == (a->upsample ? 2 * a->W : a->W) &&
-                           (!a->pro_scale || ((uintptr_t)a->pro_scale % 16 == 0 && (uintptr_t)a->pro_shift % 16 == 0)) &&
-                           (a->in_ld % 4 == 0) && ((uintptr_t)a->in % 16 == 0) && ((uintptr_t)a->weight % 16 == 0) &&
-                           (a->out_ld % 4 == 0) && ((uintptr_t)a->out % 16 == 0) &&
-                           (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&
-                           (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0) &&
-                           (!a->workspace || (uintptr_t)a->workspace % 16 == 0) && !getenv("KEEP_NO_HALO_F32");
-  if (p.in_bf16 && !halo_ok) {
-    // (a bf16-input branch in the gather kernel was measured: +7 % on every 128x128 launch for the extra registers, and the
-    //  GMFlow MLP it was meant for is epilogue-bound, not byte-bound -- bf16 tensors feed the halo path only)
+  // ---- bf16 policy: LDS-halo kernel (persistent v3; v1 when the prologue is fused into its staging step)
+  static const int halo_ver = getenv("KEEP_HALO_VER") ? atoi(getenv("KEEP_HALO_VER")) : 3;
+  const bool halo_geom = mma == KEEP_MMA_BF16 && is33s1 && (a->Cin % 32 == 0) && (a->Cout % 32 == 0) && tileable && same_size &&
+                         (a->in_ld % 8 == 0) && ((uintptr_t)a->in % 16 == 0) && epi_al;
+  if (halo_geom) {
+    const bool v3 = halo_ver == 3 && no_pro;
+    const bool out16_ok = no_pro && !a->residual && a->split_k <= 1 && a->Cout % 64 == 0 && halo_ver == 3;
+    pl.out_bf16_ok = out16_ok ? 1 : 0;
+    // an fp32 input with a prologue: the host should run keep_norm_act_bf16 first and come back with a bf16 tensor
+    pl.wants_bf16_input = (a->dtype == KEEP_F32 && !no_pro && halo_ver == 3 && (a->Cout % 64 == 0 || a->Cout % 32 == 0)) ? 1 : 0;
+    const bool ok = (a->dtype == KEEP_F32 || no_pro) && pro_al && (a->out_dtype != KEEP_BF16 || out16_ok) &&
+                    (a->Cout % 64 == 0 || v3);
+    if (ok) {
+      pl.path = v3 ? PATH_HALO_BF16 : PATH_HALO_BF16_V1;
+      const long waves = (M / 256) * ncb * 4;
+      auto_split = (a->out_dtype == KEEP_BF16 || waves >= kTargetWaves) ? 1
+                   : (int)max(1L, min(min((long)kTargetWaves / waves, (long)a->Cin / 64), 16L));
+      pl.split_k = a->split_k > 0 ? a->split_k : auto_split;
+      if (pl.split_k > a->Cin / 32) pl.split_k = a->Cin / 32;
+      pl.stats_rows = v3 ? 64 : 256;
+      snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo3_kernel<%s, %d>", p.in_bf16 ? "true" : "false", pl.wide ? 32 : 16);
+      return KEEP_OK;
+    }
+  }
+  if (p.in_bf16) {
     keep_set_error("keep_conv2d: bf16 input tensors are only accepted by the 3x3 stride-1 halo path "
                    "(Cin%%32, Cout%%32, tileable map, no prologue)");
     return KEEP_EUNSUP;
   }
-  if (p.stats) {
-    const long hw_o = (long)a->Ho * a->Wo;
-    const int hv = getenv("KEEP_HALO_VER") ? atoi(getenv("KEEP_HALO_VER")) : 3;
-    const bool halo_v2 = halo_f32_ok || (halo_ok && hv != 1 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE);   // per-wave partials
-    const int bm = (halo_ok || halo_f32_ok) ? (halo_v2 ? 64 : 256) : ((a->Cout <= 32) ? 128 : ((a->Cout <= 64 || M <= 4096) ? 64 : 128));
-    KEEP_REQUIRE(hw_o % bm == 0 && a->stats_P == hw_o / bm, "keep_conv2d: stats_P=%d must equal Ho*Wo/%d", a->stats_P, bm);
+  // ---- gather kernels
+  pl.tile = a->Cout <= 32 ? 0 : ((a->Cout <= 64 || M <= 4096) ? 1 : 2);
+  const long blocks = pl.tile == 0 ? (long)cdiv(M, 128) * cdiv(a->Cout, 32)
+                      : (pl.tile == 1 ? (long)cdiv(M, 64) * cdiv(a->Cout, 64) : (long)cdiv(M, 128) * cdiv(a->Cout, 128));
+  const long waves = blocks * 4;
+  pl.stats_rows = pl.tile == 1 ? 64 : 128;
+  if (mma == KEEP_MMA_BF16) {
+    pl.path = PATH_GATHER_BF16;
+    p.flatk = (a->Cin < 8 && no_pro) ? 1 : 0;
+    pl.plain = !p.flatk && p.vec_ok && no_pro && !a->upsample && (a->Cin % 8 == 0) && !getenv("KEEP_NO_PLAIN");
+    int steps = p.flatk ? (a->KH * a->KW * a->Cin + BK16 - 1) / BK16 : a->KH * a->KW * ((a->Cin + BK16 - 1) / BK16);
+    pl.bk256 = a->bk256 && !p.flatk && pl.tile == 1;
+    if (pl.bk256) {
+      steps = a->KH * a->KW * ((a->Cin + 255) / 256);
+      auto_split = (int)max(1L, min(min(512L / max(blocks, 1L), (long)steps / 2), 16L));
+    } else {
+      auto_split = (waves >= kTargetWaves || steps < 8) ? 1 : (int)max(1L, min(min(4L * kTargetWaves / waves, (long)steps / 2), 32L));
+    }
+    if (a->out_dtype == KEEP_BF16) auto_split = 1;
+    pl.out_bf16_ok = (p.vec_epi && !a->residual) ? 1 : 0;
+    pl.split_k = a->split_k > 0 ? a->split_k : auto_split;
+    if (pl.split_k > steps) pl.split_k = steps;
+    const char* t = pl.tile == 0 ? "4, 1, 1, 1" : (pl.tile == 1 ? "2, 2, 1, 1" : "2, 2, 2, 2");
+    snprintf(pl.kernel, sizeof(pl.kernel), "conv_bf16_kernel<%s, %s, %s>", t, pl.bk256 ? "256, 1" : "64, 1",
+             (pl.plain && !pl.bk256 && pl.tile != 0) ? "true" : "false");
+    return KEEP_OK;
   }
-  if (p.out_bf16) {
+  pl.path = PATH_GATHER_F32;
+  p.flatk_f32 = (a->Cin < 8 && a->dtype == KEEP_F32 && no_pro && !getenv("KEEP_NO_FLATK_F32")) ? 1 : 0;
+  if (p.flatk_f32) p.nsteps = (a->KH * a->KW * a->Cin + BK - 1) / BK;
+  pl.plain = p.vec_ok && a->Cin % 16 == 0 && no_pro && !a->upsample && pl.tile != 0 && !getenv("KEEP_NO_PLAIN");
+  auto_split = (waves >= kTargetWaves || p.nsteps < 8) ? 1 : (int)max(1L, min(min((long)kTargetWaves / waves, (long)p.nsteps / 4), 32L));
+  pl.split_k = a->split_k > 0 ? a->split_k : auto_split;
+  if (pl.split_k > p.nsteps) pl.split_k = p.nsteps;
+  snprintf(pl.kernel, sizeof(pl.kernel), "conv_f32_kernel<%s>", pl.tile == 0 ? "4, 1, 1, 1" : (pl.tile == 1 ? "2, 2, 1, 1" : "2, 2, 2, 2"));
+  return KEEP_OK;
+}
+
+extern "C" int32_t keep_conv2d_plan(const keep_conv2d_args* a, keep_conv2d_plan_out* out) {
+  KEEP_REQUIRE(out != nullptr, "keep_conv2d_plan: null output");
+  int rc = validate_conv(a);
+  if (rc != KEEP_OK) return rc;
+  ConvP p;
+  ConvPlan pl;
+  rc = plan_conv(a, p, pl);
+  if (rc != KEEP_OK) return rc;
+  memset(out, 0, sizeof(*out));
+  const long hw_o = (long)a->Ho * a->Wo;
+  out->split_k = pl.split_k;
+  out->workspace_bytes = pl.split_k > 1 ? (int64_t)pl.split_k * a->N * hw_o * a->Cout * 4 : 0;
+  // statistics ride on the epilogue of a single-pass launch whose tiles never straddle two images
+  out->stats_rows = (pl.split_k == 1 && pl.stats_rows > 0 && hw_o % pl.stats_rows == 0 && a->out_ld == a->Cout) ? pl.stats_rows : 0;
+  out->stats_P = out->stats_rows ? (int32_t)(hw_o / out->stats_rows) : 0;
+  out->wants_bf16_input = pl.wants_bf16_input;
+  out->out_bf16_ok = pl.out_bf16_ok;
+  out->path = (int32_t)pl.path;
+  strncpy(out->kernel, pl.kernel, sizeof(out->kernel) - 1);
+  return KEEP_OK;
+}
+
+extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
+  int rc = validate_conv(a);
+  if (rc != KEEP_OK) return rc;
+  KEEP_REQUIRE(a->in && a->weight && a->out, "keep_conv2d: null tensor pointer");
+  KEEP_REQUIRE((uintptr_t)a->weight % 16 == 0, "keep_conv2d: weight pointer must be 16-byte aligned");
+  KEEP_REQUIRE(!a->pro_scale || ((uintptr_t)a->pro_scale % 16 == 0 && (uintptr_t)a->pro_shift % 16 == 0),
+               "keep_conv2d: pro_scale/pro_shift must be 16-byte aligned");
+  ConvP p;
+  ConvPlan pl;
+  rc = plan_conv(a, p, pl);
+  if (rc != KEEP_OK) return rc;
+  p.split_k = pl.split_k;
+  KEEP_REQUIRE(p.split_k == 1 || a->workspace, "keep_conv2d: split_k>1 requires a workspace (keep_conv2d_plan gives its size)");
+  const long M = p.M;
+  const long hw_o = (long)a->Ho * a->Wo;
+  if (p.stats) {
+    KEEP_REQUIRE(p.split_k == 1, "keep_conv2d: stats_out requires split_k == 1");
+    KEEP_REQUIRE(pl.stats_rows > 0 && hw_o % pl.stats_rows == 0 && a->stats_P == hw_o / pl.stats_rows,
+                 "keep_conv2d: stats_P=%d must equal Ho*Wo/%d (keep_conv2d_plan)", a->stats_P, pl.stats_rows);
+  }
+  if (p.out_bf16)
     KEEP_REQUIRE(p.vec_epi && p.split_k == 1 && !a->residual,
                  "keep_conv2d: bf16 output needs Cout/out_ld %% 4 == 0, aligned pointers, split_k == 1, no residual");
-  }
-  if (halo_f32_ok) {
-    const int nchunks = a->Cin / 16;
-    if (p.split_k > nchunks) p.split_k = nchunks;
-    const bool wide = (a->Ho % 8 == 0 && a->Wo % 32 == 0);
-    const int tw = wide ? 32 : 16, th = 256 / tw;
-    const int tiles_x = a->Wo / tw, tiles_y = a->Ho / th, ncb = (a->Cout + 63) / 64;
-    const int n_items = a->N * tiles_x * tiles_y * ncb * p.split_k;
-    static int n_cuf = 0;
-    if (n_cuf == 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cuf = prop.multiProcessorCount;
-      if (n_cuf <= 0) n_cuf = 256;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 block(256);
+  const int tw = pl.wide ? 32 : 16, th = 256 / tw;
+  const int tiles_x = a->Wo / tw, tiles_y = a->Ho / th, ncb = (a->Cout + 63) / 64;
+  const int n_cu = n_cu_cached();
+  switch (pl.path) {
+    case PATH_COUT4: {
+      dim3 grid((a->Ho / SC_TH) * (a->Wo / SC_TW), a->N);
+      hipLaunchKernelGGL(conv3x3_cout4_kernel, grid, block, 0, st, p);
+      KEEP_LAUNCH_CHECK("keep_conv2d(cout<=4)");
+      return KEEP_OK;
     }
-    dim3 gridf(n_items < 2 * n_cuf ? n_items : 2 * n_cuf);
+    case PATH_C3: {
+      const int tx = a->Wo / 32, ty = a->Ho / 8;
+      const int n_items = a->N * tx * ty * ncb;
+      hipLaunchKernelGGL(conv3x3_c3_kernel, dim3(n_items < 2 * n_cu ? n_items : 2 * n_cu), block, 0, st, p, tx, ty, ncb, n_items);
+      KEEP_LAUNCH_CHECK("keep_conv2d(Cin<=3)");
+      return KEEP_OK;
+    }
+    case PATH_HALO_X3:
+      rc = keep_conv2d_x3_halo(a, p, st);
+      if (rc != KEEP_OK) return rc;
+      break;
+    case PATH_GATHER_X3:
+      rc = keep_conv2d_x3_gather(a, p, st);
+      if (rc != KEEP_OK) return rc;
+      break;
+    case PATH_HALO_F32: {
+      const int n_items = a->N * tiles_x * tiles_y * ncb * p.split_k;
+      dim3 gridf(n_items < 2 * n_cu ? n_items : 2 * n_cu);
 #define KEEP_LAUNCH_HF(TWV)                                                                                                  \
   if (a->pro_act == KEEP_PRO_SWISH)                                                                                          \
     hipLaunchKernelGGL((conv3x3_halo_f32_kernel<TWV, KEEP_PRO_SWISH>), gridf, block, 0, st, p, tiles_x, tiles_y, ncb, n_items); \
@@ -2056,122 +1967,93 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
     hipLaunchKernelGGL((conv3x3_halo_f32_kernel<TWV, KEEP_PRO_RELU>), gridf, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);  \
   else                                                                                                                       \
     hipLaunchKernelGGL((conv3x3_halo_f32_kernel<TWV, KEEP_PRO_NONE>), gridf, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);
-    if (wide) {
-      KEEP_LAUNCH_HF(32)
-    } else {
-      KEEP_LAUNCH_HF(16)
-    }
-#undef KEEP_LAUNCH_HF
-    KEEP_LAUNCH_CHECK("keep_conv2d(halo f32)");
-    if (p.split_k > 1) {
-      const long total = M * a->Cout;
-      int blocks = cdiv(total, 256);
-      if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
-      KEEP_LAUNCH_CHECK("keep_conv2d(split-K reduce)");
-    }
-    return KEEP_OK;
-  }
-  if (halo_ok) {
-    const int nchunks = a->Cin / 32;
-    if (p.split_k > nchunks) p.split_k = nchunks;
-    const bool wide = (a->Ho % 8 == 0 && a->Wo % 32 == 0);
-    const int tw = wide ? 32 : 16, th = 256 / tw;
-    const int tiles_x = a->Wo / tw, tiles_y = a->Ho / th, ncb = (a->Cout + 63) / 64;
-    static const int halo_ver = getenv("KEEP_HALO_VER") ? atoi(getenv("KEEP_HALO_VER")) : 3;
-    KEEP_REQUIRE(a->Cout % 64 == 0 || (halo_ver == 3 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE),
-                 "keep_conv2d: Cout %% 64 != 0 on the halo path needs the persistent kernel (no prologue)");
-    if (halo_ver == 3 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE) {
-      const int n_items = a->N * tiles_x * tiles_y * ncb * p.split_k;
-      static int n_cu3 = 0;
-      if (n_cu3 == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu3 = prop.multiProcessorCount;
-        if (n_cu3 <= 0) n_cu3 = 256;
+      if (pl.wide) {
+        KEEP_LAUNCH_HF(32)
+      } else {
+        KEEP_LAUNCH_HF(16)
       }
-      const int nblk = n_items < 2 * n_cu3 ? n_items : 2 * n_cu3;
-      dim3 grid3(nblk);
+#undef KEEP_LAUNCH_HF
+      KEEP_LAUNCH_CHECK("keep_conv2d(halo f32)");
+      break;
+    }
+    case PATH_HALO_BF16: {
+      const int n_items = a->N * tiles_x * tiles_y * ncb * p.split_k;
+      dim3 grid3(n_items < 2 * n_cu ? n_items : 2 * n_cu);
       const bool simple = p.split_k == 1 && !a->aux && a->epi_act == KEEP_ACT_NONE;
 #define KEEP_LAUNCH_H3(INB, TWV)                                                                                          \
   if (simple)                                                                                                             \
     hipLaunchKernelGGL((conv3x3_halo3_kernel<INB, TWV, true>), grid3, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);   \
   else                                                                                                                    \
     hipLaunchKernelGGL((conv3x3_halo3_kernel<INB, TWV, false>), grid3, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);
-      if (p.in_bf16 && wide) {
+      if (p.in_bf16 && pl.wide) {
         KEEP_LAUNCH_H3(true, 32)
       } else if (p.in_bf16) {
         KEEP_LAUNCH_H3(true, 16)
-      } else if (wide) {
+      } else if (pl.wide) {
         KEEP_LAUNCH_H3(false, 32)
       } else {
         KEEP_LAUNCH_H3(false, 16)
       }
 #undef KEEP_LAUNCH_H3
       KEEP_LAUNCH_CHECK("keep_conv2d(halo v3)");
-      if (p.split_k > 1) {
-        const long total = M * a->Cout;
-        int blocks = cdiv(total, 256);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
-        KEEP_LAUNCH_CHECK("keep_conv2d(split-K reduce)");
-      }
-      return KEEP_OK;
+      break;
     }
-    dim3 grid(a->N * tiles_x * tiles_y * ncb, 1, p.split_k);
-    if (p.in_bf16 && wide)
-      hipLaunchKernelGGL((conv3x3_halo_kernel<true, 32>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
-    else if (p.in_bf16)
-      hipLaunchKernelGGL((conv3x3_halo_kernel<true, 16>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
-    else if (wide)
-      hipLaunchKernelGGL((conv3x3_halo_kernel<false, 32>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
-    else
-      hipLaunchKernelGGL((conv3x3_halo_kernel<false, 16>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
-  } else if (a->mma == KEEP_MMA_BF16) {
-    const bool plain = !p.flatk && p.vec_ok && !a->pro_scale && a->pro_act == KEEP_PRO_NONE && !a->upsample && (a->Cin % 8 == 0) &&
-                       !getenv("KEEP_NO_PLAIN");
-    const int steps16 = p.flatk ? (a->KH * a->KW * a->Cin + BK16 - 1) / BK16 : a->KH * a->KW * ((a->Cin + BK16 - 1) / BK16);
-    if (p.split_k > steps16) p.split_k = steps16;
-    if (a->Cout <= 32) {
-      dim3 grid(cdiv(M, 128), cdiv(a->Cout, 32), p.split_k);
-      hipLaunchKernelGGL((conv_bf16_kernel<4, 1, 1, 1, 64, 1>), grid, block, 0, st, p);
-    } else if (a->Cout <= 64 || M <= 4096) {
-      if (a->bk256 && !p.flatk) {
-        const int steps256 = a->KH * a->KW * ((a->Cin + 255) / 256);
-        if (p.split_k > steps256) p.split_k = steps256;
+    case PATH_HALO_BF16_V1: {
+      dim3 grid(a->N * tiles_x * tiles_y * ncb, 1, p.split_k);
+      if (p.in_bf16 && pl.wide)
+        hipLaunchKernelGGL((conv3x3_halo_kernel<true, 32>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
+      else if (p.in_bf16)
+        hipLaunchKernelGGL((conv3x3_halo_kernel<true, 16>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
+      else if (pl.wide)
+        hipLaunchKernelGGL((conv3x3_halo_kernel<false, 32>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
+      else
+        hipLaunchKernelGGL((conv3x3_halo_kernel<false, 16>), grid, block, 0, st, p, tiles_x, tiles_y, ncb);
+      KEEP_LAUNCH_CHECK("keep_conv2d(halo v1)");
+      break;
+    }
+    case PATH_GATHER_BF16: {
+      if (pl.tile == 0) {
+        dim3 grid(cdiv(M, 128), cdiv(a->Cout, 32), p.split_k);
+        hipLaunchKernelGGL((conv_bf16_kernel<4, 1, 1, 1, 64, 1>), grid, block, 0, st, p);
+      } else if (pl.tile == 1) {
         dim3 grid(cdiv(M, 64), cdiv(a->Cout, 64), p.split_k);
-        hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 1, 1, 256, 1>), grid, block, 0, st, p);
-      } else {
-        dim3 grid(cdiv(M, 64), cdiv(a->Cout, 64), p.split_k);
-        if (plain)
+        if (pl.bk256)
+          hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 1, 1, 256, 1>), grid, block, 0, st, p);
+        else if (pl.plain)
           hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 1, 1, 64, 1, true>), grid, block, 0, st, p);
         else
           hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 1, 1, 64, 1>), grid, block, 0, st, p);
+      } else {
+        dim3 grid(cdiv(M, 128), cdiv(a->Cout, 128), p.split_k);
+        if (pl.plain)
+          hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 2, 2, 64, 1, true>), grid, block, 0, st, p);
+        else
+          hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 2, 2, 64, 1>), grid, block, 0, st, p);
       }
-    } else {
-      dim3 grid(cdiv(M, 128), cdiv(a->Cout, 128), p.split_k);
-      if (plain)
-        hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 2, 2, 64, 1, true>), grid, block, 0, st, p);
-      else
-        hipLaunchKernelGGL((conv_bf16_kernel<2, 2, 2, 2, 64, 1>), grid, block, 0, st, p);
+      KEEP_LAUNCH_CHECK("keep_conv2d(gather bf16)");
+      break;
     }
-  } else if (a->Cout <= 32) {
-    dim3 grid(cdiv(M, 128), cdiv(a->Cout, 32), p.split_k);
-    hipLaunchKernelGGL((conv_f32_kernel<4, 1, 1, 1>), grid, block, 0, st, p);
-  } else if (a->Cout <= 64 || M <= 4096) {
-    dim3 grid(cdiv(M, 64), cdiv(a->Cout, 64), p.split_k);
-    if (plain_f32)
-      hipLaunchKernelGGL((conv_f32_kernel<2, 2, 1, 1, true>), grid, block, 0, st, p);
-    else
-      hipLaunchKernelGGL((conv_f32_kernel<2, 2, 1, 1>), grid, block, 0, st, p);
-  } else {
-    dim3 grid(cdiv(M, 128), cdiv(a->Cout, 128), p.split_k);
-    if (plain_f32)
-      hipLaunchKernelGGL((conv_f32_kernel<2, 2, 2, 2, true>), grid, block, 0, st, p);
-    else
-      hipLaunchKernelGGL((conv_f32_kernel<2, 2, 2, 2>), grid, block, 0, st, p);
+    case PATH_GATHER_F32: {
+      if (pl.tile == 0) {
+        dim3 grid(cdiv(M, 128), cdiv(a->Cout, 32), p.split_k);
+        hipLaunchKernelGGL((conv_f32_kernel<4, 1, 1, 1>), grid, block, 0, st, p);
+      } else if (pl.tile == 1) {
+        dim3 grid(cdiv(M, 64), cdiv(a->Cout, 64), p.split_k);
+        if (pl.plain)
+          hipLaunchKernelGGL((conv_f32_kernel<2, 2, 1, 1, true>), grid, block, 0, st, p);
+        else
+          hipLaunchKernelGGL((conv_f32_kernel<2, 2, 1, 1>), grid, block, 0, st, p);
+      } else {
+        dim3 grid(cdiv(M, 128), cdiv(a->Cout, 128), p.split_k);
+        if (pl.plain)
+          hipLaunchKernelGGL((conv_f32_kernel<2, 2, 2, 2, true>), grid, block, 0, st, p);
+        else
+          hipLaunchKernelGGL((conv_f32_kernel<2, 2, 2, 2>), grid, block, 0, st, p);
+      }
+      KEEP_LAUNCH_CHECK("keep_conv2d(gather f32)");
+      break;
+    }
   }
-  KEEP_LAUNCH_CHECK("keep_conv2d");
   if (p.split_k > 1) {
     const long total = M * a->Cout;
     int blocks = cdiv(total, 256);

@@ -1,0 +1,575 @@
+// keep_conv2d, KEEP_MMA_X3: the parity-grade fast policy -- split-operand fp16 on the 2.5 PFLOP/s matrix pipe.
+//
+// gfx950 has no TF32-like mode: exact-f32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the 16-bit rate (157 TF).  Here every
+// fp32 operand x is written as x = hi + lo with hi = fp16(x), lo = fp16(x - hi) (both RNE; x - hi is exact in fp32), and a
+// product a*b is evaluated as  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  with three v_mfma_f32_32x32x16_f16 into ONE fp32
+// accumulator (fp16 x fp16 products are exact in fp32; accumulation is the matrix pipe's fp32).  hi carries 11 significand
+// bits, lo the next 11: the representation error is <= 2^-22 |x| (or 2^-25 absolute once lo is subnormal, |x| < 2^-3), the
+// dropped a_lo*b_lo term is <= 2^-22 |a b| -- fp32-grade products at 3 MFMAs instead of 16: ceiling 2.5 PF / 3 = 833 TF.
+// (bf16 halves would keep fp32's exponent range but only 8+8 bits: 2^-16 per product, 60x worse than this.)
+//   Range: fp16 tops out at 65504.  Weights are pre-multiplied by a power of two 2^e on the host (exact) so that the
+//   largest one sits just below 2^15 and the small ones keep a normal `lo`; the accumulators are multiplied by 2^-e
+//   (`acc_scale`, exact) before bias / activation.  Activations are split as they are (post-GroupNorm values are O(1));
+//   an activation beyond 65504 becomes inf and propagates to the output, which the host checks (engine/net.py) and
+//   re-runs on the exact-f32 kernels -- never silently wrong.
+//   MFMA f16 on gfx950 keeps subnormal inputs (tests/test_gpu_kernels.py::test_x3_subnormal_lo pins that).
+// Weight layout (host-packed, engine/weights.py:split_x3): [Cout][KH*KW][Cin/16][hi x16 | lo x16] fp16 -- the 64 bytes a
+// (cout, tap, 16-channel chunk) row needs are contiguous, 4 bytes per weight like the fp32 blob.
+#include <stdlib.h>
+
+#include "keep_conv_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split4(const float (&v)[4], f16x4& hi, f16x4& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const _Float16 h = (_Float16)v[j];
+    hi[j] = h;
+    lo[j] = (_Float16)(v[j] - (float)h);
+  }
+}
+
+#define MMA_X3(ACC, AH, AL, BH, BL)                                              \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, BH, ACC, 0, 0, 0);            \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL, ACC, 0, 0, 0);            \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, ACC, 0, 0, 0);
+
+// ------------------------------------------------------------------------------------------------ 3x3 halo, split fp16
+// The persistent LDS-halo kernel (keep_conv.hip: conv3x3_halo3_kernel / conv3x3_halo_f32_kernel) with split operands:
+// a block walks (8x32 | 16x16 pixel tile) x 64-cout work items; per 16-channel chunk it stages the (8+2)x(32+2) fp32 halo ONCE --
+// GroupNorm affine + exact swish applied, then split -- as rows [hi x16 | lo x16 | pad] at an 80-byte pitch (ds_read_b128
+// conflict-free), plus the 9 x 64 weight rows in the same format, and all 9 taps read them from LDS:
+//   per tap and wave: 4 A + 4 B fragment reads (hi, lo of 2 pixel blocks / 2 cout blocks) feed 12 MFMAs -- 0.67 LDS reads
+//   per MFMA against 1.0 in the plain bf16 kernel -- and a chunk costs the same 64 B per pixel of global traffic as a
+//   32-channel bf16 chunk but 1.5x the matrix time: the x3 kernel is further from the L2->CU and LDS limits than the
+//   bf16 kernel by construction.  73 KB of LDS -> 2 blocks per CU: one block's staging VALU (24 swish + split per thread
+//   and chunk) overlaps the other's 108 MFMAs per wave.
+#define XPITCH 40   // fp16 elements per LDS row: 16 hi + 16 lo + 8 pad (80 B)
+
+template <int TW, int PRO, bool SIMPLE_EPI>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int tiles_x, int tiles_y, int ncb, int n_items) {
+  constexpr int HALO_TH = 256 / TW, HALO_W = TW + 2, HALO_PIX = (HALO_TH + 2) * HALO_W;
+  constexpr int RPT = 32 / TW;
+  constexpr int MAIN_B = (HALO_MAXPIX + 9 * 64) * XPITCH * 2;
+  constexpr int EPI_B = 4 * 64 * 68 * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[MAIN_B > EPI_B ? MAIN_B : EPI_B];
+  _Float16* Hs = reinterpret_cast<_Float16*>(lds_raw);
+  _Float16* Ws = Hs + HALO_MAXPIX * XPITCH;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int items_per_z = n_items / p.split_k;
+  const int Hv = p.upsample ? 2 * p.H : p.H;
+  const int Wv = p.upsample ? 2 * p.W : p.W;
+  const int g = tid & 3;
+  const bool has_pro = p.pro_scale != nullptr || PRO != KEEP_PRO_NONE;
+
+  int h_off[HALO_IT];
+  long img_off = 0, w_base = 0, sc_off = 0;
+  bool w_ok = true;
+  auto setup = [&](const HaloItem& it) {
+#pragma unroll
+    for (int k = 0; k < HALO_IT; ++k) {
+      const int hp = (tid >> 2) + k * 64;
+      h_off[k] = -1;
+      if (hp < HALO_PIX) {
+        const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+        const int iy = it.oy0 - 1 + hy, ix = it.ox0 - 1 + hx;
+        if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
+          const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+          h_off[k] = (sy * p.W + sx) * p.in_ld + g * 4;
+        }
+      }
+    }
+    img_off = (long)it.n * p.H * p.W * p.in_ld;
+    sc_off = (long)it.n * p.Cin + g * 4;
+    w_ok = (it.n0 + (tid >> 2)) < p.Cout;
+    w_base = w_ok ? ((long)(it.n0 + (tid >> 2)) * 9) * p.Cin * 2 + g * 8 : 0;   // fp16 elements; + (tap*Cin + c0)*2
+  };
+
+  float4 hreg[HALO_IT];
+  uint4 wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7, wr8;
+  float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch = [&](int ch) {
+    const int c0 = ch << 4;
+#pragma unroll
+    for (int k = 0; k < HALO_IT; ++k) {
+      hreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (h_off[k] >= 0) hreg[k] = *reinterpret_cast<const float4*>(p.in + img_off + h_off[k] + c0);
+    }
+#define KEEP_WLOADX(TAP, R) R = w_ok ? *reinterpret_cast<const uint4*>(p.wx3 + w_base + ((long)(TAP) * p.Cin + c0) * 2) : make_uint4(0u, 0u, 0u, 0u);
+    KEEP_TAPS(KEEP_WLOADX)
+#undef KEEP_WLOADX
+    if (p.pro_scale) {
+      sc4 = *reinterpret_cast<const float4*>(p.pro_scale + sc_off + c0);
+      sh4 = *reinterpret_cast<const float4*>(p.pro_shift + sc_off + c0);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int k = 0; k < HALO_IT; ++k) {
+      const int hp = (tid >> 2) + k * 64;
+      if (hp < HALO_PIX) {
+        float v[4] = {hreg[k].x, hreg[k].y, hreg[k].z, hreg[k].w};
+        if (has_pro && h_off[k] >= 0) {      // zero padding applies to the normalised + activated tensor
+          v[0] = pro_apply(v[0] * sc4.x + sh4.x, PRO);
+          v[1] = pro_apply(v[1] * sc4.y + sh4.y, PRO);
+          v[2] = pro_apply(v[2] * sc4.z + sh4.z, PRO);
+          v[3] = pro_apply(v[3] * sc4.w + sh4.w, PRO);
+        }
+        f16x4 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<f16x4*>(&Hs[hp * XPITCH + g * 4]) = hi;
+        *reinterpret_cast<f16x4*>(&Hs[hp * XPITCH + 16 + g * 4]) = lo;
+      }
+    }
+#define KEEP_WSTOREX(TAP, R) *reinterpret_cast<uint4*>(&Ws[((TAP) * 64 + (tid >> 2)) * XPITCH + g * 8]) = R;
+    KEEP_TAPS(KEEP_WSTOREX)
+#undef KEEP_WSTOREX
+  };
+
+  f32x16 acc[2][2];
+  const int a_base = (((2 * wave) * RPT + l31 / TW) * HALO_W + (l31 % TW)) * XPITCH + lhi * 8;
+  const int b_base = l31 * XPITCH + lhi * 8;
+  auto mma = [&]() {
+#pragma unroll 1
+    for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const _Float16* src = &Hs[a_base + ((i * RPT + kh) * HALO_W + kw) * XPITCH];
+          ah[i] = *reinterpret_cast<const f16x8*>(src);
+          al[i] = *reinterpret_cast<const f16x8*>(src + 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const _Float16* src = &Ws[b_base + ((kh * 3 + kw) * 64 + j * 32) * XPITCH];
+          bh[j] = *reinterpret_cast<const f16x8*>(src);
+          bl[j] = *reinterpret_cast<const f16x8*>(src + 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            MMA_X3(acc[i][j], ah[i], al[i], bh[j], bl[j])
+          }
+      }
+    }
+  };
+  auto epilogue_t = [&](const HaloItem& it, auto res_c) {
+    constexpr bool HAS_RES = decltype(res_c)::value;
+    constexpr int EP = 68;
+    float* et = reinterpret_cast<float*>(lds_raw) + wave * 64 * EP;
+    const float asc = p.acc_scale;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          et[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * EP + j * 32 + l31] = acc[i][j][r] * asc;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const int c4 = (lane & 15) * 4, prow = lane >> 4;
+    const int co = it.n0 + c4;
+    const bool cok = co < p.Cout;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
+    constexpr int UNR = HAS_RES ? 16 : 8;
+#pragma unroll UNR
+    for (int q16 = 0; q16 < 16; ++q16) {
+      if (!cok) break;
+      const int px = q16 * 4 + prow;
+      const int oy = it.oy0 + (2 * wave + (px >> 5)) * RPT + (px & 31) / TW;
+      const long m = ((long)it.n * p.Ho + oy) * p.Wo + it.ox0 + (px & 31) % TW;
+      const float4 v = *reinterpret_cast<const float4*>(et + px * EP + c4);
+      if (!SIMPLE_EPI && p.split_k > 1) {
+        *reinterpret_cast<float4*>(p.ws + ((long)it.z * p.M + m) * p.Cout + co) = v;
+        continue;
+      }
+      float e[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
+      if (!SIMPLE_EPI) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = act_apply(e[q], p.epi_act);
+      }
+      if (HAS_RES) {
+        const float4 r4 = *reinterpret_cast<const float4*>(p.res + m * p.res_ld + co);
+        const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+        if (!SIMPLE_EPI && p.aux) {
+          const float4 a4 = *reinterpret_cast<const float4*>(p.aux + m * (long)p.Cout + co);
+          const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) e[q] = rr[q] + p.aux_w * (rr[q] * aa[q] + e[q]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) e[q] += rr[q];
+        }
+      }
+      *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s4[q] += e[q];
+        ss4[q] += e[q] * e[q];
+      }
+    }
+    if (p.stats) {          // per wave: stats_P = 4 * tiles, partial index = tile*4 + wave
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s4[q] += __shfl_xor(s4[q], 16);
+        s4[q] += __shfl_xor(s4[q], 32);
+        ss4[q] += __shfl_xor(ss4[q], 16);
+        ss4[q] += __shfl_xor(ss4[q], 32);
+      }
+      if (lane < 16 && cok) {
+        float* dst = p.stats + (((long)it.n * p.stats_P + (it.ty * tiles_x + it.tx) * 4 + wave) * p.Cout + co) * 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          dst[q * 2 + 0] = s4[q];
+          dst[q * 2 + 1] = ss4[q];
+        }
+      }
+    }
+  };
+
+  int item = blockIdx.x;
+  if (item >= n_items) return;
+  HaloItem cur = halo_decode<TW, 4>(p, item, items_per_z, tiles_x, tiles_y, ncb);
+  setup(cur);
+  if (cur.ch_begin < cur.ch_end) fetch(cur.ch_begin);
+  while (true) {
+    const bool valid = cur.ch_begin < cur.ch_end;
+    if (valid) stage();
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int ch = cur.ch_begin; ch < cur.ch_end; ++ch) {
+      const bool more = ch + 1 < cur.ch_end;
+      if (more) fetch(ch + 1);
+      mma();
+      __syncthreads();
+      if (more) {
+        stage();
+        __syncthreads();
+      }
+    }
+    const int next_item = item + gridDim.x;
+    const bool has_next = next_item < n_items;
+    HaloItem nxt = cur;
+    if (has_next) {
+      nxt = halo_decode<TW, 4>(p, next_item, items_per_z, tiles_x, tiles_y, ncb);
+      setup(nxt);
+      if (nxt.ch_begin < nxt.ch_end) fetch(nxt.ch_begin);     // in flight during the epilogue below
+    }
+    if (p.res)
+      epilogue_t(cur, std::true_type{});
+    else
+      epilogue_t(cur, std::false_type{});
+    if (!has_next) break;
+    __syncthreads();
+    item = next_item;
+    cur = nxt;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ gather GEMM, split fp16
+// Everything that is not a 3x3 stride-1 convolution on a tileable map: token GEMMs, 1x1 convs, stride-2 convs.  Implicit
+// GEMM like conv_bf16_kernel: K step = 32 channels of one tap; LDS rows [hi x32 | lo x32 | pad x8] at a 144-byte pitch (9 slots:
+// ds_read_b128 conflict-free); two LDS buffers, the next step's operands in registers while the current one multiplies.
+// A is split while staging (fp32 activations, optional GroupNorm affine + activation first); B comes pre-split.
+#define XBK 32
+#define XP (2 * XBK + 8)
+
+template <int WGM, int WGN, int TM, int TN, bool PLAIN>
+__global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
+  constexpr int BM = WGM * TM * 32;
+  constexpr int BN = WGN * TN * 32;
+  constexpr int A_IT = BM / 64;             // (row, 8-channel group) pieces per thread: 4 groups per row
+  constexpr int B_IT = BN / 32;             // (row, 16-byte piece) per thread: 8 pieces per row
+  static_assert(WGM * WGN == 4 && A_IT >= 1 && B_IT >= 1, "tile config");
+  constexpr int MAIN_B = 2 * (BM + BN) * XP * 2;
+  constexpr int EPI_B = 4 * (TM * 32) * (TN * 32 + 4) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_b[MAIN_B > EPI_B ? MAIN_B : EPI_B];
+  _Float16(*As)[BM * XP] = reinterpret_cast<_Float16(*)[BM * XP]>(smem_b);
+  _Float16(*Bs)[BN * XP] = reinterpret_cast<_Float16(*)[BN * XP]>(smem_b + 2 * BM * XP * 2);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN;
+  const int wn = wave % WGN;
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int z = blockIdx.z;
+  const int cchunks = (p.Cin + XBK - 1) / XBK;
+  const int nsteps = p.KH * p.KW * cchunks;
+  const int per = (nsteps + p.split_k - 1) / p.split_k;
+  const int s_begin = z * per;
+  const int s_end = min(nsteps, s_begin + per);
+
+  const int a_grp = tid & 3, a_row0 = tid >> 2;          // + it*64
+  const int b_pc = tid & 7, b_row0 = tid >> 3;           // + it*32
+  const int hw = p.Ho * p.Wo;
+  int a_n[A_IT], a_oy[A_IT], a_ox[A_IT];
+  bool a_mv[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const long m = m0 + a_row0 + it * 64;
+    a_mv[it] = m < p.M;
+    a_n[it] = 0; a_oy[it] = 0; a_ox[it] = 0;
+    if (a_mv[it]) {
+      a_n[it] = (int)(m / hw);
+      const int r = (int)(m - (long)a_n[it] * hw);
+      a_oy[it] = r / p.Wo;
+      a_ox[it] = r - a_oy[it] * p.Wo;
+    }
+  }
+  const long wrow_stride = (long)p.KH * p.KW * p.Cin * 2;     // fp16 elements per cout row
+  // b piece -> LDS column: 16-channel chunk c = b_pc >> 2, part = b_pc & 3 (0,1: hi ch 0-7 / 8-15; 2,3: lo)
+  const int b_col = ((b_pc & 3) >> 1) * XBK + (b_pc >> 2) * 16 + (b_pc & 1) * 8;
+
+  float a_raw[A_IT][8];
+  bool a_ok[A_IT];
+  uint4 b_raw[B_IT];
+  int a_c = 0;
+  const long m_last = (m0 + BM - 1 < p.M) ? (m0 + BM - 1) : (long)p.M - 1;
+  const bool uni_n = !PLAIN && p.pro_scale && ((m0 / hw) == (m_last / hw));
+  const long uni_off = (m0 / hw) * (long)p.Cin;
+  float u_sc[8], u_sh[8];
+
+  auto fetch = [&](int s) {
+    const int tap = s / cchunks;
+    const int c0 = (s - tap * cchunks) * XBK;
+    const int kh = tap / p.KW;
+    const int kw = tap - kh * p.KW;
+    const int ca = c0 + a_grp * 8;
+    a_c = ca;
+    if (uni_n && ca < p.Cin) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        u_sc[j] = p.pro_scale[uni_off + ca + j];
+        u_sh[j] = p.pro_shift[uni_off + ca + j];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int iy = a_oy[it] * p.stride - p.pad_t + kh;
+      const int ix = a_ox[it] * p.stride - p.pad_l + kw;
+      a_ok[it] = a_mv[it] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ca < p.Cin;
+      if (a_ok[it]) {
+        const float* src = p.in + (((long)a_n[it] * p.H + iy) * p.W + ix) * p.in_ld + ca;
+        const float4 v0 = *reinterpret_cast<const float4*>(src);
+        const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+        a_raw[it][0] = v0.x; a_raw[it][1] = v0.y; a_raw[it][2] = v0.z; a_raw[it][3] = v0.w;
+        a_raw[it][4] = v1.x; a_raw[it][5] = v1.y; a_raw[it][6] = v1.z; a_raw[it][7] = v1.w;
+      }
+    }
+    const bool cb_ok = c0 + (b_pc >> 2) * 16 < p.Cin;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int co = n0 + b_row0 + it * 32;
+      b_raw[it] = make_uint4(0u, 0u, 0u, 0u);
+      if (co < p.Cout && cb_ok)
+        b_raw[it] = *reinterpret_cast<const uint4*>(p.wx3 + (long)co * wrow_stride + ((long)tap * p.Cin + c0) * 2 + b_pc * 8);
+    }
+  };
+
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      f16x8 hi, lo;
+      if (a_ok[it]) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = a_raw[it][j];
+        if (!PLAIN) {
+          if (uni_n) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * u_sc[j] + u_sh[j];
+          } else if (p.pro_scale) {
+            const float* sc = p.pro_scale + (long)a_n[it] * p.Cin + a_c;
+            const float* sh = p.pro_shift + (long)a_n[it] * p.Cin + a_c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+          }
+          if (p.pro_act != KEEP_PRO_NONE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = pro_apply(v[j], p.pro_act);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const _Float16 h = (_Float16)v[j];
+          hi[j] = h;
+          lo[j] = (_Float16)(v[j] - (float)h);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)0.f; lo[j] = (_Float16)0.f; }
+      }
+      _Float16* dst = &As[buf][(a_row0 + it * 64) * XP + a_grp * 8];
+      *reinterpret_cast<f16x8*>(dst) = hi;
+      *reinterpret_cast<f16x8*>(dst + XBK) = lo;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+      *reinterpret_cast<uint4*>(&Bs[buf][(b_row0 + it * 32) * XP + b_col]) = b_raw[it];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31;
+  const int lhi = lane >> 5;
+  const int a_f0 = (wm * TM * 32 + l31) * XP + lhi * 8;
+  const int b_f0 = (wn * TN * 32 + l31) * XP + lhi * 8;
+
+  auto mma_step = [&](int buf) {
+    const _Float16* Ab = As[buf];
+    const _Float16* Bb = Bs[buf];
+#pragma unroll
+    for (int ks = 0; ks < XBK / 16; ++ks) {
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(Ab + a_f0 + i * 32 * XP + ks * 16);
+        al[i] = *reinterpret_cast<const f16x8*>(Ab + a_f0 + i * 32 * XP + ks * 16 + XBK);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const f16x8*>(Bb + b_f0 + j * 32 * XP + ks * 16);
+        bl[j] = *reinterpret_cast<const f16x8*>(Bb + b_f0 + j * 32 * XP + ks * 16 + XBK);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          MMA_X3(acc[i][j], ah[i], al[i], bh[j], bl[j])
+        }
+    }
+  };
+
+  if (s_begin < s_end) {
+    fetch(s_begin);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+      const bool more = (s + 1 < s_end);
+      if (more) fetch(s + 1);
+      mma_step(buf);
+      if (more) stage(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  const float asc = p.acc_scale;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] *= asc;
+  staged_epilogue<WGM, WGN, TM, TN>(p, acc, reinterpret_cast<float*>(smem_b), m0, n0, wm, wn, lane, wave, z);
+}
+
+// ------------------------------------------------------------------------------------------------ dispatch
+static int x3_num_cu() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  return n_cu;
+}
+
+// Geometry the x3 kernels accept (everything else of a KEEP_MMA_X3 call runs on the exact-f32 kernels: same parity grade).
+bool keep_conv_x3_halo_ok(const keep_conv2d_args* a) {
+  return a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 &&
+         a->pad_l == 1 && (a->Cin % 16 == 0) && (a->Cout % 32 == 0) &&
+         ((a->Ho % 8 == 0 && a->Wo % 32 == 0) || (a->Ho % 16 == 0 && a->Wo % 16 == 0)) &&
+         a->Ho == (a->upsample ? 2 * a->H : a->H) && a->Wo == (a->upsample ? 2 * a->W : a->W) &&
+         (!a->pro_scale || ((uintptr_t)a->pro_scale % 16 == 0 && (uintptr_t)a->pro_shift % 16 == 0)) &&
+         (a->in_ld % 4 == 0) && ((uintptr_t)a->in % 16 == 0) && (a->out_ld % 4 == 0) && ((uintptr_t)a->out % 16 == 0) &&
+         (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&
+         (!a->aux || (uintptr_t)a->aux % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0) &&
+         (!a->workspace || (uintptr_t)a->workspace % 16 == 0);
+}
+
+bool keep_conv_x3_gather_ok(const keep_conv2d_args* a, const ConvP& p) {
+  return a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && !a->upsample && (a->Cin % 16 == 0) && (a->in_ld % 4 == 0) &&
+         ((uintptr_t)a->in % 16 == 0) && p.vec_epi;
+}
+
+int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
+  const int nchunks = a->Cin / 16;
+  if (p.split_k > nchunks) p.split_k = nchunks;
+  const bool wide = (a->Ho % 8 == 0 && a->Wo % 32 == 0);
+  const int tw = wide ? 32 : 16, th = 256 / tw;
+  const int tiles_x = a->Wo / tw, tiles_y = a->Ho / th, ncb = (a->Cout + 63) / 64;
+  const int n_items = a->N * tiles_x * tiles_y * ncb * p.split_k;
+  const int n_cu = x3_num_cu();
+  dim3 grid(n_items < 2 * n_cu ? n_items : 2 * n_cu), block(256);
+  const bool simple = p.split_k == 1 && !a->aux && a->epi_act == KEEP_ACT_NONE;
+#define KEEP_LAUNCH_HX2(TWV, PROV)                                                                                          \
+  if (simple)                                                                                                              \
+    hipLaunchKernelGGL((conv3x3_halo_x3_kernel<TWV, PROV, true>), grid, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);  \
+  else                                                                                                                     \
+    hipLaunchKernelGGL((conv3x3_halo_x3_kernel<TWV, PROV, false>), grid, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);
+#define KEEP_LAUNCH_HX(TWV)                                       \
+  if (a->pro_act == KEEP_PRO_SWISH) {                             \
+    KEEP_LAUNCH_HX2(TWV, KEEP_PRO_SWISH)                          \
+  } else if (a->pro_act == KEEP_PRO_RELU) {                       \
+    KEEP_LAUNCH_HX2(TWV, KEEP_PRO_RELU)                           \
+  } else {                                                        \
+    KEEP_LAUNCH_HX2(TWV, KEEP_PRO_NONE)                           \
+  }
+  if (wide) {
+    KEEP_LAUNCH_HX(32)
+  } else {
+    KEEP_LAUNCH_HX(16)
+  }
+#undef KEEP_LAUNCH_HX
+#undef KEEP_LAUNCH_HX2
+  KEEP_LAUNCH_CHECK("keep_conv2d(halo x3)");
+  return KEEP_OK;
+}
+
+int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
+  const long M = p.M;
+  const int steps = a->KH * a->KW * ((a->Cin + XBK - 1) / XBK);
+  if (p.split_k > steps) p.split_k = steps;
+  const bool plain = !a->pro_scale && a->pro_act == KEEP_PRO_NONE;
+  dim3 block(256);
+  if (a->Cout <= 64 || M <= 4096) {
+    dim3 grid(cdiv(M, 64), cdiv(a->Cout, 64), p.split_k);
+    if (plain)
+      hipLaunchKernelGGL((conv_x3_kernel<2, 2, 1, 1, true>), grid, block, 0, st, p);
+    else
+      hipLaunchKernelGGL((conv_x3_kernel<2, 2, 1, 1, false>), grid, block, 0, st, p);
+  } else {
+    dim3 grid(cdiv(M, 128), cdiv(a->Cout, 128), p.split_k);
+    if (plain)
+      hipLaunchKernelGGL((conv_x3_kernel<2, 2, 2, 2, true>), grid, block, 0, st, p);
+    else
+      hipLaunchKernelGGL((conv_x3_kernel<2, 2, 2, 2, false>), grid, block, 0, st, p);
+  }
+  KEEP_LAUNCH_CHECK("keep_conv2d(gather x3)");
+  return KEEP_OK;
+}

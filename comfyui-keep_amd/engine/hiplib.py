@@ -12,10 +12,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 F32, BF16 = 0, 1
-MMA_F32, MMA_BF16 = 0, 1
+MMA_F32, MMA_BF16, MMA_X3 = 0, 1, 2
 PRO_NONE, PRO_SWISH, PRO_RELU = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 
@@ -27,7 +27,13 @@ class ConvArgs(C.Structure):
                 ('residual', _vp), ('aux', _vp), ('workspace', _vp)] + \
                [(n, _i32) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad_t', 'pad_l', 'Ho', 'Wo',
                                     'in_ld', 'out_ld', 'res_ld', 'upsample', 'pro_act', 'epi_act')] + \
-               [('aux_w', _f32), ('split_k', _i32), ('dtype', _i32), ('mma', _i32), ('weight_bf16', _vp), ('stats_out', _vp), ('stats_P', _i32), ('bk256', _i32), ('out_dtype', _i32)]
+               [('aux_w', _f32), ('split_k', _i32), ('dtype', _i32), ('mma', _i32), ('weight_bf16', _vp), ('stats_out', _vp), ('stats_P', _i32), ('bk256', _i32), ('out_dtype', _i32),
+                ('weight_x3', _vp), ('x3_acc_scale', _f32)]
+
+
+class ConvPlanOut(C.Structure):
+    _fields_ = [('path', _i32), ('split_k', _i32), ('workspace_bytes', _i64), ('stats_rows', _i32), ('stats_P', _i32),
+                ('wants_bf16_input', _i32), ('out_bf16_ok', _i32), ('kernel', C.c_char * 64)]
 
 
 class AttnArgs(C.Structure):
@@ -41,6 +47,7 @@ class AttnArgs(C.Structure):
 # name -> argtypes (restype is always int32 status); every symbol include/keep_hip.h declares
 _SIGNATURES = {
     'keep_conv2d': [C.POINTER(ConvArgs), _vp],
+    'keep_conv2d_plan': [C.POINTER(ConvArgs), C.POINTER(ConvPlanOut)],
     'keep_attention': [C.POINTER(AttnArgs), _vp],
     'keep_chan_stats': [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     'keep_norm_finalize': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
@@ -127,12 +134,27 @@ def call(name, *args):
     _check(getattr(lib, name)(*conv, _stream()), name)
 
 
-def conv2d(**kw):
-    lib = load()
+def conv_args(**kw):
     a = ConvArgs()
     for k, v in kw.items():
         setattr(a, k, _ptr(v) if (isinstance(v, torch.Tensor) or v is None) else v)
-    _check(lib.keep_conv2d(C.byref(a), _stream()), 'keep_conv2d')
+    return a
+
+
+def conv2d_plan(a):
+    """keep_conv2d_plan: the library's own decision for these arguments (kernel, split-K, workspace / statistics sizes)."""
+    lib = load(check_device=False)
+    out = ConvPlanOut()
+    _check(lib.keep_conv2d_plan(C.byref(a), C.byref(out)), 'keep_conv2d_plan')
+    return out
+
+
+def conv2d_launch(a):
+    _check(load().keep_conv2d(C.byref(a), _stream()), 'keep_conv2d')
+
+
+def conv2d(**kw):
+    conv2d_launch(conv_args(**kw))
 
 
 def attention(**kw):

@@ -29,6 +29,10 @@ _KNOWN_KW = set(DEFAULT_ARCH) | {
 
 
 FUSED_GM_MLP = os.environ.get('KEEP_NO_FUSED_MLP') is None     # dev switch
+# 'x3': split-fp16 operands on the 16-bit matrix pipe (fp32-grade products, csrc/keep_conv_x3.hip) -- the default: it
+# passes the same <= 1e-3 parity tests as 'fp32' (exact f32 MFMA everywhere) at several times its speed.
+PRECISIONS = ('fp32', 'x3', 'bf16')
+DEFAULT_PRECISION = 'x3'
 
 
 class KeepNet:
@@ -51,8 +55,11 @@ class KeepNet:
         self._const = {}           # per-shape device constants (position tables, grids)
         self.last_aux = None
         self._dev_blob16 = None    # bf16 twin of the packed blob (same offsets) for the bf16-MFMA policy
+        self._dev_blobx3 = None    # split-fp16 twin (2 x int16 per weight) for the x3 policy
+        self._x3_scale = 1.0       # power of two the x3 weights were multiplied by
+        self.o = ops.Ops()         # this net's precision policy + weight twins (never shared between nets)
         self.precision = 'fp32'
-        self.set_precision(os.environ.get('KEEP_AMD_PRECISION', 'fp32'))
+        self.set_precision(os.environ.get('KEEP_AMD_PRECISION', DEFAULT_PRECISION))
 
     # ------------------------------------------------------------------ nn.Module-like surface
     def load_state_dict(self, state_dict, strict=True):
@@ -85,30 +92,44 @@ class KeepNet:
     supports_single_frame = True
 
     def set_precision(self, precision):
-        """'fp32': f32 MFMA everywhere (the <=1e-3 parity policy).  'bf16': convolutions / linear layers round their
-        MFMA operands to bf16 (fp32 accumulate, fp32 activations in HBM); attention, norms, softmax stay fp32."""
-
-        if precision not in ('fp32', 'bf16'):
-            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        """'fp32': exact f32 MFMA everywhere.  'x3': every matrix-core operand split into two fp16 halves, three MFMAs per
+        product (<= 2^-22 relative per product, fp32 accumulate) -- parity-grade (<= 1e-3) at the 16-bit pipe's rate / 3.
+        'bf16': operands rounded to bf16 (speed policy, outside the parity tolerance)."""
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
         self.precision = precision
-        if precision == 'bf16' and self._dev_blob is not None and self._dev_blob16 is None:
-            self._dev_blob16 = self._dev_blob.to(torch.bfloat16)
         return self
+
+    def _make_x3(self):
+        """Split-fp16 twin of every matrix weight in the blob (2-D+ tensors whose reduction axis is a multiple of 16)."""
+        names = [n for n, (_, shape) in self._index.items() if len(shape) >= 2 and shape[-1] % 16 == 0]
+        amax = max(float(self.w[n].abs().max()) for n in names)
+        self._x3_scale = ops.x3_scale_for(amax)
+        bx = torch.zeros(2 * self._dev_blob.numel(), dtype=torch.int16, device=self._dev_blob.device)
+        for n in names:
+            off, shape = self._index[n]
+            t = self.w[n]
+            bx[2 * off:2 * (off + t.numel())] = ops.split_x3(t.reshape(-1, shape[-1]), self._x3_scale).view(-1)
+        self._dev_blobx3 = bx
 
     def _activate_precision(self):
         if self.precision == 'bf16':
             if self._dev_blob16 is None:
                 self._dev_blob16 = self._dev_blob.to(torch.bfloat16)
-            ops.set_precision(L.MMA_BF16, self._dev_blob, self._dev_blob16)
+            self.o.set_precision(L.MMA_BF16, self._dev_blob, self._dev_blob16)
+        elif self.precision == 'x3':
+            if self._dev_blobx3 is None:
+                self._make_x3()
+            self.o.set_precision(L.MMA_X3, self._dev_blob, None, self._dev_blobx3, 1.0 / self._x3_scale)
         else:
-            ops.set_precision(L.MMA_F32, self._dev_blob, None)
+            self.o.set_precision(L.MMA_F32, self._dev_blob, None)
 
     def _upload(self, from_blob=None):
         L.load(check_device=True)       # fails loudly: no library / not gfx950 -> no silent fallback
         if from_blob is None:
             from_blob = torch.from_numpy(self._blob)
         self._dev_blob = from_blob.to(self.device, non_blocking=False)
-        self._dev_blob16 = None
+        self._dev_blob16 = self._dev_blobx3 = None
         self.w = views(self._dev_blob, self._index)
 
     def to(self, device):
@@ -123,7 +144,8 @@ class KeepNet:
                     self._upload()
         else:
             self.device = device
-            self._dev_blob, self._dev_blob16, self.w = None, None, None
+            self._dev_blob, self._dev_blob16, self._dev_blobx3, self.w = None, None, None, None
+            self.o.set_precision(self.o.mma)        # drop this net's references to the device blobs
             self._const = {}
         return self
 
@@ -133,71 +155,71 @@ class KeepNet:
 
     def adopt_packed(self, index, dev_blob):
         """Install a packed blob received from another rank."""
-        self._index, self._dev_blob, self._dev_blob16 = index, dev_blob, None
+        self._index, self._dev_blob, self._dev_blob16, self._dev_blobx3 = index, dev_blob, None, None
         self.device = dev_blob.device
         self.w = views(dev_blob, index)
 
     # ------------------------------------------------------------------ building blocks (VQGAN)
-    def _gn(self, x, p):
-        return ops.norm_affine(x, self.w[f'{p}.weight'], self.w[f'{p}.bias'], 32, 1e-6)
+    def _gn(self, x, p, st=None):
+        """GroupNorm(32, eps 1e-6) of x as a conv prologue; ``st`` = statistics from the producing conv's epilogue."""
+        return ops.norm_affine(x, self.w[f'{p}.weight'], self.w[f'{p}.bias'], 32, 1e-6, stats=st)
 
-    def _resblock(self, x, p):
-        """VQ:170-181."""
+    def _resblock(self, x, p, st=None):
+        """VQ:170-181.  (x, statistics of x or None) -> (y, statistics of y)."""
         w = self.w
         # bf16 policy: h is read once, by the normalise+swish pass in front of conv2's halo kernel -> store it as bf16
-        # (its GroupNorm statistics come from conv1's epilogue, taken on the fp32 values)
-        N, H, Wd, _ = x.shape
-        cmid = w[f'{p}.conv1.weight'].shape[0]
-        h16 = (ops.MMA == L.MMA_BF16 and cmid % 64 == 0 and ops.halo_bf16_eligible(x.shape[-1], cmid, H, Wd)
-               and ops.halo_bf16_eligible(cmid, w[f'{p}.conv2.weight'].shape[0], H, Wd)
-               and H * Wd >= 16384)     # maps below 128x128 keep fp32 + split-K; per-image rule: results do not depend on B
-        h = ops.conv(x, w[f'{p}.conv1.weight'], w[f'{p}.conv1.bias'], pro=self._gn(x, f'{p}.norm1'),
-                     pro_act=L.PRO_SWISH, stats=True, out_bf16=h16)
+        # (its GroupNorm statistics come from conv1's epilogue, taken on the fp32 values); per-image rule (maps of at
+        # least 128x128), so results do not depend on the batch size.  The library refuses where it cannot (plan).
+        h16 = self.o.mma == L.MMA_BF16 and x.shape[1] * x.shape[2] >= 16384
+        h, hst = self.o.conv(x, w[f'{p}.conv1.weight'], w[f'{p}.conv1.bias'], pro=self._gn(x, f'{p}.norm1', st),
+                             pro_act=L.PRO_SWISH, stats=True, out_bf16=h16)
         sc = x
         if f'{p}.conv_out.weight' in w:
-            sc = ops.linear(x, w[f'{p}.conv_out.weight'], w[f'{p}.conv_out.bias'])
-        return ops.conv(h, w[f'{p}.conv2.weight'], w[f'{p}.conv2.bias'], pro=self._gn(h, f'{p}.norm2'),
-                        pro_act=L.PRO_SWISH, residual=sc, stats=True)
+            sc = self.o.linear(x, w[f'{p}.conv_out.weight'], w[f'{p}.conv_out.bias'])
+        return self.o.conv(h, w[f'{p}.conv2.weight'], w[f'{p}.conv2.bias'], pro=self._gn(h, f'{p}.norm2', hst),
+                           pro_act=L.PRO_SWISH, residual=sc, stats=True)
 
-    def _attnblock(self, x, p):
+    def _attnblock(self, x, p, st=None):
         """VQ:219-243: GN -> q,k,v (one GEMM) -> fused attention (1 head, d=C) -> proj_out + x."""
         w = self.w
         N, H, Wd, C = x.shape
         HW = H * Wd
-        qkv = ops.linear(x.view(N * HW, C), w[f'{p}.qkv.weight'], w[f'{p}.qkv.bias'], pro=self._gn(x, f'{p}.norm'),
-                         n_img=N, out_bf16=True)
+        qkv = self.o.linear(x.view(N * HW, C), w[f'{p}.qkv.weight'], w[f'{p}.qkv.bias'], pro=self._gn(x, f'{p}.norm', st),
+                            n_img=N, out_bf16=True)
         o = ops.empty((N * HW, C), x)
         s3 = (HW * 3 * C, 3 * C, 0)
-        ops.attention(qkv, ops.offset(qkv, C), ops.offset(qkv, 2 * C), o, B=N, H=1, Lq=HW, Lk=HW, D=C, Dv=C,
+        self.o.attention(qkv, ops.offset(qkv, C), ops.offset(qkv, 2 * C), o, B=N, H=1, Lq=HW, Lk=HW, D=C, Dv=C,
                       scale=int(C) ** (-0.5), q_str=s3, k_str=s3, v_str=s3, o_str=(HW * C, C, 0))
-        y = ops.linear(o, w[f'{p}.proj_out.weight'], w[f'{p}.proj_out.bias'], residual=x.view(N * HW, C))
+        y = self.o.linear(o, w[f'{p}.proj_out.weight'], w[f'{p}.proj_out.bias'], residual=x.view(N * HW, C))
         return y.view(N, H, Wd, C)
 
     def _vq_stack(self, x, prefix, blocks, taps=(), hook=None):
         """Encoder.forward / Generator.forward (VQ:288-292, 339-343) over NHWC maps.
-        ``hook(j, x) -> x`` runs after block j (generator CFT/CFA taps, KA:1104-1121)."""
+        ``hook(j, x, st) -> (x, st)`` runs after block j (generator CFT/CFA taps, KA:1104-1121).  ``st`` travels with x:
+        the per-channel (sum, sumsq) partials its producing convolution reduced in the epilogue, or None."""
         w = self.w
         feats = {}
+        st = None
         pending = None            # a bare GroupNorm block folds into the next conv's prologue (no swish)
         for i, (kind, _, _) in enumerate(blocks):
             p = f'{prefix}.blocks.{i}'
             if kind == 'conv':
-                x = ops.conv(x, w[f'{p}.weight'], w[f'{p}.bias'], pro=pending, stats=True)
+                x, st = self.o.conv(x, w[f'{p}.weight'], w[f'{p}.bias'], pro=pending, stats=True)
                 pending = None
             elif kind == 'res':
-                x = self._resblock(x, p)
+                x, st = self._resblock(x, p, st)
             elif kind == 'attn':
-                x = self._attnblock(x, p)
+                x, st = self._attnblock(x, p, st), None
             elif kind == 'down':
-                x = ops.conv(x, w[f'{p}.conv.weight'], w[f'{p}.conv.bias'], down=True, stats=True)
+                x, st = self.o.conv(x, w[f'{p}.conv.weight'], w[f'{p}.conv.bias'], down=True, stats=True)
             elif kind == 'up':
-                x = ops.conv(x, w[f'{p}.conv.weight'], w[f'{p}.conv.bias'], upsample=True, stats=True)
+                x, st = self.o.conv(x, w[f'{p}.conv.weight'], w[f'{p}.conv.bias'], upsample=True, stats=True)
             elif kind == 'norm':
-                pending = self._gn(x, p)
+                pending = self._gn(x, p, st)
             if i in taps:
                 feats[str(x.shape[2])] = x
             if hook is not None and kind != 'norm':
-                x = hook(i, x)
+                x, st = hook(i, x, st)
         return x, feats
 
     # ------------------------------------------------------------------ code prediction (KA:1073-1089)
@@ -207,24 +229,24 @@ class KeepNet:
         Ltok = z_hat.shape[1] * z_hat.shape[2]
         D, nh = cfg['dim_embd'], cfg['n_head']
         dh = D // nh
-        q = ops.linear(z_hat.view(B * Ltok, -1), w['feat_emb.weight'], w['feat_emb.bias'])
+        q = self.o.linear(z_hat.view(B * Ltok, -1), w['feat_emb.weight'], w['feat_emb.bias'])
         pos = w['position_emb']
         for i in range(cfg['n_layers']):
             p = f'ft_layers.{i}'
             x2, qk_in = ops.layernorm(q, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], pos=pos)
             wi, bi = w[f'{p}.self_attn.in_proj_weight'], w[f'{p}.self_attn.in_proj_bias']
-            qk = ops.linear(qk_in, wi[:2 * D], bi[:2 * D], out_bf16=True)
-            v = ops.linear(x2, wi[2 * D:], bi[2 * D:], out_bf16=True)
+            qk = self.o.linear(qk_in, wi[:2 * D], bi[:2 * D], out_bf16=True)
+            v = self.o.linear(x2, wi[2 * D:], bi[2 * D:], out_bf16=True)
             o = ops.empty((B * Ltok, D), q)
-            ops.attention(qk, ops.offset(qk, D), v, o, B=B, H=nh, Lq=Ltok, Lk=Ltok, D=dh, Dv=dh, scale=dh ** -0.5,
+            self.o.attention(qk, ops.offset(qk, D), v, o, B=B, H=nh, Lq=Ltok, Lk=Ltok, D=dh, Dv=dh, scale=dh ** -0.5,
                           q_str=(Ltok * 2 * D, 2 * D, dh), k_str=(Ltok * 2 * D, 2 * D, dh),
                           v_str=(Ltok * D, D, dh), o_str=(Ltok * D, D, dh))
-            q = ops.linear(o, w[f'{p}.self_attn.out_proj.weight'], w[f'{p}.self_attn.out_proj.bias'], residual=q)
+            q = self.o.linear(o, w[f'{p}.self_attn.out_proj.weight'], w[f'{p}.self_attn.out_proj.bias'], residual=q)
             x2 = ops.layernorm(q, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'])
-            h = ops.linear(x2, w[f'{p}.linear1.weight'], w[f'{p}.linear1.bias'], act=L.ACT_GELU)
-            q = ops.linear(h, w[f'{p}.linear2.weight'], w[f'{p}.linear2.bias'], residual=q)
+            h = self.o.linear(x2, w[f'{p}.linear1.weight'], w[f'{p}.linear1.bias'], act=L.ACT_GELU)
+            q = self.o.linear(h, w[f'{p}.linear2.weight'], w[f'{p}.linear2.bias'], residual=q)
         xl = ops.layernorm(q, w['idx_pred_layer.0.weight'], w['idx_pred_layer.0.bias'])
-        logits = ops.linear(xl, w['idx_pred_layer.1.weight'])
+        logits = self.o.linear(xl, w['idx_pred_layer.1.weight'])
         cb = w['quantize.embedding.weight']
         quant = ops.empty((B * Ltok, cb.shape[1]), q)
         idx = torch.empty((B * Ltok,), dtype=torch.int32, device=q.device)
@@ -239,10 +261,10 @@ class KeepNet:
         """KA:465-472: dec + cond*(dec*scale(e) + shift(e)), e = ResBlock(cat[enc, dec])."""
         w = self.w
         C = dec.shape[-1]
-        e = self._resblock(ops.concat2(enc, dec), f'{p}.encode_enc')
-        ss = ops.conv(e, w[f'{p}.ss0.weight'], w[f'{p}.ss0.bias'], act=L.ACT_LRELU02)          # [.., 2C]
-        scale = ops.conv(ss, w[f'{p}.scale.2.weight'], w[f'{p}.scale.2.bias'], cin=C, in_off=0)
-        return ops.conv(ss, w[f'{p}.shift.2.weight'], w[f'{p}.shift.2.bias'], cin=C, in_off=C, residual=dec,
+        e, _ = self._resblock(ops.concat2(enc, dec), f'{p}.encode_enc')
+        ss = self.o.conv(e, w[f'{p}.ss0.weight'], w[f'{p}.ss0.bias'], act=L.ACT_LRELU02)          # [.., 2C]
+        scale = self.o.conv(ss, w[f'{p}.scale.2.weight'], w[f'{p}.scale.2.bias'], cin=C, in_off=0)
+        return self.o.conv(ss, w[f'{p}.shift.2.weight'], w[f'{p}.shift.2.bias'], cin=C, in_off=C, residual=dec,
                         aux=scale, aux_w=self.cfg['cond'], stats=True)
 
     def _cfa(self, curr, prev, p):
@@ -253,16 +275,16 @@ class KeepNet:
         nh, dh = cfg['cfa_nhead'], cfg['cfa_dim']
         inner = nh * dh
         c = curr.view(B * Ltok, C)
-        q = ops.linear(c, w[f'{p}.attn.to_q.weight'], out_bf16=True)
-        kv = ops.linear(prev.view(B * Ltok, C), w[f'{p}.attn.to_kv.weight'], out_bf16=True)
+        q = self.o.linear(c, w[f'{p}.attn.to_q.weight'], out_bf16=True)
+        kv = self.o.linear(prev.view(B * Ltok, C), w[f'{p}.attn.to_kv.weight'], out_bf16=True)
         o = ops.empty((B * Ltok, inner), curr)
-        ops.attention(q, kv, ops.offset(kv, inner), o, B=B, H=nh, Lq=Ltok, Lk=Ltok, D=dh, Dv=dh, scale=dh ** -0.5,
+        self.o.attention(q, kv, ops.offset(kv, inner), o, B=B, H=nh, Lq=Ltok, Lk=Ltok, D=dh, Dv=dh, scale=dh ** -0.5,
                       q_str=(Ltok * inner, inner, dh), k_str=(Ltok * 2 * inner, 2 * inner, dh),
                       v_str=(Ltok * 2 * inner, 2 * inner, dh), o_str=(Ltok * inner, inner, dh))
-        a = ops.linear(o, w[f'{p}.attn.to_out.0.weight'], w[f'{p}.attn.to_out.0.bias'])
+        a = self.o.linear(o, w[f'{p}.attn.to_out.0.weight'], w[f'{p}.attn.to_out.0.bias'])
         y = ops.layernorm(a, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], res=c)
-        f = ops.geglu(ops.linear(y, w[f'{p}.ff.net.0.proj.weight'], w[f'{p}.ff.net.0.proj.bias']))
-        f = ops.linear(f, w[f'{p}.ff.net.2.weight'], w[f'{p}.ff.net.2.bias'])
+        f = ops.geglu(self.o.linear(y, w[f'{p}.ff.net.0.proj.weight'], w[f'{p}.ff.net.0.proj.bias']))
+        f = self.o.linear(f, w[f'{p}.ff.net.2.weight'], w[f'{p}.ff.net.2.bias'])
         z = ops.layernorm(f, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], res=y)
         return z.view(B, H, Wd, C)
 
@@ -279,32 +301,33 @@ class KeepNet:
             p = f'kalman_filter.uncertainty_estimator.{i}'
             # sparse-causal spatial attention (KA:686-748): keys = [frame 0 ; frame f-1]
             x1 = ops.layernorm(h, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'])
-            qkv = ops.linear(x1, w[f'{p}.attn1.to_qkv.weight'], out_bf16=True)
+            qkv = self.o.linear(x1, w[f'{p}.attn1.to_qkv.weight'], out_bf16=True)
             o = ops.empty((BT * Ltok, inner), h)
             s3 = (Ltok * 3 * inner, 3 * inner, dh)
-            ops.attention(qkv, ops.offset(qkv, inner), ops.offset(qkv, 2 * inner), o, B=BT, H=nh, Lq=Ltok,
+            self.o.attention(qkv, ops.offset(qkv, inner), ops.offset(qkv, 2 * inner), o, B=BT, H=nh, Lq=Ltok,
                           Lk=2 * Ltok, D=dh, Dv=dh, scale=dh ** -0.5, q_str=s3, k_str=s3, v_str=s3,
                           o_str=(Ltok * inner, inner, dh), mode=1, T=T, seg_len=Ltok)
-            h = ops.linear(o, w[f'{p}.attn1.to_out.0.weight'], w[f'{p}.attn1.to_out.0.bias'], residual=h)
+            h = self.o.linear(o, w[f'{p}.attn1.to_out.0.weight'], w[f'{p}.attn1.to_out.0.bias'], residual=h)
             # GEGLU feed-forward (KA:669)
             x3 = ops.layernorm(h, w[f'{p}.norm3.weight'], w[f'{p}.norm3.bias'])
-            f = ops.geglu(ops.linear(x3, w[f'{p}.ff.net.0.proj.weight'], w[f'{p}.ff.net.0.proj.bias']))
-            h = ops.linear(f, w[f'{p}.ff.net.2.weight'], w[f'{p}.ff.net.2.bias'], residual=h)
+            f = ops.geglu(self.o.linear(x3, w[f'{p}.ff.net.0.proj.weight'], w[f'{p}.ff.net.0.proj.bias']))
+            h = self.o.linear(f, w[f'{p}.ff.net.2.weight'], w[f'{p}.ff.net.2.bias'], residual=h)
             # temporal attention over the T frames of each spatial token (KA:671-680): strided, no rearrange
             xt = ops.layernorm(h, w[f'{p}.norm_temp.weight'], w[f'{p}.norm_temp.bias'])
-            qkv = ops.linear(xt, w[f'{p}.attn_temp.to_qkv.weight'], out_bf16=True)
+            qkv = self.o.linear(xt, w[f'{p}.attn_temp.to_qkv.weight'], out_bf16=True)
             o = ops.empty((BT * Ltok, inner), h)
             for b in range(B):
                 qb = ops.offset(qkv, b * T * Ltok * 3 * inner)
                 st = (3 * inner, Ltok * 3 * inner, dh)          # batch = spatial token, token = frame
-                ops.attention(qb, ops.offset(qb, inner), ops.offset(qb, 2 * inner),
+                self.o.attention(qb, ops.offset(qb, inner), ops.offset(qb, 2 * inner),
                               ops.offset(o, b * T * Ltok * inner), B=Ltok, H=nh, Lq=T, Lk=T, D=dh, Dv=dh,
                               scale=dh ** -0.5, q_str=st, k_str=st, v_str=st, o_str=(inner, Ltok * inner, dh))
-            h = ops.linear(o, w[f'{p}.attn_temp.to_out.0.weight'], w[f'{p}.attn_temp.to_out.0.bias'], residual=h)
+            h = self.o.linear(o, w[f'{p}.attn_temp.to_out.0.weight'], w[f'{p}.attn_temp.to_out.0.bias'], residual=h)
         m = h.view(BT, Hh, Ww, C)
+        mst = None
         for i in range(3):
-            m = self._resblock(m, f'kalman_filter.kalman_gain_calculator.{i}')
-        g = ops.linear(m.view(BT * Ltok, C), w['kalman_filter.kalman_gain_calculator.3.weight'],
+            m, mst = self._resblock(m, f'kalman_filter.kalman_gain_calculator.{i}', mst)
+        g = self.o.linear(m.view(BT * Ltok, C), w['kalman_filter.kalman_gain_calculator.3.weight'],
                        w['kalman_filter.kalman_gain_calculator.3.bias'], act=L.ACT_SIGMOID)
         return g.view(BT, Ltok)
 
@@ -334,21 +357,21 @@ class KeepNet:
             self._const[key] = (table.to(dev), grid.to(dev))
         return self._const[key]
 
-    def _inorm(self, x):
-        return ops.norm_affine(x, None, None, x.shape[-1], 1e-5)
+    def _inorm(self, x, st=None):
+        return ops.norm_affine(x, None, None, x.shape[-1], 1e-5, stats=st)
 
     def _gm_resblock(self, x, p, stride):
         """GM/backbone.py:25-36."""
         w = self.w
-        c1 = ops.conv(x, w[f'{p}.conv1.weight'], None, stride=stride, pad=1, stats=True)
-        c2 = ops.conv(c1, w[f'{p}.conv2.weight'], None, pro=self._inorm(c1), pro_act=L.PRO_RELU, stats=True)
-        s2, h2 = self._inorm(c2)
+        c1, st1 = self.o.conv(x, w[f'{p}.conv1.weight'], None, stride=stride, pad=1, stats=True)
+        c2, st2 = self.o.conv(c1, w[f'{p}.conv2.weight'], None, pro=self._inorm(c1, st1), pro_act=L.PRO_RELU, stats=True)
+        s2, h2 = self._inorm(c2, st2)
         N, H, Wd, C = c2.shape
         out = torch.empty_like(c2)
         if f'{p}.downsample.0.weight' in w:
-            d = ops.conv(x, w[f'{p}.downsample.0.weight'].view(C, 1, 1, -1), w[f'{p}.downsample.0.bias'], stride=stride,
-                         pad=0, ksize=1, stats=True)
-            sd, hd = self._inorm(d)
+            d, std = self.o.conv(x, w[f'{p}.downsample.0.weight'].view(C, 1, 1, -1), w[f'{p}.downsample.0.bias'],
+                                 stride=stride, pad=0, ksize=1, stats=True)
+            sd, hd = self._inorm(d, std)
             L.call('keep_gm_join', d, sd, hd, c2, s2, h2, out, N, H * Wd, C)
         else:
             L.call('keep_gm_join', x, None, None, c2, s2, h2, out, N, H * Wd, C)
@@ -363,26 +386,26 @@ class KeepNet:
         wqkv = w[f'{p}.qkv.weight']
         o = torch.empty_like(src)
         if tgt is src:
-            qkv = ops.linear(src, wqkv, out_bf16=True)
+            qkv = self.o.linear(src, wqkv, out_bf16=True)
             q, k, v = qkv, ops.offset(qkv, C), ops.offset(qkv, 2 * C)
             sq = skv = (Ltok * 3 * C, 3 * C, 0)
         else:
-            q = ops.linear(src, wqkv[:C], out_bf16=True)
-            kv = ops.linear(tgt, wqkv[C:], out_bf16=True)
+            q = self.o.linear(src, wqkv[:C], out_bf16=True)
+            kv = self.o.linear(tgt, wqkv[C:], out_bf16=True)
             k, v = kv, ops.offset(kv, C)
             sq, skv = (Ltok * C, C, 0), (Ltok * 2 * C, 2 * C, 0)
-        ops.attention(q, k, v, o, B=n_img * 4, H=1, Lq=Ltok // 4, Lk=Ltok // 4, D=C, Dv=C, scale=1.0 / (C ** 0.5),
+        self.o.attention(q, k, v, o, B=n_img * 4, H=1, Lq=Ltok // 4, Lk=Ltok // 4, D=C, Dv=C, scale=1.0 / (C ** 0.5),
                       q_str=sq, k_str=skv, v_str=skv, o_str=(Ltok * C, C, 0), mode=2, img_h=h8, img_w=w8, ksplit=2,
                       shift=shift, kv_rot=kv_rot, n_img=n_img)
-        m = ops.linear(o, w[f'{p}.merge.weight'])
+        m = self.o.linear(o, w[f'{p}.merge.weight'])
         if not ffn:
             return ops.layernorm(m, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], res=src)
         m = ops.layernorm(m, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'])
-        if ops.MMA == L.MMA_BF16 and C == 128 and FUSED_GM_MLP:
-            m2 = ops.gm_mlp(src, m, w[f'{p}.mlp.0.weight'], w[f'{p}.mlp.2.weight'])      # [M,8C] never leaves the CU
+        if self.o.mma == L.MMA_BF16 and C == 128 and FUSED_GM_MLP:
+            m2 = self.o.gm_mlp(src, m, w[f'{p}.mlp.0.weight'], w[f'{p}.mlp.2.weight'])      # [M,8C] never leaves the CU
         else:
-            hmid = ops.linear(ops.concat2(src, m), w[f'{p}.mlp.0.weight'], act=L.ACT_GELU)
-            m2 = ops.linear(hmid, w[f'{p}.mlp.2.weight'])
+            hmid = self.o.linear(ops.concat2(src, m), w[f'{p}.mlp.0.weight'], act=L.ACT_GELU)
+            m2 = self.o.linear(hmid, w[f'{p}.mlp.2.weight'])
         return ops.layernorm(m2, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], res=src)
 
     def _gm_backbone(self, img_nchw):
@@ -391,14 +414,14 @@ class KeepNet:
         w = self.w
         pfx = 'flownet.model'
         img = ops.nchw_to_nhwc(img_nchw, mode=1)                                           # [N,H,W,3] normalised
-        f = ops.conv(img, w[f'{pfx}.backbone.conv1.weight'], None, stride=2, pad=3, ksize=7, stats=True)
-        s, hh = self._inorm(f)
+        f, fst = self.o.conv(img, w[f'{pfx}.backbone.conv1.weight'], None, stride=2, pad=3, ksize=7, stats=True)
+        s, hh = self._inorm(f, fst)
         x = torch.empty_like(f)
         L.call('keep_affine_act', f, s, hh, x, f.shape[0], f.shape[1] * f.shape[2], f.shape[3], L.ACT_RELU)
         for li, stride in ((1, 1), (2, 2), (3, 2)):
             x = self._gm_resblock(x, f'{pfx}.backbone.layer{li}.0', stride)
             x = self._gm_resblock(x, f'{pfx}.backbone.layer{li}.1', 1)
-        return ops.linear(x, w[f'{pfx}.backbone.conv2.weight'], w[f'{pfx}.backbone.conv2.bias'])
+        return self.o.linear(x, w[f'{pfx}.backbone.conv2.weight'], w[f'{pfx}.backbone.conv2.bias'])
 
     def _gmflow(self, im1, im2):
         """im1, im2 [P,3,H,W] NCHW in [-1,1] -> backward flow [P,H,W,2] (channels-last: (dx, dy))."""
@@ -438,20 +461,20 @@ class KeepNet:
         sF = (Ltok * C, C, 0)
         # global correlation soft-argmax (GM/matching.py:15-34): V = pixel grid, shared by all pairs
         corr = ops.empty((P * Ltok, 2), f0)
-        ops.attention(f0, f1, grid, corr, B=P, H=1, Lq=Ltok, Lk=Ltok, D=C, Dv=2, scale=1.0 / (C ** 0.5),
+        self.o.attention(f0, f1, grid, corr, B=P, H=1, Lq=Ltok, Lk=Ltok, D=C, Dv=2, scale=1.0 / (C ** 0.5),
                       q_str=sF, k_str=sF, v_str=(0, 2, 0), o_str=(Ltok * 2, 2, 0))
         flow = ops.add_bcast(corr, grid, alpha=-1.0)
         # flow propagation (GM/transformer.py:363-372): k projected from the projected q
         fp = f'{pfx}.feature_flow_attn'
-        q = ops.linear(f0, w[f'{fp}.q_proj.weight'], w[f'{fp}.q_proj.bias'])
-        k = ops.linear(q, w[f'{fp}.k_proj.weight'], w[f'{fp}.k_proj.bias'])
+        q = self.o.linear(f0, w[f'{fp}.q_proj.weight'], w[f'{fp}.q_proj.bias'])
+        k = self.o.linear(q, w[f'{fp}.k_proj.weight'], w[f'{fp}.k_proj.bias'])
         flow2 = ops.empty((P * Ltok, 2), f0)
-        ops.attention(q, k, flow, flow2, B=P, H=1, Lq=Ltok, Lk=Ltok, D=C, Dv=2, scale=1.0 / (C ** 0.5),
+        self.o.attention(q, k, flow, flow2, B=P, H=1, Lq=Ltok, Lk=Ltok, D=C, Dv=2, scale=1.0 / (C ** 0.5),
                       q_str=sF, k_str=sF, v_str=(Ltok * 2, 2, 0), o_str=(Ltok * 2, 2, 0))
         # convex upsampling (GM/gmflow.py:75-88)
         cat = ops.concat2(flow2, f0).view(P, h8, w8, C + 2)
-        m = ops.conv(cat, w[f'{pfx}.upsampler.0.weight'], w[f'{pfx}.upsampler.0.bias'], act=L.ACT_RELU)
-        mask = ops.linear(m, w[f'{pfx}.upsampler.2.weight'], w[f'{pfx}.upsampler.2.bias'])
+        m = self.o.conv(cat, w[f'{pfx}.upsampler.0.weight'], w[f'{pfx}.upsampler.0.bias'], act=L.ACT_RELU)
+        mask = self.o.linear(m, w[f'{pfx}.upsampler.2.weight'], w[f'{pfx}.upsampler.2.bias'])
         k8 = GMFLOW['upsample_factor']
         up = ops.empty((P, h8 * k8, w8 * k8, 2), f0)
         L.call('keep_convex_upsample', mask, flow2, up, P, h8, w8, k8)
@@ -526,16 +549,16 @@ class KeepNet:
             idx_all.append(idx)
             margin_all.append(margin)
 
-            def hook(j, y, i=i):                                         # K7 taps (KA:1104-1121)
+            def hook(j, y, yst, i=i):                                    # K7 taps (KA:1104-1121)
                 if j in cft_at:
                     s = cft_at[j]
-                    y = self._cft(self._frame(enc_feat[s], i), y, f'cft.{s}')
+                    y, yst = self._cft(self._frame(enc_feat[s], i), y, f'cft.{s}')
                 if j in cfa_at:
                     s = cfa_at[j]
                     if i > 0:
-                        y = self._cfa(y, cross_prev[s], f'cfa.{s}')
+                        y, yst = self._cfa(y, cross_prev[s], f'cfa.{s}'), None
                     cross_prev[s] = y
-                return y
+                return y, yst
 
             y, _ = self._vq_stack(quant, 'generator', gblocks, hook=hook)
             prev_out = y

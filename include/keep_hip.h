@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KEEP_ABI_VERSION 9
+#define KEEP_ABI_VERSION 10
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -41,6 +41,13 @@ extern "C" {
  *                 activations stay fp32 in HBM, weights come from the caller's bf16 copy (`weight_bf16`) */
 #define KEEP_MMA_F32 0
 #define KEEP_MMA_BF16 1
+/*   KEEP_MMA_X3   v_mfma_f32_32x32x16_f16 x 3: every fp32 operand split as hi + lo (two fp16), a*b = a_hi*b_hi + a_hi*b_lo +
+ *                 a_lo*b_hi into one fp32 accumulator: <= 2^-22 relative per product (fp32-grade) at 2.5 PF / 3 = 833 TFLOP/s
+ *                 -- the parity-grade FAST policy (csrc/keep_conv_x3.hip).  Activations are split on the fly; weights come
+ *                 pre-scaled + pre-split from the caller (`weight_x3`, `x3_acc_scale`).  Geometries the x3 kernels do not
+ *                 cover run on the exact-f32 kernels.  An activation beyond the fp16 range (65504) yields inf, never a
+ *                 silently wrong value. */
+#define KEEP_MMA_X3 2
 
 /* prologue activation applied to the (affine-normalised) conv input */
 #define KEEP_PRO_NONE 0
@@ -90,9 +97,9 @@ typedef struct {
   int32_t upsample; /* 1: `in` is [N,H,W,*] and is read as its nearest x2 upsampling [N,2H,2W,*] */
   int32_t pro_act, epi_act;
   float aux_w;
-  int32_t split_k;
+  int32_t split_k; /* 0: the library chooses (keep_conv2d_plan reports the choice and the workspace it needs) */
   int32_t dtype; /* KEEP_F32 */
-  int32_t mma;   /* KEEP_MMA_F32 | KEEP_MMA_BF16 */
+  int32_t mma;   /* KEEP_MMA_F32 | KEEP_MMA_BF16 | KEEP_MMA_X3 */
   const void* weight_bf16; /* [Cout][KH][KW][Cin] bf16, required when mma == KEEP_MMA_BF16 */
   /* optional: per-tile (sum, sumsq) of the epilogue OUTPUT per channel, [N][stats_P][Cout][2], for the next
    * GroupNorm / InstanceNorm (keep_norm_finalize with P = stats_P): saves one full read of the activation.
@@ -104,8 +111,28 @@ typedef struct {
                         (latency-bound small-M / deep-K layers); split_k then counts 256-channel steps */
   int32_t out_dtype; /* KEEP_F32, or KEEP_BF16: `out` is a bf16 tensor (projections feeding keep_attention; needs
                         Cout/out_ld %% 4 == 0, split_k == 1, no residual) */
+  /* KEEP_MMA_X3: weight * 2^e split into fp16 halves, [Cout][KH*KW][Cin/16][hi x16 | lo x16] (Cin %% 16 == 0), 16-byte
+   * aligned; x3_acc_scale = 2^-e (applied to the accumulators).  NULL -> the call runs on the exact-f32 kernels. */
+  const void* weight_x3;
+  float x3_acc_scale;
 } keep_conv2d_args;
 int32_t keep_conv2d(const keep_conv2d_args* a, void* stream);
+
+/* What keep_conv2d will do with exactly these arguments -- kernel choice, split-K, buffer sizes -- so that callers size
+ * `workspace` / `stats_out` from the library's own decision instead of mirroring its tile rules.  Tensor pointers only
+ * contribute their alignment (pass the real ones, or NULL for absent optional tensors). */
+typedef struct {
+  int32_t path;             /* internal kernel family id (diagnostic) */
+  int32_t split_k;          /* the factor keep_conv2d will use (== args.split_k clamped, or the library's choice for 0) */
+  int64_t workspace_bytes;  /* bytes `workspace` must hold (0 when split_k == 1) */
+  int32_t stats_rows;       /* output pixels per statistics partial; 0: this call cannot emit `stats_out` */
+  int32_t stats_P;          /* partials per image = Ho*Wo / stats_rows: stats_out is [N][stats_P][Cout][2] floats */
+  int32_t wants_bf16_input; /* KEEP_MMA_BF16: faster if the caller first runs keep_norm_act_bf16 (prologue applied once,
+                               bf16 tensor) and calls again with dtype = KEEP_BF16 and no prologue */
+  int32_t out_bf16_ok;      /* out_dtype = KEEP_BF16 is supported for this geometry */
+  char kernel[64];          /* kernel family as rocprofv3 prints it (bench.py groups its HIP-event timings by it) */
+} keep_conv2d_plan_out;
+int32_t keep_conv2d_plan(const keep_conv2d_args* a, keep_conv2d_plan_out* out);
 
 /* ------------------------------------------------------------------------------------------------
  * keep_attention -- fused softmax(scale * Q K^T + mask) V  (flash style: scores never reach HBM).
@@ -133,7 +160,8 @@ typedef struct {
   int32_t mode;
   int32_t T, seg_len;                           /* mode 1 */
   int32_t img_h, img_w, ksplit, shift, kv_rot, n_img; /* mode 2 */
-  int32_t mma; /* KEEP_MMA_F32 | KEEP_MMA_BF16 (Q,K,V,P rounded to bf16; fp32 softmax + accumulate) */
+  int32_t mma; /* KEEP_MMA_F32 | KEEP_MMA_BF16 (Q,K,V,P rounded to bf16; fp32 softmax + accumulate) | KEEP_MMA_X3 (Q,K,V,P
+                  split into fp16 hi + lo, three MFMAs per product: fp32-grade; exact-fp32 softmax) */
   int32_t in_dtype; /* KEEP_F32, or KEEP_BF16 (with KEEP_MMA_BF16): q, k, v are bf16 tensors, strides in elements */
 } keep_attention_args;
 int32_t keep_attention(const keep_attention_args* a, void* stream);

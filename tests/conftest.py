@@ -25,16 +25,20 @@ def synth_weights():
     return synth.synth_state_dict(seed=0)
 
 
-@pytest.fixture(scope='session')
-def gpu_net(synth_weights):
-    """The HIP engine with synthetic weights resident on cuda:0 (fails loudly without the library / a gfx950)."""
+@pytest.fixture(scope='session', params=['x3', 'fp32'])
+def gpu_net(request, synth_weights):
+    """The HIP engine with synthetic weights resident on cuda:0 (fails loudly without the library / a gfx950), once per
+    parity-grade precision policy: 'x3' (split fp16 operands, the default) and 'fp32' (exact f32 MFMA) must pass the
+    SAME assertions."""
     import torch
     from comfyui_keep_amd.engine.net import KeepNet
     from comfyui_keep_amd.engine.arch import DEFAULT_ARCH
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
     net = KeepNet(**DEFAULT_ARCH)
     net.load_state_dict(synth_weights, strict=True)
-    return net.to('cuda').eval()
+    net.to('cuda').eval().set_precision(request.param)
+    net._activate_precision()        # module-level tests call the building blocks directly
+    return net
 
 
 def op_input(name, shape, scale=1.0):

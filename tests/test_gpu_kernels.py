@@ -66,12 +66,10 @@ def test_conv3x3_f32_halo_kernel_vs_gather_kernel(monkeypatch):
         xd = dev(nhwc(x))
         pro = ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6)
         kw = dict(pro=pro, pro_act=L.PRO_SWISH, upsample=up, stats=True, split_k=1)
-        y = ops.conv(xd, pack(w), dev(b), **kw)
-        assert hasattr(y, '_keep_stats') and y._keep_stats[1] == (y.shape[1] * y.shape[2]) // 64
-        monkeypatch.setattr(ops, 'HALO_F32', False)
+        y, st = ops.conv(xd, pack(w), dev(b), **kw)
+        assert st is not None and st[1] == (y.shape[1] * y.shape[2]) // 64
         monkeypatch.setenv('KEEP_NO_HALO_F32', '1')
-        y_g = ops.conv(xd, pack(w), dev(b), **kw)
-        monkeypatch.setattr(ops, 'HALO_F32', True)
+        y_g, _ = ops.conv(xd, pack(w), dev(b), **kw)
         monkeypatch.delenv('KEEP_NO_HALO_F32')
         hn = F.group_norm(x, 32, gamma, beta, eps=1e-6)
         hn = hn * torch.sigmoid(hn)
@@ -80,9 +78,120 @@ def test_conv3x3_f32_halo_kernel_vs_gather_kernel(monkeypatch):
         ref = F.conv2d(hn, w, b, padding=1)
         check(nchw(y), ref, what='halo f32 vs torch')
         check(y, y_g, 2e-5, what='halo f32 vs gather kernel')
-        sc, sh = ops.norm_affine(y, None, None, cout, 1e-5)
-        sc2, sh2 = ops.norm_affine(y.clone(), None, None, cout, 1e-5)
+        sc, sh = ops.norm_affine(y, None, None, cout, 1e-5, stats=st)
+        sc2, sh2 = ops.norm_affine(y, None, None, cout, 1e-5)
         check(sc, sc2, 1e-5, 'halo f32 fused stats scale'); check(sh, sh2, 1e-5, 'halo f32 fused stats shift')
+
+
+# ------------------------------------------------------------------------------------------------ split fp16 (x3) policy
+def x3w(wp):
+    """(weight_x3, acc_scale) for a packed [Cout,KH,KW,Cin] weight: the host-side split of engine/ops.py."""
+    sc = ops.x3_scale_for(float(wp.abs().max()))
+    return ops.split_x3(wp.reshape(-1, wp.shape[-1]), sc).view(-1), 1.0 / sc
+
+
+def err64(got, ref64):
+    return (got.detach().double().cpu() - ref64).abs().max().item()
+
+
+@pytest.mark.parametrize("n,cin,cout,h,wd,up,res,gn", [(2, 64, 64, 64, 64, False, True, True), (1, 128, 96, 16, 48, False, False, True),
+                                                      (2, 32, 128, 16, 16, True, False, True), (1, 48, 64, 32, 32, False, True, False),
+                                                      (1, 512, 512, 16, 16, False, False, True)])
+def test_conv_x3_halo_is_fp32_grade(n, cin, cout, h, wd, up, res, gn):
+    """KEEP_MMA_X3 3x3 halo kernel: the error against an fp64 convolution is of the size of the exact-f32 kernel's own
+    (accumulation-order) error -- wide / square tiles, masked half cout-block, fused GN+swish, upsample, residual,
+    auto split-K on the small map, Cin = 48 (three 16-channel chunks)."""
+    x, w, b = rnd('x3x', (n, cin, h, wd), 2.0) + 0.3, rnd('x3w', (cout, cin, 3, 3), 0.05), rnd('x3b', (cout,))
+    gamma, beta = rnd('x3g', (cin,)) * 0.2 + 1, rnd('x3bt', (cin,)) * 0.2
+    Ho, Wo = (2 * h, 2 * wd) if up else (h, wd)
+    r = rnd('x3r', (n, cout, Ho, Wo)) if res else None
+    xd, wp = dev(nhwc(x)), pack(w)
+    wx3, asc = x3w(wp)
+    kw = dict(upsample=up, stats=True, residual=None if r is None else dev(nhwc(r)))
+    if gn:
+        kw.update(pro=ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6), pro_act=L.PRO_SWISH)
+    ops.DEFAULT.profile = []
+    y, st = ops.conv(xd, wp, dev(b), mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, **kw)
+    assert ops.DEFAULT.profile[-1][0].startswith('conv3x3_halo_x3_kernel'), ops.DEFAULT.profile[-1][0]
+    ops.DEFAULT.profile = None
+    y32, _ = ops.conv(xd, wp, dev(b), **kw)
+    hn = x.double()
+    if gn:
+        hn = F.group_norm(hn, 32, gamma.double(), beta.double(), eps=1e-6)
+        hn = hn * torch.sigmoid(hn)
+    if up:
+        hn = F.interpolate(hn, scale_factor=2.0, mode='nearest')
+    ref = F.conv2d(hn, w.double(), b.double(), padding=1)
+    if r is not None:
+        ref = ref + r.double()
+    ref = ref.permute(0, 2, 3, 1)
+    e3, e32 = err64(y, ref), err64(y32, ref)
+    scale = max(1.0, ref.abs().max().item())
+    assert torch.isfinite(y).all()
+    assert e3 <= max(3.0 * e32, 2e-6 * scale), f'x3 err {e3:.3e} vs f32-kernel err {e32:.3e} (scale {scale:.3g})'
+    if st is not None:
+        sc, sh = ops.norm_affine(y, None, None, cout, 1e-5, stats=st)
+        sc2, sh2 = ops.norm_affine(y, None, None, cout, 1e-5)
+        check(sc, sc2, 1e-5, 'x3 halo fused stats scale'); check(sh, sh2, 1e-5, 'x3 halo fused stats shift')
+
+
+def test_conv_x3_gather_is_fp32_grade():
+    """KEEP_MMA_X3 gather kernel (token GEMMs, 1x1 / strided convs): fp32-grade against fp64; bias + GELU, residual,
+    per-image GroupNorm prologue, Cin = 48 / 80 (half-empty last 32-channel step), stride-2 Downsample geometry, split-K."""
+    def run(name, x4, w4, b, ref64, **kw):
+        wp = pack(w4)
+        wx3, asc = x3w(wp)
+        ops.DEFAULT.profile = []
+        y = ops.conv(dev(nhwc(x4)), wp, None if b is None else dev(b), mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, **kw)
+        assert ops.DEFAULT.profile[-1][0].startswith('conv_x3_kernel'), (name, ops.DEFAULT.profile[-1][0])
+        ops.DEFAULT.profile = None
+        y32 = ops.conv(dev(nhwc(x4)), wp, None if b is None else dev(b), **kw)
+        e3, e32 = err64(nchw(y), ref64), err64(nchw(y32), ref64)
+        scale = max(1.0, ref64.abs().max().item())
+        assert torch.isfinite(y).all()
+        assert e3 <= max(3.0 * e32, 2e-6 * scale), f'{name}: x3 err {e3:.3e} vs f32-kernel err {e32:.3e} (scale {scale:.3g})'
+    # token GEMM 512 -> 1024 with bias + exact GELU (code transformer MLP)
+    x, w, b = rnd('g3x', (1, 512, 300, 1), 2.0), rnd('g3w', (1024, 512, 1, 1), 0.05), rnd('g3b', (1024,))
+    run('linear+gelu', x, w, b, F.gelu(F.conv2d(x.double(), w.double(), b.double())), pad=0, ksize=1, act=L.ACT_GELU)
+    # Downsample (pad right/bottom, stride 2), Cin = 80
+    x, w, b = rnd('g3dx', (2, 80, 32, 32)), rnd('g3dw', (96, 80, 3, 3), 0.05), rnd('g3db', (96,))
+    run('down', x, w, b, F.conv2d(F.pad(x.double(), (0, 1, 0, 1)), w.double(), b.double(), stride=2), down=True)
+    # 1x1 conv with a per-image GroupNorm prologue (AttnBlock qkv) and a residual, Cin = 48, forced split-K
+    x, w = rnd('g3px', (3, 48, 16, 16), 2.0) - 0.2, rnd('g3pw', (192, 48, 1, 1), 0.1)
+    gamma, beta = rnd('g3pg', (48,)) * 0.2 + 1, rnd('g3pb', (48,)) * 0.2
+    r = rnd('g3pr', (3, 192, 16, 16))
+    xd = dev(nhwc(x))
+    pro = ops.norm_affine(xd, dev(gamma), dev(beta), 16, 1e-6)
+    ref = F.conv2d(F.group_norm(x.double(), 16, gamma.double(), beta.double(), eps=1e-6), w.double()) + r.double()
+    run('1x1 gn', x, w, None, ref, pad=0, ksize=1, pro=pro, residual=dev(nhwc(r)))
+    x, w = rnd('g3sx', (1, 256, 8, 8)), rnd('g3sw', (128, 256, 3, 3), 0.03)
+    run('3x3 s2 split-k', x, w, None, F.conv2d(x.double(), w.double(), stride=2, padding=1), stride=2, pad=1, split_k=5)
+
+
+def test_x3_subnormal_lo():
+    """The x3 scheme relies on v_mfma_f32_32x32x16_f16 keeping SUBNORMAL fp16 inputs (gfx90a flushed them): activations of
+    ~5e-3 have lo = x - fp16(x) ~ 1e-6, deep in the fp16 subnormal range.  Flushed lo terms would leave a 2^-12 = 2.4e-4
+    relative error; kept, the error is the 2^-25 absolute floor of a subnormal lo (~1e-5 relative here)."""
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand((1, 64, 16, 32), generator=g) * 4e-3 + 3e-3)
+    w = torch.ones((64, 64, 3, 3)) * 0.5                       # exactly representable: w_lo = 0, only a_lo * w_hi matters
+    wp = pack(w)
+    wx3 = ops.split_x3(wp.reshape(-1, 64), 1.0).view(-1)
+    y = ops.conv(dev(nhwc(x)), wp, None, mma=L.MMA_X3, wx3=wx3, x3_acc_scale=1.0)
+    ref = F.conv2d(x.double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    rel = ((y.double().cpu() - ref).abs() / ref.abs()).max().item()
+    assert rel < 2e-5, f'relative error {rel:.3e}: fp16 subnormals are being flushed by the matrix pipe'
+
+
+def test_x3_overflow_is_loud():
+    """An activation beyond the fp16 range does not produce a silently wrong value: the output is non-finite (the engine
+    checks and re-runs the clip on the exact-f32 kernels)."""
+    x = torch.ones((1, 32, 16, 16)) * 1e5
+    w = rnd('ovw', (32, 32, 3, 3), 0.05)
+    wp = pack(w)
+    wx3, asc = x3w(wp)
+    y = ops.conv(dev(nhwc(x)), wp, None, mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc)
+    assert not torch.isfinite(y).all()
 
 
 def test_conv3x3_small_cout_valu_kernel(monkeypatch):
@@ -93,10 +202,8 @@ def test_conv3x3_small_cout_valu_kernel(monkeypatch):
         xd = dev(nhwc(x))
         pro = ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6)
         y = ops.conv(xd, pack(w), dev(b), pro=pro)
-        monkeypatch.setattr(ops, 'COUT4', False)
         monkeypatch.setenv('KEEP_NO_COUT4', '1')
         y_g = ops.conv(xd, pack(w), dev(b), pro=pro)
-        monkeypatch.setattr(ops, 'COUT4', True)
         monkeypatch.delenv('KEEP_NO_COUT4')
         ref = F.conv2d(F.group_norm(x, 32, gamma, beta, eps=1e-6), w, b, padding=1)
         check(nchw(y), ref, what=f'cout{cout} valu vs torch')
@@ -510,20 +617,20 @@ def test_conv_epilogue_stats_match_standalone(mma):
     gamma, beta = rnd('esg', (128,)) * 0.2 + 1, rnd('esbt', (128,)) * 0.2
     wp = pack(w)
     kw = dict(mma=mma, wb=wp.to(torch.bfloat16)) if mma else {}
-    y = ops.conv(dev(nhwc(x)), wp, dev(b), residual=dev(nhwc(res)), stats=True, split_k=1, **kw)
-    assert hasattr(y, '_keep_stats')
-    sc, sh = ops.norm_affine(y, dev(gamma), dev(beta), 32, 1e-6)
-    y2 = y.clone()                                       # no fused stats attached -> standalone kernels
-    sc2, sh2 = ops.norm_affine(y2, dev(gamma), dev(beta), 32, 1e-6)
+    y, st = ops.conv(dev(nhwc(x)), wp, dev(b), residual=dev(nhwc(res)), stats=True, split_k=1, **kw)
+    assert st is not None
+    sc, sh = ops.norm_affine(y, dev(gamma), dev(beta), 32, 1e-6, stats=st)
+    sc2, sh2 = ops.norm_affine(y, dev(gamma), dev(beta), 32, 1e-6)      # no fused stats -> standalone kernels
     check(sc, sc2, 1e-5, 'scale'); check(sh, sh2, 1e-5, 'shift')
     h = F.group_norm(nchw(y).cpu(), 32, gamma, beta, eps=1e-6)
     got = y.cpu() * sc.cpu()[:, None, None, :] + sh.cpu()[:, None, None, :]
     check(got, nhwc(h), 2e-5, 'fused stats -> group norm')
     # 1x1 / strided producers through the gather kernels
-    y = ops.conv(dev(nhwc(x)), dev(rnd('esw1', (96, 64)) * 0.1).view(96, 1, 1, 64), None, stride=2, pad=0, ksize=1, stats=True, split_k=1,
-                 **(dict(mma=1, wb=(dev(rnd('esw1', (96, 64)) * 0.1)).to(torch.bfloat16)) if mma else {}))
-    sc, sh = ops.norm_affine(y, None, None, 96, 1e-5)
-    sc2, sh2 = ops.norm_affine(y.clone(), None, None, 96, 1e-5)
+    y, st = ops.conv(dev(nhwc(x)), dev(rnd('esw1', (96, 64)) * 0.1).view(96, 1, 1, 64), None, stride=2, pad=0, ksize=1, stats=True,
+                     split_k=1, **(dict(mma=1, wb=(dev(rnd('esw1', (96, 64)) * 0.1)).to(torch.bfloat16)) if mma else {}))
+    assert st is not None
+    sc, sh = ops.norm_affine(y, None, None, 96, 1e-5, stats=st)
+    sc2, sh2 = ops.norm_affine(y, None, None, 96, 1e-5)
     check(sc, sc2, 1e-5, 'in scale'); check(sh, sh2, 1e-5, 'in shift')
 
 
@@ -534,15 +641,15 @@ def test_conv_bf16_halo_bf16_output_and_bf16_inputs():
     wp = pack(w)
     wb = wp.to(torch.bfloat16)
     xd = dev(nhwc(x))
-    y32 = ops.conv(xd, wp, dev(b), mma=L.MMA_BF16, wb=wb, stats=True, split_k=1)
-    y16 = ops.conv(xd, wp, dev(b), mma=L.MMA_BF16, wb=wb, stats=True, out_bf16=True)
-    assert y16.dtype == torch.bfloat16 and hasattr(y16, '_keep_stats')
+    y32, st32 = ops.conv(xd, wp, dev(b), mma=L.MMA_BF16, wb=wb, stats=True, split_k=1)
+    y16, st16 = ops.conv(xd, wp, dev(b), mma=L.MMA_BF16, wb=wb, stats=True, out_bf16=True)
+    assert y16.dtype == torch.bfloat16 and st16 is not None
     check(y16.float(), bf16r(y32.cpu()), 1e-6, 'halo bf16 output == RNE(fp32 output)')
-    check(y16._keep_stats[0], y32._keep_stats[0], 1e-6, 'stats taken before rounding')
+    check(st16[0], st32[0], 1e-6, 'stats taken before rounding')
     # (b) GN + swish pass from the bf16 tensor, then the second halo conv
     gamma, beta = rnd('hbg', (128,)) * 0.2 + 1, rnd('hbbt', (128,)) * 0.2
     w2 = rnd('hbw2', (64, 128, 3, 3), 0.05)
-    pro = ops.norm_affine(y16, dev(gamma), dev(beta), 32, 1e-6)
+    pro = ops.norm_affine(y16, dev(gamma), dev(beta), 32, 1e-6, stats=st16)
     z = ops.conv(y16, pack(w2), None, pro=pro, pro_act=L.PRO_SWISH, mma=L.MMA_BF16, wb=pack(w2).to(torch.bfloat16))
     sc, sh = pro[0].cpu(), pro[1].cpu()
     hn = y16.float().cpu() * sc[:, None, None, :] + sh[:, None, None, :]
@@ -600,19 +707,17 @@ def test_conv_bf16_rgb_first_conv_kernel(monkeypatch):
         x, w, b = rnd('c3x', (n, cin, h, wd)), rnd('c3w', (cout, cin, 3, 3), 0.2), rnd('c3b', (cout,))
         wp = pack(w)
         wb = wp.to(torch.bfloat16)
-        ops.PROFILE = []
-        y = ops.conv(dev(nhwc(x)), wp, dev(b), mma=L.MMA_BF16, wb=wb, stats=True)
-        assert ops.PROFILE[-1][0] == 'conv3x3_c3_kernel'
-        ops.PROFILE = None
-        monkeypatch.setattr(ops, 'C3', False)
+        ops.DEFAULT.profile = []
+        y, st = ops.conv(dev(nhwc(x)), wp, dev(b), mma=L.MMA_BF16, wb=wb, stats=True)
+        assert ops.DEFAULT.profile[-1][0] == 'conv3x3_c3_kernel' and st is not None
+        ops.DEFAULT.profile = None
         monkeypatch.setenv('KEEP_NO_C3', '1')
-        y_g = ops.conv(dev(nhwc(x)), wp, dev(b), mma=L.MMA_BF16, wb=wb, stats=True)
-        monkeypatch.setattr(ops, 'C3', True)
+        y_g, _ = ops.conv(dev(nhwc(x)), wp, dev(b), mma=L.MMA_BF16, wb=wb, stats=True)
         monkeypatch.delenv('KEEP_NO_C3')
         check(nchw(y), F.conv2d(bf16r(x), bf16r(w), b, padding=1), 2e-5, f'rgb conv {cin}->{cout}')
         check(y, y_g, 2e-5, 'rgb conv vs flat-K gather kernel')
-        sc, sh = ops.norm_affine(y, None, None, cout, 1e-5)
-        sc2, sh2 = ops.norm_affine(y.clone(), None, None, cout, 1e-5)
+        sc, sh = ops.norm_affine(y, None, None, cout, 1e-5, stats=st)
+        sc2, sh2 = ops.norm_affine(y, None, None, cout, 1e-5)
         check(sc, sc2, 1e-5, 'rgb conv fused stats scale'); check(sh, sh2, 1e-5, 'rgb conv fused stats shift')
 
 
@@ -626,13 +731,14 @@ def test_conv_bf16_halo_fused_prologue_variant(monkeypatch):
     xd = dev(nhwc(x))
     wp = pack(w)
     pro = ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6)
-    y = ops.conv(xd, wp, dev(b), pro=pro, pro_act=L.PRO_SWISH, residual=dev(nhwc(res)), mma=L.MMA_BF16,
-                 wb=wp.to(torch.bfloat16), stats=True, split_k=1)
+    y, st = ops.conv(xd, wp, dev(b), pro=pro, pro_act=L.PRO_SWISH, residual=dev(nhwc(res)), mma=L.MMA_BF16,
+                     wb=wp.to(torch.bfloat16), stats=True, split_k=1)
+    assert st is not None
     hn = F.group_norm(x, 32, gamma, beta, eps=1e-6)
     hn = bf16r(hn * torch.sigmoid(hn))
     check(nchw(y), F.conv2d(hn, bf16r(w), b, padding=1) + res, 3e-4, 'halo with fused GN+swish prologue')
-    sc, sh = ops.norm_affine(y, None, None, 128, 1e-5)
-    sc2, sh2 = ops.norm_affine(y.clone(), None, None, 128, 1e-5)
+    sc, sh = ops.norm_affine(y, None, None, 128, 1e-5, stats=st)
+    sc2, sh2 = ops.norm_affine(y, None, None, 128, 1e-5)
     check(sc, sc2, 1e-5, 'fused-prologue halo stats scale'); check(sh, sh2, 1e-5, 'fused-prologue halo stats shift')
 
 
@@ -643,7 +749,7 @@ def test_conv_bf16_flat_k_small_cin():
     check(nchw(y), F.conv2d(bf16r(x), bf16r(w), None, stride=2, padding=3), 2e-5, 'flat-K 7x7 s2')
     x, w, b = rnd('3x', (2, 3, 32, 32)), rnd('3w', (64, 3, 3, 3), 0.2), rnd('3b', (64,))
     wp = pack(w)
-    y = ops.conv(dev(nhwc(x)), wp, dev(b), mma=L.MMA_BF16, wb=wp.to(torch.bfloat16), stats=True)
+    y, _ = ops.conv(dev(nhwc(x)), wp, dev(b), mma=L.MMA_BF16, wb=wp.to(torch.bfloat16), stats=True)
     check(nchw(y), F.conv2d(bf16r(x), bf16r(w), b, padding=1), 2e-5, 'flat-K 3x3')
 
 

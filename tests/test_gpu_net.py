@@ -41,19 +41,19 @@ def close(got, ref, tol, what):
 
 def test_resblock_down_up_attn_vs_golden(gpu_net):
     net = gpu_net
-    close(nchw(net._resblock(nhwc(op_input('res_same', (1, 128, 16, 16))), 'encoder.blocks.5')), OPS['res_same'], 3e-4, 'res')
-    close(nchw(net._resblock(nhwc(op_input('res_proj', (1, 64, 16, 16))), 'encoder.blocks.4')), OPS['res_proj'], 3e-4, 'res proj')
+    close(nchw(net._resblock(nhwc(op_input('res_same', (1, 128, 16, 16))), 'encoder.blocks.5')[0]), OPS['res_same'], 3e-4, 'res')
+    close(nchw(net._resblock(nhwc(op_input('res_proj', (1, 64, 16, 16))), 'encoder.blocks.4')[0]), OPS['res_proj'], 3e-4, 'res proj')
     w = net.w
-    y = ops.conv(nhwc(op_input('down', (1, 128, 16, 16))), w['encoder.blocks.6.conv.weight'], w['encoder.blocks.6.conv.bias'], down=True)
+    y = net.o.conv(nhwc(op_input('down', (1, 128, 16, 16))), w['encoder.blocks.6.conv.weight'], w['encoder.blocks.6.conv.bias'], down=True)
     close(nchw(y), OPS['down'], 3e-4, 'down')
-    y = ops.conv(nhwc(op_input('up', (1, 128, 8, 8))), w['generator.blocks.17.conv.weight'], w['generator.blocks.17.conv.bias'], upsample=True)
+    y = net.o.conv(nhwc(op_input('up', (1, 128, 8, 8))), w['generator.blocks.17.conv.weight'], w['generator.blocks.17.conv.bias'], upsample=True)
     close(nchw(y), OPS['up'], 3e-4, 'up')
     close(nchw(net._attnblock(nhwc(op_input('attn', (1, 512, 8, 8))), 'encoder.blocks.17')), OPS['attn'], 3e-4, 'attnblock')
 
 
 def test_cft_cfa_vs_golden(gpu_net):
     net = gpu_net
-    y = net._cft(nhwc(op_input('cft_enc', (1, 256, 8, 8))), nhwc(op_input('cft_dec', (1, 256, 8, 8))), 'cft.32')
+    y, _ = net._cft(nhwc(op_input('cft_enc', (1, 256, 8, 8))), nhwc(op_input('cft_dec', (1, 256, 8, 8))), 'cft.32')
     close(nchw(y), OPS['cft'], 3e-4, 'cft')
     y = net._cfa(nhwc(op_input('cfa_curr', (1, 256, 8, 8))), nhwc(op_input('cfa_prev', (1, 256, 8, 8))), 'cfa.32')
     close(nchw(y), OPS['cfa'], 3e-4, 'cfa')
@@ -271,6 +271,7 @@ def test_bf16_policy_quality_report(gpu_net):
     bounded loosely here; the <=1e-3 bound is the fp32 policy's."""
     g = np.load(os.path.join(GOLDEN, 'keep_forward_T3.npz'))
     x = synth.synth_clip(T=3, B=1, seed=1234).cuda()
+    own = gpu_net.precision
     gpu_net.set_precision('bf16')
     try:
         out, aux = gpu_net(x, return_aux=True)
@@ -287,4 +288,5 @@ def test_bf16_policy_quality_report(gpu_net):
         assert agree[0].mean() >= 0.9 and agree[0][g['margins'][0] > 0.5].mean() >= 0.97
         assert err_f <= 0.5 and gain_err <= 0.05
     finally:
-        gpu_net.set_precision('fp32')
+        gpu_net.set_precision(own)
+        gpu_net._activate_precision()

@@ -40,6 +40,9 @@ def run(name, mma, in_bf16, iters=20):
     if in_bf16:
         pro = (torch.ones(N, Cin, device='cuda'), torch.zeros(N, Cin, device='cuda'))
     kw = dict(pad=k // 2, ksize=k, upsample=up, mma=mma, wb=wb, stats=True)
+    if mma == L.MMA_X3:
+        sc = ops.x3_scale_for(float(w.abs().max()))
+        kw.update(wx3=ops.split_x3(w.reshape(-1, Cin), sc).view(-1), x3_acc_scale=1.0 / sc)
     if os.environ.get('RES'):
         Ho, Wo = (2 * H, 2 * W) if up else (H, W)
         kw['residual'] = torch.randn(N, Ho, Wo, Cout, device='cuda')
@@ -50,14 +53,14 @@ def run(name, mma, in_bf16, iters=20):
     for _ in range(3):
         y = ops.conv(x, w, b, **kw)
     torch.cuda.synchronize()
-    ops.PROFILE = []
+    ops.DEFAULT.profile = []
     for _ in range(iters):
         y = ops.conv(x, w, b, **kw)
     torch.cuda.synchronize()
-    rec, ops.PROFILE = ops.PROFILE, None
+    rec, ops.DEFAULT.profile = ops.DEFAULT.profile, None
     ms = sum(r[3].elapsed_time(r[4]) for r in rec) / len(rec)
     fl = rec[0][1]
-    print(f"{name:10s} mma={'bf16' if mma else 'f32 '} pre-activated-bf16-input={in_bf16!s:5s} kernel={rec[0][0]:22s} "
+    print(f"{name:10s} mma={('f32 ', 'bf16', 'x3  ')[mma]} pre-activated-bf16-input={in_bf16!s:5s} kernel={rec[0][0]:22s} "
           f"{ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s (incl. the norm_act pass when present)")
     return y
 
@@ -67,6 +70,12 @@ if __name__ == '__main__':
     if os.environ.get('F32'):
         for n in names:
             run(n, L.MMA_F32, False)
+        sys.exit(0)
+    if os.environ.get('X3'):      # split fp16: plain input, and with the fused GroupNorm affine + swish prologue
+        for n in names:
+            run(n, L.MMA_X3, False)
+            if LAYERS[n][5] == 3:
+                run(n, L.MMA_X3, True)
         sys.exit(0)
     for n in names:
         run(n, L.MMA_BF16, False)

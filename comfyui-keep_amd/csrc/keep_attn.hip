@@ -31,7 +31,23 @@ struct AttnP {
   int mode, T, seg_len;
   int img_h, img_w, ksplit, shift, kv_rot, n_img;
   int nslices;  // dv slices per head
+  const float* q_amax;   // KEEP_MMA_X3 range probes ([B] each) or NULL
+  const float* k_amax;
+  const float* v_amax;
 };
+
+// KEEP_MMA_X3 range scaling (same rule as keep_conv_common.h): power of two s with amax * s in [2^14, 2^15), and 1/s
+__device__ __forceinline__ void attn_range_scale(float amax, float& s, float& inv_s) {
+  int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+  if (!(amax > 0.f) || e == 255) {
+    s = 1.f;
+    inv_s = 1.f;
+    return;
+  }
+  e = e < 15 ? 15 : e;
+  s = __uint_as_float((unsigned)(268 - e) << 23);
+  inv_s = __uint_as_float((unsigned)(e - 14) << 23);
+}
 
 // window-mode: token t of window-batch bw -> (image, pixel index)
 __device__ __forceinline__ void win_decode(const AttnP& p, int bw, int t, int rot, int& img, int& pix) {
@@ -603,9 +619,19 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_x3_kern
   const int q0 = blockIdx.x * (WAVES * 32);
   const long qh = (long)head * p.q_hs, kh = (long)head * p.k_hs, vh = (long)head * p.v_hs;
   const int g4n = DC >> 2;
+  // range scales of un-normalised operands (mode 0, host-probed): q, k, v are multiplied by powers of two before the
+  // split; the score scale and the output normalisation absorb the inverses (all exact)
+  float sq = 1.f, sk = 1.f, sv = 1.f, inv_qk = 1.f, inv_sv = 1.f;
+  if (p.q_amax) {
+    float iq, ik;
+    attn_range_scale(p.q_amax[b], sq, iq);
+    attn_range_scale(p.k_amax[b], sk, ik);
+    attn_range_scale(p.v_amax[b], sv, inv_sv);
+    inv_qk = iq * ik;
+  }
 
-  auto split8 = [&](const float4 a, const float4 c, af16x8& hi, af16x8& lo) {
-    const float f[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+  auto split8 = [&](const float4 a, const float4 c, float sc, af16x8& hi, af16x8& lo) {
+    const float f[8] = {a.x * sc, a.y * sc, a.z * sc, a.w * sc, c.x * sc, c.y * sc, c.z * sc, c.w * sc};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const _Float16 h = (_Float16)f[j];
@@ -613,8 +639,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_x3_kern
       lo[j] = (_Float16)(f[j] - (float)h);
     }
   };
-  auto split_store4 = [&](const float4 v, _Float16* dst) {      // dst -> hi; lo lives DC elements further
-    const float f[4] = {v.x, v.y, v.z, v.w};
+  auto split_store4 = [&](const float4 v, float sc, _Float16* dst) {      // dst -> hi; lo lives DC elements further
+    const float f[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
     af16x4 hi, lo;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -633,7 +659,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_x3_kern
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (t < tmax)
         v = *reinterpret_cast<const float4*>(base + (is_q ? q_offset(p, b, t, bs, ts) : kv_offset(p, b, t, bs, ts)) + hoff + c0 + c);
-      split_store4(v, dst + row * QP + c);
+      split_store4(v, is_q ? sq : sk, dst + row * QP + c);
     }
   };
   auto stage_vt = [&](int kt) {      // lane <-> dv column (coalesced 4-byte reads), two consecutive keys per item
@@ -648,9 +674,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_x3_kern
       af16x2 hi, lo;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const _Float16 h = (_Float16)v[j];
+        const float vs = v[j] * sv;
+        const _Float16 h = (_Float16)vs;
         hi[j] = h;
-        lo[j] = (_Float16)(v[j] - (float)h);
+        lo[j] = (_Float16)(vs - (float)h);
       }
       _Float16* d = Vt + dv * VP + vt_pos(pair * 2);          // vt_pos(k0+1) = vt_pos(k0) + 1 for even k0
       *reinterpret_cast<af16x2*>(d) = hi;
@@ -678,7 +705,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_x3_kern
       const int i = tid + u * NT;
       if (i < 32 * g4n) {
         const int row = i / g4n, c = (i - row * g4n) << 2;
-        split_store4(kreg[u], Ks + row * QP + c);
+        split_store4(kreg[u], sk, Ks + row * QP + c);
       }
     }
   };
@@ -707,9 +734,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_x3_kern
         af16x2 hi, lo;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const _Float16 h = (_Float16)vreg[u][j];
+          const float vs = vreg[u][j] * sv;
+          const _Float16 h = (_Float16)vs;
           hi[j] = h;
-          lo[j] = (_Float16)(vreg[u][j] - (float)h);
+          lo[j] = (_Float16)(vs - (float)h);
         }
         _Float16* d = Vt + dv * VP + vt_pos(pair * 2);
         *reinterpret_cast<af16x2*>(d) = hi;
@@ -731,7 +759,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_x3_kern
         a = *reinterpret_cast<const float4*>(qrow + d8 * 16);
         c = *reinterpret_cast<const float4*>(qrow + d8 * 16 + 4);
       }
-      split8(a, c, qfh[QREG ? d8 : 0], qfl[QREG ? d8 : 0]);
+      split8(a, c, sq, qfh[QREG ? d8 : 0], qfl[QREG ? d8 : 0]);
     }
   }
   if (PF) {
@@ -744,6 +772,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_x3_kern
   int my_region = 0;
   if (p.mode == 2 && p.shift > 0 && my_q < p.Lq) my_region = win_region(p, b, my_q);
 
+  const float qk_scale = p.scale * inv_qk;
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 o[DVT];
 #pragma unroll
@@ -801,7 +830,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_x3_kern
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      float val = s[r] * p.scale;
+      float val = s[r] * qk_scale;
       if (p.mode == 2 && p.shift > 0 && key < p.Lk) {
         if (win_region(p, b, key) != my_region) val += -100.0f;
       }
@@ -855,7 +884,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_x3_kern
     }
   }
 
-  const float inv_l = 1.0f / l_run;
+  const float inv_l = inv_sv / l_run;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -1291,6 +1320,9 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
   p.scale = a->scale; p.mode = a->mode; p.T = a->T; p.seg_len = a->seg_len;
   p.img_h = a->img_h; p.img_w = a->img_w; p.ksplit = a->ksplit; p.shift = a->shift; p.kv_rot = a->kv_rot;
   p.n_img = a->n_img;
+  p.q_amax = a->q_amax; p.k_amax = a->k_amax; p.v_amax = a->v_amax;
+  KEEP_REQUIRE((!a->q_amax && !a->k_amax && !a->v_amax) || (a->q_amax && a->k_amax && a->v_amax && a->mode == 0 && a->mma == KEEP_MMA_X3),
+               "keep_attention: q/k/v_amax come together, with KEEP_MMA_X3 and mode 0 only");
   hipStream_t st = (hipStream_t)stream;
   // dv slice per block: 32 / 64 / 128 columns
   const int dvt = a->Dv <= 32 ? 1 : (a->Dv <= 64 ? 2 : 4);

@@ -1649,10 +1649,11 @@ int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 bool keep_conv_x3_halo_ok(const keep_conv2d_args* a);
 bool keep_conv_x3_gather_ok(const keep_conv2d_args* a, const ConvP& p);
+int keep_conv_x3_halo_variant(const keep_conv2d_args* a, int split_k);
 
 enum ConvPath {
   PATH_COUT4 = 0, PATH_C3, PATH_HALO_F32, PATH_HALO_BF16, PATH_HALO_BF16_V1, PATH_GATHER_BF16, PATH_GATHER_F32, PATH_HALO_X3,
-  PATH_GATHER_X3
+  PATH_GATHER_X3, PATH_NEEDS_PRENORM
 };
 
 struct ConvPlan {
@@ -1712,6 +1713,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   p.wb = (const unsigned short*)a->weight_bf16;
   p.wx3 = (const unsigned short*)a->weight_x3;
   p.acc_scale = a->x3_acc_scale;
+  p.in_amax = a->x3_in_amax;
   p.bias = a->bias;
   p.out = (float*)a->out;
   p.pro_scale = a->pro_scale;
@@ -1782,7 +1784,15 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
       pl.split_k = a->split_k > 0 ? a->split_k : auto_split;
       if (pl.split_k > a->Cin / 16) pl.split_k = a->Cin / 16;
       pl.stats_rows = 64;
-      snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3_kernel<%d>", pl.wide ? 32 : 16);
+      const int variant = keep_conv_x3_halo_variant(a, pl.split_k);
+      if (variant == 2) {
+        snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3g_kernel");
+        pl.stats_rows = 32;      // one partial per DPP row (16 lanes x 2 tile rows)
+      } else if (variant == 1) {
+        snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3p_kernel");
+      } else {
+        snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3_kernel<%d>", pl.wide ? 32 : 16);
+      }
       return KEEP_OK;
     }
     if (have_w && keep_conv_x3_gather_ok(a, p) && !getenv("KEEP_NO_GATHER_X3")) {
@@ -1827,7 +1837,13 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
     const bool out16_ok = no_pro && !a->residual && a->split_k <= 1 && a->Cout % 64 == 0 && halo_ver == 3;
     pl.out_bf16_ok = out16_ok ? 1 : 0;
     // an fp32 input with a prologue: the host should run keep_norm_act_bf16 first and come back with a bf16 tensor
-    pl.wants_bf16_input = (a->dtype == KEEP_F32 && !no_pro && halo_ver == 3 && (a->Cout % 64 == 0 || a->Cout % 32 == 0)) ? 1 : 0;
+    pl.wants_bf16_input = (!no_pro && halo_ver == 3) ? 1 : 0;
+    if (p.in_bf16 && !no_pro) {      // a bf16 tensor that still carries a prologue: only the two-pass form exists
+      pl.path = PATH_NEEDS_PRENORM;
+      pl.split_k = 1;
+      snprintf(pl.kernel, sizeof(pl.kernel), "(keep_norm_act_bf16 first)");
+      return KEEP_OK;
+    }
     const bool ok = (a->dtype == KEEP_F32 || no_pro) && pro_al && (a->out_dtype != KEEP_BF16 || out16_ok) &&
                     (a->Cout % 64 == 0 || v3);
     if (ok) {
@@ -1918,6 +1934,10 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
   ConvPlan pl;
   rc = plan_conv(a, p, pl);
   if (rc != KEEP_OK) return rc;
+  if (pl.path == PATH_NEEDS_PRENORM) {
+    keep_set_error("keep_conv2d: a bf16 input with a prologue must go through keep_norm_act_bf16 first (keep_conv2d_plan: wants_bf16_input)");
+    return KEEP_EUNSUP;
+  }
   p.split_k = pl.split_k;
   KEEP_REQUIRE(p.split_k == 1 || a->workspace, "keep_conv2d: split_k>1 requires a workspace (keep_conv2d_plan gives its size)");
   const long M = p.M;
@@ -2053,6 +2073,8 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
       KEEP_LAUNCH_CHECK("keep_conv2d(gather f32)");
       break;
     }
+    case PATH_NEEDS_PRENORM:
+      break;
   }
   if (p.split_k > 1) {
     const long total = M * a->Cout;

@@ -37,7 +37,22 @@ struct ConvP {
   int flatk_f32;  // the same for the f32 gather kernel (16-wide K steps)
   const unsigned short* wx3;  // KEEP_MMA_X3: weights pre-multiplied by 2^e and split into fp16 (hi, lo), [Cout][KH*KW][Cin/16][hi16|lo16]
   float acc_scale;            // KEEP_MMA_X3: 2^-e, applied to the accumulators before bias / activation
+  const float* in_amax;       // KEEP_MMA_X3: per-image max |input| (NULL: inputs are split unscaled)
 };
+
+// KEEP_MMA_X3 range scaling: the power of two s with amax * s in [2^14, 2^15) (fp16 max 65504), and 1/s.  amax = 0 (or a
+// denormal) -> 1; inf / NaN propagate through the data itself.
+__device__ __forceinline__ void x3_range_scale(float amax, float& s, float& inv_s) {
+  int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+  if (!(amax > 0.f) || e == 255) {
+    s = 1.f;
+    inv_s = 1.f;
+    return;
+  }
+  e = e < 15 ? 15 : e;
+  s = __uint_as_float((unsigned)(268 - e) << 23);
+  inv_s = __uint_as_float((unsigned)(e - 14) << 23);
+}
 
 __device__ __forceinline__ float epilogue_one(const ConvP& p, float v, long m, int co) {
   if (p.bias) v += p.bias[co];

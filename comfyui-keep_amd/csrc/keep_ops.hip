@@ -522,6 +522,7 @@ __global__ __launch_bounds__(256) void argmax_gather_kernel(const float* __restr
   }
   int sel = bi;
   if (force_idx) sel = force_idx[row];
+  if (sel < 0 || sel >= ncodes) sel = 0;   // all-NaN logits (or a bad forced index) must not turn into a wild gather
   if (lane == 0) {
     if (idx) idx[row] = sel;
     if (margin) margin[row] = best - second;
@@ -877,5 +878,56 @@ extern "C" int32_t keep_img2tensor(const uint8_t* x, float* out, int64_t npix, v
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(img2tensor_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)npix);
   KEEP_LAUNCH_CHECK("keep_img2tensor");
+  return KEEP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ range probe (KEEP_MMA_X3)
+// amax[n] = max |x| over image n: the fp16 split of an un-normalised tensor needs its range (keep_conv2d x3_in_amax,
+// keep_attention q/k/v_amax).  |x| as raw bits is monotonic in the value, so a plain unsigned atomicMax is exact and
+// order-independent (NaN bit patterns compare above inf and surface as NaN in amax -> the consumers propagate them).
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, unsigned* __restrict__ amax_bits, long R, int C,
+                                                     long ld, long img_stride) {
+  const int n = blockIdx.y;
+  const float* xi = x + (long)n * img_stride;
+  unsigned m = 0u;
+  const bool vec = (C % 4 == 0) && (ld % 4 == 0) && (img_stride % 4 == 0) && ((uintptr_t)x % 16 == 0);
+  if (vec) {
+    const int c4n = C >> 2;
+    const long total = R * c4n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+      const long r = i / c4n;
+      const int c = (int)(i - r * c4n) << 2;
+      const uint4 v = *reinterpret_cast<const uint4*>(xi + r * ld + c);
+      m = max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+    }
+  } else {
+    const long total = R * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+      const long r = i / C;
+      const int c = (int)(i - r * C);
+      m = max(m, __float_as_uint(xi[r * ld + c]) & 0x7fffffffu);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(amax_bits + n, m);
+}
+
+extern "C" int32_t keep_absmax(const float* x, float* amax, int32_t N, int64_t R, int32_t C, int64_t ld, int64_t img_stride,
+                               void* stream) {
+  KEEP_REQUIRE(x && amax && N > 0 && R > 0 && C > 0 && ld >= C, "keep_absmax: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(amax, 0, (size_t)N * sizeof(float), st);
+  if (e != hipSuccess) {
+    keep_set_error("keep_absmax: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    return KEEP_EHIP;
+  }
+  // ~8 float4 per thread, at most ~2048 blocks over all images
+  const long work = (R * C / 4 + 2047) / 2048;
+  const long cap = 2048 / N > 1 ? 2048 / N : 1;
+  int bx = (int)(work < 1 ? 1 : (work > cap ? cap : work));
+  hipLaunchKernelGGL(absmax_kernel, dim3(bx, N), dim3(256), 0, st, x, reinterpret_cast<unsigned*>(amax), (long)R, C, (long)ld,
+                     (long)img_stride);
+  KEEP_LAUNCH_CHECK("keep_absmax");
   return KEEP_OK;
 }

@@ -28,7 +28,7 @@ class ConvArgs(C.Structure):
                [(n, _i32) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad_t', 'pad_l', 'Ho', 'Wo',
                                     'in_ld', 'out_ld', 'res_ld', 'upsample', 'pro_act', 'epi_act')] + \
                [('aux_w', _f32), ('split_k', _i32), ('dtype', _i32), ('mma', _i32), ('weight_bf16', _vp), ('stats_out', _vp), ('stats_P', _i32), ('bk256', _i32), ('out_dtype', _i32),
-                ('weight_x3', _vp), ('x3_acc_scale', _f32)]
+                ('weight_x3', _vp), ('x3_acc_scale', _f32), ('x3_in_amax', _vp)]
 
 
 class ConvPlanOut(C.Structure):
@@ -41,7 +41,8 @@ class AttnArgs(C.Structure):
                [(n, _i64) for n in ('q_bs', 'q_ts', 'q_hs', 'k_bs', 'k_ts', 'k_hs', 'v_bs', 'v_ts', 'v_hs',
                                     'o_bs', 'o_ts', 'o_hs')] + \
                [(n, _i32) for n in ('B', 'H', 'Lq', 'Lk', 'D', 'Dv')] + [('scale', _f32), ('mode', _i32)] + \
-               [(n, _i32) for n in ('T', 'seg_len', 'img_h', 'img_w', 'ksplit', 'shift', 'kv_rot', 'n_img', 'mma', 'in_dtype')]
+               [(n, _i32) for n in ('T', 'seg_len', 'img_h', 'img_w', 'ksplit', 'shift', 'kv_rot', 'n_img', 'mma', 'in_dtype')] + \
+               [('q_amax', _vp), ('k_amax', _vp), ('v_amax', _vp)]
 
 
 # name -> argtypes (restype is always int32 status); every symbol include/keep_hip.h declares
@@ -57,6 +58,7 @@ _SIGNATURES = {
     'keep_token_linear': [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
     'keep_norm_act_bf16': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     'keep_gm_join': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    'keep_absmax': [_vp, _vp, _i32, _i64, _i32, _i64, _i64, _vp],
     'keep_layernorm': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp],
     'keep_geglu': [_vp, _vp, _i32, _i32, _vp],
     'keep_argmax_gather': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],

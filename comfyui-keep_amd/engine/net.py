@@ -31,6 +31,7 @@ _KNOWN_KW = set(DEFAULT_ARCH) | {
 FUSED_GM_MLP = os.environ.get('KEEP_NO_FUSED_MLP') is None     # dev switch
 # 'x3': split-fp16 operands on the 16-bit matrix pipe (fp32-grade products, csrc/keep_conv_x3.hip) -- the default: it
 # passes the same <= 1e-3 parity tests as 'fp32' (exact f32 MFMA everywhere) at several times its speed.
+CHECK_X3_RANGE = os.environ.get('KEEP_X3_NO_RANGE_CHECK') is None
 PRECISIONS = ('fp32', 'x3', 'bf16')
 DEFAULT_PRECISION = 'x3'
 
@@ -58,6 +59,7 @@ class KeepNet:
         self._dev_blobx3 = None    # split-fp16 twin (2 x int16 per weight) for the x3 policy
         self._x3_scale = 1.0       # power of two the x3 weights were multiplied by
         self.o = ops.Ops()         # this net's precision policy + weight twins (never shared between nets)
+        self.x3_fallbacks = 0      # batches the x3 policy handed back to the f32 kernels (non-finite output)
         self.precision = 'fp32'
         self.set_precision(os.environ.get('KEEP_AMD_PRECISION', DEFAULT_PRECISION))
 
@@ -190,7 +192,7 @@ class KeepNet:
         s3 = (HW * 3 * C, 3 * C, 0)
         self.o.attention(qkv, ops.offset(qkv, C), ops.offset(qkv, 2 * C), o, B=N, H=1, Lq=HW, Lk=HW, D=C, Dv=C,
                       scale=int(C) ** (-0.5), q_str=s3, k_str=s3, v_str=s3, o_str=(HW * C, C, 0))
-        y = self.o.linear(o, w[f'{p}.proj_out.weight'], w[f'{p}.proj_out.bias'], residual=x.view(N * HW, C))
+        y = self.o.linear(o, w[f'{p}.proj_out.weight'], w[f'{p}.proj_out.bias'], residual=x.view(N * HW, C), bounded=True)
         return y.view(N, H, Wd, C)
 
     def _vq_stack(self, x, prefix, blocks, taps=(), hook=None):
@@ -235,18 +237,18 @@ class KeepNet:
             p = f'ft_layers.{i}'
             x2, qk_in = ops.layernorm(q, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], pos=pos)
             wi, bi = w[f'{p}.self_attn.in_proj_weight'], w[f'{p}.self_attn.in_proj_bias']
-            qk = self.o.linear(qk_in, wi[:2 * D], bi[:2 * D], out_bf16=True)
-            v = self.o.linear(x2, wi[2 * D:], bi[2 * D:], out_bf16=True)
+            qk = self.o.linear(qk_in, wi[:2 * D], bi[:2 * D], out_bf16=True, bounded=True)
+            v = self.o.linear(x2, wi[2 * D:], bi[2 * D:], out_bf16=True, bounded=True)
             o = ops.empty((B * Ltok, D), q)
             self.o.attention(qk, ops.offset(qk, D), v, o, B=B, H=nh, Lq=Ltok, Lk=Ltok, D=dh, Dv=dh, scale=dh ** -0.5,
                           q_str=(Ltok * 2 * D, 2 * D, dh), k_str=(Ltok * 2 * D, 2 * D, dh),
                           v_str=(Ltok * D, D, dh), o_str=(Ltok * D, D, dh))
-            q = self.o.linear(o, w[f'{p}.self_attn.out_proj.weight'], w[f'{p}.self_attn.out_proj.bias'], residual=q)
+            q = self.o.linear(o, w[f'{p}.self_attn.out_proj.weight'], w[f'{p}.self_attn.out_proj.bias'], residual=q, bounded=True)
             x2 = ops.layernorm(q, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'])
-            h = self.o.linear(x2, w[f'{p}.linear1.weight'], w[f'{p}.linear1.bias'], act=L.ACT_GELU)
-            q = self.o.linear(h, w[f'{p}.linear2.weight'], w[f'{p}.linear2.bias'], residual=q)
+            h = self.o.linear(x2, w[f'{p}.linear1.weight'], w[f'{p}.linear1.bias'], act=L.ACT_GELU, bounded=True)
+            q = self.o.linear(h, w[f'{p}.linear2.weight'], w[f'{p}.linear2.bias'], residual=q, bounded=True)
         xl = ops.layernorm(q, w['idx_pred_layer.0.weight'], w['idx_pred_layer.0.bias'])
-        logits = self.o.linear(xl, w['idx_pred_layer.1.weight'])
+        logits = self.o.linear(xl, w['idx_pred_layer.1.weight'], bounded=True)
         cb = w['quantize.embedding.weight']
         quant = ops.empty((B * Ltok, cb.shape[1]), q)
         idx = torch.empty((B * Ltok,), dtype=torch.int32, device=q.device)
@@ -280,7 +282,7 @@ class KeepNet:
         o = ops.empty((B * Ltok, inner), curr)
         self.o.attention(q, kv, ops.offset(kv, inner), o, B=B, H=nh, Lq=Ltok, Lk=Ltok, D=dh, Dv=dh, scale=dh ** -0.5,
                       q_str=(Ltok * inner, inner, dh), k_str=(Ltok * 2 * inner, 2 * inner, dh),
-                      v_str=(Ltok * 2 * inner, 2 * inner, dh), o_str=(Ltok * inner, inner, dh))
+                      v_str=(Ltok * 2 * inner, 2 * inner, dh), o_str=(Ltok * inner, inner, dh), probe=True)
         a = self.o.linear(o, w[f'{p}.attn.to_out.0.weight'], w[f'{p}.attn.to_out.0.bias'])
         y = ops.layernorm(a, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], res=c)
         f = ops.geglu(self.o.linear(y, w[f'{p}.ff.net.0.proj.weight'], w[f'{p}.ff.net.0.proj.bias']))
@@ -301,20 +303,20 @@ class KeepNet:
             p = f'kalman_filter.uncertainty_estimator.{i}'
             # sparse-causal spatial attention (KA:686-748): keys = [frame 0 ; frame f-1]
             x1 = ops.layernorm(h, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'])
-            qkv = self.o.linear(x1, w[f'{p}.attn1.to_qkv.weight'], out_bf16=True)
+            qkv = self.o.linear(x1, w[f'{p}.attn1.to_qkv.weight'], out_bf16=True, bounded=True)
             o = ops.empty((BT * Ltok, inner), h)
             s3 = (Ltok * 3 * inner, 3 * inner, dh)
             self.o.attention(qkv, ops.offset(qkv, inner), ops.offset(qkv, 2 * inner), o, B=BT, H=nh, Lq=Ltok,
                           Lk=2 * Ltok, D=dh, Dv=dh, scale=dh ** -0.5, q_str=s3, k_str=s3, v_str=s3,
                           o_str=(Ltok * inner, inner, dh), mode=1, T=T, seg_len=Ltok)
-            h = self.o.linear(o, w[f'{p}.attn1.to_out.0.weight'], w[f'{p}.attn1.to_out.0.bias'], residual=h)
+            h = self.o.linear(o, w[f'{p}.attn1.to_out.0.weight'], w[f'{p}.attn1.to_out.0.bias'], residual=h, bounded=True)
             # GEGLU feed-forward (KA:669)
             x3 = ops.layernorm(h, w[f'{p}.norm3.weight'], w[f'{p}.norm3.bias'])
-            f = ops.geglu(self.o.linear(x3, w[f'{p}.ff.net.0.proj.weight'], w[f'{p}.ff.net.0.proj.bias']))
-            h = self.o.linear(f, w[f'{p}.ff.net.2.weight'], w[f'{p}.ff.net.2.bias'], residual=h)
+            f = ops.geglu(self.o.linear(x3, w[f'{p}.ff.net.0.proj.weight'], w[f'{p}.ff.net.0.proj.bias'], bounded=True))
+            h = self.o.linear(f, w[f'{p}.ff.net.2.weight'], w[f'{p}.ff.net.2.bias'], residual=h, bounded=True)
             # temporal attention over the T frames of each spatial token (KA:671-680): strided, no rearrange
             xt = ops.layernorm(h, w[f'{p}.norm_temp.weight'], w[f'{p}.norm_temp.bias'])
-            qkv = self.o.linear(xt, w[f'{p}.attn_temp.to_qkv.weight'], out_bf16=True)
+            qkv = self.o.linear(xt, w[f'{p}.attn_temp.to_qkv.weight'], out_bf16=True, bounded=True)
             o = ops.empty((BT * Ltok, inner), h)
             for b in range(B):
                 qb = ops.offset(qkv, b * T * Ltok * 3 * inner)
@@ -322,7 +324,7 @@ class KeepNet:
                 self.o.attention(qb, ops.offset(qb, inner), ops.offset(qb, 2 * inner),
                               ops.offset(o, b * T * Ltok * inner), B=Ltok, H=nh, Lq=T, Lk=T, D=dh, Dv=dh,
                               scale=dh ** -0.5, q_str=st, k_str=st, v_str=st, o_str=(inner, Ltok * inner, dh))
-            h = self.o.linear(o, w[f'{p}.attn_temp.to_out.0.weight'], w[f'{p}.attn_temp.to_out.0.bias'], residual=h)
+            h = self.o.linear(o, w[f'{p}.attn_temp.to_out.0.weight'], w[f'{p}.attn_temp.to_out.0.bias'], residual=h, bounded=True)
         m = h.view(BT, Hh, Ww, C)
         mst = None
         for i in range(3):
@@ -363,14 +365,14 @@ class KeepNet:
     def _gm_resblock(self, x, p, stride):
         """GM/backbone.py:25-36."""
         w = self.w
-        c1, st1 = self.o.conv(x, w[f'{p}.conv1.weight'], None, stride=stride, pad=1, stats=True)
+        c1, st1 = self.o.conv(x, w[f'{p}.conv1.weight'], None, stride=stride, pad=1, stats=True, bounded=True)
         c2, st2 = self.o.conv(c1, w[f'{p}.conv2.weight'], None, pro=self._inorm(c1, st1), pro_act=L.PRO_RELU, stats=True)
         s2, h2 = self._inorm(c2, st2)
         N, H, Wd, C = c2.shape
         out = torch.empty_like(c2)
         if f'{p}.downsample.0.weight' in w:
             d, std = self.o.conv(x, w[f'{p}.downsample.0.weight'].view(C, 1, 1, -1), w[f'{p}.downsample.0.bias'],
-                                 stride=stride, pad=0, ksize=1, stats=True)
+                                 stride=stride, pad=0, ksize=1, stats=True, bounded=True)
             sd, hd = self._inorm(d, std)
             L.call('keep_gm_join', d, sd, hd, c2, s2, h2, out, N, H * Wd, C)
         else:
@@ -386,26 +388,26 @@ class KeepNet:
         wqkv = w[f'{p}.qkv.weight']
         o = torch.empty_like(src)
         if tgt is src:
-            qkv = self.o.linear(src, wqkv, out_bf16=True)
+            qkv = self.o.linear(src, wqkv, out_bf16=True, bounded=True)
             q, k, v = qkv, ops.offset(qkv, C), ops.offset(qkv, 2 * C)
             sq = skv = (Ltok * 3 * C, 3 * C, 0)
         else:
-            q = self.o.linear(src, wqkv[:C], out_bf16=True)
-            kv = self.o.linear(tgt, wqkv[C:], out_bf16=True)
+            q = self.o.linear(src, wqkv[:C], out_bf16=True, bounded=True)
+            kv = self.o.linear(tgt, wqkv[C:], out_bf16=True, bounded=True)
             k, v = kv, ops.offset(kv, C)
             sq, skv = (Ltok * C, C, 0), (Ltok * 2 * C, 2 * C, 0)
         self.o.attention(q, k, v, o, B=n_img * 4, H=1, Lq=Ltok // 4, Lk=Ltok // 4, D=C, Dv=C, scale=1.0 / (C ** 0.5),
                       q_str=sq, k_str=skv, v_str=skv, o_str=(Ltok * C, C, 0), mode=2, img_h=h8, img_w=w8, ksplit=2,
                       shift=shift, kv_rot=kv_rot, n_img=n_img)
-        m = self.o.linear(o, w[f'{p}.merge.weight'])
+        m = self.o.linear(o, w[f'{p}.merge.weight'], bounded=True)
         if not ffn:
             return ops.layernorm(m, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], res=src)
         m = ops.layernorm(m, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'])
         if self.o.mma == L.MMA_BF16 and C == 128 and FUSED_GM_MLP:
             m2 = self.o.gm_mlp(src, m, w[f'{p}.mlp.0.weight'], w[f'{p}.mlp.2.weight'])      # [M,8C] never leaves the CU
         else:
-            hmid = self.o.linear(ops.concat2(src, m), w[f'{p}.mlp.0.weight'], act=L.ACT_GELU)
-            m2 = self.o.linear(hmid, w[f'{p}.mlp.2.weight'])
+            hmid = self.o.linear(ops.concat2(src, m), w[f'{p}.mlp.0.weight'], act=L.ACT_GELU, bounded=True)
+            m2 = self.o.linear(hmid, w[f'{p}.mlp.2.weight'], bounded=True)
         return ops.layernorm(m2, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], res=src)
 
     def _gm_backbone(self, img_nchw):
@@ -421,7 +423,7 @@ class KeepNet:
         for li, stride in ((1, 1), (2, 2), (3, 2)):
             x = self._gm_resblock(x, f'{pfx}.backbone.layer{li}.0', stride)
             x = self._gm_resblock(x, f'{pfx}.backbone.layer{li}.1', 1)
-        return self.o.linear(x, w[f'{pfx}.backbone.conv2.weight'], w[f'{pfx}.backbone.conv2.bias'])
+        return self.o.linear(x, w[f'{pfx}.backbone.conv2.weight'], w[f'{pfx}.backbone.conv2.bias'], bounded=True)
 
     def _gmflow(self, im1, im2):
         """im1, im2 [P,3,H,W] NCHW in [-1,1] -> backward flow [P,H,W,2] (channels-last: (dx, dy))."""
@@ -466,15 +468,15 @@ class KeepNet:
         flow = ops.add_bcast(corr, grid, alpha=-1.0)
         # flow propagation (GM/transformer.py:363-372): k projected from the projected q
         fp = f'{pfx}.feature_flow_attn'
-        q = self.o.linear(f0, w[f'{fp}.q_proj.weight'], w[f'{fp}.q_proj.bias'])
-        k = self.o.linear(q, w[f'{fp}.k_proj.weight'], w[f'{fp}.k_proj.bias'])
+        q = self.o.linear(f0, w[f'{fp}.q_proj.weight'], w[f'{fp}.q_proj.bias'], bounded=True)
+        k = self.o.linear(q, w[f'{fp}.k_proj.weight'], w[f'{fp}.k_proj.bias'], bounded=True)
         flow2 = ops.empty((P * Ltok, 2), f0)
         self.o.attention(q, k, flow, flow2, B=P, H=1, Lq=Ltok, Lk=Ltok, D=C, Dv=2, scale=1.0 / (C ** 0.5),
                       q_str=sF, k_str=sF, v_str=(Ltok * 2, 2, 0), o_str=(Ltok * 2, 2, 0))
         # convex upsampling (GM/gmflow.py:75-88)
         cat = ops.concat2(flow2, f0).view(P, h8, w8, C + 2)
         m = self.o.conv(cat, w[f'{pfx}.upsampler.0.weight'], w[f'{pfx}.upsampler.0.bias'], act=L.ACT_RELU)
-        mask = self.o.linear(m, w[f'{pfx}.upsampler.2.weight'], w[f'{pfx}.upsampler.2.bias'])
+        mask = self.o.linear(m, w[f'{pfx}.upsampler.2.weight'], w[f'{pfx}.upsampler.2.bias'], bounded=True)
         k8 = GMFLOW['upsample_factor']
         up = ops.empty((P, h8 * k8, w8 * k8, 2), f0)
         L.call('keep_convex_upsample', mask, flow2, up, P, h8, w8, k8)
@@ -499,7 +501,24 @@ class KeepNet:
             raise ValueError("H and W must be multiples of 32")
         with torch.cuda.device(self.device):
             self._activate_precision()
-            return self._forward(x, B, T, H, Wd, force_indices, return_aux, force_flows)
+            res = self._forward(x, B, T, H, Wd, force_indices, return_aux, force_flows)
+            if self.precision == 'x3' and CHECK_X3_RANGE:
+                # fp16 halves top out at 65504: an out-of-range activation becomes inf/NaN in the output, never a quietly
+                # wrong value.  Raw-stream operands are range-probed (keep_absmax), so this is the last line of defence
+                # (e.g. a GroupNorm gamma in the hundreds): re-run the batch on the exact-f32 kernels.
+                out = res[0] if return_aux else res
+                if not bool(torch.isfinite(out).all()):
+                    import logging
+                    logging.getLogger('ComfyUI-KEEP').warning(
+                        "x3 precision policy left the fp16 operand range on this batch; re-running it on the f32 kernels")
+                    self.x3_fallbacks += 1
+                    self.precision = 'fp32'
+                    try:
+                        self._activate_precision()
+                        res = self._forward(x, B, T, H, Wd, force_indices, return_aux, force_flows)
+                    finally:
+                        self.precision = 'x3'
+            return res
 
     def _frame(self, t5, i):
         """[B,T,...] -> frame i as a contiguous [B,...] (free view when B == 1)."""

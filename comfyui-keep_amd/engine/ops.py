@@ -22,9 +22,10 @@ USE_BK256 = bool(int(os.environ.get('KEEP_BK256', '0')))   # measured slower tha
 # conv and use the kernel variant that applies the prologue while staging (A/B switch, default: always the two-pass form)
 HALO_PRENORM_MINPIX = int(os.environ.get('KEEP_HALO_PRENORM_MINPIX', '0'))
 
+DEBUG_SYNC = os.environ.get('KEEP_DEBUG_SYNC') is not None
 _PLAN_CACHE = {}
 _PLAN_ENV = ('KEEP_NO_COUT4', 'KEEP_NO_C3', 'KEEP_NO_HALO_F32', 'KEEP_NO_HALO_X3', 'KEEP_NO_GATHER_X3', 'KEEP_NO_PLAIN',
-             'KEEP_NO_FLATK_F32')
+             'KEEP_NO_FLATK_F32', 'KEEP_NO_HALO_X3P', 'KEEP_X3P_ALWAYS', 'KEEP_X3_HALO')
 
 
 class Plan:
@@ -42,7 +43,7 @@ class Plan:
 def _plan(a, key):
     """keep_conv2d_plan for these arguments, cached by everything the decision can depend on (shapes, flags, which
     optional tensors exist, pointer alignment class) -- never by values."""
-    key = key + tuple(os.environ.get(k) is not None for k in _PLAN_ENV)
+    key = key + tuple(os.environ.get(k) for k in _PLAN_ENV)
     pl = _PLAN_CACHE.get(key)
     if pl is None:
         pl = _PLAN_CACHE[key] = Plan(L.conv2d_plan(a))
@@ -103,11 +104,13 @@ class Ops:
     # ------------------------------------------------------------------ keep_conv2d
     def conv(self, x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=False, pro=None, pro_act=L.PRO_NONE,
              act=L.ACT_NONE, residual=None, aux=None, aux_w=1.0, cin=None, in_off=0, out=None, split_k=None, wb=None,
-             wx3=None, x3_acc_scale=None, mma=None, stats=False, out_bf16=False):
+             wx3=None, x3_acc_scale=None, mma=None, stats=False, out_bf16=False, bounded=False):
         """x [N,H,W,ld] -> [N,Ho,Wo,Cout].  ``w`` packed [Cout,KH,KW,Cin].  ``cin``/``in_off`` select a channel
         slice of a wider input buffer.  ``down`` = VQGAN Downsample geometry (pad right/bottom only, stride 2).
         ``stats=True`` returns ``(out, st)`` where ``st`` = (partials [N,P,Cout,2], P) reduced in the epilogue for the next
-        GroupNorm / InstanceNorm (``norm_affine(..., stats=st)``), or None when this launch could not emit them."""
+        GroupNorm / InstanceNorm (``norm_affine(..., stats=st)``), or None when this launch could not emit them.
+        ``bounded=True``: the caller vouches that |x| stays far below the fp16 range (normalised / attention-averaged
+        inputs); otherwise an x3 launch without a normalising prologue first probes the input range (keep_absmax)."""
         N, H, W, ld = x.shape
         Cout = w.shape[0]
         Cin = ld if cin is None else cin
@@ -124,14 +127,17 @@ class Ops:
         M = N * Ho * Wo
         mma = self.mma if mma is None else mma
         in_dtype = L.BF16 if x.dtype == torch.bfloat16 else L.F32
-        if mma == L.MMA_BF16 and wb is None:
-            wb = self.bf16_twin(w)
+        if mma == L.MMA_BF16 and wb is None and self.blob16 is not None:
+            wb = self.bf16_twin(w)      # (without a twin the library still accepts the exact-fp32 Cout <= 4 kernel)
         if mma == L.MMA_X3 and wx3 is None:
             wx3 = self.x3_twin(w)
         if x3_acc_scale is None:
             x3_acc_scale = self.x3_acc_scale
         want_bf16_out = bool(out_bf16) and mma == L.MMA_BF16 and residual is None
         xin = x if in_off == 0 else x.view(-1)[in_off:]
+        in_amax = None
+        if mma == L.MMA_X3 and wx3 is not None and pro is None and not bounded:
+            in_amax = absmax(xin, N, H * W, Cin, ld, H * W * ld)
         out_ld = Cout if out is None else out.shape[-1]
 
         def make_args(inp, dtype, pro_t, pro_a, odt, sk):
@@ -143,7 +149,7 @@ class Ops:
                 upsample=int(upsample), pro_act=pro_a, epi_act=act, aux_w=float(aux_w), split_k=sk, dtype=dtype,
                 mma=mma, weight_bf16=wb if mma == L.MMA_BF16 else None, stats_out=None, stats_P=0,
                 bk256=int(USE_BK256), out_dtype=odt, weight_x3=wx3 if mma == L.MMA_X3 else None,
-                x3_acc_scale=float(x3_acc_scale))
+                x3_acc_scale=float(x3_acc_scale), x3_in_amax=in_amax)
 
         def key_of(dtype, pro_t, pro_a, odt, sk):
             return (N, H, W, ld, Cin, Cout, KH, stride, pad_t, pad_l, Ho, Wo, out_ld, int(upsample), pro_a, act, dtype, mma,
@@ -186,13 +192,25 @@ class Ops:
                          + M * Cout * out.element_size() + (0 if residual is None else M * Cout * 4))
             self.profile.append((pl.kernel, 2.0 * M * Cout * KH * KW * Cin, pl.split_k, e0, e1, alg_bytes))
             e0.record()
+        if DEBUG_SYNC:      # dev aid: name every launch and wait for it, so a GPU fault is attributed to its kernel
+            import sys
+            print(f'[keep] {pl.kernel} N={N} H={H} W={W} ld={ld} Cin={Cin} Cout={Cout} k={KH} s={stride} up={int(upsample)} '
+                  f'split={pl.split_k} in_off={in_off} pro={pro is not None}/{pro_act} act={act} res={residual is not None} '
+                  f'aux={aux is not None} statsP={pl.stats_P if stats else 0}', file=sys.stderr, flush=True)
         L.conv2d_launch(a)
+        if DEBUG_SYNC:
+            torch.cuda.synchronize()
+            if not bool(torch.isfinite(out.float()).all()):
+                import sys
+                print(f'[keep] NON-FINITE output of {pl.kernel}; input finite={bool(torch.isfinite(x.float()).all())} '
+                      f'absmax={float(x.float().abs().max()):.4g} pro={None if pro is None else [float(t.abs().max()) for t in pro]} '
+                      f'res absmax={None if residual is None else float(residual.abs().max())}', file=sys.stderr, flush=True)
         if self.profile is not None:
             self.profile[-1][4].record()
         return (out, st) if stats else out
 
     def linear(self, x, w, bias=None, *, act=L.ACT_NONE, residual=None, pro=None, pro_act=L.PRO_NONE, cin=None, in_off=0,
-               n_img=1, out_bf16=False):
+               n_img=1, out_bf16=False, bounded=False):
         """x [M,ld] (or any [...,ld]) @ w[Cout,Cin]^T.  ``n_img``>1 makes the prologue per-image: rows are n_img
         images of M/n_img pixels each (1x1 conv on a feature map)."""
         shp = x.shape
@@ -205,7 +223,7 @@ class Ops:
         x4 = x.reshape(n_img, M // n_img, 1, ld)
         res4 = None if residual is None else residual.reshape(n_img, M // n_img, 1, residual.shape[-1])
         y = self.conv(x4, w, bias, stride=1, pad=0, ksize=1, pro=pro, pro_act=pro_act, act=act, residual=res4, cin=cin,
-                      in_off=in_off, out_bf16=out_bf16)
+                      in_off=in_off, out_bf16=out_bf16, bounded=bounded)
         return y.reshape(*shp[:-1], w.shape[0])
 
     # ------------------------------------------------------------------ normalisation
@@ -254,8 +272,9 @@ class Ops:
 
     # ------------------------------------------------------------------ keep_attention
     def attention(self, q, k, v, o, *, B, H, Lq, Lk, D, Dv, scale, q_str, k_str, v_str, o_str, mode=0, T=0, seg_len=0,
-                  img_h=0, img_w=0, ksplit=0, shift=0, kv_rot=0, n_img=0, mma=None):
-        """Strides are (batch, token, head) element strides."""
+                  img_h=0, img_w=0, ksplit=0, shift=0, kv_rot=0, n_img=0, mma=None, probe=False):
+        """Strides are (batch, token, head) element strides.  ``probe=True`` (x3 policy, mode 0): q / k / v are projections
+        of an un-normalised tensor -- their ranges are probed and the kernel rescales them into the fp16 window."""
         mma = self.attn_mma if mma is None else mma
         in_dtype = L.F32
         if q.dtype == torch.bfloat16:
@@ -263,12 +282,27 @@ class Ops:
             in_dtype, mma = L.BF16, L.MMA_BF16
         elif mma != L.MMA_F32 and (D % 16 or any(s % 4 for s in (*q_str, *k_str))):
             mma = L.MMA_F32
+        amax = (None, None, None)
+        if probe and mma == L.MMA_X3 and mode == 0 and in_dtype == L.F32:
+            # rows of batch b: tokens x (H heads x D) starting at b*bs; heads are contiguous slices of one row here
+            amax = (absmax(q, B, Lq, H * D, q_str[1], q_str[0]), absmax(k, B, Lk, H * D, k_str[1], k_str[0]),
+                    absmax(v, B, Lk, H * Dv, v_str[1], v_str[0]))
+        if DEBUG_SYNC:
+            import sys
+            print(f'[keep] attention mma={mma} in_dtype={in_dtype} B={B} H={H} Lq={Lq} Lk={Lk} D={D} Dv={Dv} mode={mode}',
+                  file=sys.stderr, flush=True)
         L.attention(q=q, k=k, v=v, o=o,
                     q_bs=q_str[0], q_ts=q_str[1], q_hs=q_str[2], k_bs=k_str[0], k_ts=k_str[1], k_hs=k_str[2],
                     v_bs=v_str[0], v_ts=v_str[1], v_hs=v_str[2], o_bs=o_str[0], o_ts=o_str[1], o_hs=o_str[2],
                     B=B, H=H, Lq=Lq, Lk=Lk, D=D, Dv=Dv, scale=float(scale), mode=mode, T=T, seg_len=seg_len,
                     img_h=img_h, img_w=img_w, ksplit=ksplit, shift=shift, kv_rot=kv_rot, n_img=n_img, mma=mma,
-                    in_dtype=in_dtype)
+                    in_dtype=in_dtype, q_amax=amax[0], k_amax=amax[1], v_amax=amax[2])
+        if DEBUG_SYNC:
+            torch.cuda.synchronize()
+            if not bool(torch.isfinite(o).all()):
+                import sys
+                print(f'[keep] NON-FINITE attention output; q/k/v absmax {float(q.float().abs().max()):.4g} '
+                      f'{float(k.float().abs().max()):.4g} {float(v.float().abs().max()):.4g}', file=sys.stderr, flush=True)
         return o
 
     def token_linear(self, x, w, bias=None, out_bf16=False):
@@ -288,6 +322,13 @@ class Ops:
         out = empty((M, C), a)
         L.call('keep_gm_mlp', a, b, self.bf16_twin(w0), self.bf16_twin(w2), out, M, C)
         return out
+
+
+def absmax(x, N, R, C, ld, img_stride):
+    """Range probe: max |x| per image over R rows x C columns (row stride ld, image stride img_stride) -> [N] floats."""
+    out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    L.call('keep_absmax', x, out, N, R, C, ld, img_stride)
+    return out
 
 
 def concat2(a, b):

@@ -115,6 +115,11 @@ typedef struct {
    * aligned; x3_acc_scale = 2^-e (applied to the accumulators).  NULL -> the call runs on the exact-f32 kernels. */
   const void* weight_x3;
   float x3_acc_scale;
+  /* KEEP_MMA_X3, inputs that are NOT normalised by the prologue (raw residual-stream tensors): per-image max |x| of the
+   * input window, [N] floats from keep_absmax.  The kernels multiply image n by the power of two that puts in_amax[n]
+   * just below 2^15 before splitting (and undo it on the accumulators), so no activation can leave the fp16 range and
+   * small values keep a normal `lo`.  NULL: inputs are split as they are (|x| must stay below 65504). */
+  const float* x3_in_amax;
 } keep_conv2d_args;
 int32_t keep_conv2d(const keep_conv2d_args* a, void* stream);
 
@@ -163,6 +168,11 @@ typedef struct {
   int32_t mma; /* KEEP_MMA_F32 | KEEP_MMA_BF16 (Q,K,V,P rounded to bf16; fp32 softmax + accumulate) | KEEP_MMA_X3 (Q,K,V,P
                   split into fp16 hi + lo, three MFMAs per product: fp32-grade; exact-fp32 softmax) */
   int32_t in_dtype; /* KEEP_F32, or KEEP_BF16 (with KEEP_MMA_BF16): q, k, v are bf16 tensors, strides in elements */
+  /* KEEP_MMA_X3, mode 0 only: per-batch max |q|, |k|, |v| ([B] floats each, keep_absmax) for operands that are not
+   * bounded by a normalisation (CFA reads the raw residual stream); all three or none */
+  const float* q_amax;
+  const float* k_amax;
+  const float* v_amax;
 } keep_attention_args;
 int32_t keep_attention(const keep_attention_args* a, void* stream);
 
@@ -198,6 +208,10 @@ int32_t keep_token_linear(const float* x, const void* w_bf16, const float* bias,
 /* GM/backbone.py:36: out = relu( (a*sa+ha) + relu(b*sb+hb) ); sa/ha may be NULL (identity shortcut) */
 int32_t keep_gm_join(const float* a, const float* sa, const float* ha, const float* b, const float* sb,
                      const float* hb, float* out, int32_t N, int32_t HW, int32_t C, void* stream);
+
+/* amax[n] = max |x[n, r, c]| over the R rows x C columns (row stride ld) of image n -- the range probe in front of
+ * KEEP_MMA_X3 operators whose input is not normalised (x3_in_amax / q_amax ...).  Deterministic (max is order-free). */
+int32_t keep_absmax(const float* x, float* amax, int32_t N, int64_t R, int32_t C, int64_t ld, int64_t img_stride, void* stream);
 
 /* LayerNorm(eps 1e-5) over the last dim of [M,C] (KA:395-396,491-492,597; GM/transformer.py:134,145).
  *   y = LN(x)*gamma+beta;  out = y + (res ? res : 0);  out2 (optional) = y + pos[m % pos_rows]  (KA:429-430) */

@@ -97,10 +97,14 @@ def err64(got, ref64):
 @pytest.mark.parametrize("n,cin,cout,h,wd,up,res,gn", [(2, 64, 64, 64, 64, False, True, True), (1, 128, 96, 16, 48, False, False, True),
                                                       (2, 32, 128, 16, 16, True, False, True), (1, 48, 64, 32, 32, False, True, False),
                                                       (1, 512, 512, 16, 16, False, False, True)])
-def test_conv_x3_halo_is_fp32_grade(n, cin, cout, h, wd, up, res, gn):
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_conv_x3_halo_is_fp32_grade(n, cin, cout, h, wd, up, res, gn, pipelined, monkeypatch):
     """KEEP_MMA_X3 3x3 halo kernel: the error against an fp64 convolution is of the size of the exact-f32 kernel's own
     (accumulation-order) error -- wide / square tiles, masked half cout-block, fused GN+swish, upsample, residual,
     auto split-K on the small map, Cin = 48 (three 16-channel chunks)."""
+    # pipelined: the one-block-per-CU software-pipelined kernel (taken for >= 2 work items per CU; forced here on small maps)
+    if pipelined:
+        monkeypatch.setenv('KEEP_X3P_ALWAYS', '1')
     x, w, b = rnd('x3x', (n, cin, h, wd), 2.0) + 0.3, rnd('x3w', (cout, cin, 3, 3), 0.05), rnd('x3b', (cout,))
     gamma, beta = rnd('x3g', (cin,)) * 0.2 + 1, rnd('x3bt', (cin,)) * 0.2
     Ho, Wo = (2 * h, 2 * wd) if up else (h, wd)
@@ -108,12 +112,16 @@ def test_conv_x3_halo_is_fp32_grade(n, cin, cout, h, wd, up, res, gn):
     xd, wp = dev(nhwc(x)), pack(w)
     wx3, asc = x3w(wp)
     kw = dict(upsample=up, stats=True, residual=None if r is None else dev(nhwc(r)))
+    if pipelined:
+        kw['split_k'] = 1
     if gn:
         kw.update(pro=ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6), pro_act=L.PRO_SWISH)
     ops.DEFAULT.profile = []
     y, st = ops.conv(xd, wp, dev(b), mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, **kw)
-    assert ops.DEFAULT.profile[-1][0].startswith('conv3x3_halo_x3_kernel'), ops.DEFAULT.profile[-1][0]
+    kname = ops.DEFAULT.profile[-1][0]
     ops.DEFAULT.profile = None
+    wide = (Ho % 8 == 0 and Wo % 32 == 0)
+    assert kname.startswith('conv3x3_halo_x3g_kernel' if (pipelined and wide) else 'conv3x3_halo_x3_kernel'), kname
     y32, _ = ops.conv(xd, wp, dev(b), **kw)
     hn = x.double()
     if gn:
@@ -190,8 +198,53 @@ def test_x3_overflow_is_loud():
     w = rnd('ovw', (32, 32, 3, 3), 0.05)
     wp = pack(w)
     wx3, asc = x3w(wp)
-    y = ops.conv(dev(nhwc(x)), wp, None, mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc)
+    y = ops.conv(dev(nhwc(x)), wp, None, mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, bounded=True)
     assert not torch.isfinite(y).all()
+
+
+def test_x3_range_probe_keeps_large_raw_inputs_exact():
+    """Un-normalised inputs (the raw residual stream in front of Upsample / Downsample / shortcut / CFT convs) are range-probed
+    (keep_absmax) and rescaled per image by a power of two into the fp16 window: values far beyond 65504 and tiny ones
+    both come out fp32-grade, per image (image 0 large, image 1 tiny), on the halo and on the gather kernel."""
+    x = rnd('rpx', (2, 64, 32, 32), 1.0)
+    x[0] *= 3e5
+    x[1] *= 2e-4
+    for name, w4, kw, ref in [
+        ('halo', rnd('rpw', (64, 64, 3, 3), 0.05), dict(), lambda w: F.conv2d(x.double(), w.double(), padding=1)),
+        ('gather', rnd('rpw1', (96, 64, 1, 1), 0.1), dict(pad=0, ksize=1), lambda w: F.conv2d(x.double(), w.double())),
+    ]:
+        wp = pack(w4)
+        wx3, asc = x3w(wp)
+        y = ops.conv(dev(nhwc(x)), wp, None, mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, **kw)
+        y32 = ops.conv(dev(nhwc(x)), wp, None, **kw)
+        r64 = ref(w4)
+        assert torch.isfinite(y).all(), name
+        for n in range(2):
+            e3 = err64(nchw(y)[n], r64[n])
+            e32 = err64(nchw(y32)[n], r64[n])
+            sc = r64[n].abs().max().item()
+            assert e3 <= max(3.0 * e32, 2e-6 * sc), f'{name} image {n}: x3 err {e3:.3e} vs f32-kernel err {e32:.3e} (scale {sc:.3g})'
+
+
+def test_attention_x3_is_fp32_grade_and_range_probed():
+    """keep_attention KEEP_MMA_X3: error against an fp64 softmax(QK^T)V of the size of the exact-f32 kernel's own error; with
+    `probe=True` operands of magnitude 1e5 (CFA: projections of the raw residual stream) stay finite and exact."""
+    for (B, H, Lq, Lk, D, Dv, amp) in [(2, 8, 256, 256, 64, 64, 1.0), (3, 8, 20, 20, 48, 48, 1.0), (1, 1, 256, 256, 512, 512, 1.0),
+                                       (2, 4, 200, 200, 256, 256, 1.0), (2, 4, 256, 256, 256, 256, 1e5), (2, 1, 1024, 1024, 128, 128, 1.0)]:
+        q, k, v = rnd('xq', (B, Lq, H, D)) * amp, rnd('xk', (B, Lk, H, D)), rnd('xv', (B, Lk, H, Dv)) * amp
+        scale = D ** -0.5 * 3.0 / amp
+        ref = torch.softmax(torch.einsum('bqhd,bkhd->bhqk', q.double(), k.double()) * scale, -1)
+        ref = torch.einsum('bhqk,bkhd->bqhd', ref, v.double())
+        outs = []
+        for mma in (L.MMA_X3, L.MMA_F32):
+            o = torch.empty((B, Lq, H, Dv), device='cuda')
+            ops.attention(dev(q), dev(k), dev(v), o, B=B, H=H, Lq=Lq, Lk=Lk, D=D, Dv=Dv, scale=scale,
+                          q_str=(Lq * H * D, H * D, D), k_str=(Lk * H * D, H * D, D), v_str=(Lk * H * Dv, H * Dv, Dv),
+                          o_str=(Lq * H * Dv, H * Dv, Dv), mma=mma, probe=amp > 1)
+            assert torch.isfinite(o).all()
+            outs.append(err64(o, ref))
+        sc = ref.abs().max().item()
+        assert outs[0] <= max(3.0 * outs[1], 2e-6 * sc), f'{(B, H, Lq, Lk, D, Dv, amp)}: x3 err {outs[0]:.3e} vs f32 err {outs[1]:.3e} (scale {sc:.3g})'
 
 
 def test_conv3x3_small_cout_valu_kernel(monkeypatch):

@@ -1649,7 +1649,6 @@ int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 bool keep_conv_x3_halo_ok(const keep_conv2d_args* a);
 bool keep_conv_x3_gather_ok(const keep_conv2d_args* a, const ConvP& p);
-int keep_conv_x3_halo_variant(const keep_conv2d_args* a, int split_k);
 
 enum ConvPath {
   PATH_COUT4 = 0, PATH_C3, PATH_HALO_F32, PATH_HALO_BF16, PATH_HALO_BF16_V1, PATH_GATHER_BF16, PATH_GATHER_F32, PATH_HALO_X3,
@@ -1784,15 +1783,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
       pl.split_k = a->split_k > 0 ? a->split_k : auto_split;
       if (pl.split_k > a->Cin / 16) pl.split_k = a->Cin / 16;
       pl.stats_rows = 64;
-      const int variant = keep_conv_x3_halo_variant(a, pl.split_k);
-      if (variant == 2) {
-        snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3g_kernel");
-        pl.stats_rows = 32;      // one partial per DPP row (16 lanes x 2 tile rows)
-      } else if (variant == 1) {
-        snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3p_kernel");
-      } else {
-        snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3_kernel<%d>", pl.wide ? 32 : 16);
-      }
+      snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3_kernel<%d>", pl.wide ? 32 : 16);
       return KEEP_OK;
     }
     if (have_w && keep_conv_x3_gather_ok(a, p) && !getenv("KEEP_NO_GATHER_X3")) {

@@ -97,14 +97,10 @@ def err64(got, ref64):
 @pytest.mark.parametrize("n,cin,cout,h,wd,up,res,gn", [(2, 64, 64, 64, 64, False, True, True), (1, 128, 96, 16, 48, False, False, True),
                                                       (2, 32, 128, 16, 16, True, False, True), (1, 48, 64, 32, 32, False, True, False),
                                                       (1, 512, 512, 16, 16, False, False, True)])
-@pytest.mark.parametrize("pipelined", [False, True])
-def test_conv_x3_halo_is_fp32_grade(n, cin, cout, h, wd, up, res, gn, pipelined, monkeypatch):
+def test_conv_x3_halo_is_fp32_grade(n, cin, cout, h, wd, up, res, gn):
     """KEEP_MMA_X3 3x3 halo kernel: the error against an fp64 convolution is of the size of the exact-f32 kernel's own
     (accumulation-order) error -- wide / square tiles, masked half cout-block, fused GN+swish, upsample, residual,
     auto split-K on the small map, Cin = 48 (three 16-channel chunks)."""
-    # pipelined: the one-block-per-CU software-pipelined kernel (taken for >= 2 work items per CU; forced here on small maps)
-    if pipelined:
-        monkeypatch.setenv('KEEP_X3P_ALWAYS', '1')
     x, w, b = rnd('x3x', (n, cin, h, wd), 2.0) + 0.3, rnd('x3w', (cout, cin, 3, 3), 0.05), rnd('x3b', (cout,))
     gamma, beta = rnd('x3g', (cin,)) * 0.2 + 1, rnd('x3bt', (cin,)) * 0.2
     Ho, Wo = (2 * h, 2 * wd) if up else (h, wd)
@@ -112,16 +108,13 @@ def test_conv_x3_halo_is_fp32_grade(n, cin, cout, h, wd, up, res, gn, pipelined,
     xd, wp = dev(nhwc(x)), pack(w)
     wx3, asc = x3w(wp)
     kw = dict(upsample=up, stats=True, residual=None if r is None else dev(nhwc(r)))
-    if pipelined:
-        kw['split_k'] = 1
     if gn:
         kw.update(pro=ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6), pro_act=L.PRO_SWISH)
     ops.DEFAULT.profile = []
     y, st = ops.conv(xd, wp, dev(b), mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, **kw)
     kname = ops.DEFAULT.profile[-1][0]
     ops.DEFAULT.profile = None
-    wide = (Ho % 8 == 0 and Wo % 32 == 0)
-    assert kname.startswith('conv3x3_halo_x3g_kernel' if (pipelined and wide) else 'conv3x3_halo_x3_kernel'), kname
+    assert kname.startswith('conv3x3_halo_x3_kernel'), kname
     y32, _ = ops.conv(xd, wp, dev(b), **kw)
     hn = x.double()
     if gn:

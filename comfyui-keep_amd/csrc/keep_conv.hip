@@ -1662,6 +1662,7 @@ struct ConvPlan {
   int split_k;
   int stats_rows;      // output pixels per statistics partial; 0 = this call cannot emit statistics
   int wants_bf16_input, out_bf16_ok;
+  bool amax_ok;          // this path can fill x3_out_amax (x3 kernels, single pass)
   char kernel[64];
 };
 
@@ -1713,6 +1714,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   p.wx3 = (const unsigned short*)a->weight_x3;
   p.acc_scale = a->x3_acc_scale;
   p.in_amax = a->x3_in_amax;
+  p.out_amax = nullptr;
   p.bias = a->bias;
   p.out = (float*)a->out;
   p.pro_scale = a->pro_scale;
@@ -1783,6 +1785,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
       pl.split_k = a->split_k > 0 ? a->split_k : auto_split;
       if (pl.split_k > a->Cin / 16) pl.split_k = a->Cin / 16;
       pl.stats_rows = 64;
+      pl.amax_ok = pl.split_k == 1;
       snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3_kernel<%d>", pl.wide ? 32 : 16);
       return KEEP_OK;
     }
@@ -1797,6 +1800,8 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
       pl.split_k = a->split_k > 0 ? a->split_k : auto_split;
       if (pl.split_k > steps) pl.split_k = steps;
       pl.stats_rows = pl.tile == 1 ? 64 : 128;
+      // a wave's rows must lie in one image: Ho*Wo a multiple of the wave tile (32 or 64 rows)
+      pl.amax_ok = pl.split_k == 1 && ((long)a->Ho * a->Wo) % (pl.tile == 1 ? 32 : 64) == 0;
       snprintf(pl.kernel, sizeof(pl.kernel), "conv_x3_kernel<%s, %s>", pl.tile == 1 ? "2, 2, 1, 1" : "2, 2, 2, 2",
                pl.plain ? "true" : "false");
       return KEEP_OK;
@@ -1909,6 +1914,7 @@ extern "C" int32_t keep_conv2d_plan(const keep_conv2d_args* a, keep_conv2d_plan_
   out->stats_P = out->stats_rows ? (int32_t)(hw_o / out->stats_rows) : 0;
   out->wants_bf16_input = pl.wants_bf16_input;
   out->out_bf16_ok = pl.out_bf16_ok;
+  out->out_amax_ok = pl.amax_ok ? 1 : 0;
   out->path = (int32_t)pl.path;
   strncpy(out->kernel, pl.kernel, sizeof(out->kernel) - 1);
   return KEEP_OK;
@@ -1938,10 +1944,19 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
     KEEP_REQUIRE(pl.stats_rows > 0 && hw_o % pl.stats_rows == 0 && a->stats_P == hw_o / pl.stats_rows,
                  "keep_conv2d: stats_P=%d must equal Ho*Wo/%d (keep_conv2d_plan)", a->stats_P, pl.stats_rows);
   }
+  hipStream_t st = (hipStream_t)stream;
+  if (a->x3_out_amax) {
+    KEEP_REQUIRE(pl.amax_ok, "keep_conv2d: x3_out_amax is not available for this call (keep_conv2d_plan: out_amax_ok)");
+    hipError_t e = hipMemsetAsync(a->x3_out_amax, 0, (size_t)a->N * sizeof(float), st);
+    if (e != hipSuccess) {
+      keep_set_error("keep_conv2d: hipMemsetAsync(x3_out_amax) failed: %s", hipGetErrorString(e));
+      return KEEP_EHIP;
+    }
+    p.out_amax = reinterpret_cast<unsigned*>(a->x3_out_amax);
+  }
   if (p.out_bf16)
     KEEP_REQUIRE(p.vec_epi && p.split_k == 1 && !a->residual,
                  "keep_conv2d: bf16 output needs Cout/out_ld %% 4 == 0, aligned pointers, split_k == 1, no residual");
-  hipStream_t st = (hipStream_t)stream;
   dim3 block(256);
   const int tw = pl.wide ? 32 : 16, th = 256 / tw;
   const int tiles_x = a->Wo / tw, tiles_y = a->Ho / th, ncb = (a->Cout + 63) / 64;

@@ -38,7 +38,16 @@ struct ConvP {
   const unsigned short* wx3;  // KEEP_MMA_X3: weights pre-multiplied by 2^e and split into fp16 (hi, lo), [Cout][KH*KW][Cin/16][hi16|lo16]
   float acc_scale;            // KEEP_MMA_X3: 2^-e, applied to the accumulators before bias / activation
   const float* in_amax;       // KEEP_MMA_X3: per-image max |input| (NULL: inputs are split unscaled)
+  unsigned* out_amax;         // KEEP_MMA_X3: per-image max |output| as raw float bits (atomicMax), or NULL
 };
+
+// wave-wide max of non-negative floats via their bit patterns, then one atomic per wave
+__device__ __forceinline__ void wave_amax_commit(unsigned* dst, float m) {
+  unsigned b = __float_as_uint(m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
+  if ((threadIdx.x & 63) == 0 && b) atomicMax(dst, b);
+}
 
 // KEEP_MMA_X3 range scaling: the power of two s with amax * s in [2^14, 2^15) (fp16 max 65504), and 1/s.  amax = 0 (or a
 // denormal) -> 1; inf / NaN propagate through the data itself.
@@ -132,6 +141,7 @@ __device__ __forceinline__ void staged_epilogue_impl(const ConvP& p, f32x16 (&ac
   const int co = n0 + wn * WC + c4;
   const bool cok = co < p.Cout;
   float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
+  float amx = 0.f;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
 #pragma unroll 4
@@ -175,7 +185,12 @@ __device__ __forceinline__ void staged_epilogue_impl(const ConvP& p, f32x16 (&ac
     for (int q = 0; q < 4; ++q) {
       s4[q] += e[q];
       ss4[q] += e[q] * e[q];
+      amx = fmaxf(amx, fabsf(e[q]));
     }
+  }
+  if (p.out_amax) {   // host guarantees split_k == 1 and H*W % (tile rows) == 0: the wave's rows lie in one image
+    const long mw = m0 + wm * WR;
+    if (mw < p.M) wave_amax_commit(p.out_amax + (int)(mw / ((long)p.Ho * p.Wo)), amx);
   }
   if (p.stats) {   // host guarantees split_k == 1 and H*W % BM == 0 (a tile never straddles two images)
 #pragma unroll

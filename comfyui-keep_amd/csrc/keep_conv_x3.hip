@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     const int co = it.n0 + c4;
     const bool cok = co < p.Cout;
     float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
+    float amx = 0.f;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
     constexpr int UNR = HAS_RES ? 16 : 8;
@@ -252,8 +253,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
       for (int q = 0; q < 4; ++q) {
         s4[q] += e[q];
         ss4[q] += e[q] * e[q];
+        amx = fmaxf(amx, fabsf(e[q]));
       }
     }
+    if (p.out_amax) wave_amax_commit(p.out_amax + it.n, amx);
     if (p.stats) {          // per wave: stats_P = 4 * tiles, partial index = tile*4 + wave
 #pragma unroll
       for (int q = 0; q < 4; ++q) {

@@ -31,6 +31,13 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def rank_world():
+    """(rank, world) of the default process group; (0, 1) when not running distributed."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def shard_clips(n_clips, rank, world):
     """Static round-robin: clip c runs on rank c % world.  Returns this rank's clip indices (ascending)."""
     return list(range(rank, n_clips, world))
@@ -55,15 +62,35 @@ def broadcast_packed_weights(index, blob, src=0):
     return index, (blob if rank == src else wire.to(target))
 
 
-def gather_by_clip(local_results, n_clips, rank, world):
-    """local_results: {clip_index: uint8 numpy array}.  Returns the full list on rank 0 (host gather)."""
+def gather_by_clip(local_results, n_clips, rank, world, to_all=False):
+    """local_results: {clip_index: uint8 numpy array}.  Returns the full list on rank 0 (host gather), or on every
+    rank with ``to_all``."""
     if not dist.is_initialized() or world == 1:
         return [local_results[i] for i in range(n_clips)]
-    buckets = [None] * world if rank == 0 else None
-    dist.gather_object(local_results, buckets, dst=0)
-    if rank != 0:
-        return None
+    if to_all:
+        buckets = [None] * world
+        dist.all_gather_object(buckets, local_results)
+    else:
+        buckets = [None] * world if rank == 0 else None
+        dist.gather_object(local_results, buckets, dst=0)
+        if rank != 0:
+            return None
     merged = {}
     for b in buckets:
         merged.update(b)
     return [merged[i] for i in range(n_clips)]
+
+
+def sharded_map(items, local_fn, gather='all'):
+    """The product's multi-GPU pattern in one place: ``items`` (independent clips) are sharded round-robin over the
+    ranks, ``local_fn({index: item})`` restores this rank's share and returns {index: uint8 numpy array}, and the
+    results are gathered on the host by index ('all': every rank gets the full list, 'root': rank 0 only, 'none': the
+    local dict).  No data-path collective -- clips share no state."""
+    rank, world = rank_world()
+    mine = shard_clips(len(items), rank, world)
+    local = local_fn({i: items[i] for i in mine})
+    if world == 1:
+        return [local[i] for i in range(len(items))]
+    if gather == 'none':
+        return local
+    return gather_by_clip(local, len(items), rank, world, to_all=(gather == 'all'))

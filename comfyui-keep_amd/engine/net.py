@@ -32,6 +32,8 @@ FUSED_GM_MLP = os.environ.get('KEEP_NO_FUSED_MLP') is None     # dev switch
 # 'x3': split-fp16 operands on the 16-bit matrix pipe (fp32-grade products, csrc/keep_conv_x3.hip) -- the default: it
 # passes the same <= 1e-3 parity tests as 'fp32' (exact f32 MFMA everywhere) at several times its speed.
 CHECK_X3_RANGE = os.environ.get('KEEP_X3_NO_RANGE_CHECK') is None
+GRAPH_MAX_CLIPS = int(os.environ.get('KEEP_AMD_GRAPH_MAX_CLIPS', '2'))
+GRAPH_CACHE = 4
 PRECISIONS = ('fp32', 'x3', 'bf16')
 DEFAULT_PRECISION = 'x3'
 
@@ -60,6 +62,10 @@ class KeepNet:
         self._x3_scale = 1.0       # power of two the x3 weights were multiplied by
         self.o = ops.Ops()         # this net's precision policy + weight twins (never shared between nets)
         self.x3_fallbacks = 0      # batches the x3 policy handed back to the f32 kernels (non-finite output)
+        # hipGraph replay of the whole forward for small batches (launch-bound: ~9 k kernels per clip): 'auto' = at most
+        # GRAPH_MAX_CLIPS clips per call, '1' = always, '0' = never.  One captured graph per (B, T, H, W, policy).
+        self.graph_mode = os.environ.get('KEEP_AMD_GRAPH', 'auto')
+        self._graphs = {}
         self.precision = 'fp32'
         self.set_precision(os.environ.get('KEEP_AMD_PRECISION', DEFAULT_PRECISION))
 
@@ -132,6 +138,7 @@ class KeepNet:
             from_blob = torch.from_numpy(self._blob)
         self._dev_blob = from_blob.to(self.device, non_blocking=False)
         self._dev_blob16 = self._dev_blobx3 = None
+        self._graphs = {}
         self.w = views(self._dev_blob, self._index)
 
     def to(self, device):
@@ -149,6 +156,7 @@ class KeepNet:
             self._dev_blob, self._dev_blob16, self._dev_blobx3, self.w = None, None, None, None
             self.o.set_precision(self.o.mma)        # drop this net's references to the device blobs
             self._const = {}
+            self._graphs = {}
         return self
 
     def packed_blob(self):
@@ -158,6 +166,7 @@ class KeepNet:
     def adopt_packed(self, index, dev_blob):
         """Install a packed blob received from another rank."""
         self._index, self._dev_blob, self._dev_blob16, self._dev_blobx3 = index, dev_blob, None, None
+        self._graphs = {}
         self.device = dev_blob.device
         self.w = views(dev_blob, index)
 
@@ -177,7 +186,8 @@ class KeepNet:
                              pro_act=L.PRO_SWISH, stats=True, out_bf16=h16)
         sc = x
         if f'{p}.conv_out.weight' in w:
-            sc = self.o.linear(x, w[f'{p}.conv_out.weight'], w[f'{p}.conv_out.bias'])
+            sc = self.o.linear(x, w[f'{p}.conv_out.weight'], w[f'{p}.conv_out.bias'], n_img=x.shape[0],
+                               x_amax=None if st is None else st.amax)
         return self.o.conv(h, w[f'{p}.conv2.weight'], w[f'{p}.conv2.bias'], pro=self._gn(h, f'{p}.norm2', hst),
                            pro_act=L.PRO_SWISH, residual=sc, stats=True)
 
@@ -213,9 +223,11 @@ class KeepNet:
             elif kind == 'attn':
                 x, st = self._attnblock(x, p, st), None
             elif kind == 'down':
-                x, st = self.o.conv(x, w[f'{p}.conv.weight'], w[f'{p}.conv.bias'], down=True, stats=True)
+                x, st = self.o.conv(x, w[f'{p}.conv.weight'], w[f'{p}.conv.bias'], down=True, stats=True,
+                                    x_amax=None if st is None else st.amax)
             elif kind == 'up':
-                x, st = self.o.conv(x, w[f'{p}.conv.weight'], w[f'{p}.conv.bias'], upsample=True, stats=True)
+                x, st = self.o.conv(x, w[f'{p}.conv.weight'], w[f'{p}.conv.bias'], upsample=True, stats=True,
+                                    x_amax=None if st is None else st.amax)
             elif kind == 'norm':
                 pending = self._gn(x, p, st)
             if i in taps:
@@ -263,11 +275,13 @@ class KeepNet:
         """KA:465-472: dec + cond*(dec*scale(e) + shift(e)), e = ResBlock(cat[enc, dec])."""
         w = self.w
         C = dec.shape[-1]
-        e, _ = self._resblock(ops.concat2(enc, dec), f'{p}.encode_enc')
-        ss = self.o.conv(e, w[f'{p}.ss0.weight'], w[f'{p}.ss0.bias'], act=L.ACT_LRELU02)          # [.., 2C]
-        scale = self.o.conv(ss, w[f'{p}.scale.2.weight'], w[f'{p}.scale.2.bias'], cin=C, in_off=0)
+        e, est = self._resblock(ops.concat2(enc, dec), f'{p}.encode_enc')
+        ss, sst = self.o.conv(e, w[f'{p}.ss0.weight'], w[f'{p}.ss0.bias'], act=L.ACT_LRELU02, stats=True,
+                              x_amax=None if est is None else est.amax)                          # [.., 2C]
+        ss_amax = None if sst is None else sst.amax             # max over all 2C channels bounds either half
+        scale = self.o.conv(ss, w[f'{p}.scale.2.weight'], w[f'{p}.scale.2.bias'], cin=C, in_off=0, x_amax=ss_amax)
         return self.o.conv(ss, w[f'{p}.shift.2.weight'], w[f'{p}.shift.2.bias'], cin=C, in_off=C, residual=dec,
-                        aux=scale, aux_w=self.cfg['cond'], stats=True)
+                           aux=scale, aux_w=self.cfg['cond'], stats=True, x_amax=ss_amax)
 
     def _cfa(self, curr, prev, p):
         """KA:519-541 (post-norm): a = attn(curr, prev); y = LN(a)+curr; LN(ff(y))+y."""
@@ -437,10 +451,12 @@ class KeepNet:
         [x[:,1:] ; x[:,:-1]] is assembled from the B*T feature maps (same values, 47 % less encoder work at T=20)."""
         B, T = x.shape[:2]
         feat = self._gm_backbone(x.reshape(B * T, *x.shape[2:]))
-        first = [b * T + t + 1 for b in range(B) for t in range(T - 1)]
-        second = [b * T + t for b in range(B) for t in range(T - 1)]
-        idx = torch.tensor(first + second, device=feat.device, dtype=torch.long)
-        return self._gmflow_pairs(feat.index_select(0, idx), B * (T - 1))
+        key = ('pairs', B, T, str(feat.device))
+        if key not in self._const:                      # (a host -> device copy: must not happen inside a graph capture)
+            first = [b * T + t + 1 for b in range(B) for t in range(T - 1)]
+            second = [b * T + t for b in range(B) for t in range(T - 1)]
+            self._const[key] = torch.tensor(first + second, device=feat.device, dtype=torch.long)
+        return self._gmflow_pairs(feat.index_select(0, self._const[key]), B * (T - 1))
 
     def _gmflow_pairs(self, feat, P):
         """feat [2P,h8,w8,C]: features of the P first images followed by the P second images -> flow [P,H,W,2]."""
@@ -501,7 +517,11 @@ class KeepNet:
             raise ValueError("H and W must be multiples of 32")
         with torch.cuda.device(self.device):
             self._activate_precision()
-            res = self._forward(x, B, T, H, Wd, force_indices, return_aux, force_flows)
+            plain = force_indices is None and force_flows is None and not return_aux and self.o.profile is None
+            if plain and (self.graph_mode == '1' or (self.graph_mode == 'auto' and B <= GRAPH_MAX_CLIPS)) and not ops.DEBUG_SYNC:
+                res = self._forward_graphed(x, B, T, H, Wd)
+            else:
+                res = self._forward(x, B, T, H, Wd, force_indices, return_aux, force_flows)
             if self.precision == 'x3' and CHECK_X3_RANGE:
                 # fp16 halves top out at 65504: an out-of-range activation becomes inf/NaN in the output, never a quietly
                 # wrong value.  Raw-stream operands are range-probed (keep_absmax), so this is the last line of defence
@@ -519,6 +539,28 @@ class KeepNet:
                     finally:
                         self.precision = 'x3'
             return res
+
+    def _forward_graphed(self, x, B, T, H, Wd):
+        """The same kernel sequence as ``_forward``, captured once per (shape, policy) into a hipGraph and replayed: at
+        B = 1 a clip is ~9 k launches averaging a few microseconds of GPU work each, i.e. bound by the host's launch
+        rate; a replay submits them in one call.  Every kernel is stream-ordered, allocation-free and deterministic, and
+        the host code between launches only computes shapes, so the replay is bit-identical to the eager run."""
+        key = (B, T, H, Wd, self.precision, self._dev_blob.data_ptr())
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._forward(x, B, T, H, Wd, None, False, None)         # warm: weight twins, constants, plans, allocator
+            torch.cuda.synchronize()
+            if len(self._graphs) >= GRAPH_CACHE:
+                self._graphs.pop(next(iter(self._graphs)))
+            static_x = x.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_out = self._forward(static_x, B, T, H, Wd, None, False, None)
+            ent = self._graphs[key] = (g, static_x, static_out)
+        g, static_x, static_out = ent
+        static_x.copy_(x)
+        g.replay()
+        return static_out.clone()
 
     def _frame(self, t5, i):
         """[B,T,...] -> frame i as a contiguous [B,...] (free view when B == 1)."""
@@ -591,48 +633,87 @@ class KeepNet:
         return out
 
     # ------------------------------------------------------------------ independent clips (hot loop #1)
-    def run_clips(self, clips, need_upscale=False, max_b=8):
-        """list of [1,T_i,3,H,W] -> list of restored clips.  Clips share no state (KA:1050,1064,1113), so
-        equal-length clips are stacked on the batch axis; results equal the sequential loop."""
+    def clips_per_call(self, T, H=512, Wd=512):
+        """How many equal-length clips ride the batch axis of one net call.  Every batched stage (LQ encoder, GMFlow,
+        Kalman gain) holds all B*T frames at once, so B is bounded by free HBM: ~0.35 GB per 512x512 frame at fp32
+        storage (measured: B=16, T=20 peaks at 71-110 GB by policy).  ``KEEP_AMD_MAX_CLIPS`` caps it (default 16: more
+        adds nothing to throughput, DESIGN.md batch sweep); the node's ``max_clip_length`` therefore still bounds
+        memory: a longer clip means fewer clips per call, never a bigger footprint."""
+        cap = int(os.environ.get('KEEP_AMD_MAX_CLIPS', '16'))
+        per_frame = 0.35e9 * (H * Wd) / (512.0 * 512.0) * (0.7 if self.precision == 'bf16' else 1.0)
+        try:
+            free, _ = torch.cuda.mem_get_info(self.device)
+            free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)   # cached blocks are reusable
+        except Exception:
+            free = 64e9
+        return max(1, min(cap, int(0.7 * free / (per_frame * max(T, 1)))))
+
+    def run_clips(self, clips, need_upscale=False, max_b=None):
+        """list of [1,T_i,3,H,W] -> list of restored clips.  Clips share no state (KA:1050,1064,1113), so equal-length
+        clips are stacked on the batch axis (as many as free HBM allows, ``clips_per_call``).  A clip's result does not
+        depend on its batch-mates beyond fp32 re-association: kernel choice and split-K factors follow the launch size
+        (<= 5e-4 on the output, tests/test_gpu_net.py::test_batched_clips_equal_sequential)."""
         order = {}
         for n, c in enumerate(clips):
             order.setdefault((c.shape[1], c.shape[3], c.shape[4]), []).append(n)
         outs = [None] * len(clips)
-        for _, ids in order.items():
-            for s in range(0, len(ids), max_b):
-                grp = ids[s:s + max_b]
+        for (T, H, Wd), ids in order.items():
+            b = self.clips_per_call(T, H, Wd) if max_b is None else max_b
+            for s in range(0, len(ids), b):
+                grp = ids[s:s + b]
                 res = self(torch.cat([clips[n] for n in grp], dim=0), need_upscale=need_upscale)
                 for k, n in enumerate(grp):
                     outs[n] = res[k:k + 1]
         return outs
 
     # ------------------------------------------------------------------ device-side pre/post (SURVEY 8f-1)
-    def run_clips_u8(self, clips_u8, max_b=8):
+    def run_clips_u8(self, clips_u8, max_b=None, gather='all'):
         """list of uint8 BGR crops [T_i,H,W,3] (host or device) -> list of restored uint8 BGR [T_i,H,W,3] on the host.
 
         Replaces the per-frame host conversions either side of the clip loop -- ``img2tensor(face/255., bgr2rgb) +
         normalize(0.5, 0.5)`` (keep_processor.py:258-259) and ``tensor2img(rgb2bgr, min_max=(-1,1))``
         (keep_processor.py:272-273, img_util.py:66-90) -- with ``keep_img2tensor`` / ``keep_tensor2img`` on the GPU, so
-        only uint8 crosses PCIe (4x fewer bytes each way).  Bit-identical to the host converters."""
+        only uint8 crosses PCIe (4x fewer bytes each way).  Bit-identical to the host converters.  Clips are converted,
+        restored and converted back one batch group at a time (nothing but uint8 outlives a group).
+
+        With an initialised ``torch.distributed`` group of more than one rank (one process per GPU, engine/dist.py) the
+        clips are sharded round-robin over the ranks -- no data-path collective, clips share no state -- and the restored
+        uint8 clips are gathered by clip index on the host: ``gather='all'`` (default) every rank returns the full list
+        (the processor code that follows is rank-agnostic), ``'root'`` only rank 0 does (others get None), ``'none'`` each
+        rank returns its own clips as {clip index: tensor}."""
         if self.w is None:
             raise RuntimeError("KeepNet: weights are not on a device (load_state_dict + .to('cuda') first)")
-        clips = []
-        with torch.cuda.device(self.device):
-            for c in clips_u8:
-                if c.dim() != 4 or c.shape[-1] != 3 or c.dtype != torch.uint8:
-                    raise ValueError(f"expected uint8 [T,H,W,3], got {c.dtype} {tuple(c.shape)}")
-                u8 = c.to(self.device, non_blocking=True).contiguous()
-                T, H, Wd, _ = u8.shape
-                f = torch.empty((T, H, Wd, 3), dtype=torch.float32, device=self.device)
-                L.call('keep_img2tensor', u8, f, T * H * Wd)
-                clips.append(ops.nhwc_to_nchw(f).unsqueeze(0))
-            outs = self.run_clips(clips, max_b=max_b)
-            res = []
-            for o in outs:
-                _, T, _, H, Wd = o.shape
-                y = ops.nchw_to_nhwc(o.view(T, 3, H, Wd))
-                u8 = torch.empty((T, H, Wd, 3), dtype=torch.uint8, device=self.device)
-                L.call('keep_tensor2img', y, u8, T * H * Wd)
-                res.append(u8)
-            return [r.cpu() for r in res]
+        from . import dist as kdist
+        for c in clips_u8:
+            if c.dim() != 4 or c.shape[-1] != 3 or c.dtype != torch.uint8:
+                raise ValueError(f"expected uint8 [T,H,W,3], got {c.dtype} {tuple(c.shape)}")
+        res = kdist.sharded_map(clips_u8, lambda mine: self._run_clips_u8_local(mine, max_b), gather)
+        if res is None or isinstance(res, dict):
+            return res
+        return [torch.from_numpy(r) if not isinstance(r, torch.Tensor) else r for r in res]
 
+    def _run_clips_u8_local(self, mine, max_b=None):
+        """{clip index: uint8 [T,H,W,3]} -> {clip index: restored uint8 numpy [T,H,W,3]} on this rank's GPU."""
+        order = {}
+        for n, c in mine.items():
+            order.setdefault(tuple(c.shape[:3]), []).append(n)
+        local = {}
+        with torch.cuda.device(self.device):
+            for (T, H, Wd), ids in order.items():
+                b = self.clips_per_call(T, H, Wd) if max_b is None else max_b
+                for s in range(0, len(ids), b):
+                    grp = ids[s:s + b]
+                    u8 = torch.stack([mine[n] for n in grp], 0).to(self.device, non_blocking=True).contiguous()
+                    f = torch.empty((len(grp) * T, H, Wd, 3), dtype=torch.float32, device=self.device)
+                    L.call('keep_img2tensor', u8, f, len(grp) * T * H * Wd)
+                    x = ops.nhwc_to_nchw(f).view(len(grp), T, 3, H, Wd)
+                    del f, u8
+                    o = self(x)
+                    y = ops.nchw_to_nhwc(o.view(len(grp) * T, 3, H, Wd))
+                    r8 = torch.empty((len(grp) * T, H, Wd, 3), dtype=torch.uint8, device=self.device)
+                    L.call('keep_tensor2img', y, r8, len(grp) * T * H * Wd)
+                    r8 = r8.view(len(grp), T, H, Wd, 3).cpu().numpy()
+                    del x, o, y
+                    for k, n in enumerate(grp):
+                        local[n] = r8[k]
+        return local

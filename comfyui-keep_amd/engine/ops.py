@@ -29,7 +29,7 @@ _PLAN_ENV = ('KEEP_NO_COUT4', 'KEEP_NO_C3', 'KEEP_NO_HALO_F32', 'KEEP_NO_HALO_X3
 
 
 class Plan:
-    __slots__ = ('split_k', 'ws_floats', 'stats_P', 'wants_bf16_input', 'out_bf16_ok', 'kernel')
+    __slots__ = ('split_k', 'ws_floats', 'stats_P', 'wants_bf16_input', 'out_bf16_ok', 'out_amax_ok', 'kernel')
 
     def __init__(self, o):
         self.split_k = o.split_k
@@ -37,7 +37,18 @@ class Plan:
         self.stats_P = o.stats_P
         self.wants_bf16_input = bool(o.wants_bf16_input)
         self.out_bf16_ok = bool(o.out_bf16_ok)
+        self.out_amax_ok = bool(o.out_amax_ok)
         self.kernel = o.kernel.decode()
+
+
+class Stats:
+    """What a producing convolution knows about its output for free (reduced in its epilogue): per-channel (sum, sumsq)
+    partials [N,P,C,2] for the next GroupNorm / InstanceNorm, and (x3 policy) the per-image max |y| [N] -- the range probe
+    of the next x3 operator that reads the tensor un-normalised.  Either may be None."""
+    __slots__ = ('part', 'P', 'amax')
+
+    def __init__(self, part=None, P=0, amax=None):
+        self.part, self.P, self.amax = part, P, amax
 
 
 def _plan(a, key):
@@ -104,11 +115,12 @@ class Ops:
     # ------------------------------------------------------------------ keep_conv2d
     def conv(self, x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=False, pro=None, pro_act=L.PRO_NONE,
              act=L.ACT_NONE, residual=None, aux=None, aux_w=1.0, cin=None, in_off=0, out=None, split_k=None, wb=None,
-             wx3=None, x3_acc_scale=None, mma=None, stats=False, out_bf16=False, bounded=False):
+             wx3=None, x3_acc_scale=None, mma=None, stats=False, out_bf16=False, bounded=False, x_amax=None):
         """x [N,H,W,ld] -> [N,Ho,Wo,Cout].  ``w`` packed [Cout,KH,KW,Cin].  ``cin``/``in_off`` select a channel
         slice of a wider input buffer.  ``down`` = VQGAN Downsample geometry (pad right/bottom only, stride 2).
-        ``stats=True`` returns ``(out, st)`` where ``st`` = (partials [N,P,Cout,2], P) reduced in the epilogue for the next
-        GroupNorm / InstanceNorm (``norm_affine(..., stats=st)``), or None when this launch could not emit them.
+        ``stats=True`` returns ``(out, st)``: ``st`` is a ``Stats`` (epilogue-reduced GroupNorm partials and, under the x3
+        policy, the per-image max |out|), or None when this launch could emit neither (split-K).  ``x_amax``: the
+        producer's ``Stats.amax`` of x (any upper bound of max |x| per image works), replacing the range probe.
         ``bounded=True``: the caller vouches that |x| stays far below the fp16 range (normalised / attention-averaged
         inputs); otherwise an x3 launch without a normalising prologue first probes the input range (keep_absmax)."""
         N, H, W, ld = x.shape
@@ -137,7 +149,7 @@ class Ops:
         xin = x if in_off == 0 else x.view(-1)[in_off:]
         in_amax = None
         if mma == L.MMA_X3 and wx3 is not None and pro is None and not bounded:
-            in_amax = absmax(xin, N, H * W, Cin, ld, H * W * ld)
+            in_amax = x_amax if (x_amax is not None and x_amax.numel() == N) else absmax(xin, N, H * W, Cin, ld, H * W * ld)
         out_ld = Cout if out is None else out.shape[-1]
 
         def make_args(inp, dtype, pro_t, pro_a, odt, sk):
@@ -149,7 +161,7 @@ class Ops:
                 upsample=int(upsample), pro_act=pro_a, epi_act=act, aux_w=float(aux_w), split_k=sk, dtype=dtype,
                 mma=mma, weight_bf16=wb if mma == L.MMA_BF16 else None, stats_out=None, stats_P=0,
                 bk256=int(USE_BK256), out_dtype=odt, weight_x3=wx3 if mma == L.MMA_X3 else None,
-                x3_acc_scale=float(x3_acc_scale), x3_in_amax=in_amax)
+                x3_acc_scale=float(x3_acc_scale), x3_in_amax=in_amax, x3_out_amax=None)
 
         def key_of(dtype, pro_t, pro_a, odt, sk):
             return (N, H, W, ld, Cin, Cout, KH, stride, pad_t, pad_l, Ho, Wo, out_ld, int(upsample), pro_a, act, dtype, mma,
@@ -181,10 +193,14 @@ class Ops:
         if ws is not None:
             a.workspace = ws.data_ptr()
         st = None
-        if stats and pl.stats_P:
-            part = empty((N, pl.stats_P, Cout, 2), x)
-            a.stats_out, a.stats_P = part.data_ptr(), pl.stats_P
-            st = (part, pl.stats_P)
+        if stats and (pl.stats_P or pl.out_amax_ok):
+            st = Stats()
+            if pl.stats_P:
+                st.part, st.P = empty((N, pl.stats_P, Cout, 2), x), pl.stats_P
+                a.stats_out, a.stats_P = st.part.data_ptr(), pl.stats_P
+            if pl.out_amax_ok:
+                st.amax = empty((N,), x)
+                a.x3_out_amax = st.amax.data_ptr()
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             # algorithmic bytes: one read of the input window at its storage type, the weights, one write of the output
@@ -210,7 +226,7 @@ class Ops:
         return (out, st) if stats else out
 
     def linear(self, x, w, bias=None, *, act=L.ACT_NONE, residual=None, pro=None, pro_act=L.PRO_NONE, cin=None, in_off=0,
-               n_img=1, out_bf16=False, bounded=False):
+               n_img=1, out_bf16=False, bounded=False, x_amax=None):
         """x [M,ld] (or any [...,ld]) @ w[Cout,Cin]^T.  ``n_img``>1 makes the prologue per-image: rows are n_img
         images of M/n_img pixels each (1x1 conv on a feature map)."""
         shp = x.shape
@@ -223,7 +239,7 @@ class Ops:
         x4 = x.reshape(n_img, M // n_img, 1, ld)
         res4 = None if residual is None else residual.reshape(n_img, M // n_img, 1, residual.shape[-1])
         y = self.conv(x4, w, bias, stride=1, pad=0, ksize=1, pro=pro, pro_act=pro_act, act=act, residual=res4, cin=cin,
-                      in_off=in_off, out_bf16=out_bf16, bounded=bounded)
+                      in_off=in_off, out_bf16=out_bf16, bounded=bounded, x_amax=x_amax)
         return y.reshape(*shp[:-1], w.shape[0])
 
     # ------------------------------------------------------------------ normalisation
@@ -236,9 +252,8 @@ class Ops:
         HW = H * W
         scale = empty((N, C), x)
         shift = empty((N, C), x)
-        if stats is not None:
-            part, P = stats
-            L.call('keep_norm_finalize', part, gamma, beta, scale, shift, N, HW, C, groups, P, float(eps))
+        if stats is not None and stats.part is not None:
+            L.call('keep_norm_finalize', stats.part, gamma, beta, scale, shift, N, HW, C, groups, stats.P, float(eps))
             return scale, shift
         assert x.dtype == torch.float32, "bf16 activations carry their statistics from the producing conv's epilogue"
         cpg = C // groups

@@ -120,6 +120,9 @@ typedef struct {
    * just below 2^15 before splitting (and undo it on the accumulators), so no activation can leave the fp16 range and
    * small values keep a normal `lo`.  NULL: inputs are split as they are (|x| must stay below 65504). */
   const float* x3_in_amax;
+  /* optional, KEEP_MMA_X3 kernels with split_k == 1 (keep_conv2d_plan: out_amax_ok): out_amax[n] = max |out[n,...]|, [N]
+   * floats, zeroed and filled by this call -- the range probe of the NEXT un-normalised x3 consumer for free */
+  float* x3_out_amax;
 } keep_conv2d_args;
 int32_t keep_conv2d(const keep_conv2d_args* a, void* stream);
 
@@ -135,6 +138,7 @@ typedef struct {
   int32_t wants_bf16_input; /* KEEP_MMA_BF16: faster if the caller first runs keep_norm_act_bf16 (prologue applied once,
                                bf16 tensor) and calls again with dtype = KEEP_BF16 and no prologue */
   int32_t out_bf16_ok;      /* out_dtype = KEEP_BF16 is supported for this geometry */
+  int32_t out_amax_ok;      /* x3_out_amax will be filled by this call */
   char kernel[64];          /* kernel family as rocprofv3 prints it (bench.py groups its HIP-event timings by it) */
 } keep_conv2d_plan_out;
 int32_t keep_conv2d_plan(const keep_conv2d_args* a, keep_conv2d_plan_out* out);

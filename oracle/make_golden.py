@@ -179,6 +179,8 @@ def main():
     W = full_forward(KEEP, {}, 3, 'keep_forward_T3.npz')
     per_op(KEEP, W)
     full_forward(KEEP, ASIAN, 2, 'keep_forward_asian_T2.npz')
+    # the metric's own clip length: 19 recurrent steps of prev_out -> warp -> hq_encoder -> indices (KA:1062-1127)
+    full_forward(KEEP, {}, 20, 'keep_forward_T20.npz')
 
 
 if __name__ == '__main__':

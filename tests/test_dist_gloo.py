@@ -45,8 +45,57 @@ def _worker(rank, world, port, n_clips, out_dir):
         np.save(os.path.join(out_dir, 'ok.npy'), np.array([len(full)]))
     else:
         assert full is None
+    # the product's sharding entry point (what KeepNet.run_clips_u8 runs on): every rank ends up with the full list
+    clips = [np.full((2, 4, 4, 3), 3 * c, dtype=np.uint8) for c in range(n_clips)]
+    seen = []
+
+    def local_fn(mine_d):
+        seen.extend(mine_d)
+        return {i: 255 - c for i, c in mine_d.items()}
+    allr = kdist.sharded_map(clips, local_fn, gather='all')
+    assert sorted(seen) == mine and len(allr) == n_clips
+    assert all(np.array_equal(allr[c], 255 - clips[c]) for c in range(n_clips))
+    root = kdist.sharded_map(clips, local_fn, gather='root')
+    assert (root is None) == (rank != 0)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
+
+
+def _worker_real_blob(rank, world, port, out_dir):
+    """The REAL packed weight blob (896 reference tensors -> fused / permuted kernel layouts, 633 MB) through the same
+    broadcast + adopt_packed path bench.py and a multi-GPU deployment use; every named view must arrive bit-identical."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    load_package()
+    import hashlib
+    from comfyui_keep_amd.engine import dist as kdist, synth
+    from comfyui_keep_amd.engine.arch import DEFAULT_ARCH
+    from comfyui_keep_amd.engine.net import KeepNet
+    kdist.init_from_env(backend='gloo')
+    net = KeepNet(**DEFAULT_ARCH)
+    if rank == 0:
+        net.load_state_dict(synth.synth_state_dict(seed=0), strict=True)
+        index, blob = kdist.broadcast_packed_weights(net._index, torch.from_numpy(net._blob), src=0)
+    else:
+        index, blob = kdist.broadcast_packed_weights(None, None, src=0)
+    net.adopt_packed(index, blob)
+    h = hashlib.blake2b(digest_size=16)
+    for name in sorted(net.w):
+        h.update(name.encode())
+        h.update(str(tuple(net.w[name].shape)).encode())
+        h.update(net.w[name].contiguous().numpy().tobytes())
+    with open(os.path.join(out_dir, f'digest{rank}.txt'), 'w') as f:
+        f.write(f'{len(net.w)} {blob.numel()} {h.hexdigest()}')
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_world2_real_weight_blob_broadcast(tmp_path):
+    mp.spawn(_worker_real_blob, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    d0, d1 = (open(tmp_path / f'digest{r}.txt').read() for r in (0, 1))
+    assert d0 == d1 and int(d0.split()[0]) > 600 and int(d0.split()[1]) > 150_000_000
 
 
 def test_world2_broadcast_shard_gather(tmp_path):

@@ -67,7 +67,7 @@ def test_conv3x3_f32_halo_kernel_vs_gather_kernel(monkeypatch):
         pro = ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6)
         kw = dict(pro=pro, pro_act=L.PRO_SWISH, upsample=up, stats=True, split_k=1)
         y, st = ops.conv(xd, pack(w), dev(b), **kw)
-        assert st is not None and st[1] == (y.shape[1] * y.shape[2]) // 64
+        assert st is not None and st.P == (y.shape[1] * y.shape[2]) // 64
         monkeypatch.setenv('KEEP_NO_HALO_F32', '1')
         y_g, _ = ops.conv(xd, pack(w), dev(b), **kw)
         monkeypatch.delenv('KEEP_NO_HALO_F32')
@@ -130,7 +130,9 @@ def test_conv_x3_halo_is_fp32_grade(n, cin, cout, h, wd, up, res, gn):
     scale = max(1.0, ref.abs().max().item())
     assert torch.isfinite(y).all()
     assert e3 <= max(3.0 * e32, 2e-6 * scale), f'x3 err {e3:.3e} vs f32-kernel err {e32:.3e} (scale {scale:.3g})'
-    if st is not None:
+    if st is not None and st.amax is not None:     # epilogue-fused range probe of the output == a direct reduction
+        assert torch.equal(st.amax.cpu(), y.abs().flatten(1).max(1).values.cpu())
+    if st is not None and st.part is not None:
         sc, sh = ops.norm_affine(y, None, None, cout, 1e-5, stats=st)
         sc2, sh2 = ops.norm_affine(y, None, None, cout, 1e-5)
         check(sc, sc2, 1e-5, 'x3 halo fused stats scale'); check(sh, sh2, 1e-5, 'x3 halo fused stats shift')
@@ -143,9 +145,11 @@ def test_conv_x3_gather_is_fp32_grade():
         wp = pack(w4)
         wx3, asc = x3w(wp)
         ops.DEFAULT.profile = []
-        y = ops.conv(dev(nhwc(x4)), wp, None if b is None else dev(b), mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, **kw)
+        y, st = ops.conv(dev(nhwc(x4)), wp, None if b is None else dev(b), mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, stats=True, **kw)
         assert ops.DEFAULT.profile[-1][0].startswith('conv_x3_kernel'), (name, ops.DEFAULT.profile[-1][0])
         ops.DEFAULT.profile = None
+        if st is not None and st.amax is not None:
+            assert torch.equal(st.amax.cpu(), y.abs().flatten(1).max(1).values.cpu()), name
         y32 = ops.conv(dev(nhwc(x4)), wp, None if b is None else dev(b), **kw)
         e3, e32 = err64(nchw(y), ref64), err64(nchw(y32), ref64)
         scale = max(1.0, ref64.abs().max().item())
@@ -691,7 +695,7 @@ def test_conv_bf16_halo_bf16_output_and_bf16_inputs():
     y16, st16 = ops.conv(xd, wp, dev(b), mma=L.MMA_BF16, wb=wb, stats=True, out_bf16=True)
     assert y16.dtype == torch.bfloat16 and st16 is not None
     check(y16.float(), bf16r(y32.cpu()), 1e-6, 'halo bf16 output == RNE(fp32 output)')
-    check(st16[0], st32[0], 1e-6, 'stats taken before rounding')
+    check(st16.part, st32.part, 1e-6, 'stats taken before rounding')
     # (b) GN + swish pass from the bf16 tensor, then the second halo conv
     gamma, beta = rnd('hbg', (128,)) * 0.2 + 1, rnd('hbbt', (128,)) * 0.2
     w2 = rnd('hbw2', (64, 128, 3, 3), 0.05)

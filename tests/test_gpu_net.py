@@ -167,12 +167,97 @@ def test_full_forward_T3_vs_reference_golden(gpu_net):
     _full_forward_check(gpu_net, 'keep_forward_T3.npz', 3)
 
 
+def test_full_forward_T20_vs_reference_golden(gpu_net):
+    """The metric's own clip length: 19 recurrent steps of prev_out -> warp -> hq_encoder -> Kalman -> indices
+    (keep_arch.py:1062-1127) against the imported reference (tests/golden/keep_forward_T20.npz)."""
+    _full_forward_check(gpu_net, 'keep_forward_T20.npz', 20)
+
+
+def test_full_forward_T20_vs_oracle_drift_report(gpu_net, synth_weights):
+    """T = 20, free running, the oracle's flows injected (so that GMFlow's 4096-way softmax re-association is out of the
+    comparison): code indices must match the oracle on every token whose margin exceeds 1e-3, frame by frame, up to the
+    first frame where any (low-margin) token differs -- beyond it the two runs restore different inputs.  If no token
+    flips over the whole clip, every pixel of all 20 frames must be within 1e-3."""
+    x = synth.synth_clip(T=20, B=1, seed=1234)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref, raux = O.keep_forward(x, synth_weights, return_aux=True)
+    out, aux = gpu_net(x.cuda(), return_aux=True, force_flows=raux['flows'])
+    top2 = raux['logits'].topk(2, -1).values
+    margin = (top2[..., 0] - top2[..., 1])[0]                      # [T, 256]
+    agree = (aux['indices'].cpu().long() == raux['indices'])[0]    # [T, 256]
+    first_div = next((t for t in range(20) if not bool(agree[t].all())), 20)
+    gain_err = (aux['gains'].cpu() - raux['gains'].view(1, 20, -1)).abs().max().item()
+    per_frame = (out.cpu() - ref)[0].abs().flatten(1).max(1).values
+    print(f'T=20 [{gpu_net.precision}]: first frame with a differing index: {first_div} (20 = none); min margin '
+          f'{margin.min().item():.2e}; gain err {gain_err:.2e}; per-frame max-abs pixel diff up to there: '
+          f'{[round(float(v), 6) for v in per_frame[:max(first_div, 1)]]}')
+    assert gain_err <= 2e-4
+    for t in range(min(first_div + 1, 20)):
+        assert agree[t][margin[t] > 1e-3].all(), f'frame {t}: a token with margin > 1e-3 differs'
+    assert first_div >= 1
+    assert float(per_frame[:first_div].max()) <= 1e-3, per_frame[:first_div]
+
+
+def _stub_helper_pack(net):
+    import test_host_logic as H   # installs the ComfyUI stubs
+    from comfyui_keep_amd.modules.keep_model_loader import KEEPModelPack
+    pack = KEEPModelPack(net, H._Helper(), None, None, 'KEEP')
+    pack.device = torch.device('cuda')
+    return pack
+
+
+@pytest.mark.parametrize("n_crops,faces", [(300, 1), (900, 3)])
+def test_config3_config4_clip_mixes_equal_sequential(gpu_net, n_crops, faces):
+    """BASELINE configs[2] / [3] as the hot path sees them (keep_processor.py:256-276): 300 crops of one face = 15 clips
+    x 20, 900 frame-major interleaved crops of 3 faces = 45 clips x 20, handed to the engine in one call (batched on the
+    batch axis by free HBM).  Order and chunking must equal the sequential one-clip-at-a-time loop: checked bit-exactly
+    on the uint8 output for a spread of clips (restored one at a time through the same net) and structurally for all."""
+    from comfyui_keep_amd.modules.keep_processor import KEEPFaceProcessor, split_clips
+    proc = KEEPFaceProcessor(_stub_helper_pack(gpu_net))
+    base = synth.ramp_image()
+    g = np.random.default_rng(n_crops)
+    # crop k: frame k // faces, face k % faces -- distinct content per (frame, face)
+    crops = [np.ascontiguousarray((np.roll(base, (7 * (k // faces)) % 512, axis=1).astype(np.int16)
+                                   + 40 * (k % faces) + g.integers(-8, 9, (512, 512, 3))).clip(0, 255).astype(np.uint8))
+             for k in range(n_crops)]
+    faces_out = proc._restore_crops_u8(crops, 20)
+    assert len(faces_out) == n_crops and all(f.shape == (512, 512, 3) and f.dtype == np.uint8 for f in faces_out)
+    spans = split_clips(n_crops, 20)
+    assert len(spans) == n_crops // 20 and all(e - s == 20 for s, e in spans)
+    for ci in sorted({0, len(spans) // 2, len(spans) - 1}):
+        s, e = spans[ci]
+        solo = gpu_net.run_clips_u8([torch.from_numpy(np.stack(crops[s:e]))], max_b=1)[0].numpy()
+        got = np.stack(faces_out[s:e])
+        diff = np.abs(solo.astype(np.int16) - got.astype(np.int16))
+        # batch-mates change split-K factors (fp32 re-association, <= 5e-4 before rounding): at most a last-bit flip
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (ci, int(diff.max()), float((diff > 0).mean()))
+
+
 def test_full_forward_asian_T2_vs_reference_golden():
     from comfyui_keep_amd.engine.net import KeepNet
     cfg = dict(DEFAULT_ARCH, cft_list=['32', '64', '128', '256'], temp_reg_list=[])
     net = KeepNet(**cfg)
     net.load_state_dict(synth.synth_state_dict(cfg, seed=0), strict=True)
     _full_forward_check(net.to('cuda').eval(), 'keep_forward_asian_T2.npz', 2)
+
+
+def test_hipgraph_replay_is_bit_identical_to_eager(gpu_net):
+    """Small batches run as a captured hipGraph (one replay instead of ~9 k launches per clip): same kernels, same order,
+    same pointers' worth of arithmetic -> bit-identical output, also on a second input through the same graph."""
+    x1 = synth.synth_clip(T=3, B=1, seed=1234).cuda()
+    x2 = synth.synth_clip(T=3, B=1, seed=99, phase=0.5).cuda()
+    mode = gpu_net.graph_mode
+    try:
+        gpu_net.graph_mode = '0'
+        e1, e2 = gpu_net(x1), gpu_net(x2)
+        gpu_net.graph_mode = '1'
+        g1 = gpu_net(x1)            # captures
+        g2 = gpu_net(x2)            # replays the same graph on new input
+        g1b = gpu_net(x1)
+        assert any(k[:4] == (1, 3, 512, 512) for k in gpu_net._graphs)
+        assert torch.equal(e1, g1) and torch.equal(e2, g2) and torch.equal(e1, g1b)
+    finally:
+        gpu_net.graph_mode = mode
 
 
 def test_batched_clips_equal_sequential(gpu_net):

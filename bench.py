@@ -162,16 +162,15 @@ def synth_crops(n, seed=0):
 def processor_leg(net, n_crops, faces):
     """BASELINE configs[2] / [3] as the hot path sees them: `n_crops` crops stacked frame-major (`faces` crops per frame,
     interleaved: keep_processor.py:252-253) and cut into max_clip_length = 20 chunks by the processor's own code."""
-    from comfyui_keep_amd.modules.keep_model_loader import KEEPModelPack
+    import types
     from comfyui_keep_amd.modules.keep_processor import KEEPFaceProcessor, split_clips
-
-    class _NoHelper:
-        pass
-    pack = KEEPModelPack(net, _NoHelper(), None, None, 'KEEP')
-    pack.device = net.device
+    # the six attributes KEEPFaceProcessor copies from a KEEPModelPack (keep_processor.py:118-124); detection / paste-back
+    # are not on this leg, so no face helper (and no ComfyUI runtime) is needed
+    pack = types.SimpleNamespace(keep_net=net, face_helper=None, bg_upscale_model=None, face_upscale_model=None,
+                                 device=net.device, model_type_str='KEEP')
     proc = KEEPFaceProcessor(pack)
     crops = synth_crops(n_crops, seed=faces)
-    proc._restore_crops_u8(crops[:40], 20)          # warm: allocator + plan cache for this clip mix
+    proc._restore_crops_u8(crops, 20)               # warm: allocator, plan cache, batch shapes of this clip mix
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = proc._restore_crops_u8(crops, 20)
@@ -289,14 +288,20 @@ def main():
             for pol, (o, a) in results.items():
                 if pol == 'fp32':
                     continue
-                agree = (a['indices'] == ref_aux['indices'])
-                same_clip = agree.flatten(1).all(1)                       # clips whose every code index matches
-                rec = {"code_index_agreement_all_frames": round(float(agree.float().mean()), 5),
-                       "frame0_code_index_agreement": round(float(agree[:, 0].float().mean()), 5),
-                       "clips_with_identical_indices": int(same_clip.sum()),
-                       "max_abs_pixel_diff_on_those_clips": (round(float((o[same_clip] - ref_out[same_clip]).abs().max()), 6)
-                                                             if bool(same_clip.any()) else None),
-                       "frame0_median_abs_pixel_diff": round(float((o[:, 0] - ref_out[:, 0]).abs().median()), 6)}
+                # The frame recurrence is chaotic once a single low-margin token flips (the next frame restores a different
+                # prev_out), so policies are compared clip by clip up to the first frame with a differing index, and by
+                # the logit margin (exact-f32 run) of the tokens that flipped there: parity means margins below ~1e-3.
+                agree = (a['indices'] == ref_aux['indices'])                       # [B, T, 256]
+                frame_ok = agree.flatten(2).all(2)                                  # [B, T]
+                first = [next((t for t in range(T_CLIP) if not bool(frame_ok[b, t])), T_CLIP) for b in range(B)]
+                flip_margins = [float(ref_aux['margins'][b, first[b]][~agree[b, first[b]]].max()) for b in range(B) if first[b] < T_CLIP]
+                common = [(o[b, :first[b]] - ref_out[b, :first[b]]).abs().max() for b in range(B) if first[b] > 0]
+                rec = {"frame0_code_index_agreement": round(float(agree[:, 0].float().mean()), 5),
+                       "frames_until_first_index_flip_per_clip": first,
+                       "largest_margin_among_first_flips": (round(max(flip_margins), 6) if flip_margins else None),
+                       "max_abs_pixel_diff_before_first_flip": round(float(torch.stack(common).max()), 6) if common else None,
+                       "output_abs_max": round(float(ref_out.abs().max()), 3),
+                       "code_index_agreement_all_frames": round(float(agree.float().mean()), 5)}
                 if pol == args.precision:
                     line["vs_exact_f32_policy"] = rec
                 else:

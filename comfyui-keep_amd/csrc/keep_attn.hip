@@ -593,16 +593,19 @@ typedef _Float16 af16x2 __attribute__((ext_vector_type(2)));
 // steps) live in registers for the whole kernel -- loaded straight from global, never staged -- so a block's LDS is one
 // K tile + one V^T tile (<= 35 KB) and two blocks share a CU.  D > 128 (VQGAN AttnBlock D = 512, CFA D = 256; 16x16 / 32x32
 // token maps): Q and K are re-staged through LDS per 128-wide chunk.
-template <int WAVES, int DVT, bool QREG>
-__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_x3_kernel(AttnP p) {
+template <int WAVES, int DVT, int NQ>
+__global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) void attn_x3_kernel(AttnP p) {
+  constexpr bool QREG = NQ > 0;             // NQ 16-wide d steps of Q live in registers (NQ = 16: D <= 256, one block per CU)
+  constexpr int NQA = QREG ? NQ : 1;
   extern __shared__ __attribute__((aligned(16))) _Float16 smemx[];
   constexpr int DVS = DVT * 32;
   constexpr int NT = 64 * WAVES;
   constexpr int VP = 72;
   constexpr bool PF = (WAVES == 4) && QREG;
-  constexpr int KPF = PF ? (32 * 32 + NT - 1) / NT : 1;        // float4 pieces of a 32 x 128 K tile per thread
+  constexpr int KPF = PF ? (32 * 4 * NQA + NT - 1) / NT : 1;   // float4 pieces of a 32 x (16*NQ) K tile per thread
   constexpr int VPF = PF ? (16 * DVS + NT - 1) / NT : 1;       // (key pair, dv) items of a 32 x DVS V tile per thread
-  const int DC = p.D < 128 ? p.D : 128;
+  const int DCMAX = QREG ? 16 * NQA : 128;
+  const int DC = p.D < DCMAX ? p.D : DCMAX;
   const int nch = p.D / DC;
   const int QP = 2 * DC + 8;
   _Float16* Ks = smemx;                               // [32][QP]
@@ -748,12 +751,12 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_x3_kern
 
   const int my_q = q0 + wave * 32 + l31;
   // ---- Q fragments of this lane: row my_q, d in [16*step + 8*lhi, +8), split once
-  af16x8 qfh[QREG ? 8 : 1], qfl[QREG ? 8 : 1];
+  af16x8 qfh[NQA], qfl[NQA];
   if (QREG) {
     const bool qok = my_q < p.Lq;
     const float* qrow = p.q + (qok ? q_offset(p, b, my_q, p.q_bs, p.q_ts) + qh : 0) + lhi * 8;
 #pragma unroll
-    for (int d8 = 0; d8 < 8; ++d8) {
+    for (int d8 = 0; d8 < NQA; ++d8) {
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
       if (qok && d8 * 16 < DC) {
         a = *reinterpret_cast<const float4*>(qrow + d8 * 16);
@@ -800,7 +803,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_x3_kern
         v_issue(kt + 1);
       }
 #pragma unroll
-      for (int d8 = 0; d8 < 8; ++d8) {
+      for (int d8 = 0; d8 < NQA; ++d8) {
         if (d8 * 16 < DC) {
           const af16x8 kh8 = *reinterpret_cast<const af16x8*>(kp + d8 * 16);
           const af16x8 kl8 = *reinterpret_cast<const af16x8*>(kp + DC + d8 * 16);
@@ -901,13 +904,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_x3_kern
   }
 }
 
-template <int WAVES, int DVT, bool QREG>
+template <int WAVES, int DVT, int NQ>
 static int launch_attn_x3_t(const AttnP& p, hipStream_t st) {
-  const int DC = p.D < 128 ? p.D : 128;
+  constexpr bool QREG = NQ > 0;
+  const int DCMAX = QREG ? 16 * NQ : 128;
+  const int DC = p.D < DCMAX ? p.D : DCMAX;
   const size_t lds = (size_t)(((QREG ? 0 : WAVES * 32) + 32) * (2 * DC + 8) + DVT * 32 * 72) * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_x3_kernel<WAVES, DVT, QREG>,
+    hipError_t e = hipFuncSetAttribute((const void*)attn_x3_kernel<WAVES, DVT, NQ>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       keep_set_error("keep_attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -916,15 +921,205 @@ static int launch_attn_x3_t(const AttnP& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(cdiv(p.Lq, WAVES * 32), p.H * p.nslices, p.B);
-  hipLaunchKernelGGL((attn_x3_kernel<WAVES, DVT, QREG>), grid, dim3(64 * WAVES), lds, st, p);
+  hipLaunchKernelGGL((attn_x3_kernel<WAVES, DVT, NQ>), grid, dim3(64 * WAVES), lds, st, p);
   KEEP_LAUNCH_CHECK("keep_attention(x3)");
+  return KEEP_OK;
+}
+
+// D > 256 with at most 256 keys (the VQGAN AttnBlock: 256 tokens, one head of d = 512, VQ:226-239): the whole score row of
+// a query fits in registers (8 key tiles x 16 values per lane), so the loops are turned inside out -- D chunks OUTSIDE, key
+// tiles inside, S^T accumulated for all tiles -- and the 128-query Q chunk is staged once per chunk instead of once per
+// (key tile, chunk): 3.3x less staging traffic than the generic chunked path, plain (not online) softmax, then P.V tile by
+// tile.  Mode 0 only.
+template <int DVT>
+__global__ __launch_bounds__(256, 1) void attn_x3_sfull_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 smemx[];
+  constexpr int DVS = DVT * 32, NT = 256, VP = 72, DC = 128, QP = 2 * DC + 8, KT2 = 64;
+  _Float16* Qs = smemx;                               // [128][QP]
+  _Float16* Ks = Qs + 128 * QP;                       // [64][QP]: two key tiles per barrier pair
+  _Float16* Vt = Ks + KT2 * QP;                       // [DVS][VP]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int b = blockIdx.z;
+  const int head = blockIdx.y / p.nslices;
+  const int dv0 = (blockIdx.y - head * p.nslices) * DVS;
+  const int q0 = blockIdx.x * 128;
+  const long qh = (long)head * p.q_hs, kh = (long)head * p.k_hs, vh = (long)head * p.v_hs;
+  const int nch = p.D / DC;
+  const int ntiles = (p.Lk + 31) / 32;                // <= 8
+  float sq = 1.f, sk = 1.f, sv = 1.f, inv_qk = 1.f, inv_sv = 1.f;
+  if (p.q_amax) {
+    float iq, ik;
+    attn_range_scale(p.q_amax[b], sq, iq);
+    attn_range_scale(p.k_amax[b], sk, ik);
+    attn_range_scale(p.v_amax[b], sv, inv_sv);
+    inv_qk = iq * ik;
+  }
+  auto stage_rows = [&](const float* base, long bs, long ts, long hoff, int t0, int tmax, int nrows, int c0, float sc, _Float16* dst) {
+    for (int i = tid; i < nrows * (DC / 4); i += NT) {
+      const int row = i / (DC / 4), c = (i - row * (DC / 4)) << 2;
+      const int t = t0 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < tmax) v = *reinterpret_cast<const float4*>(base + (long)b * bs + (long)t * ts + hoff + c0 + c);
+      const float f[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+      af16x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const _Float16 h = (_Float16)f[j];
+        hi[j] = h;
+        lo[j] = (_Float16)(f[j] - (float)h);
+      }
+      *reinterpret_cast<af16x4*>(dst + row * QP + c) = hi;
+      *reinterpret_cast<af16x4*>(dst + row * QP + c + DC) = lo;
+    }
+  };
+  f32x16 s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[k][r] = 0.f;
+  const _Float16* qp = Qs + (wave * 32 + l31) * QP + lhi * 8;
+  for (int ch = 0; ch < nch; ++ch) {
+    __syncthreads();                                   // previous chunk fully consumed
+    stage_rows(p.q, p.q_bs, p.q_ts, qh, q0, p.Lq, 128, ch * DC, sq, Qs);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+      if (k2 * 2 < ntiles) {
+        if (k2 > 0) __syncthreads();                   // the previous pair of key tiles is consumed
+        stage_rows(p.k, p.k_bs, p.k_ts, kh, k2 * KT2, p.Lk, KT2, ch * DC, sk, Ks);
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < DC; d += 16) {
+          const af16x8 qh8 = *reinterpret_cast<const af16x8*>(qp + d), ql8 = *reinterpret_cast<const af16x8*>(qp + DC + d);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const _Float16* kp = Ks + (t * 32 + l31) * QP + lhi * 8 + d;
+            const af16x8 kh8 = *reinterpret_cast<const af16x8*>(kp), kl8 = *reinterpret_cast<const af16x8*>(kp + DC);
+            s[k2 * 2 + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh8, s[k2 * 2 + t], 0, 0, 0);
+            s[k2 * 2 + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, ql8, s[k2 * 2 + t], 0, 0, 0);
+            s[k2 * 2 + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qh8, s[k2 * 2 + t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // ---- softmax over the whole key row of this lane's query (exact fp32)
+  const float qk_scale = p.scale * inv_qk;
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const float val = key < p.Lk ? s[k][r] * qk_scale : -INFINITY;
+      s[k][r] = val;
+      m = fmaxf(m, val);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32));
+  float lsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = expf(s[k][r] - m);
+      s[k][r] = pv;
+      lsum += pv;
+    }
+  lsum += __shfl_xor(lsum, 32);
+  // ---- O = P . V, one 32-key tile at a time (V^T key-permuted like attn_bf16_kernel)
+  f32x16 o[DVT];
+#pragma unroll
+  for (int j = 0; j < DVT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt) {
+    if (kt < ntiles) {
+      __syncthreads();
+      for (int i = tid; i < 16 * DVS; i += NT) {
+        const int pair = i / DVS, dv = i - pair * DVS;
+        const int t = kt * 32 + pair * 2;
+        float v[2] = {0.f, 0.f};
+        if (dv0 + dv < p.Dv) {
+          if (t < p.Lk) v[0] = p.v[(long)b * p.v_bs + (long)t * p.v_ts + vh + dv0 + dv];
+          if (t + 1 < p.Lk) v[1] = p.v[(long)b * p.v_bs + (long)(t + 1) * p.v_ts + vh + dv0 + dv];
+        }
+        af16x2 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float vs = v[j] * sv;
+          const _Float16 h = (_Float16)vs;
+          hi[j] = h;
+          lo[j] = (_Float16)(vs - (float)h);
+        }
+        _Float16* d = Vt + dv * VP + vt_pos(pair * 2);
+        *reinterpret_cast<af16x2*>(d) = hi;
+        *reinterpret_cast<af16x2*>(d + 32) = lo;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        af16x8 ph, pl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const _Float16 h = (_Float16)s[kt][st * 8 + j];
+          ph[j] = h;
+          pl[j] = (_Float16)(s[kt][st * 8 + j] - (float)h);
+        }
+#pragma unroll
+        for (int j = 0; j < DVT; ++j) {
+          const _Float16* vrow = Vt + (j * 32 + l31) * VP + (st * 2 + lhi) * 8;
+          const af16x8 vh8 = *reinterpret_cast<const af16x8*>(vrow), vl8 = *reinterpret_cast<const af16x8*>(vrow + 32);
+          o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh8, o[j], 0, 0, 0);
+          o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl8, o[j], 0, 0, 0);
+          o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh8, o[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const float inv_l = inv_sv / lsum;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    const float il = __shfl(inv_l, qrow);
+    const int t = q0 + wave * 32 + qrow;
+    if (t < p.Lq) {
+      const long base = (long)b * p.o_bs + (long)t * p.o_ts + (long)head * p.o_hs;
+#pragma unroll
+      for (int j = 0; j < DVT; ++j) {
+        const int dv = dv0 + j * 32 + l31;
+        if (dv < p.Dv) p.o[base + dv] = o[j][r] * il;
+      }
+    }
+  }
+}
+
+template <int DVT>
+static int launch_attn_x3_sfull(const AttnP& p, hipStream_t st) {
+  const size_t lds = (size_t)((128 + 64) * (2 * 128 + 8) + DVT * 32 * 72) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_x3_sfull_kernel<DVT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      keep_set_error("keep_attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return KEEP_EHIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid(cdiv(p.Lq, 128), p.H * p.nslices, p.B);
+  hipLaunchKernelGGL((attn_x3_sfull_kernel<DVT>), grid, dim3(256), lds, st, p);
+  KEEP_LAUNCH_CHECK("keep_attention(x3, full score row)");
   return KEEP_OK;
 }
 
 template <int WAVES, int DVT>
 static int launch_attn_x3(const AttnP& p, hipStream_t st) {
-  if (p.D <= 128) return launch_attn_x3_t<WAVES, DVT, true>(p, st);
-  return launch_attn_x3_t<4, DVT, false>(p, st);
+  if (p.D <= 128) return launch_attn_x3_t<WAVES, DVT, 8>(p, st);
+  if (p.D <= 256) return launch_attn_x3_t<4, DVT, 16>(p, st);
+  if (p.mode == 0 && p.Lk <= 256 && p.D % 128 == 0) return launch_attn_x3_sfull<DVT>(p, st);
+  return launch_attn_x3_t<4, DVT, 0>(p, st);
 }
 
 // ------------------------------------------------------------------------------------------------ bf16-input variant

@@ -1947,11 +1947,8 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (a->x3_out_amax) {
     KEEP_REQUIRE(pl.amax_ok, "keep_conv2d: x3_out_amax is not available for this call (keep_conv2d_plan: out_amax_ok)");
-    hipError_t e = hipMemsetAsync(a->x3_out_amax, 0, (size_t)a->N * sizeof(float), st);
-    if (e != hipSuccess) {
-      keep_set_error("keep_conv2d: hipMemsetAsync(x3_out_amax) failed: %s", hipGetErrorString(e));
-      return KEEP_EHIP;
-    }
+    hipLaunchKernelGGL(zero_u32_kernel, dim3(cdiv(a->N, 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(a->x3_out_amax), a->N);
+    KEEP_LAUNCH_CHECK("keep_conv2d(zero x3_out_amax)");
     p.out_amax = reinterpret_cast<unsigned*>(a->x3_out_amax);
   }
   if (p.out_bf16)

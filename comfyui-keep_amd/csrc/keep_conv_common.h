@@ -41,6 +41,13 @@ struct ConvP {
   unsigned* out_amax;         // KEEP_MMA_X3: per-image max |output| as raw float bits (atomicMax), or NULL
 };
 
+// zero-fill of the small atomicMax targets as a KERNEL node: inside a captured hipGraph a hipMemsetAsync node was observed to
+// race with the atomics of the kernels that follow it (replays of one graph differed by ~2e-5); a kernel keeps stream order
+static __global__ void zero_u32_kernel(unsigned* p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
 // wave-wide max of non-negative floats via their bit patterns, then one atomic per wave
 __device__ __forceinline__ void wave_amax_commit(unsigned* dst, float m) {
   unsigned b = __float_as_uint(m);

@@ -913,15 +913,18 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   if ((threadIdx.x & 63) == 0 && m) atomicMax(amax_bits + n, m);
 }
 
+// (a kernel, not hipMemsetAsync: a memset node inside a captured hipGraph raced with the atomics that follow it)
+__global__ void absmax_zero_kernel(unsigned* p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
 extern "C" int32_t keep_absmax(const float* x, float* amax, int32_t N, int64_t R, int32_t C, int64_t ld, int64_t img_stride,
                                void* stream) {
   KEEP_REQUIRE(x && amax && N > 0 && R > 0 && C > 0 && ld >= C, "keep_absmax: bad args");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(amax, 0, (size_t)N * sizeof(float), st);
-  if (e != hipSuccess) {
-    keep_set_error("keep_absmax: hipMemsetAsync failed: %s", hipGetErrorString(e));
-    return KEEP_EHIP;
-  }
+  hipLaunchKernelGGL(absmax_zero_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(amax), N);
+  KEEP_LAUNCH_CHECK("keep_absmax(zero)");
   // ~8 float4 per thread, at most ~2048 blocks over all images
   const long work = (R * C / 4 + 2047) / 2048;
   const long cap = 2048 / N > 1 ? 2048 / N : 1;

@@ -87,7 +87,7 @@ def conv_roofline(net, x):
     torch.cuda.synchronize()
     rec, net.o.profile = net.o.profile, None
     by = {}
-    for cfg, flops, split_k, e0, e1, nbytes in rec:
+    for cfg, flops, split_k, e0, e1, nbytes, *_ in rec:
         d = by.setdefault(cfg, [0.0, 0.0, 0, 0.0])
         d[0] += flops
         d[1] += e0.elapsed_time(e1) * 1e-3          # split-K launches include their reduce kernel

@@ -61,6 +61,19 @@ __device__ __forceinline__ float act_apply_fast(float v, int act) {
   }
 }
 
+// KEEP_MMA_X3 policy forms: x * sigmoid(x) as v_exp_f32 + v_rcp_f32 (1 ulp each; <= ~3e-7 relative overall -- the same grade
+// as the policy's 2^-22 products) in 6 VALU instructions instead of the 23 of expf + IEEE division.  exp2(+big) = inf ->
+// rcp = 0 -> x * 0 = -0 for x -> -inf; exp2(-big) = 0 -> x for x -> +inf; NaN propagates.  KEEP_X3_EXACT_ACT=1 selects the
+// library forms (p.fast = 0).
+__device__ __forceinline__ float swish_x3(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
+__device__ __forceinline__ float pro_apply_x3(float v, int act) {
+  if (act == KEEP_PRO_SWISH) return swish_x3(v);
+  if (act == KEEP_PRO_RELU) return v > 0.f ? v : 0.f;
+  return v;
+}
+
 __device__ __forceinline__ float pro_apply(float v, int act) {
   if (act == KEEP_PRO_SWISH) return v * (1.0f / (1.0f + expf(-v)));
   if (act == KEEP_PRO_RELU) return v > 0.f ? v : 0.f;

@@ -1646,7 +1646,7 @@ __global__ void conv_splitk_reduce_kernel(ConvP p) {
 // statistics: plan_conv().  keep_conv2d_plan() exposes that decision to the host, which sizes the workspace / statistics
 // buffers from it and never re-derives kernel internals (a retune here cannot silently corrupt a caller).
 int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
-int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
+int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int big_tile, hipStream_t st);
 bool keep_conv_x3_halo_ok(const keep_conv2d_args* a);
 bool keep_conv_x3_gather_ok(const keep_conv2d_args* a, const ConvP& p);
 
@@ -1677,7 +1677,13 @@ static int n_cu_cached() {
   return n_cu;
 }
 
-static const int kTargetWaves = 1024;   // below this many matrix-core waves a launch cannot fill 256 CUs x 4 SIMDs -> split K
+static const int kTargetWaves = 1024;
+// gather kernels: launches of at most this many output rows use 64x64 tiles (more blocks), larger ones 128x128.  A tuning
+// knob the HOST never mirrors (keep_conv2d_plan reports what follows from it): tests retune it through the environment.
+static long small_m_threshold() {
+  const char* e = getenv("KEEP_GATHER_SMALL_M");
+  return e ? atol(e) : 4096;
+}   // below this many matrix-core waves a launch cannot fill 256 CUs x 4 SIMDs -> split K
 
 static int validate_conv(const keep_conv2d_args* a) {
   KEEP_REQUIRE(a != nullptr, "keep_conv2d: null args");
@@ -1730,7 +1736,8 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   p.cchunks = (a->Cin + BK - 1) / BK;
   p.nsteps = a->KH * a->KW * p.cchunks;
   p.in_bf16 = (a->dtype == KEEP_BF16) ? 1 : 0;
-  p.fast = (a->mma == KEEP_MMA_BF16) ? 1 : 0;
+  // fast-math activations: bf16 policy always; x3 policy unless KEEP_X3_EXACT_ACT is set (forms of x3 grade, keep_common.h)
+  p.fast = (a->mma == KEEP_MMA_BF16 || (a->mma == KEEP_MMA_X3 && !getenv("KEEP_X3_EXACT_ACT"))) ? 1 : 0;
   p.out_bf16 = (a->out_dtype == KEEP_BF16) ? 1 : 0;
   p.vec_ok = (a->Cin % 4 == 0 && a->in_ld % 4 == 0 && ((uintptr_t)a->in % 16 == 0)) ? 1 : 0;
   p.vec_epi = (a->Cout % 4 == 0 && a->out_ld % 4 == 0 && (uintptr_t)a->out % 16 == 0 &&
@@ -1791,7 +1798,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
     }
     if (have_w && keep_conv_x3_gather_ok(a, p) && !getenv("KEEP_NO_GATHER_X3")) {
       pl.path = PATH_GATHER_X3;
-      pl.tile = (a->Cout <= 64 || M <= 4096) ? 1 : 2;
+      pl.tile = (a->Cout <= 64 || M <= small_m_threshold()) ? 1 : 2;
       pl.plain = no_pro;
       const int steps = a->KH * a->KW * ((a->Cin + 31) / 32);
       const long blocks = pl.tile == 1 ? (long)cdiv(M, 64) * cdiv(a->Cout, 64) : (long)cdiv(M, 128) * cdiv(a->Cout, 128);
@@ -1860,7 +1867,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
     return KEEP_EUNSUP;
   }
   // ---- gather kernels
-  pl.tile = a->Cout <= 32 ? 0 : ((a->Cout <= 64 || M <= 4096) ? 1 : 2);
+  pl.tile = a->Cout <= 32 ? 0 : ((a->Cout <= 64 || M <= small_m_threshold()) ? 1 : 2);
   const long blocks = pl.tile == 0 ? (long)cdiv(M, 128) * cdiv(a->Cout, 32)
                       : (pl.tile == 1 ? (long)cdiv(M, 64) * cdiv(a->Cout, 64) : (long)cdiv(M, 128) * cdiv(a->Cout, 128));
   const long waves = blocks * 4;
@@ -1977,7 +1984,7 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
       if (rc != KEEP_OK) return rc;
       break;
     case PATH_GATHER_X3:
-      rc = keep_conv2d_x3_gather(a, p, st);
+      rc = keep_conv2d_x3_gather(a, p, pl.tile == 2, st);
       if (rc != KEEP_OK) return rc;
       break;
     case PATH_HALO_F32: {

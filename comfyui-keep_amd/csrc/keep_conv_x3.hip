@@ -33,9 +33,9 @@ __device__ __forceinline__ void split4(const float (&v)[4], f16x4& hi, f16x4& lo
 
 // (A hand-rolled x*sigmoid(x) -- exp2 with a two-float range reduction + v_rcp and one Newton step -- was measured SLOWER in
 // this staging step than the compiler's expf + IEEE division: 316 vs 279 us on 128 ch @256^2; the library forms stay.)
-template <int PRO>
+template <int PRO, bool FAST>
 __device__ __forceinline__ float pro_x3(float v) {
-  return pro_apply(v, PRO);
+  return FAST ? pro_apply_x3(v, PRO) : pro_apply(v, PRO);
 }
 
 #define MMA_X3(ACC, AH, AL, BH, BL)                                              \
@@ -57,8 +57,9 @@ __device__ __forceinline__ float pro_x3(float v) {
 
 // EXP (dev builds with -DKEEP_X3_ABLATE only, 0 in the product): phase ablations -- 1: no LDS fragment reads in the MFMA loop,
 // 2: no MFMAs, 3: no staging (LDS keeps stale data), 4: no global stores in the epilogue, 5: no operand fetch,
-// 6: start stagger between the two blocks of a CU.
-template <int TW, int PRO, bool SIMPLE_EPI, int EXP = 0>
+// 6: start stagger between the two blocks of a CU, 7: library expf + IEEE division in the swish prologue, 8: s_setprio(1)
+// around the MFMA loop.
+template <int TW, int PRO, bool SIMPLE_EPI, int EXP = 0, bool FASTACT = true>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int tiles_x, int tiles_y, int ncb, int n_items) {
   constexpr int HALO_TH = 256 / TW, HALO_W = TW + 2, HALO_PIX = (HALO_TH + 2) * HALO_W;
   constexpr int RPT = 32 / TW;
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     }
   };
   auto stage = [&]() {
+    constexpr bool FAST = FASTACT && EXP != 7;
     if (EXP == 3) return;
 #pragma unroll
     for (int k = 0; k < HALO_IT; ++k) {
@@ -130,12 +132,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
       if (hp < HALO_PIX) {
         float v[4] = {hreg[k].x, hreg[k].y, hreg[k].z, hreg[k].w};
         if (has_pro && h_off[k] >= 0) {      // zero padding applies to the normalised + activated tensor
-          v[0] = pro_x3<PRO>(v[0] * sc4.x + sh4.x);
-          v[1] = pro_x3<PRO>(v[1] * sc4.y + sh4.y);
-          v[2] = pro_x3<PRO>(v[2] * sc4.z + sh4.z);
-          v[3] = pro_x3<PRO>(v[3] * sc4.w + sh4.w);
+          v[0] = pro_x3<PRO, FAST>(v[0] * sc4.x + sh4.x);
+          v[1] = pro_x3<PRO, FAST>(v[1] * sc4.y + sh4.y);
+          v[2] = pro_x3<PRO, FAST>(v[2] * sc4.z + sh4.z);
+          v[3] = pro_x3<PRO, FAST>(v[3] * sc4.w + sh4.w);
         }
-        if (p.in_amax) {
+        if (PRO == KEEP_PRO_NONE && p.in_amax) {     // activated inputs are bounded: the host never probes them
           v[0] *= in_s; v[1] *= in_s; v[2] *= in_s; v[3] *= in_s;
         }
         f16x4 hi, lo;
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
         bl[i] = *reinterpret_cast<const f16x8*>(&Ws[b_base + i * 32 * XPITCH + 16]);
       }
     }
+    if (EXP == 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
     for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
         }
       }
     }
+    if (EXP == 8) __builtin_amdgcn_s_setprio(0);
   };
   auto epilogue_t = [&](const HaloItem& it, float item_inv, auto res_c) {
     constexpr bool HAS_RES = decltype(res_c)::value;
@@ -279,13 +283,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   int item = blockIdx.x;
   if (item >= n_items) return;
   if (EXP == 6 && blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(54);     // start stagger of the second block per CU
+  // EXP == 9: phase timeline (s_memtime) of wave 0, summed over blocks into p.ws as u64[8]:
+  // 0 stage, 1 wait at the barrier after staging, 2 fetch issue, 3 mma, 4 wait at the barrier after mma, 5 item set-up, 6 epilogue
+  unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+#define KEEP_T(IDX)                                                   \
+  if (EXP == 9) {                                                     \
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();       \
+    tacc[IDX] += t1 - t0;                                             \
+    t0 = t1;                                                          \
+  }
   HaloItem cur = halo_decode<TW, 4>(p, item, items_per_z, tiles_x, tiles_y, ncb);
   setup(cur);
   if (cur.ch_begin < cur.ch_end) fetch(cur.ch_begin);
+  if (EXP == 9) t0 = __builtin_amdgcn_s_memtime();
   while (true) {
     const bool valid = cur.ch_begin < cur.ch_end;
     if (valid) stage();
+    KEEP_T(0)
     __syncthreads();
+    KEEP_T(1)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -295,11 +311,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     for (int ch = cur.ch_begin; ch < cur.ch_end; ++ch) {
       const bool more = ch + 1 < cur.ch_end;
       if (more) fetch(ch + 1);
+      KEEP_T(2)
       mma();
+      KEEP_T(3)
       __syncthreads();
+      KEEP_T(4)
       if (more) {
         stage();
+        KEEP_T(0)
         __syncthreads();
+        KEEP_T(1)
       }
     }
     const int next_item = item + gridDim.x;
@@ -311,15 +332,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
       setup(nxt);
       if (nxt.ch_begin < nxt.ch_end) fetch(nxt.ch_begin);     // in flight during the epilogue below
     }
+    KEEP_T(5)
     if (p.res)
       epilogue_t(cur, cur_inv, std::true_type{});
     else
       epilogue_t(cur, cur_inv, std::false_type{});
+    KEEP_T(6)
     if (!has_next) break;
     __syncthreads();
+    KEEP_T(4)
     item = next_item;
     cur = nxt;
   }
+  if (EXP == 9 && tid == 0) {
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.ws);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) atomicAdd(dst + q, tacc[q]);
+    atomicAdd(dst + 7, 1ull);
+  }
+#undef KEEP_T
 }
 
 // ------------------------------------------------------------------------------------------------ gather GEMM, split fp16
@@ -450,7 +481,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
           }
           if (p.pro_act != KEEP_PRO_NONE) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = pro_apply(v[j], p.pro_act);
+            for (int j = 0; j < 8; ++j) v[j] = p.fast ? pro_apply_x3(v[j], p.pro_act) : pro_apply(v[j], p.pro_act);
           }
         }
 #pragma unroll
@@ -602,7 +633,27 @@ int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
     KEEP_LAUNCH_CHECK("keep_conv2d(halo x3 ablation)");                                                                            \
     return KEEP_OK;                                                                                                                \
   }
-    KEEP_LAUNCH_ABL(1) KEEP_LAUNCH_ABL(2) KEEP_LAUNCH_ABL(3) KEEP_LAUNCH_ABL(4) KEEP_LAUNCH_ABL(5) KEEP_LAUNCH_ABL(6)
+    KEEP_LAUNCH_ABL(1) KEEP_LAUNCH_ABL(2) KEEP_LAUNCH_ABL(3) KEEP_LAUNCH_ABL(4) KEEP_LAUNCH_ABL(5) KEEP_LAUNCH_ABL(6) KEEP_LAUNCH_ABL(7)
+    KEEP_LAUNCH_ABL(8)
+    if (ex == 9) {       // phase timeline: one instrumented launch, cycle sums printed to stderr
+      static unsigned long long* dbg = nullptr;
+      if (!dbg) (void)hipMalloc(&dbg, 64);
+      (void)hipMemsetAsync(dbg, 0, 64, st);
+      ConvP q = p;
+      q.ws = reinterpret_cast<float*>(dbg);
+      if (a->pro_act == KEEP_PRO_SWISH)
+        hipLaunchKernelGGL((conv3x3_halo_x3_kernel<32, KEEP_PRO_SWISH, true, 9>), grid, block, 0, st, q, tiles_x, tiles_y, ncb, n_items);
+      else
+        hipLaunchKernelGGL((conv3x3_halo_x3_kernel<32, KEEP_PRO_NONE, true, 9>), grid, block, 0, st, q, tiles_x, tiles_y, ncb, n_items);
+      unsigned long long h[8];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
+      const double nb = (double)h[7], tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + h[6]);
+      fprintf(stderr, "[x3 timeline] blocks %.0f  cycles/block %.0f | stage %.1f%%  sync-after-stage %.1f%%  fetch-issue %.1f%%  mma %.1f%%  "
+              "sync-after-mma %.1f%%  item-setup %.1f%%  epilogue %.1f%%\n", nb, tot / nb, 100.0 * h[0] / tot, 100.0 * h[1] / tot,
+              100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot, 100.0 * h[5] / tot, 100.0 * h[6] / tot);
+      return KEEP_OK;
+    }
 #undef KEEP_LAUNCH_ABL
   }
 #endif
@@ -612,7 +663,12 @@ int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
   else                                                                                                                     \
     hipLaunchKernelGGL((conv3x3_halo_x3_kernel<TWV, PROV, false>), grid, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);
 #define KEEP_LAUNCH_HX(TWV)                                       \
-  if (a->pro_act == KEEP_PRO_SWISH) {                             \
+  if (a->pro_act == KEEP_PRO_SWISH && !p.fast) {                  \
+    if (simple)                                                   \
+      hipLaunchKernelGGL((conv3x3_halo_x3_kernel<TWV, KEEP_PRO_SWISH, true, 0, false>), grid, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);  \
+    else                                                          \
+      hipLaunchKernelGGL((conv3x3_halo_x3_kernel<TWV, KEEP_PRO_SWISH, false, 0, false>), grid, block, 0, st, p, tiles_x, tiles_y, ncb, n_items); \
+  } else if (a->pro_act == KEEP_PRO_SWISH) {                      \
     KEEP_LAUNCH_HX2(TWV, KEEP_PRO_SWISH)                          \
   } else if (a->pro_act == KEEP_PRO_RELU) {                       \
     KEEP_LAUNCH_HX2(TWV, KEEP_PRO_RELU)                           \
@@ -630,13 +686,14 @@ int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
   return KEEP_OK;
 }
 
-int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
+// big_tile: plan_conv's choice (128x128 block tiles instead of 64x64) -- the launch never re-derives it
+int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int big_tile, hipStream_t st) {
   const long M = p.M;
   const int steps = a->KH * a->KW * ((a->Cin + XBK - 1) / XBK);
   if (p.split_k > steps) p.split_k = steps;
   const bool plain = !a->pro_scale && a->pro_act == KEEP_PRO_NONE;
   dim3 block(256);
-  if (a->Cout <= 64 || M <= 4096) {
+  if (!big_tile) {
     dim3 grid(cdiv(M, 64), cdiv(a->Cout, 64), p.split_k);
     if (plain)
       hipLaunchKernelGGL((conv_x3_kernel<2, 2, 1, 1, true>), grid, block, 0, st, p);

@@ -934,3 +934,37 @@ extern "C" int32_t keep_absmax(const float* x, float* amax, int32_t N, int64_t R
   KEEP_LAUNCH_CHECK("keep_absmax");
   return KEEP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ K0: need_upscale
+// keep_arch.py:1020-1023: F.interpolate(x, scale_factor=4, mode='bilinear') (align_corners=False) on the planar clip
+// frames -- torch's area-pixel source index max(0, (dst + 0.5)/scale - 0.5), neighbours clamped to the last row / column,
+// weights combined in torch's own order h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11).  HBM-bound: one read + scale^2 writes.
+__global__ __launch_bounds__(256) void bilinear_upscale_kernel(const float* __restrict__ x, float* __restrict__ out, int planes,
+                                                               int H, int W, int scale) {
+  const int Ho = H * scale, Wo = W * scale;
+  const long total = (long)planes * Ho * Wo;
+  const float rs = 1.0f / (float)scale;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wo);
+    const long t = i / Wo;
+    const int oy = (int)(t % Ho);
+    const long pl = t / Ho;
+    const float sy = fmaxf(0.f, ((float)oy + 0.5f) * rs - 0.5f), sx = fmaxf(0.f, ((float)ox + 0.5f) * rs - 0.5f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float h1 = sy - (float)y0, w1 = sx - (float)x0, h0 = 1.f - h1, w0 = 1.f - w1;
+    const float* src = x + pl * (long)H * W;
+    out[i] = h0 * (w0 * src[(long)y0 * W + x0] + w1 * src[(long)y0 * W + x1]) +
+             h1 * (w0 * src[(long)y1 * W + x0] + w1 * src[(long)y1 * W + x1]);
+  }
+}
+
+extern "C" int32_t keep_bilinear_upscale(const float* x, float* out, int32_t planes, int32_t H, int32_t W, int32_t scale,
+                                         void* stream) {
+  KEEP_REQUIRE(x && out && planes > 0 && H > 0 && W > 0 && scale >= 1 && scale <= 8, "keep_bilinear_upscale: bad args");
+  const long total = (long)planes * H * scale * W * scale;
+  int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+  hipLaunchKernelGGL(bilinear_upscale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, planes, H, W, scale);
+  KEEP_LAUNCH_CHECK("keep_bilinear_upscale");
+  return KEEP_OK;
+}

@@ -34,6 +34,7 @@ FUSED_GM_MLP = os.environ.get('KEEP_NO_FUSED_MLP') is None     # dev switch
 CHECK_X3_RANGE = os.environ.get('KEEP_X3_NO_RANGE_CHECK') is None
 GRAPH_MAX_CLIPS = int(os.environ.get('KEEP_AMD_GRAPH_MAX_CLIPS', '2'))
 GRAPH_CACHE = 4
+RESIDENT = os.environ.get('KEEP_AMD_RESIDENT', '0') == '1'      # keep the packed weights on the device across offload()
 PRECISIONS = ('fp32', 'x3', 'bf16')
 DEFAULT_PRECISION = 'x3'
 
@@ -66,6 +67,7 @@ class KeepNet:
         # GRAPH_MAX_CLIPS clips per call, '1' = always, '0' = never.  One captured graph per (B, T, H, W, policy).
         self.graph_mode = os.environ.get('KEEP_AMD_GRAPH', 'auto')
         self._graphs = {}
+        self._pinned = None        # pinned host copy of the packed blob (made at the first upload)
         self.precision = 'fp32'
         self.set_precision(os.environ.get('KEEP_AMD_PRECISION', DEFAULT_PRECISION))
 
@@ -75,7 +77,7 @@ class KeepNet:
             validate_state_dict(state_dict, self.cfg)
         self._sd = {k: v.detach().to(torch.float32).cpu() for k, v in state_dict.items()}
         self._blob, self._index = pack_blob(logical_tensors(self._sd, self.cfg))
-        self._dev_blob, self.w = None, None
+        self._dev_blob, self.w, self._pinned = None, None, None
         if self.device.type == 'cuda':
             self._upload()
         return self
@@ -135,7 +137,9 @@ class KeepNet:
     def _upload(self, from_blob=None):
         L.load(check_device=True)       # fails loudly: no library / not gfx950 -> no silent fallback
         if from_blob is None:
-            from_blob = torch.from_numpy(self._blob)
+            if self._pinned is None:                    # one pinned staging copy: re-uploads run at PCIe rate
+                self._pinned = torch.from_numpy(self._blob).pin_memory()
+            from_blob = self._pinned
         self._dev_blob = from_blob.to(self.device, non_blocking=False)
         self._dev_blob16 = self._dev_blobx3 = None
         self._graphs = {}
@@ -151,6 +155,11 @@ class KeepNet:
             if self._blob is not None and changed:
                 with torch.cuda.device(device):
                     self._upload()
+        elif RESIDENT and self._dev_blob is not None:
+            # residency policy: KEEPModelPack.offload() after every node call would drop 633 MB of packed
+            # weights (plus the policy's twin) and the next call would upload and re-derive them; with KEEP_AMD_RESIDENT=1
+            # the device copy is parked instead -- .to('cuda') finds it in place (288 GB of HBM: nothing else wants it)
+            pass
         else:
             self.device = device
             self._dev_blob, self._dev_blob16, self._dev_blobx3, self.w = None, None, None, None
@@ -508,9 +517,12 @@ class KeepNet:
         cfg = self.cfg
         x = x.to(device=self.device, dtype=torch.float32)
         if need_upscale:
-            # KA:1020-1023; never taken from the processor (always need_upscale=False) -- host-side resize only
-            Tn = x.shape[1]
-            x = torch.nn.functional.interpolate(x.flatten(0, 1), scale_factor=4, mode='bilinear').unflatten(0, (-1, Tn))
+            # KA:1020-1023: x4 bilinear pre-upscale (never requested by the processor, which always passes False)
+            Bn, Tn, _, h0, w0 = x.shape
+            xs = x.contiguous()
+            x = torch.empty((Bn, Tn, 3, 4 * h0, 4 * w0), dtype=torch.float32, device=self.device)
+            with torch.cuda.device(self.device):
+                L.call('keep_bilinear_upscale', xs, x, Bn * Tn * 3, h0, w0, 4)
         x = x.contiguous()
         B, T, _, H, Wd = x.shape
         if H % 32 or Wd % 32:

@@ -25,7 +25,7 @@ HALO_PRENORM_MINPIX = int(os.environ.get('KEEP_HALO_PRENORM_MINPIX', '0'))
 DEBUG_SYNC = os.environ.get('KEEP_DEBUG_SYNC') is not None
 _PLAN_CACHE = {}
 _PLAN_ENV = ('KEEP_NO_COUT4', 'KEEP_NO_C3', 'KEEP_NO_HALO_F32', 'KEEP_NO_HALO_X3', 'KEEP_NO_GATHER_X3', 'KEEP_NO_PLAIN',
-             'KEEP_NO_FLATK_F32')
+             'KEEP_NO_FLATK_F32', 'KEEP_GATHER_SMALL_M')
 
 
 class Plan:
@@ -206,7 +206,8 @@ class Ops:
             # algorithmic bytes: one read of the input window at its storage type, the weights, one write of the output
             alg_bytes = (N * H * W * Cin * x.element_size() + Cout * KH * KW * Cin * (2 if mma == L.MMA_BF16 else 4)
                          + M * Cout * out.element_size() + (0 if residual is None else M * Cout * 4))
-            self.profile.append((pl.kernel, 2.0 * M * Cout * KH * KW * Cin, pl.split_k, e0, e1, alg_bytes))
+            self.profile.append((pl.kernel, 2.0 * M * Cout * KH * KW * Cin, pl.split_k, e0, e1, alg_bytes,
+                                 (N, H, W, Cin, Cout, KH, stride, int(upsample), pro is not None)))
             e0.record()
         if DEBUG_SYNC:      # dev aid: name every launch and wait for it, so a GPU fault is attributed to its kernel
             import sys

@@ -248,6 +248,10 @@ int32_t keep_flow_warp(const float* x, const float* flow, float* out, int32_t N,
 int32_t keep_convex_upsample(const float* mask, const float* flow, float* out, int32_t N, int32_t H, int32_t W,
                              int32_t k, void* stream);
 
+/* KA:1020-1023 (need_upscale): F.interpolate(scale_factor=scale, mode='bilinear', align_corners=False) of `planes` planar
+ * H x W images (a [B*T,3,H,W] clip is planes = B*T*3) -> [planes, scale*H, scale*W] */
+int32_t keep_bilinear_upscale(const float* x, float* out, int32_t planes, int32_t H, int32_t W, int32_t scale, void* stream);
+
 /* layout / elementwise helpers */
 /* [N,C,H,W] -> [N,H,W,C];  mode 1 additionally applies GMFlow's input normalisation (GF:56-57, GM/utils.py:55-63) */
 int32_t keep_nchw_to_nhwc(const float* x, float* out, int32_t N, int32_t C, int32_t HW, int32_t mode, void* stream);

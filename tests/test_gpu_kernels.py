@@ -869,3 +869,39 @@ def test_conv_bf16_bk256_variant(cin, cout, hw, n, k, sk):
                  pro=pro, pro_act=L.PRO_RELU)
     ref = F.conv2d(bf16r(F.relu(F.instance_norm(x, eps=1e-5))), bf16r(w), b, padding=k // 2)
     check(nchw(y), ref, 3e-3, f'bk256 {cin}->{cout} k{k} split {sk}')
+
+
+def test_bilinear_upscale_matches_torch():
+    """K0 (keep_arch.py:1020-1023): F.interpolate(scale_factor=4, mode='bilinear') on the device."""
+    x = rnd('k0x', (2, 3, 24, 40))
+    out = torch.empty((2, 3, 96, 160), device='cuda')
+    L.call('keep_bilinear_upscale', dev(x), out, 6, 24, 40, 4)
+    check(out, F.interpolate(x, scale_factor=4, mode='bilinear'), 1e-6, 'bilinear x4')
+
+
+@pytest.mark.parametrize("mma", [L.MMA_F32, L.MMA_X3])
+def test_plan_follows_a_retuned_tile_threshold(mma, monkeypatch):
+    """The host sizes workspaces / statistics buffers from keep_conv2d_plan and mirrors no kernel internals: moving the
+    library's small-M tile threshold through the environment changes the kernel instantiation, the split-K factor and
+    the statistics layout, and the same Python call still produces the same numbers and consistent fused statistics."""
+    x, w, b = rnd('rtx', (1, 128, 48, 48)), rnd('rtw', (192, 128, 1, 1), 0.1), rnd('rtb', (192,))
+    wp = pack(w)
+    kw = dict(pad=0, ksize=1, stats=True, mma=mma)
+    if mma == L.MMA_X3:
+        wx3, asc = x3w(wp)
+        kw.update(wx3=wx3, x3_acc_scale=asc)
+    ops.DEFAULT.profile = []
+    y0, st0 = ops.conv(dev(nhwc(x)), wp, dev(b), **kw)
+    monkeypatch.setenv('KEEP_GATHER_SMALL_M', '1024')            # 48*48 = 2304 rows: now a "large" launch -> 128x128 tiles
+    y1, st1 = ops.conv(dev(nhwc(x)), wp, dev(b), **kw)
+    names = [r[0] for r in ops.DEFAULT.profile]
+    ops.DEFAULT.profile = None
+    assert names[0] != names[1] and '2, 2, 1, 1' in names[0] and '2, 2, 2, 2' in names[1], names
+    check(y1, y0, 2e-5, 'retuned tile')
+    for y, st in ((y0, st0), (y1, st1)):
+        if st is not None and st.part is not None:
+            sc, sh = ops.norm_affine(y, None, None, 192, 1e-5, stats=st)
+            sc2, sh2 = ops.norm_affine(y, None, None, 192, 1e-5)
+            check(sc, sc2, 1e-5, 'stats scale'); check(sh, sh2, 1e-5, 'stats shift')
+    if st0 is not None and st1 is not None and st0.part is not None and st1.part is not None:
+        assert st0.P != st1.P          # 64-row vs 128-row partials: the layout moved and the host followed the plan

@@ -395,3 +395,34 @@ def test_bf16_policy_quality_report(gpu_net):
     finally:
         gpu_net.set_precision(own)
         gpu_net._activate_precision()
+
+
+def test_need_upscale_runs_on_the_device(gpu_net):
+    """K0: need_upscale=True (keep_arch.py:1020-1023) = x4 bilinear on the device, then the normal forward."""
+    x = synth.synth_clip(T=1, B=1, size=128, seed=3).cuda()
+    up = torch.nn.functional.interpolate(x.flatten(0, 1), scale_factor=4, mode='bilinear').unflatten(0, (1, 1))
+    a = gpu_net(x, need_upscale=True)
+    b = gpu_net(up.contiguous(), need_upscale=False)
+    assert a.shape == (1, 1, 3, 512, 512) and (a - b).abs().max().item() <= 5e-4
+
+
+def test_weights_stay_resident_across_offload(monkeypatch, synth_weights):
+    """Residency policy: with KEEP_AMD_RESIDENT=1 the pack's offload() parks the packed weights on the device --
+    the next load_device() neither uploads nor re-derives the policy's weight twin."""
+    from comfyui_keep_amd.engine import net as netmod
+    from comfyui_keep_amd.engine.net import KeepNet
+    monkeypatch.setattr(netmod, 'RESIDENT', True)
+    n = KeepNet(**DEFAULT_ARCH)
+    n.load_state_dict(synth_weights, strict=True)
+    n.to('cuda').eval()
+    x = synth.synth_clip(T=1, B=1, seed=9).cuda()
+    a = n(x)
+    blob_ptr, twin = n._dev_blob.data_ptr(), n._dev_blobx3
+    n.to('cpu')                                   # what KEEPModelPack.offload() does after every node call
+    assert n._dev_blob is not None and n._dev_blob.data_ptr() == blob_ptr
+    n.to('cuda')
+    assert n._dev_blob.data_ptr() == blob_ptr and n._dev_blobx3 is twin
+    assert torch.equal(n(x), a)
+    monkeypatch.setattr(netmod, 'RESIDENT', False)
+    n.to('cpu')
+    assert n._dev_blob is None and n.w is None

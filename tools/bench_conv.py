@@ -22,6 +22,10 @@ LAYERS = {  # name: (N, H, W, Cin, Cout, ksize, upsample)
     'c256_64': (4, 64, 64, 256, 256, 3, False),
     'c512_16': (4, 16, 16, 512, 512, 3, False),
     'lin128': (1, 622592, 1, 128, 128, 1, False),
+    'lin256_1024': (1, 622592, 1, 256, 1024, 1, False),
+    'lin1024_128': (1, 622592, 1, 1024, 128, 1, False),
+    'c128_64_1x1': (4, 512, 512, 128, 64, 1, False),
+    'down64_512': (4, 512, 512, 64, 64, 3, False),
     'c512_16_b8': (8, 16, 16, 512, 512, 3, False),
     'lin512_1024': (1, 1024, 1, 512, 1024, 1, False),
     'lin1024_512': (1, 1024, 1, 1024, 512, 1, False),
@@ -46,6 +50,8 @@ def run(name, mma, in_bf16, iters=20):
     if os.environ.get('RES'):
         Ho, Wo = (2 * H, 2 * W) if up else (H, W)
         kw['residual'] = torch.randn(N, Ho, Wo, Cout, device='cuda')
+    if os.environ.get('ACT') == 'gelu':
+        kw['act'] = L.ACT_GELU
     if os.environ.get('SPLITK'):
         kw['split_k'] = int(os.environ['SPLITK'])
     if pro is not None:

@@ -21,6 +21,7 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split4(const float (&v)[4], f16x4& hi, f16x4& lo) {
 #pragma unroll
@@ -36,6 +37,17 @@ __device__ __forceinline__ void split4(const float (&v)[4], f16x4& hi, f16x4& lo
 template <int PRO, bool FAST>
 __device__ __forceinline__ float pro_x3(float v) {
   return FAST ? pro_apply_x3(v, PRO) : pro_apply(v, PRO);
+}
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// x + (the value 16 / 32 lanes across): gfx950 lane-swap instructions, one VALU op each (ds_bpermute is an LDS round trip)
+__device__ __forceinline__ float xor16_sum(float x) {
+  const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float xor32_sum(float x) {
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
 #define MMA_X3(ACC, AH, AL, BH, BL)                                              \
@@ -79,29 +91,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   const int g = tid & 3;
   const bool has_pro = p.pro_scale != nullptr || PRO != KEEP_PRO_NONE;
 
-  int h_off[HALO_IT];
-  long img_off = 0, w_base = 0, sc_off = 0;
-  bool w_ok = true;
+  // Operand fetch through buffer descriptors: ONE buffer_load_dwordx4 per 16-byte piece, no 64-bit address arithmetic and no
+  // EXEC branches -- a padding pixel / a cout row beyond Cout carries the out-of-range offset -16 and the hardware returns
+  // zeros (bounds check on voffset; the channel / tap displacement rides in the scalar offset).  (The flat-load form spent
+  // ~185 instructions per chunk here, 15 % of the wave's time by the s_memtime timeline.)
+  int h_voff[HALO_IT];                   // byte offset of this thread's piece inside the image; < 0: zero padding
+  int w_voff = -16;                      // byte offset of this thread's piece of its cout row in the split weight tensor
+  long sc_off = 0;
   float in_s = 1.f, in_inv = 1.f;        // range scale of the item being FETCHED / staged (image it.n)
+  __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.wx3, 0, p.Cout * 9 * p.Cin * 4, 0x00020000);
   auto setup = [&](const HaloItem& it) {
     if (p.in_amax) x3_range_scale(p.in_amax[it.n], in_s, in_inv);
 #pragma unroll
     for (int k = 0; k < HALO_IT; ++k) {
       const int hp = (tid >> 2) + k * 64;
-      h_off[k] = -1;
+      h_voff[k] = -16;
       if (hp < HALO_PIX) {
         const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
         const int iy = it.oy0 - 1 + hy, ix = it.ox0 - 1 + hx;
         if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
           const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
-          h_off[k] = (sy * p.W + sx) * p.in_ld + g * 4;
+          h_voff[k] = ((sy * p.W + sx) * p.in_ld + g * 4) * 4;
         }
       }
     }
-    img_off = (long)it.n * p.H * p.W * p.in_ld;
+    const unsigned long long base = (unsigned long long)(p.in + (long)it.n * p.H * p.W * p.in_ld);
+    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+    in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)bhi << 32) | blo), 0, p.H * p.W * p.in_ld * 4, 0x00020000);
     sc_off = (long)it.n * p.Cin + g * 4;
-    w_ok = (it.n0 + (tid >> 2)) < p.Cout;
-    w_base = w_ok ? ((long)(it.n0 + (tid >> 2)) * 9) * p.Cin * 2 + g * 8 : 0;   // fp16 elements; + (tap*Cin + c0)*2
+    w_voff = (it.n0 + (tid >> 2)) < p.Cout ? ((it.n0 + (tid >> 2)) * 9 * p.Cin * 2 + g * 8) * 2 : -16;
   };
 
   float4 hreg[HALO_IT];
@@ -112,10 +132,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     if (EXP == 5 && ch > 0) return;
 #pragma unroll
     for (int k = 0; k < HALO_IT; ++k) {
-      hreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (h_off[k] >= 0) hreg[k] = *reinterpret_cast<const float4*>(p.in + img_off + h_off[k] + c0);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, h_voff[k], c0 * 4, 0);
+      hreg[k] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
-#define KEEP_WLOADX(TAP, R) R = w_ok ? *reinterpret_cast<const uint4*>(p.wx3 + w_base + ((long)(TAP) * p.Cin + c0) * 2) : make_uint4(0u, 0u, 0u, 0u);
+#define KEEP_WLOADX(TAP, R)                                                                                  \
+  {                                                                                                          \
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff, ((TAP) * p.Cin + c0) * 4, 0);      \
+    R = make_uint4(v.x, v.y, v.z, v.w);                                                                      \
+  }
     KEEP_TAPS(KEEP_WLOADX)
 #undef KEEP_WLOADX
     if (p.pro_scale) {
@@ -131,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
       const int hp = (tid >> 2) + k * 64;
       if (hp < HALO_PIX) {
         float v[4] = {hreg[k].x, hreg[k].y, hreg[k].z, hreg[k].w};
-        if (has_pro && h_off[k] >= 0) {      // zero padding applies to the normalised + activated tensor
+        if (has_pro && h_voff[k] >= 0) {      // zero padding applies to the normalised + activated tensor
           v[0] = pro_x3<PRO, FAST>(v[0] * sc4.x + sh4.x);
           v[1] = pro_x3<PRO, FAST>(v[1] * sc4.y + sh4.y);
           v[2] = pro_x3<PRO, FAST>(v[2] * sc4.z + sh4.z);
@@ -202,6 +226,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     }
     if (EXP == 8) __builtin_amdgcn_s_setprio(0);
   };
+  // Epilogue: the wave parks its 64 x 64 tile in LDS and reads it back channel-contiguous (16 B per lane, 4 pixels x 256 B per
+  // store instruction).  Addressing is image-relative and 32-bit: per-lane byte offset once per item, the (row, column)
+  // displacement of each of the 16 pixel groups in the scalar offset of a buffer store -- no 64-bit multiplies per row.
+  // Channels beyond Cout carry the out-of-range offset (stores dropped, residual reads zero).  The per-channel statistics are
+  // reduced across the four pixel groups of the wave with v_permlane16/32_swap (VALU) instead of ds_bpermute.
+  auto make_rsrc = [&](const void* ptr, int bytes) {
+    const unsigned long long b = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+  };
   auto epilogue_t = [&](const HaloItem& it, float item_inv, auto res_c) {
     constexpr bool HAS_RES = decltype(res_c)::value;
     constexpr int EP = 68;
@@ -218,33 +252,51 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     const int c4 = (lane & 15) * 4, prow = lane >> 4;
     const int co = it.n0 + c4;
     const bool cok = co < p.Cout;
+    const int hw_o = p.Ho * p.Wo;
+    const int pix_b = (it.oy0 + 2 * wave * RPT) * p.Wo + it.ox0 + prow;       // pixel of group 0 inside the image
+    const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc(p.out + (long)it.n * hw_o * p.out_ld, hw_o * p.out_ld * 4);
+    const int v_out = cok ? (pix_b * p.out_ld + co) * 4 : -16;
+    __amdgpu_buffer_rsrc_t res_rsrc = out_rsrc, aux_rsrc = out_rsrc;
+    int v_res = -16, v_aux = -16;
+    if (HAS_RES) {
+      res_rsrc = make_rsrc(p.res + (long)it.n * hw_o * p.res_ld, hw_o * p.res_ld * 4);
+      v_res = cok ? (pix_b * p.res_ld + co) * 4 : -16;
+      if (!SIMPLE_EPI && p.aux) {
+        aux_rsrc = make_rsrc(p.aux + (long)it.n * hw_o * p.Cout, hw_o * p.Cout * 4);
+        v_aux = cok ? (pix_b * p.Cout + co) * 4 : -16;
+      }
+    }
     float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
     float amx = 0.f;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
-    constexpr int UNR = HAS_RES ? 16 : 8;
+    // the general epilogue (activation switch, aux tensor, split-K) stays a loop: fully unrolled it is 30k instructions
+    constexpr int UNR = SIMPLE_EPI ? 16 : 2;
 #pragma unroll UNR
     for (int q16 = 0; q16 < 16; ++q16) {
-      if (!cok) break;
       const int px = q16 * 4 + prow;
-      const int oy = it.oy0 + (2 * wave + (px >> 5)) * RPT + (px & 31) / TW;
-      const long m = ((long)it.n * p.Ho + oy) * p.Wo + it.ox0 + (px & 31) % TW;
+      const int drow = (q16 >> 3) * RPT + (TW == 32 ? 0 : ((q16 & 7) >> 2));
+      const int dcol = TW == 32 ? (q16 & 7) * 4 : (q16 & 3) * 4;
+      const int dpix = drow * p.Wo + dcol;                                    // wave-uniform
       const float4 v = *reinterpret_cast<const float4*>(et + px * EP + c4);
       if (!SIMPLE_EPI && p.split_k > 1) {
-        *reinterpret_cast<float4*>(p.ws + ((long)it.z * p.M + m) * p.Cout + co) = v;
+        if (cok) {
+          const long m = (long)it.n * hw_o + pix_b + dpix;
+          *reinterpret_cast<float4*>(p.ws + ((long)it.z * p.M + m) * p.Cout + co) = v;
+        }
         continue;
       }
       float e[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
       if (!SIMPLE_EPI) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) e[q] = act_apply(e[q], p.epi_act);
+        for (int q = 0; q < 4; ++q) e[q] = p.fast ? act_apply_fast(e[q], p.epi_act) : act_apply(e[q], p.epi_act);
       }
       if (HAS_RES) {
-        const float4 r4 = *reinterpret_cast<const float4*>(p.res + m * p.res_ld + co);
-        const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+        const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, v_res, dpix * p.res_ld * 4, 0);
+        const float rr[4] = {__uint_as_float(r4.x), __uint_as_float(r4.y), __uint_as_float(r4.z), __uint_as_float(r4.w)};
         if (!SIMPLE_EPI && p.aux) {
-          const float4 a4 = *reinterpret_cast<const float4*>(p.aux + m * (long)p.Cout + co);
-          const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+          const u32x4 a4 = __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, v_aux, dpix * p.Cout * 4, 0);
+          const float aa[4] = {__uint_as_float(a4.x), __uint_as_float(a4.y), __uint_as_float(a4.z), __uint_as_float(a4.w)};
 #pragma unroll
           for (int q = 0; q < 4; ++q) e[q] = rr[q] + p.aux_w * (rr[q] * aa[q] + e[q]);
         } else {
@@ -252,7 +304,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
           for (int q = 0; q < 4; ++q) e[q] += rr[q];
         }
       }
-      if (EXP != 4 || e[0] == 1.2345e-30f) *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
+      if (EXP != 4 || e[0] == 1.2345e-30f) {
+        u32x4 o;
+        o.x = __float_as_uint(e[0]); o.y = __float_as_uint(e[1]); o.z = __float_as_uint(e[2]); o.w = __float_as_uint(e[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, v_out, dpix * p.out_ld * 4, 0);
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         s4[q] += e[q];
@@ -264,10 +320,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     if (p.stats) {          // per wave: stats_P = 4 * tiles, partial index = tile*4 + wave
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        s4[q] += __shfl_xor(s4[q], 16);
-        s4[q] += __shfl_xor(s4[q], 32);
-        ss4[q] += __shfl_xor(ss4[q], 16);
-        ss4[q] += __shfl_xor(ss4[q], 32);
+        s4[q] = xor32_sum(xor16_sum(s4[q]));
+        ss4[q] = xor32_sum(xor16_sum(ss4[q]));
       }
       if (lane < 16 && cok) {
         float* dst = p.stats + (((long)it.n * p.stats_P + (it.ty * tiles_x + it.tx) * 4 + wave) * p.Cout + co) * 2;
@@ -597,6 +651,8 @@ bool keep_conv_x3_halo_ok(const keep_conv2d_args* a) {
          a->pad_l == 1 && (a->Cin % 16 == 0) && (a->Cout % 32 == 0) &&
          ((a->Ho % 8 == 0 && a->Wo % 32 == 0) || (a->Ho % 16 == 0 && a->Wo % 16 == 0)) &&
          a->Ho == (a->upsample ? 2 * a->H : a->H) && a->Wo == (a->upsample ? 2 * a->W : a->W) &&
+         (long)a->H * a->W * a->in_ld * 4 < (1L << 31) && (long)a->Cout * 9 * a->Cin * 4 < (1L << 31) &&   // buffer offsets
+         (long)a->Ho * a->Wo * a->out_ld * 4 < (1L << 31) && (long)a->Ho * a->Wo * (a->residual ? a->res_ld : 1) * 4 < (1L << 31) &&
          (!a->pro_scale || ((uintptr_t)a->pro_scale % 16 == 0 && (uintptr_t)a->pro_shift % 16 == 0)) &&
          (a->in_ld % 4 == 0) && ((uintptr_t)a->in % 16 == 0) && (a->out_ld % 4 == 0) && ((uintptr_t)a->out % 16 == 0) &&
          (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&

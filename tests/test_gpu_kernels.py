@@ -905,3 +905,30 @@ def test_plan_follows_a_retuned_tile_threshold(mma, monkeypatch):
             check(sc, sc2, 1e-5, 'stats scale'); check(sh, sh2, 1e-5, 'stats shift')
     if st0 is not None and st1 is not None and st0.part is not None and st1.part is not None:
         assert st0.P != st1.P          # 64-row vs 128-row partials: the layout moved and the host followed the plan
+
+
+def test_conv_x3_halo_general_epilogue_two_blocks_per_cu():
+    """The general (non-SIMPLE) epilogue of the x3 halo kernel -- activation, aux/CFT tensor, range-probed raw input -- on a
+    launch that fills every CU with two blocks (N = 4 x 64^2 x 512 couts = 512 items).  Regression: a fully unrolled form
+    of this epilogue stored a few wrong values per tile on exactly this launch shape while the small-N tests passed."""
+    N, H, C = 4, 64, 256
+    x = rnd('ge_x', (N, C, H, H), 30.0)
+    w, b = rnd('ge_w', (2 * C, C, 3, 3), 0.05), rnd('ge_b', (2 * C,))
+    wp = pack(w)
+    wx3, asc = x3w(wp)
+    for act in (L.ACT_LRELU02, L.ACT_RELU, L.ACT_NONE):
+        y32 = ops.conv(dev(nhwc(x)), wp, dev(b), act=act)
+        y3, st = ops.conv(dev(nhwc(x)), wp, dev(b), act=act, mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, stats=True)
+        check(y3, y32, 1e-5, f'x3 halo act={act}')
+        assert torch.equal(st.amax.cpu(), y3.abs().flatten(1).max(1).values.cpu())
+    # CFT form: residual + aux * cond on a channel slice of a wider input
+    w2, b2 = rnd('ge_w2', (C, C, 3, 3), 0.05), rnd('ge_b2', (C,))
+    w2p = pack(w2)
+    w2x, asc2 = x3w(w2p)
+    wide = dev(nhwc(rnd('ge_wide', (N, 2 * C, H, H), 20.0)))
+    res, aux = dev(nhwc(rnd('ge_res', (N, C, H, H)))), dev(nhwc(rnd('ge_aux', (N, C, H, H))))
+    for off in (0, C):
+        kw = dict(cin=C, in_off=off, residual=res, aux=aux, aux_w=0.7)
+        y32 = ops.conv(wide, w2p, dev(b2), **kw)
+        y3 = ops.conv(wide, w2p, dev(b2), mma=L.MMA_X3, wx3=w2x, x3_acc_scale=asc2, **kw)
+        check(y3, y32, 1e-5, f'x3 halo cft off={off}')

@@ -109,7 +109,8 @@ def _full_forward_check(net, gold_name, T):
     (~5e-5 relative, ~1e-2 px) moves a few logits by more than the smallest margins.  Short clips (T <= 3): agreement on
     confidently-decided tokens and >= 99 % overall.  Long clips: the recurrence is chaotic once ONE token flips (the next
     frame restores a different prev_out), so indices are compared frame by frame up to the first frame with a flip, and
-    the flipped tokens of that frame must be low-margin ones (<= 2e-3: the size of the logit shift a 0.02 px flow
+    the flipped tokens of that frame must be low-margin ones (<= 4e-3: the T=3 golden shows flips of margin 3.1e-3 at frame 2
+    for the exact-f32 policy and the x3 policy alike -- the size of the logit shift a 0.02 px flow
     difference causes); beyond it only frame-independent quantities (gains, flows) are comparable.  The arithmetic is
     pinned separately with the reference's indices injected.  The strict all-frames free-running check runs against the
     oracle with its flows injected (tests below)."""
@@ -132,7 +133,7 @@ def _full_forward_check(net, gold_name, T):
     if T <= 3:
         assert agree[g['margins'] > 0.1].all() and agree.mean() >= 0.99, report
     else:
-        assert first_div >= 1 and all(m <= 2e-3 for m in report['margins_of_first_flips']), report
+        assert first_div >= 1 and all(m <= 4e-3 for m in report['margins_of_first_flips']), report
     # arithmetic drift with the reference's indices injected (separates index flips from drift)
     forced = torch.from_numpy(g['indices'].astype(np.int32)).view(1, T, -1)
     out_f = net(x, need_upscale=False, force_indices=forced)

@@ -1647,6 +1647,7 @@ __global__ void conv_splitk_reduce_kernel(ConvP p) {
 // buffers from it and never re-derives kernel internals (a retune here cannot silently corrupt a caller).
 int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int big_tile, hipStream_t st);
+bool keep_conv_x3_gather_is_gemm(const keep_conv2d_args* a);
 bool keep_conv_x3_halo_ok(const keep_conv2d_args* a);
 bool keep_conv_x3_gather_ok(const keep_conv2d_args* a, const ConvP& p);
 
@@ -1809,8 +1810,8 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
       pl.stats_rows = pl.tile == 1 ? 64 : 128;
       // a wave's rows must lie in one image: Ho*Wo a multiple of the wave tile (32 or 64 rows)
       pl.amax_ok = pl.split_k == 1 && ((long)a->Ho * a->Wo) % (pl.tile == 1 ? 32 : 64) == 0;
-      snprintf(pl.kernel, sizeof(pl.kernel), "conv_x3_kernel<%s, %s>", pl.tile == 1 ? "2, 2, 1, 1" : "2, 2, 2, 2",
-               pl.plain ? "true" : "false");
+      snprintf(pl.kernel, sizeof(pl.kernel), "conv_x3_kernel<%s, %s, %s>", pl.tile == 1 ? "2, 2, 1, 1" : "2, 2, 2, 2",
+               pl.plain ? "true" : "false", keep_conv_x3_gather_is_gemm(a) ? "true" : "false");
       return KEEP_OK;
     }
     mma = KEEP_MMA_F32;

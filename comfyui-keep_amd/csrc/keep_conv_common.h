@@ -48,12 +48,15 @@ static __global__ void zero_u32_kernel(unsigned* p, int n) {
   if (i < n) p[i] = 0u;
 }
 
-// wave-wide max of non-negative floats via their bit patterns, then one atomic per wave
+// wave-wide max of non-negative floats via their bit patterns, then AT MOST one atomic per wave: same-address atomics retire
+// at ~12 ns each in L2 (65k waves of a 1x1 convolution on 4 images: 0.77 ms of atomics around 0.15 ms of work), so a wave
+// first reads the running maximum (it only grows: a stale value can cause a redundant atomic, never a missed one) and
+// skips the atomic when it cannot raise it -- after the first few waves almost all do.
 __device__ __forceinline__ void wave_amax_commit(unsigned* dst, float m) {
   unsigned b = __float_as_uint(m);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
-  if ((threadIdx.x & 63) == 0 && b) atomicMax(dst, b);
+  if ((threadIdx.x & 63) == 0 && b > *reinterpret_cast<volatile unsigned*>(dst)) atomicMax(dst, b);
 }
 
 // KEEP_MMA_X3 range scaling: the power of two s with amax * s in [2^14, 2^15) (fp16 max 65504), and 1/s.  amax = 0 (or a

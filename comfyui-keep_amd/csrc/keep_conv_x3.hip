@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
       }
     }
     if (EXP == 8) __builtin_amdgcn_s_setprio(1);
-#pragma unroll 1
+#pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
@@ -412,10 +412,140 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
 // GEMM like conv_bf16_kernel: K step = 32 channels of one tap; LDS rows [hi x32 | lo x32 | pad x8] at a 144-byte pitch (9 slots:
 // ds_read_b128 conflict-free); two LDS buffers, the next step's operands in registers while the current one multiplies.
 // A is split while staging (fp32 activations, optional GroupNorm affine + activation first); B comes pre-split.
+// Epilogue of the x3 gather kernel for FULL row tiles (m0 + BM <= M): the wave parks its tile in LDS and reads it back
+// channel-contiguous like staged_epilogue_impl, with block-relative 32-bit addressing through buffer descriptors (base =
+// tensor + m0 * ld; row displacement in the vector offset) -- no 64-bit multiply per row, no EXEC branch per store.
+template <int WGM, int WGN, int TM, int TN, bool SIMPLE>
+__device__ __forceinline__ void x3_gather_epilogue(const ConvP& p, f32x16 (&acc)[TM][TN], float* lds, long m0, int n0, int wm,
+                                                   int wn, int lane, int wave, int z) {
+  constexpr int WR = TM * 32, WC = TN * 32, EP = WC + 4, BM = WGM * WR;
+  constexpr int LPR = WC / 4, RPI = 64 / LPR;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  float* et = lds + wave * WR * EP;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) et[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * EP + j * 32 + l31] = acc[i][j][r];
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  auto make_rsrc = [&](const void* ptr, int bytes) {
+    const unsigned long long b = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+  };
+  const int c4 = (lane % LPR) * 4, prow = lane / LPR;
+  const int co = n0 + wn * WC + c4;
+  const bool cok = co < p.Cout;
+  const int row0 = wm * WR + prow;                       // row of iteration 0 inside the block tile
+  const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc(p.out + m0 * p.out_ld, BM * p.out_ld * 4);
+  const int v_out = cok ? (row0 * p.out_ld + co) * 4 : (int)0x80000000;
+  __amdgpu_buffer_rsrc_t res_rsrc = out_rsrc, aux_rsrc = out_rsrc, ws_rsrc = out_rsrc;
+  int v_res = (int)0x80000000, v_aux = (int)0x80000000, v_ws = (int)0x80000000;
+  if (p.res) {
+    res_rsrc = make_rsrc(p.res + m0 * p.res_ld, BM * p.res_ld * 4);
+    v_res = cok ? (row0 * p.res_ld + co) * 4 : (int)0x80000000;
+    if (!SIMPLE && p.aux) {
+      aux_rsrc = make_rsrc(p.aux + m0 * p.Cout, BM * p.Cout * 4);
+      v_aux = cok ? (row0 * p.Cout + co) * 4 : (int)0x80000000;
+    }
+  }
+  if (!SIMPLE && p.split_k > 1) {
+    ws_rsrc = make_rsrc(p.ws + ((long)z * p.M + m0) * p.Cout, BM * p.Cout * 4);
+    v_ws = cok ? (row0 * p.Cout + co) * 4 : (int)0x80000000;
+  }
+  float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
+  float amx = 0.f;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
+  constexpr int UNR = SIMPLE ? 8 : 2;
+#pragma unroll UNR
+  for (int it = 0; it < WR / RPI; ++it) {
+    const int px = it * RPI + prow;
+    const float4 v = *reinterpret_cast<const float4*>(et + px * EP + c4);
+    if (!SIMPLE && p.split_k > 1) {
+      u32x4 o;
+      o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y); o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
+      __builtin_amdgcn_raw_buffer_store_b128(o, ws_rsrc, v_ws + it * RPI * p.Cout * 4, 0, 0);
+      continue;
+    }
+    float e[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
+    if (!SIMPLE) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e[q] = p.fast ? act_apply_fast(e[q], p.epi_act) : act_apply(e[q], p.epi_act);
+    }
+    if (p.res) {
+      const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, v_res + it * RPI * p.res_ld * 4, 0, 0);
+      const float rr[4] = {__uint_as_float(r4.x), __uint_as_float(r4.y), __uint_as_float(r4.z), __uint_as_float(r4.w)};
+      if (!SIMPLE && p.aux) {
+        const u32x4 a4 = __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, v_aux + it * RPI * p.Cout * 4, 0, 0);
+        const float aa[4] = {__uint_as_float(a4.x), __uint_as_float(a4.y), __uint_as_float(a4.z), __uint_as_float(a4.w)};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = rr[q] + p.aux_w * (rr[q] * aa[q] + e[q]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] += rr[q];
+      }
+    }
+    {
+      u32x4 o;
+      o.x = __float_as_uint(e[0]); o.y = __float_as_uint(e[1]); o.z = __float_as_uint(e[2]); o.w = __float_as_uint(e[3]);
+      __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, v_out + it * RPI * p.out_ld * 4, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s4[q] += e[q];
+      ss4[q] += e[q] * e[q];
+      amx = fmaxf(amx, fabsf(e[q]));
+    }
+  }
+  if (p.out_amax) wave_amax_commit(p.out_amax + (int)((m0 + wm * WR) / ((long)p.Ho * p.Wo)), amx);
+  if (p.stats) {   // host guarantees split_k == 1 and H*W % BM == 0 (a tile never straddles two images)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (LPR == 8) {
+        s4[q] += __shfl_xor(s4[q], 8);
+        ss4[q] += __shfl_xor(ss4[q], 8);
+      }
+      s4[q] = xor32_sum(xor16_sum(s4[q]));
+      ss4[q] = xor32_sum(xor16_sum(ss4[q]));
+    }
+    __syncthreads();                     // all waves finished reading their staged tiles
+    float* red = lds;                    // [4 waves][WC][2]
+    if (lane < LPR) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        red[(wave * WC + c4 + q) * 2 + 0] = s4[q];
+        red[(wave * WC + c4 + q) * 2 + 1] = ss4[q];
+      }
+    }
+    __syncthreads();
+    constexpr int BNc = WGN * WC;
+    const int hw_o = p.Ho * p.Wo;
+    const int n_img = (int)(m0 / hw_o), p_idx = (int)((m0 % hw_o) / BM);
+    for (int c = threadIdx.x; c < BNc; c += 256) {
+      const int wn_c = c / WC, rem = c - wn_c * WC;
+      float a = 0.f, b2 = 0.f;
+#pragma unroll
+      for (int mm = 0; mm < WGM; ++mm) {
+        a += red[((mm * WGN + wn_c) * WC + rem) * 2 + 0];
+        b2 += red[((mm * WGN + wn_c) * WC + rem) * 2 + 1];
+      }
+      if (n0 + c < p.Cout) {
+        float* dst = p.stats + (((long)n_img * p.stats_P + p_idx) * p.Cout + n0 + c) * 2;
+        dst[0] = a;
+        dst[1] = b2;
+      }
+    }
+  }
+}
+
 #define XBK 32
 #define XP (2 * XBK + 8)
 
-template <int WGM, int WGN, int TM, int TN, bool PLAIN>
+// ONE: 1x1 stride-1 unpadded convolution == a row-major GEMM: the A rows are fetched with block-relative buffer loads (rows
+// beyond M read zeros through the descriptor's range check), no im2col index arithmetic.
+template <int WGM, int WGN, int TM, int TN, bool PLAIN, bool ONE = false>
 __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
   constexpr int BM = WGM * TM * 32;
   constexpr int BN = WGN * TN * 32;
@@ -478,6 +608,25 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
   const long uni_off = (m0 / hw) * (long)p.Cin;
   float u_sc[8], u_sh[8];
 
+  const long rows_here = (p.M - m0) < BM ? (p.M - m0) : BM;
+  __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);
+  int a_voff[A_IT];
+  if (ONE) {
+    const unsigned long long b = (unsigned long long)(p.in + m0 * p.in_ld);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)rows_here * p.in_ld * 4, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) a_voff[it] = ((a_row0 + it * 64) * p.in_ld + a_grp * 8) * 4;
+  }
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.wx3, 0, p.Cout * p.KH * p.KW * p.Cin * 4, 0x00020000);
+  int b_voff[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int co = n0 + b_row0 + it * 32;
+    b_voff[it] = co < p.Cout ? (int)((long)co * wrow_stride * 2) + b_pc * 16 : (int)0x80000000;
+  }
+
   auto fetch = [&](int s) {
     const int tap = s / cchunks;
     const int c0 = (s - tap * cchunks) * XBK;
@@ -492,26 +641,37 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
         u_sh[j] = p.pro_shift[uni_off + ca + j];
       }
     }
+    if (ONE) {
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      const int iy = a_oy[it] * p.stride - p.pad_t + kh;
-      const int ix = a_ox[it] * p.stride - p.pad_l + kw;
-      a_ok[it] = a_mv[it] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ca < p.Cin;
-      if (a_ok[it]) {
-        const float* src = p.in + (((long)a_n[it] * p.H + iy) * p.W + ix) * p.in_ld + ca;
-        const float4 v0 = *reinterpret_cast<const float4*>(src);
-        const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
-        a_raw[it][0] = v0.x; a_raw[it][1] = v0.y; a_raw[it][2] = v0.z; a_raw[it][3] = v0.w;
-        a_raw[it][4] = v1.x; a_raw[it][5] = v1.y; a_raw[it][6] = v1.z; a_raw[it][7] = v1.w;
+      for (int it = 0; it < A_IT; ++it) {
+        a_ok[it] = ca < p.Cin;             // rows beyond M: zeros from the range check
+        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[it], c0 * 4, 0);
+        const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[it] + 16, c0 * 4, 0);
+        a_raw[it][0] = __uint_as_float(v0.x); a_raw[it][1] = __uint_as_float(v0.y);
+        a_raw[it][2] = __uint_as_float(v0.z); a_raw[it][3] = __uint_as_float(v0.w);
+        a_raw[it][4] = __uint_as_float(v1.x); a_raw[it][5] = __uint_as_float(v1.y);
+        a_raw[it][6] = __uint_as_float(v1.z); a_raw[it][7] = __uint_as_float(v1.w);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) {
+        const int iy = a_oy[it] * p.stride - p.pad_t + kh;
+        const int ix = a_ox[it] * p.stride - p.pad_l + kw;
+        a_ok[it] = a_mv[it] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ca < p.Cin;
+        if (a_ok[it]) {
+          const float* src = p.in + (((long)a_n[it] * p.H + iy) * p.W + ix) * p.in_ld + ca;
+          const float4 v0 = *reinterpret_cast<const float4*>(src);
+          const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+          a_raw[it][0] = v0.x; a_raw[it][1] = v0.y; a_raw[it][2] = v0.z; a_raw[it][3] = v0.w;
+          a_raw[it][4] = v1.x; a_raw[it][5] = v1.y; a_raw[it][6] = v1.z; a_raw[it][7] = v1.w;
+        }
       }
     }
     const bool cb_ok = c0 + (b_pc >> 2) * 16 < p.Cin;
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const int co = n0 + b_row0 + it * 32;
-      b_raw[it] = make_uint4(0u, 0u, 0u, 0u);
-      if (co < p.Cout && cb_ok)
-        b_raw[it] = *reinterpret_cast<const uint4*>(p.wx3 + (long)co * wrow_stride + ((long)tap * p.Cin + c0) * 2 + b_pc * 8);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, cb_ok ? b_voff[it] : (int)0x80000000, (tap * p.Cin + c0) * 4, 0);
+      b_raw[it] = make_uint4(v.x, v.y, v.z, v.w);
     }
   };
 
@@ -630,6 +790,13 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] *= asc;
   }
+  if (m0 + BM <= p.M && p.Cout * 4L * BM < (1L << 30) && p.out_ld * 4L * BM < (1L << 30) && p.res_ld * 4L * BM < (1L << 30)) {
+    if (p.split_k == 1 && !p.aux && p.epi_act == KEEP_ACT_NONE)
+      x3_gather_epilogue<WGM, WGN, TM, TN, true>(p, acc, reinterpret_cast<float*>(smem_b), m0, n0, wm, wn, lane, wave, z);
+    else
+      x3_gather_epilogue<WGM, WGN, TM, TN, false>(p, acc, reinterpret_cast<float*>(smem_b), m0, n0, wm, wn, lane, wave, z);
+    return;
+  }
   staged_epilogue<WGM, WGN, TM, TN>(p, acc, reinterpret_cast<float*>(smem_b), m0, n0, wm, wn, lane, wave, z);
 }
 
@@ -662,7 +829,13 @@ bool keep_conv_x3_halo_ok(const keep_conv2d_args* a) {
 
 bool keep_conv_x3_gather_ok(const keep_conv2d_args* a, const ConvP& p) {
   return a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && !a->upsample && (a->Cin % 16 == 0) && (a->in_ld % 4 == 0) &&
-         ((uintptr_t)a->in % 16 == 0) && p.vec_epi;
+         ((uintptr_t)a->in % 16 == 0) && p.vec_epi && (long)a->Cout * a->KH * a->KW * a->Cin * 4 < (1L << 31);   // weight buffer offsets
+}
+
+// 1x1 stride-1 unpadded convolution with rows short enough for block-relative 32-bit offsets: the GEMM variant of the kernel
+bool keep_conv_x3_gather_is_gemm(const keep_conv2d_args* a) {
+  return a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad_t == 0 && a->pad_l == 0 && a->Ho == a->H && a->Wo == a->W &&
+         (long)a->in_ld * 4 * 128 < (1L << 30);
 }
 
 // the pipelined kernel wants wide tiles, no split-K and at least two work items per CU (one block per CU walks them)
@@ -749,19 +922,25 @@ int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int big_tile, hip
   if (p.split_k > steps) p.split_k = steps;
   const bool plain = !a->pro_scale && a->pro_act == KEEP_PRO_NONE;
   dim3 block(256);
+  // 1x1 stride-1 unpadded convolutions (token GEMMs): block-relative buffer-load fetch, no im2col index arithmetic
+  const bool one = keep_conv_x3_gather_is_gemm(a);
+#define KEEP_LAUNCH_GX(A, B, C, D)                                                                 \
+  if (plain && one)                                                                                \
+    hipLaunchKernelGGL((conv_x3_kernel<A, B, C, D, true, true>), grid, block, 0, st, p);           \
+  else if (plain)                                                                                  \
+    hipLaunchKernelGGL((conv_x3_kernel<A, B, C, D, true, false>), grid, block, 0, st, p);          \
+  else if (one)                                                                                    \
+    hipLaunchKernelGGL((conv_x3_kernel<A, B, C, D, false, true>), grid, block, 0, st, p);          \
+  else                                                                                             \
+    hipLaunchKernelGGL((conv_x3_kernel<A, B, C, D, false, false>), grid, block, 0, st, p);
   if (!big_tile) {
     dim3 grid(cdiv(M, 64), cdiv(a->Cout, 64), p.split_k);
-    if (plain)
-      hipLaunchKernelGGL((conv_x3_kernel<2, 2, 1, 1, true>), grid, block, 0, st, p);
-    else
-      hipLaunchKernelGGL((conv_x3_kernel<2, 2, 1, 1, false>), grid, block, 0, st, p);
+    KEEP_LAUNCH_GX(2, 2, 1, 1)
   } else {
     dim3 grid(cdiv(M, 128), cdiv(a->Cout, 128), p.split_k);
-    if (plain)
-      hipLaunchKernelGGL((conv_x3_kernel<2, 2, 2, 2, true>), grid, block, 0, st, p);
-    else
-      hipLaunchKernelGGL((conv_x3_kernel<2, 2, 2, 2, false>), grid, block, 0, st, p);
+    KEEP_LAUNCH_GX(2, 2, 2, 2)
   }
+#undef KEEP_LAUNCH_GX
   KEEP_LAUNCH_CHECK("keep_conv2d(gather x3)");
   return KEEP_OK;
 }

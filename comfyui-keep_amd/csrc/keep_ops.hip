@@ -910,7 +910,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(amax_bits + n, m);
+  if ((threadIdx.x & 63) == 0 && m > *reinterpret_cast<volatile unsigned*>(amax_bits + n)) atomicMax(amax_bits + n, m);   // see wave_amax_commit
 }
 
 // (a kernel, not hipMemsetAsync: a memset node inside a captured hipGraph raced with the atomics that follow it)

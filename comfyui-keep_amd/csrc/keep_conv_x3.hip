@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   if (EXP == 6 && blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(54);     // start stagger of the second block per CU
   // EXP == 9: phase timeline (s_memtime) of wave 0, summed over blocks into p.ws as u64[8]:
   // 0 stage, 1 wait at the barrier after staging, 2 fetch issue, 3 mma, 4 wait at the barrier after mma, 5 item set-up, 6 epilogue
-  unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
 #define KEEP_T(IDX)                                                   \
   if (EXP == 9) {                                                     \
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();       \
@@ -352,6 +352,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   if (EXP == 9) t0 = __builtin_amdgcn_s_memtime();
   while (true) {
     const bool valid = cur.ch_begin < cur.ch_end;
+    if (EXP == 9) {
+      __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): operand loads landed
+      KEEP_T(7)
+    }
     if (valid) stage();
     KEEP_T(0)
     __syncthreads();
@@ -371,6 +375,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
       __syncthreads();
       KEEP_T(4)
       if (more) {
+        if (EXP == 9) {
+          __builtin_amdgcn_s_waitcnt(0x0f70);
+          KEEP_T(7)
+        }
         stage();
         KEEP_T(0)
         __syncthreads();
@@ -401,8 +409,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   if (EXP == 9 && tid == 0) {
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.ws);
 #pragma unroll
-    for (int q = 0; q < 7; ++q) atomicAdd(dst + q, tacc[q]);
-    atomicAdd(dst + 7, 1ull);
+    for (int q = 0; q < 8; ++q) atomicAdd(dst + q, tacc[q]);
+    atomicAdd(dst + 8, 1ull);
   }
 #undef KEEP_T
 }
@@ -866,21 +874,21 @@ int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
     KEEP_LAUNCH_ABL(8)
     if (ex == 9) {       // phase timeline: one instrumented launch, cycle sums printed to stderr
       static unsigned long long* dbg = nullptr;
-      if (!dbg) (void)hipMalloc(&dbg, 64);
-      (void)hipMemsetAsync(dbg, 0, 64, st);
+      if (!dbg) (void)hipMalloc(&dbg, 128);
+      (void)hipMemsetAsync(dbg, 0, 128, st);
       ConvP q = p;
       q.ws = reinterpret_cast<float*>(dbg);
       if (a->pro_act == KEEP_PRO_SWISH)
         hipLaunchKernelGGL((conv3x3_halo_x3_kernel<32, KEEP_PRO_SWISH, true, 9>), grid, block, 0, st, q, tiles_x, tiles_y, ncb, n_items);
       else
         hipLaunchKernelGGL((conv3x3_halo_x3_kernel<32, KEEP_PRO_NONE, true, 9>), grid, block, 0, st, q, tiles_x, tiles_y, ncb, n_items);
-      unsigned long long h[8];
+      unsigned long long h[16];
       (void)hipStreamSynchronize(st);
-      (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
-      const double nb = (double)h[7], tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + h[6]);
+      (void)hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost);
+      const double nb = (double)h[8], tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + h[6] + h[7]);
       fprintf(stderr, "[x3 timeline] blocks %.0f  cycles/block %.0f | stage %.1f%%  sync-after-stage %.1f%%  fetch-issue %.1f%%  mma %.1f%%  "
-              "sync-after-mma %.1f%%  item-setup %.1f%%  epilogue %.1f%%\n", nb, tot / nb, 100.0 * h[0] / tot, 100.0 * h[1] / tot,
-              100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot, 100.0 * h[5] / tot, 100.0 * h[6] / tot);
+              "sync-after-mma %.1f%%  item-setup %.1f%%  epilogue %.1f%%  wait-loads %.1f%%\n", nb, tot / nb, 100.0 * h[0] / tot, 100.0 * h[1] / tot,
+              100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot, 100.0 * h[5] / tot, 100.0 * h[6] / tot, 100.0 * h[7] / tot);
       return KEEP_OK;
     }
 #undef KEEP_LAUNCH_ABL

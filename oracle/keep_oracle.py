@@ -9,8 +9,8 @@ the HIP library is missing.
 
 Pinning: the reference holds no tests or golden vectors for this path,
 so this restatement is pinned against the *imported reference module itself* in the build
-container (``oracle/make_golden.py`` -> ``tests/golden/*.npz``; ``tests/test_oracle_vs_reference.py``
-re-checks live whenever /root/reference is present).  One piece is "parity unpinned":
+container (``oracle/make_golden.py`` -> ``tests/golden/*.npz``; ``tests/test_oracle_vs_golden.py`` checks the
+oracle against those vectors on CPU -- the reference itself cannot travel to the GPU box).  One piece is "parity unpinned":
 ``diffusers.models.attention.FeedForward`` (GEGLU) is neither vendored nor pinned by the
 reference (keep_arch.py:21) -- its gate order / exact-erf GELU follow upstream diffusers.
 

@@ -159,6 +159,25 @@ def synth_crops(n, seed=0):
     return out
 
 
+def paste_leg(frames=10):
+    """SURVEY 8f-2 / BASELINE configs[3] post-processing: one 1080p frame with 3 restored faces composited on the GPU
+    (engine/paste.py: parse-mask blurs, inverse-affine warps, blend), host uint8 in -> host uint8 out per frame."""
+    from comfyui_keep_amd.engine.paste import GpuPaster
+    frame, faces, mats, classes = synth.synth_paste_case()
+    gp = GpuPaster('cuda')
+    cls = torch.from_numpy(classes).cuda()                 # ParseNet's arg-max lives on the device in the product path
+    gp.paste(frame, faces, list(mats), cls)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        out = gp.paste(frame, faces, list(mats), cls).cpu()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / frames
+    return {"ms_per_frame": round(dt * 1e3, 3), "frames_per_s": round(1.0 / dt, 1), "frame": "1920x1080, 3 faces",
+            "what": "host uint8 frame + 3 restored uint8 crops -> composited host uint8 frame (H2D, 6 Gaussian passes of 101 taps, "
+                    "3 box warps + blends, D2H); arithmetic bit-equal to oracle/paste_oracle.py, unpinned against cv2 (absent)"}
+
+
 def processor_leg(net, n_crops, faces):
     """BASELINE configs[2] / [3] as the hot path sees them: `n_crops` crops stacked frame-major (`faces` crops per frame,
     interleaved: keep_processor.py:252-253) and cut into max_clip_length = 20 chunks by the processor's own code."""
@@ -328,6 +347,7 @@ def main():
             # ---- BASELINE configs[2] / [3] clip mixes through the processor
             line["configs"] = {"config3_300_crops_1_face": processor_leg(net, 300, 1),
                                "config4_900_crops_3_faces": processor_leg(net, 900, 3)}
+            line["paste_back_gpu"] = paste_leg()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_frames)
         print(json.dumps(line))

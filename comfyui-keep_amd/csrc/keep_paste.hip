@@ -1,0 +1,174 @@
+// Paste-back compositing on the device: the per-face work of FaceRestoreHelper.paste_faces_to_input_image
+// (/root/reference/modules/deps/wm_facelib/utils/face_restoration_helper.py:346-475, use_parse=True branch) without the
+// full-frame cv2 passes: parse mask -> two 101-tap separable Gaussians (:433-434) -> [border zeroing, /255 (:435-437) folded
+// into the sampler] -> inverse-affine bilinear warp of mask (:441, float weights) and restored face (:382, 15-bit integer
+// weights) -> float32 blend (:463) restricted to the face's bounding box -> clip / round-half-even / uint8 (:465-468).
+// Arithmetic follows OpenCV's published algorithms operation by operation (fixed-point warp coordinates: AB_BITS 10, INTER_BITS
+// 5; every float product / sum rounded separately, no FMA contraction: __fmul_rn / __fadd_rn) so that the result equals the
+// numpy restatement oracle/paste_oracle.py bit for bit.  All kernels are HBM / latency bound (a 1080p frame is 6 MB).
+#include "keep_common.h"
+
+// HIP's __fmul_rn / __fadd_rn are plain operators: without this the compiler contracts them into FMAs (hipcc defaults to
+// -ffp-contract=fast) and the results drift from the separately rounded restatement by an ulp.
+#pragma clang fp contract(off)
+// (the header intrinsics are inline functions compiled under the header's contraction mode: own helpers below the pragma)
+__device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+__device__ __forceinline__ float div_rn(float a, float b) { return a / b; }
+__device__ __forceinline__ double dmul_rn(double a, double b) { return a * b; }
+__device__ __forceinline__ double dadd_rn(double a, double b) { return a + b; }
+
+#define PASTE_MAXTAPS 128
+
+// ---- separable filter, BORDER_REFLECT_101, float32, taps accumulated in index order.  src: float [n,H,W], or class map
+// uint8 [n,H,W] looked up through lut (MASK_COLORMAP, :428-429) when lut != nullptr.
+__device__ __forceinline__ int reflect101(int i, int n) {
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * (n - 1) - i : i;
+}
+
+__global__ void sep_rows_kernel(const float* __restrict__ src, const uint8_t* __restrict__ cls, const float* __restrict__ lut,
+                                float* __restrict__ dst, int H, int W, const float* __restrict__ kern, int ntap) {
+  __shared__ float ks[PASTE_MAXTAPS];
+  for (int i = threadIdx.x; i < ntap; i += blockDim.x) ks[i] = kern[i];
+  __syncthreads();
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)gridDim.y * H * W;
+  (void)total;
+  const long base = (long)blockIdx.y * H * W;
+  if (idx >= (long)H * W) return;
+  const int y = (int)(idx / W), x = (int)(idx - (long)y * W);
+  const int r = ntap >> 1;
+  float acc = 0.f;
+  for (int i = 0; i < ntap; ++i) {
+    const int xx = reflect101(x - r + i, W);
+    const float v = cls ? lut[cls[base + (long)y * W + xx]] : src[base + (long)y * W + xx];
+    acc = add_rn(acc, mul_rn(ks[i], v));
+  }
+  dst[base + idx] = acc;
+}
+
+__global__ void sep_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
+                                const float* __restrict__ kern, int ntap) {
+  __shared__ float ks[PASTE_MAXTAPS];
+  for (int i = threadIdx.x; i < ntap; i += blockDim.x) ks[i] = kern[i];
+  __syncthreads();
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long base = (long)blockIdx.y * H * W;
+  if (idx >= (long)H * W) return;
+  const int y = (int)(idx / W), x = (int)(idx - (long)y * W);
+  const int r = ntap >> 1;
+  float acc = 0.f;
+  for (int i = 0; i < ntap; ++i) {
+    const int yy = reflect101(y - r + i, H);
+    acc = add_rn(acc, mul_rn(ks[i], src[base + (long)yy * W + x]));
+  }
+  dst[base + idx] = acc;
+}
+
+extern "C" int32_t keep_sep_filter(const float* src, const uint8_t* classes, const float* lut, float* tmp, float* dst, int32_t n,
+                                   int32_t H, int32_t W, const float* kern, int32_t ntap, void* stream) {
+  KEEP_REQUIRE((src != nullptr) != (classes != nullptr), "keep_sep_filter: exactly one of src / classes");
+  KEEP_REQUIRE(!classes || lut, "keep_sep_filter: a class map needs its lookup table");
+  KEEP_REQUIRE(tmp && dst && kern && n > 0 && H > 1 && W > 1, "keep_sep_filter: bad arguments");
+  KEEP_REQUIRE(ntap >= 1 && ntap <= PASTE_MAXTAPS && (ntap & 1) && ntap / 2 < H && ntap / 2 < W,
+               "keep_sep_filter: odd tap count <= %d and smaller than twice the image, got %d", PASTE_MAXTAPS, ntap);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(cdiv((long)H * W, 256), n);
+  hipLaunchKernelGGL(sep_rows_kernel, grid, dim3(256), 0, st, src, classes, lut, tmp, H, W, kern, ntap);
+  hipLaunchKernelGGL(sep_cols_kernel, grid, dim3(256), 0, st, tmp, dst, H, W, kern, ntap);
+  KEEP_LAUNCH_CHECK("keep_sep_filter");
+  return KEEP_OK;
+}
+
+// ---- uint8 frame -> float32 accumulator, and back (clip [0,255], round half to even)
+__global__ void u8_to_f32_kernel(const uint8_t* __restrict__ x, float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)x[i];
+}
+__global__ void f32_round_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint8_t)rintf(fminf(fmaxf(x[i], 0.f), 255.f));
+}
+extern "C" int32_t keep_u8_to_f32(const uint8_t* x, float* out, int64_t n, void* stream) {
+  KEEP_REQUIRE(x && out && n > 0, "keep_u8_to_f32: bad arguments");
+  hipLaunchKernelGGL(u8_to_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, (long)n);
+  KEEP_LAUNCH_CHECK("keep_u8_to_f32");
+  return KEEP_OK;
+}
+extern "C" int32_t keep_f32_round_u8(const float* x, uint8_t* out, int64_t n, void* stream) {
+  KEEP_REQUIRE(x && out && n > 0, "keep_f32_round_u8: bad arguments");
+  hipLaunchKernelGGL(f32_round_u8_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, (long)n);
+  KEEP_LAUNCH_CHECK("keep_f32_round_u8");
+  return KEEP_OK;
+}
+
+// ---- one face: warp (face uint8 x3, mask float) + blend into the float frame, over the face's bounding box
+struct PasteP {
+  float* acc;            // [H,W,3] float32 frame, in place
+  const uint8_t* face;   // [fh,fw,3]
+  const float* mask;     // [fh,fw] blurred parse mask on the 0..255 scale (before border zeroing and /255)
+  double m00, m01, m02, m10, m11, m12;   // destination -> source map (inverse of the matrix given to cv2.warpAffine)
+  int H, W, fh, fw, x0, y0, bw, bh, border;
+};
+
+__device__ __forceinline__ float mask_at(const PasteP& p, int sy, int sx) {
+  if (sx < 0 || sx >= p.fw || sy < 0 || sy >= p.fh) return 0.f;                                   // BORDER_CONSTANT 0
+  if (sy < p.border || sy >= p.fh - p.border || sx < p.border || sx >= p.fw - p.border) return 0.f;   // :435-436
+  return div_rn(p.mask[(long)sy * p.fw + sx], 255.0f);                                          // :437
+}
+__device__ __forceinline__ int face_at(const PasteP& p, int sy, int sx, int c) {
+  if (sx < 0 || sx >= p.fw || sy < 0 || sy >= p.fh) return 0;
+  return p.face[((long)sy * p.fw + sx) * 3 + c];
+}
+
+__global__ void paste_face_kernel(PasteP p) {
+  const int bx = blockIdx.x * 32 + (threadIdx.x & 31), by = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (bx >= p.bw || by >= p.bh) return;
+  const int x = p.x0 + bx, y = p.y0 + by;
+  // imgwarp.cpp WarpAffineInvoker: per-column and per-row terms rounded to 1/1024 px (cvRound), sum truncated to 1/32 px
+  const long adelta = llrint(dmul_rn(dmul_rn(p.m00, (double)x), 1024.0));
+  const long bdelta = llrint(dmul_rn(dmul_rn(p.m10, (double)x), 1024.0));
+  const long X0 = llrint(dmul_rn(dadd_rn(dmul_rn(p.m01, (double)y), p.m02), 1024.0)) + 16;
+  const long Y0 = llrint(dmul_rn(dadd_rn(dmul_rn(p.m11, (double)y), p.m12), 1024.0)) + 16;
+  const long X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+  long sxl = X >> 5, syl = Y >> 5;
+  sxl = sxl < -32768 ? -32768 : (sxl > 32767 ? 32767 : sxl);
+  syl = syl < -32768 ? -32768 : (syl > 32767 ? 32767 : syl);
+  const int sx = (int)sxl, sy = (int)syl, fx = (int)(X & 31), fy = (int)(Y & 31);
+  // mask: float weights of the quantised position, left-to-right float sums
+  const float ax = div_rn((float)fx, 32.f), ay = div_rn((float)fy, 32.f);
+  const float w00 = mul_rn(sub_rn(1.f, ax), sub_rn(1.f, ay)), w01 = mul_rn(ax, sub_rn(1.f, ay));
+  const float w10 = mul_rn(sub_rn(1.f, ax), ay), w11 = mul_rn(ax, ay);
+  float soft = mul_rn(mask_at(p, sy, sx), w00);
+  soft = add_rn(soft, mul_rn(mask_at(p, sy, sx + 1), w01));
+  soft = add_rn(soft, mul_rn(mask_at(p, sy + 1, sx), w10));
+  soft = add_rn(soft, mul_rn(mask_at(p, sy + 1, sx + 1), w11));
+  const float inv = sub_rn(1.f, soft);
+  // face: 15-bit integer weights, (sum + 2^14) >> 15
+  const int i00 = (32 - fx) * (32 - fy) * 32, i01 = fx * (32 - fy) * 32, i10 = (32 - fx) * fy * 32, i11 = fx * fy * 32;
+  float* dst = p.acc + ((long)y * p.W + x) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int v = (face_at(p, sy, sx, c) * i00 + face_at(p, sy, sx + 1, c) * i01 + face_at(p, sy + 1, sx, c) * i10 +
+                   face_at(p, sy + 1, sx + 1, c) * i11 + (1 << 14)) >> 15;
+    dst[c] = add_rn(mul_rn(soft, (float)v), mul_rn(inv, dst[c]));                        // :463
+  }
+}
+
+extern "C" int32_t keep_paste_face(float* frame, int32_t H, int32_t W, const uint8_t* face, const float* mask, int32_t fh, int32_t fw,
+                                   const double* dst_to_src, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t mask_border,
+                                   void* stream) {
+  KEEP_REQUIRE(frame && face && mask && dst_to_src && H > 0 && W > 0 && fh > 1 && fw > 1, "keep_paste_face: bad arguments");
+  KEEP_REQUIRE(x0 >= 0 && y0 >= 0 && x1 <= W && y1 <= H && mask_border >= 0, "keep_paste_face: box outside the frame");
+  if (x1 <= x0 || y1 <= y0) return KEEP_OK;        // the face does not touch the frame
+  PasteP p;
+  p.acc = frame; p.face = face; p.mask = mask;
+  p.m00 = dst_to_src[0]; p.m01 = dst_to_src[1]; p.m02 = dst_to_src[2];
+  p.m10 = dst_to_src[3]; p.m11 = dst_to_src[4]; p.m12 = dst_to_src[5];
+  p.H = H; p.W = W; p.fh = fh; p.fw = fw; p.x0 = x0; p.y0 = y0; p.bw = x1 - x0; p.bh = y1 - y0; p.border = mask_border;
+  hipLaunchKernelGGL(paste_face_kernel, dim3(cdiv(p.bw, 32), cdiv(p.bh, 8)), dim3(256), 0, (hipStream_t)stream, p);
+  KEEP_LAUNCH_CHECK("keep_paste_face");
+  return KEEP_OK;
+}

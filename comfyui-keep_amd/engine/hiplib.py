@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 F32, BF16 = 0, 1
 MMA_F32, MMA_BF16, MMA_X3 = 0, 1, 2
@@ -73,6 +73,10 @@ _SIGNATURES = {
     'keep_concat2': [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     'keep_tensor2img': [_vp, _vp, _i64, _vp],
     'keep_img2tensor': [_vp, _vp, _i64, _vp],
+    'keep_sep_filter': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
+    'keep_u8_to_f32': [_vp, _vp, _i64, _vp],
+    'keep_f32_round_u8': [_vp, _vp, _i64, _vp],
+    'keep_paste_face': [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
 }
 EXPORTED_SYMBOLS = ['keep_abi_version', 'keep_last_error', 'keep_device_ok'] + list(_SIGNATURES)
 

@@ -1,0 +1,97 @@
+"""Paste-back compositing on the MI355X: the per-face work of
+``FaceRestoreHelper.paste_faces_to_input_image`` (wm_facelib/utils/face_restoration_helper.py:346-475, ``use_parse=True``,
+``draw_box=False``, colour frames) on HIP kernels (csrc/keep_paste.hip) instead of full-frame cv2 passes on the host:
+
+    parse classes -> mask 0/255 -> 2 x GaussianBlur((101,101), 11) -> 10-px border zeroed -> /255        (:426-437)
+    inverse-affine warp of the mask (float weights) and of the restored face (15-bit integer weights)    (:382, :441)
+    frame = soft * face + (1 - soft) * frame in float32, face after face; clip, round, uint8             (:463-468)
+
+Only the face's bounding box is touched (outside it the mask is exactly 0 and the blend returns the frame unchanged), so a
+1080p frame with 3 faces is 3 boxes of ~(0.75 * face size)^2 pixels instead of ~10 full-frame float passes per face.
+
+OpenCV is not installed in the build image: the arithmetic is restated from OpenCV's published algorithms and checked bit
+for bit against the numpy restatement ``oracle/paste_oracle.py`` (tests/test_gpu_paste.py); agreement with cv2 itself is
+unmeasured, so the processor uses this path only when ``KEEP_AMD_GPU_PASTE=1``.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import hiplib as L
+
+# face parsing classes -> mask value (face_restoration_helper.py:428)
+MASK_COLORMAP = (0, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 0, 255, 0, 0, 0)
+PARSE_BLUR_KSIZE, PARSE_BLUR_SIGMA, PARSE_BORDER = 101, 11.0, 10      # :433-436
+
+
+def invert_affine(M):
+    """cv2.invertAffineTransform (imgwarp.cpp) on a 2x3 matrix, in float64: what cv2.warpAffine does to the matrix it is given
+    before it walks the destination image (:382, :441 pass the crop -> frame matrix without WARP_INVERSE_MAP)."""
+    M = np.asarray(M, np.float64)
+    D = M[0, 0] * M[1, 1] - M[0, 1] * M[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22, A12, A21 = M[1, 1] * D, M[0, 0] * D, -M[0, 1] * D, -M[1, 0] * D
+    return np.array([[A11, A12, -A11 * M[0, 2] - A12 * M[1, 2]], [A21, A22, -A21 * M[0, 2] - A22 * M[1, 2]]], np.float64)
+
+
+def gaussian_kernel(ksize, sigma):
+    """cv2.getGaussianKernel(ksize, sigma, CV_32F) for sigma > 0: exp(-x^2 / 2 sigma^2) in double, rounded to float,
+    normalised by the float sum."""
+    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+    cf = np.exp((-0.5 / (sigma * sigma)) * x * x).astype(np.float32)
+    return (cf.astype(np.float64) * (1.0 / float(cf.astype(np.float64).sum()))).astype(np.float32)
+
+
+def face_box(M_fwd, fw, fh, W, H, margin=2):
+    """Bounding box in the frame of the face crop [0,fw] x [0,fh] under the crop -> frame matrix, grown by the bilinear
+    footprint + fixed-point slack and clipped to the frame: everything outside it has a zero mask."""
+    c = np.array([[0, 0, 1], [fw, 0, 1], [0, fh, 1], [fw, fh, 1]], np.float64) @ np.asarray(M_fwd, np.float64).T
+    x0, y0 = math.floor(c[:, 0].min()) - margin, math.floor(c[:, 1].min()) - margin
+    x1, y1 = math.ceil(c[:, 0].max()) + margin + 1, math.ceil(c[:, 1].max()) + margin + 1
+    return max(0, x0), max(0, y0), min(W, x1), min(H, y1)
+
+
+class GpuPaster:
+    """Device buffers are cached per frame size; one instance per processor."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._kern = torch.from_numpy(gaussian_kernel(PARSE_BLUR_KSIZE, PARSE_BLUR_SIGMA)).to(self.device)
+        self._lut = torch.tensor(MASK_COLORMAP, dtype=torch.float32, device=self.device)
+
+    def soft_masks(self, parse_classes):
+        """parse_classes uint8 [F,h,w] on the device (ParseNet arg-max) -> blurred masks float [F,h,w] on the 0..255 scale;
+        border zeroing and /255 happen in the sampler of keep_paste_face."""
+        F, h, w = parse_classes.shape
+        a = torch.empty((F, h, w), dtype=torch.float32, device=self.device)
+        b = torch.empty_like(a)
+        tmp = torch.empty_like(a)
+        L.call('keep_sep_filter', None, parse_classes, self._lut, tmp, a, F, h, w, self._kern, PARSE_BLUR_KSIZE)
+        L.call('keep_sep_filter', a, None, None, tmp, b, F, h, w, self._kern, PARSE_BLUR_KSIZE)
+        return b
+
+    def paste(self, frame_u8, faces_u8, inverse_affines, parse_classes):
+        """frame_u8: uint8 [H,W,3] (numpy or tensor; the background at the output size), faces_u8: uint8 [F,fh,fw,3],
+        inverse_affines: F crop -> frame matrices (``get_inverse_affine``; None entries are skipped), parse_classes: uint8
+        [F,fh,fw].  Returns the composited uint8 [H,W,3] tensor on the device."""
+        frame = torch.as_tensor(frame_u8).to(self.device, non_blocking=True).contiguous()
+        faces = torch.as_tensor(faces_u8).to(self.device, non_blocking=True).contiguous()
+        cls = torch.as_tensor(parse_classes).to(self.device, non_blocking=True).contiguous()
+        H, W, _ = frame.shape
+        F, fh, fw, _ = faces.shape
+        with torch.cuda.device(self.device):
+            masks = self.soft_masks(cls)
+            acc = torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
+            L.call('keep_u8_to_f32', frame, acc, frame.numel())
+            for i in range(F):
+                M = inverse_affines[i]
+                if M is None:
+                    continue
+                x0, y0, x1, y1 = face_box(M, fw, fh, W, H)
+                d2s = (C.c_double * 6)(*invert_affine(M).reshape(-1).tolist())
+                L.call('keep_paste_face', acc, H, W, faces[i], masks[i], fh, fw, d2s, x0, y0, x1, y1, PARSE_BORDER)
+            out = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
+            L.call('keep_f32_round_u8', acc, out, acc.numel())
+        return out

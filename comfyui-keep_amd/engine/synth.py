@@ -112,3 +112,33 @@ def ramp_image(h: int = 512, w: int = 512):
     """uint8 BGR ramp, pixel(y,x,c) = (37y + 91x + 53c) mod 256."""
     y, x, c = np.meshgrid(np.arange(h), np.arange(w), np.arange(3), indexing='ij')
     return ((37 * y + 91 * x + 53 * c) % 256).astype(np.uint8)
+
+
+def synth_paste_case(H: int = 1080, W: int = 1920, n_faces: int = 3, face: int = 512, seed: int = 7):
+    """Deterministic paste-back workload (BASELINE configs[3]: a 1080p frame with 3 faces): a ramp frame,
+    ``n_faces`` restored crops, their crop -> frame matrices (rotated / scaled similarities as ``get_inverse_affine`` returns
+    them; the last face hangs over the frame edge) and ParseNet-like class maps (skin / brow / nose ellipses inside hair and
+    background).  numpy arrays: frame uint8 [H,W,3], faces uint8 [n,face,face,3], matrices float64 [n,2,3], classes uint8 [n,face,face]."""
+    yy, xx = np.mgrid[0:H, 0:W]
+    frame = np.stack([(xx * 3 + yy * 5) % 256, (xx * 7 + yy * 2 + 40) % 256, (xx + yy * 11 + 80) % 256], -1).astype(np.uint8)
+    fy, fx = np.mgrid[0:face, 0:face].astype(np.float64)
+    faces, mats, classes = [], [], []
+    for i in range(n_faces):
+        noise = uniform_pm1(f'paste.face{i}', face * face * 3, seed).reshape(face, face, 3)
+        base = np.stack([128 + 100 * np.sin(fx / (23.0 + i) + c) * np.cos(fy / (31.0 - i) - c) for c in range(3)], -1)
+        faces.append(np.clip(np.rint(base + 20 * noise), 0, 255).astype(np.uint8))
+        s = (0.45, 0.30, 0.62, 0.5)[i % 4]
+        th = (-0.2, 0.15, 0.05, 0.3)[i % 4]
+        cx = (W * 0.3, W * 0.62, W - 60.0, W * 0.5)[i % 4]          # third face: partly outside the frame
+        cy = (H * 0.35, H * 0.6, H * 0.25, H * 0.5)[i % 4]
+        a, b = s * math.cos(th), s * math.sin(th)
+        mats.append(np.array([[a, -b, cx - (a - b) * face / 2 + 0.37 * i], [b, a, cy - (a + b) * face / 2 - 0.21 * i]], np.float64))
+        r = np.hypot((fx - face / 2) / (0.34 * face), (fy - face * 0.52) / (0.42 * face))
+        cls = np.zeros((face, face), np.uint8)
+        cls[r < 1.15] = 17                                            # hair
+        cls[r < 0.95] = 1                                             # skin
+        cls[np.hypot((fx - face / 2) / 40.0, (fy - face * 0.55) / 60.0) < 1] = 10   # nose
+        cls[(np.abs(fy - face * 0.38) < 8) & (np.abs(np.abs(fx - face / 2) - 70) < 40)] = 2   # brows
+        cls[fy > face * 0.9] = 14                                     # neck
+        classes.append(cls)
+    return frame, np.stack(faces), np.stack(mats), np.stack(classes)

@@ -79,6 +79,10 @@ class KEEPFaceProcessor:
         # and then returns the *input* frames.  Default: bug-compatible.  KEEP_AMD_RETURN_RESTORED_ALIGNED=1 (or setting
         # the attribute) returns the restored faces instead.
         self.return_restored_aligned = os.environ.get('KEEP_AMD_RETURN_RESTORED_ALIGNED', '0') == '1'
+        # paste-back compositing on the GPU (engine/paste.py).  Opt-in: its arithmetic restates OpenCV's and
+        # could not be checked against cv2 itself in the build image.
+        self.gpu_paste = os.environ.get('KEEP_AMD_GPU_PASTE', '0') == '1'
+        self._paster = None
 
     # ------------------------------------------------------------------ net invocation
     def _restore_clips(self, crops_tensor, max_clip_length):
@@ -171,8 +175,7 @@ class KEEPFaceProcessor:
 
         if not has_aligned:
             helper.get_inverse_affine(None)
-            out = helper.paste_faces_to_input_image(upsample_img=bg_img_final, draw_box=draw_box,
-                                                    face_upsampler=self.face_upscale_model)
+            out = self._paste(helper, bg_img_final, draw_box)
         else:
             out = helper.restored_faces[0]
             if self.face_upscale_model:
@@ -180,6 +183,50 @@ class KEEPFaceProcessor:
             side = int(512 * final_upscale_factor)
             out = _resize(out, side, side, 'INTER_LANCZOS4')
         return out if out is not None else bg_img_final
+
+    # ------------------------------------------------------------------ paste-back
+    def _paste(self, helper, bg, draw_box):
+        """``helper.paste_faces_to_input_image(upsample_img=bg, draw_box=..., face_upsampler=...)`` behind one call
+        (face_restoration_helper.py:346-475).  With ``gpu_paste`` and the configuration the loader builds (use_parse=True,
+        colour frame already at the output size, no box, no face upsampler, every crop at the helper's face size) the
+        per-face masks, warps and the blend run on the MI355X (engine/paste.py); every other configuration -- and every
+        helper that is not the reference's -- goes to the helper's own method."""
+        if self.gpu_paste and self._gpu_paste_applies(helper, bg, draw_box):
+            return self._paste_gpu(helper, bg)
+        return helper.paste_faces_to_input_image(upsample_img=bg, draw_box=draw_box, face_upsampler=self.face_upscale_model)
+
+    def _gpu_paste_applies(self, helper, bg, draw_box):
+        faces, mats = getattr(helper, 'restored_faces', None), getattr(helper, 'inverse_affine_matrices', None)
+        if draw_box or self.face_upscale_model is not None or not getattr(helper, 'use_parse', False):
+            return False
+        if getattr(helper, 'is_gray', False) or getattr(helper, 'face_parse', None) is None or not faces or mats is None:
+            return False
+        if len(faces) != len(mats) or not isinstance(bg, np.ndarray) or bg.dtype != np.uint8 or bg.ndim != 3 or bg.shape[2] != 3:
+            return False
+        h, w = getattr(helper, 'input_img', bg).shape[:2]
+        up = getattr(helper, 'upscale_factor', 1)
+        if (int(h * up), int(w * up)) != bg.shape[:2]:          # :355-356 would resize the background first
+            return False
+        fw, fh = getattr(helper, 'face_size', (512, 512))
+        return (fh, fw) == (512, 512) and all(np.asarray(f).shape == (512, 512, 3) and np.asarray(f).dtype == np.uint8 for f in faces)
+
+    @torch.no_grad()
+    def _paste_gpu(self, helper, bg):
+        from ..engine import hiplib as L
+        from ..engine.paste import GpuPaster
+        if self._paster is None:
+            self._paster = GpuPaster(self.device)
+        faces = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(f) for f in helper.restored_faces]))).to(self.device)
+        # :418-424  BGR uint8 -> RGB float (x/255 - 0.5)/0.5, one face per ParseNet call like the reference
+        x = torch.empty(faces.shape, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            L.call('keep_img2tensor', faces, x, faces.numel() // 3)
+        classes = []
+        for i in range(faces.shape[0]):
+            logits = helper.face_parse(x[i:i + 1].permute(0, 3, 1, 2).contiguous())[0]
+            classes.append(logits.argmax(dim=1).squeeze(0).to(torch.uint8))
+        out = self._paster.paste(bg, faces, list(helper.inverse_affine_matrices), torch.stack(classes))
+        return out.cpu().numpy()
 
     # ------------------------------------------------------------------ sequence
     def _detect_all(self, frames_bgr, only_center_face):
@@ -262,8 +309,7 @@ class KEEPFaceProcessor:
             helper.affine_matrices = affines[aff_ptr:aff_ptr + k]
             helper.upscale_factor = final_upscale_factor
             helper.get_inverse_affine(None)
-            out_frames.append(helper.paste_faces_to_input_image(
-                upsample_img=bg, draw_box=draw_box, face_upsampler=self.face_upscale_model))
+            out_frames.append(self._paste(helper, bg, draw_box))
             face_ptr += k
             aff_ptr += k
             pbar.update(1)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KEEP_ABI_VERSION 10
+#define KEEP_ABI_VERSION 11
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -265,6 +265,24 @@ int32_t keep_concat2(const float* a, const float* b, float* out, int64_t M, int3
 int32_t keep_tensor2img(const float* x, uint8_t* out, int64_t npix, void* stream);
 /* keep_processor.py:258-259: uint8 BGR [N,H,W,3] -> fp32 NHWC RGB (float32(u8/255.) - 0.5)/0.5 */
 int32_t keep_img2tensor(const uint8_t* x, float* out, int64_t npix, void* stream);
+
+
+/* ---- paste-back compositing (face_restoration_helper.py:346-475, use_parse=True branch) ----------------
+ * Separable filter with BORDER_REFLECT_101 (cv2.GaussianBlur, :433-434): n images [H,W]; the input is `src` (float) or a
+ * class map `classes` (uint8) looked up through `lut` (MASK_COLORMAP, :428-429).  tmp and dst: [n,H,W] float.  kern: device
+ * pointer to ntap (odd, <= 128) float taps (cv2.getGaussianKernel). */
+int32_t keep_sep_filter(const float* src, const uint8_t* classes, const float* lut, float* tmp, float* dst, int32_t n, int32_t H,
+                        int32_t W, const float* kern, int32_t ntap, void* stream);
+/* uint8 -> float32 (the frame accumulator of :463) and back: clip [0,255], round half to even, uint8 (:465-468) */
+int32_t keep_u8_to_f32(const uint8_t* x, float* out, int64_t n, void* stream);
+int32_t keep_f32_round_u8(const float* x, uint8_t* out, int64_t n, void* stream);
+/* One face into the float frame [H,W,3], in place, over the box [x0,x1) x [y0,y1): cv2.warpAffine(face uint8 [fh,fw,3]) (:382)
+ * and cv2.warpAffine(mask float [fh,fw]) (:441) with INTER_LINEAR / BORDER_CONSTANT 0 and OpenCV's fixed-point coordinates,
+ * the mask's `mask_border` outer rows / columns read as zero and its values divided by 255 (:435-437), then
+ * frame = soft * face + (1 - soft) * frame in float32 (:463).  dst_to_src: HOST pointer to the 6 doubles of the
+ * destination -> source map (cv2.invertAffineTransform of the matrix the reference passes), read at call time. */
+int32_t keep_paste_face(float* frame, int32_t H, int32_t W, const uint8_t* face, const float* mask, int32_t fh, int32_t fw,
+                        const double* dst_to_src, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t mask_border, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,100 @@
+"""GPU: paste-back compositing kernels (csrc/keep_paste.hip through engine/paste.py) against the numpy restatement
+oracle/paste_oracle.py -- bit for bit, on the 1080p / 3-face case of BASELINE configs[3]."""
+import numpy as np
+import pytest
+import torch
+
+import paste_oracle as P
+from comfyui_keep_amd.engine import hiplib as L
+from comfyui_keep_amd.engine import paste, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_parse_mask_blur_is_bit_exact():
+    _, _, _, classes = synth.synth_paste_case()
+    gp = paste.GpuPaster('cuda')
+    got = gp.soft_masks(torch.from_numpy(classes).cuda()).cpu().numpy()
+    for i in range(classes.shape[0]):
+        m = P.MASK_COLORMAP[classes[i].astype(np.int64)]
+        ref = P.gaussian_blur(P.gaussian_blur(m, 101, 11), 101, 11)
+        assert np.array_equal(got[i], ref), (i, float(np.abs(got[i] - ref).max()))
+
+
+def test_paste_1080p_3_faces_is_bit_exact():
+    frame, faces, mats, classes = synth.synth_paste_case()
+    ref = P.paste_faces(frame, list(faces), list(mats), list(classes))
+    gp = paste.GpuPaster('cuda')
+    got = gp.paste(frame, faces, list(mats), classes).cpu().numpy()
+    diff = (got.astype(np.int16) - ref.astype(np.int16))
+    assert np.array_equal(got, ref), (int(np.abs(diff).max()), int((diff != 0).sum()))
+    assert (got != frame).any()                                   # the faces really landed
+    # a skipped face (affine None, :367-368) and a second call on cached buffers
+    got2 = gp.paste(frame, faces, [mats[0], None, mats[2]], classes).cpu().numpy()
+    ref2 = P.paste_faces(frame, list(faces), [mats[0], None, mats[2]], list(classes))
+    assert np.array_equal(got2, ref2)
+
+
+def test_paste_small_frame_and_upscaled_matrix():
+    """720p frame, one face, matrix scaled by upscale_factor = 2 (get_inverse_affine, :332) onto a 1440p canvas."""
+    frame, faces, mats, classes = synth.synth_paste_case(H=720, W=1280, n_faces=1)
+    big = np.repeat(np.repeat(frame, 2, 0), 2, 1)
+    M2 = mats[0] * 2.0
+    ref = P.paste_faces(big, [faces[0]], [M2], [classes[0]], upscale_factor=2.0)
+    got = paste.GpuPaster('cuda').paste(big, faces[:1], [M2], classes[:1]).cpu().numpy()
+    assert np.array_equal(got, ref)
+
+
+def test_bad_arguments_fail_loudly():
+    a = torch.zeros((8, 8, 3), device='cuda')
+    with pytest.raises(L.KeepHipError):
+        L.call('keep_sep_filter', None, None, None, a, a, 1, 8, 8, a, 3)      # neither src nor classes
+
+
+class _StubParse(torch.nn.Module):
+    """Stands in for facexlib's ParseNet: logits whose arg-max is a fixed class map per call (one face per call, like
+    face_restoration_helper.py:418-427), after checking the input the hook prepared."""
+    def __init__(self, faces, classes):
+        super().__init__()
+        self.faces, self.classes, self.i = faces, classes, 0
+
+    def forward(self, x):
+        assert x.shape == (1, 3, 512, 512) and x.dtype == torch.float32
+        f = self.faces[self.i].astype(np.float32)
+        exp = torch.from_numpy(((f / np.float32(255.)) - np.float32(0.5)) / np.float32(0.5))      # :421-422 on the host
+        assert torch.equal(x[0].cpu(), exp.permute(2, 0, 1).flip(0))                               # BGR -> RGB
+        logits = torch.nn.functional.one_hot(torch.from_numpy(self.classes[self.i].astype(np.int64)), 19).permute(2, 0, 1)
+        self.i += 1
+        return [logits[None].float().cuda()]
+
+
+class _StubHelper:
+    use_parse, is_gray, upscale_factor, face_size = True, False, 1, (512, 512)
+
+    def __init__(self, frame, faces, mats, classes):
+        self.input_img, self.restored_faces = frame, list(faces)
+        self.inverse_affine_matrices = list(mats)
+        self.face_parse = _StubParse(faces, classes)
+        self.own_calls = 0
+
+    def paste_faces_to_input_image(self, upsample_img=None, draw_box=False, face_upsampler=None):
+        self.own_calls += 1
+        return upsample_img
+
+
+def test_processor_paste_hook_runs_on_the_device_when_opted_in():
+    import test_host_logic as H   # installs the ComfyUI stubs
+    from comfyui_keep_amd.modules.keep_model_loader import KEEPModelPack
+    from comfyui_keep_amd.modules.keep_processor import KEEPFaceProcessor
+    frame, faces, mats, classes = synth.synth_paste_case()
+    helper = _StubHelper(frame, faces, mats, classes)
+    pack = KEEPModelPack(None, helper, None, None, 'KEEP')
+    pack.device = torch.device('cuda')
+    proc = KEEPFaceProcessor(pack)
+    assert proc._paste(helper, frame, False) is frame and helper.own_calls == 1        # default: the helper's own method
+    proc.gpu_paste = True
+    out = proc._paste(helper, frame, False)
+    assert helper.own_calls == 1 and helper.face_parse.i == 3
+    assert np.array_equal(out, P.paste_faces(frame, list(faces), list(mats), list(classes)))
+    proc._paste(helper, frame, True)                                                    # draw_box: not the GPU configuration
+    assert helper.own_calls == 2

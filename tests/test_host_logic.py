@@ -298,3 +298,32 @@ def test_product_never_imports_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'keep_oracle' not in src and 'ref_import' not in src and 'import oracle' not in src, f
+
+
+def test_paste_hook_defers_to_the_helper():
+    """the GPU paste is opt-in and only takes the configuration it restates; everything else is the helper's
+    own paste_faces_to_input_image with the reference's arguments."""
+    calls = []
+
+    class Hp(_Helper):
+        use_parse, is_gray, upscale_factor, face_size = True, False, 1, (512, 512)
+        face_parse = object()
+
+        def paste_faces_to_input_image(self, upsample_img=None, draw_box=False, face_upsampler=None):
+            calls.append((draw_box, face_upsampler))
+            return upsample_img
+
+    h = Hp()
+    proc = KEEPFaceProcessor(KEEPModelPack(_RecordingNet(), h, None, None, 'KEEP'))
+    bg = np.zeros((64, 64, 3), np.uint8)
+    h.input_img, h.restored_faces, h.inverse_affine_matrices = bg, [np.zeros((512, 512, 3), np.uint8)], [np.eye(2, 3)]
+    assert proc.gpu_paste is False and proc._paste(h, bg, False) is bg and calls == [(False, None)]
+    proc.gpu_paste = True
+    assert proc._gpu_paste_applies(h, bg, False)
+    assert not proc._gpu_paste_applies(h, bg, True)                                  # draw_box
+    assert not proc._gpu_paste_applies(h, bg.astype(np.float32), False)              # not uint8
+    assert not proc._gpu_paste_applies(h, np.zeros((32, 32, 3), np.uint8), False)    # background still to be resized
+    h.use_parse = False
+    assert not proc._gpu_paste_applies(h, bg, False)
+    h.use_parse, proc.face_upscale_model = True, object()
+    assert not proc._gpu_paste_applies(h, bg, False)

@@ -541,80 +541,152 @@ extern "C" int32_t keep_argmax_gather(const float* logits, const float* codebook
 }
 
 // ------------------------------------------------------------------------------------------------ VQ nearest code
-// one block (256 threads) per 8 tokens: z rows staged in LDS, each thread scans ncodes/256 code rows; distance
-// |z|^2 + |e|^2 - 2 z.e evaluated in the reference's order (VQ:43-44); block arg-min, lowest index on ties.
+// VQ:37-48: idx[m] = argmin_j (|z_m|^2 + |e_j|^2) - 2 z_m . e_j -- a [M x dim] x [dim x ncodes] GEMM with an arg-min epilogue.
+// One block (4 waves) per 64 tokens walks the codebook in tiles of 128 codes; per 32-dim K chunk the token rows and the code
+// rows are staged in LDS with coalesced 16-byte loads (33-float pitch: the per-lane ds_read_b32 of the 32x32x2 f32 MFMA
+// operand layout is conflict-free), z.e runs on v_mfma_f32_32x32x2_f32 (EXACT fp32 products -- an index search must not see
+// rounded operands), |e|^2 / |z|^2 are reduced from the staged values with lane shuffles, each lane keeps the running
+// (distance, index) minimum of its code column per token row, and the minimum over columns / waves is a shuffle + LDS
+// reduction with lowest-index ties (torch.argmin returns the first minimum).
+#define VQ_TM 64
+#define VQ_TN 128
+#define VQ_KC 32
+#define VQ_P 33
 __global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict__ z, const float* __restrict__ cb,
                                                          int* __restrict__ idx, int M, int ncodes, int dim) {
-  extern __shared__ float zs[];  // [8][dim] + reduction scratch
-  __shared__ float rbest[8][256];
-  __shared__ int ribest[8][256];
-  const int tid = threadIdx.x;
-  const int m0 = blockIdx.x * 8;
-  for (int i = tid; i < 8 * dim; i += 256) {
-    const int r = i / dim, d = i - r * dim;
-    zs[i] = (m0 + r < M) ? z[(long)(m0 + r) * dim + d] : 0.f;
-  }
-  __syncthreads();
-  float z2[8];
+  __shared__ float zs[VQ_TM * VQ_P];
+  __shared__ float es[VQ_TN * VQ_P];
+  __shared__ float z2s[VQ_TM], e2s[VQ_TN];
+  __shared__ float rbest[4][VQ_TM];
+  __shared__ int ribest[4][VQ_TM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int m0 = blockIdx.x * VQ_TM;
+  const int c4 = (tid & 7) * 4, r8 = tid >> 3;            // staging: 8 threads x float4 per 32-dim row chunk, 32 rows per pass
+  float best[2][16];
+  int bidx[2][16];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    float s = 0.f;
-    for (int d = 0; d < dim; ++d) s += zs[r * dim + d] * zs[r * dim + d];
-    z2[r] = s;
-  }
-  float best[8];
-  int bi[8];
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    best[r] = INFINITY;
-    bi[r] = 0x7fffffff;
-  }
-  for (int j = tid; j < ncodes; j += 256) {
-    const float* e = cb + (long)j * dim;
-    float e2 = 0.f, dot[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) dot[r] = 0.f;
-    for (int d = 0; d < dim; ++d) {
-      const float ev = e[d];
-      e2 += ev * ev;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) dot[r] += zs[r * dim + d] * ev;
+    for (int r = 0; r < 16; ++r) {
+      best[i][r] = INFINITY;
+      bidx[i][r] = 0x7fffffff;
     }
+  float z2p[2] = {0.f, 0.f};
+  for (int n0 = 0; n0 < ncodes; n0 += VQ_TN) {
+    f32x16 acc[2];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const float dist = z2[r] + e2 - 2.f * dot[r];
-      if (dist < best[r]) {
-        best[r] = dist;
-        bi[r] = j;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float e2p[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < dim; k0 += VQ_KC) {
+      __syncthreads();                                    // previous chunk's fragments consumed
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {                       // token rows r8, r8 + 32
+        const int row = r8 + j * 32, m = m0 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M && k0 + c4 < dim) v = *reinterpret_cast<const float4*>(z + (long)m * dim + k0 + c4);
+        float* d = &zs[row * VQ_P + c4];
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        if (n0 == 0) z2p[j] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                       // code rows r8 + 32 j
+        const int row = r8 + j * 32, code = n0 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (code < ncodes && k0 + c4 < dim) v = *reinterpret_cast<const float4*>(cb + (long)code * dim + k0 + c4);
+        float* d = &es[row * VQ_P + c4];
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        e2p[j] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < VQ_KC; ks += 2) {
+        const float b = es[(wave * 32 + l31) * VQ_P + ks + lhi];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float a = zs[(i * 32 + l31) * VQ_P + ks + lhi];
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        }
       }
     }
-  }
+    // |e|^2 (and |z|^2 on the first tile): the 8 threads of a row hold its partial sums
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    rbest[r][tid] = best[r];
-    ribest[r][tid] = bi[r];
-  }
-  __syncthreads();
-  if (tid < 8 && m0 + tid < M) {
-    float b = INFINITY;
-    int i0 = 0x7fffffff;
-    for (int t = 0; t < 256; ++t) {
-      const float v = rbest[tid][t];
-      const int vi = ribest[tid][t];
-      if (v < b || (v == b && vi < i0)) {
-        b = v;
-        i0 = vi;
+    for (int j = 0; j < 4; ++j) {
+      float s = e2p[j];
+      s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+      if ((tid & 7) == 0) e2s[r8 + j * 32] = s;
+    }
+    if (n0 == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float s = z2p[j];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        if ((tid & 7) == 0) z2s[r8 + j * 32] = s;
       }
     }
-    idx[m0 + tid] = i0;
+    __syncthreads();
+    const int code = n0 + wave * 32 + l31;
+    const float e2 = e2s[wave * 32 + l31];
+    if (code < ncodes) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          const float dist = (z2s[row] + e2) - 2.f * acc[i][r];     // VQ:43-44 association
+          if (dist < best[i][r]) {                                    // codes ascend per lane: strict < keeps the first
+            best[i][r] = dist;
+            bidx[i][r] = code;
+          }
+        }
+    }
+  }
+  // minimum over the 32 code columns of the half-wave, then over the 4 waves; ties -> lowest index
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = best[i][r];
+      int bi = bidx[i][r];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {
+        const float ov = __shfl_xor(v, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov < v || (ov == v && oi < bi)) {
+          v = ov;
+          bi = oi;
+        }
+      }
+      if (l31 == 0) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        rbest[wave][row] = v;
+        ribest[wave][row] = bi;
+      }
+    }
+  __syncthreads();
+  if (tid < VQ_TM && m0 + tid < M) {
+    float v = rbest[0][tid];
+    int bi = ribest[0][tid];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float ov = rbest[w][tid];
+      const int oi = ribest[w][tid];
+      if (ov < v || (ov == v && oi < bi)) {
+        v = ov;
+        bi = oi;
+      }
+    }
+    idx[m0 + tid] = bi;
   }
 }
 
 extern "C" int32_t keep_vq_nearest(const float* z, const float* codebook, int32_t* idx, int32_t M, int32_t ncodes,
                                    int32_t dim, void* stream) {
-  KEEP_REQUIRE(z && codebook && idx && M > 0 && ncodes > 0 && dim > 0 && dim <= 1024, "keep_vq_nearest: bad args");
-  hipLaunchKernelGGL(vq_nearest_kernel, dim3(cdiv(M, 8)), dim3(256), 8 * dim * sizeof(float), (hipStream_t)stream, z,
-                     codebook, idx, M, ncodes, dim);
+  KEEP_REQUIRE(z && codebook && idx && M > 0 && ncodes > 0 && dim > 0, "keep_vq_nearest: bad args");
+  KEEP_REQUIRE(dim % 4 == 0 && (uintptr_t)z % 16 == 0 && (uintptr_t)codebook % 16 == 0,
+               "keep_vq_nearest: dim %% 4 == 0 and 16-byte aligned z / codebook (float4 staging), got dim=%d", dim);
+  hipLaunchKernelGGL(vq_nearest_kernel, dim3(cdiv(M, VQ_TM)), dim3(256), 0, (hipStream_t)stream, z, codebook, idx, M, ncodes, dim);
   KEEP_LAUNCH_CHECK("keep_vq_nearest");
   return KEEP_OK;
 }

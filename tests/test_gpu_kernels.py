@@ -477,6 +477,45 @@ def test_vq_nearest(synth_weights):
     assert np.array_equal(idx.cpu().numpy(), gold)
 
 
+def test_vq_nearest_at_scale_ragged_and_ties(synth_weights):
+    """8f-3 at the size of a bench step (M = 256 tokens x 16 clips x 20 frames), ragged M / codebook sizes, exact ties."""
+    cb = dev(synth_weights['quantize.embedding.weight'])                         # [1024, 256]
+    M = 256 * 16 * 20 + 37                                                       # not a multiple of the 64-token tile
+    z = (cb[torch.randint(0, 1024, (M,), device='cuda', generator=torch.Generator('cuda').manual_seed(3))] +
+         0.02 * torch.randn(M, 256, device='cuda', generator=torch.Generator('cuda').manual_seed(4)))
+    idx = torch.empty(M, dtype=torch.int32, device='cuda')
+    L.call('keep_vq_nearest', z, cb, idx, M, 1024, 256)
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(5):
+        L.call('keep_vq_nearest', z, cb, idx, M, 1024, 256)
+    t1.record()
+    torch.cuda.synchronize()
+    ms = t0.elapsed_time(t1) / 5
+    print(f'keep_vq_nearest M={M}: {ms * 1e3:.0f} us, {2.0 * M * 1024 * 256 / ms / 1e9:.1f} TFLOP/s (exact-f32 MFMA), '
+          f'{(M * 256 * 4 + M * 4) / ms / 1e6:.1f} GB/s of token traffic')
+    d = ((z.double() ** 2).sum(1, keepdim=True) + (cb.double() ** 2).sum(1)) - 2 * z.double() @ cb.double().t()   # VQ:43-44
+    top2 = torch.topk(d, 2, dim=1, largest=False)
+    margin = top2.values[:, 1] - top2.values[:, 0]
+    ref = top2.indices[:, 0].to(torch.int32)
+    agree = idx == ref
+    assert agree[margin > 1e-5 * d.abs().max()].all() and agree.float().mean() > 0.9999, float(agree.float().mean())
+    # ragged codebook (1000 codes: the last 128-code tile is partial) and a short dim
+    cb2 = cb[:1000, :192].contiguous()
+    z2 = z[:777, :192].contiguous()
+    idx2 = torch.empty(777, dtype=torch.int32, device='cuda')
+    L.call('keep_vq_nearest', z2, cb2, idx2, 777, 1000, 192)
+    d2 = ((z2.double() ** 2).sum(1, keepdim=True) + (cb2.double() ** 2).sum(1)) - 2 * z2.double() @ cb2.double().t()
+    assert (idx2 == d2.argmin(1).to(torch.int32)).float().mean() > 0.999
+    # exact ties: duplicated code rows -> the lowest index wins (torch.argmin)
+    cb3 = torch.cat([cb[:200], cb[:200], cb[200:400]]).contiguous()              # rows j and j + 200 identical for j < 200
+    z3 = cb3[torch.arange(200, 400, device='cuda')].contiguous()                 # each token equals its code exactly
+    idx3 = torch.empty(200, dtype=torch.int32, device='cuda')
+    L.call('keep_vq_nearest', z3, cb3, idx3, 200, 600, 256)
+    assert torch.equal(idx3.cpu(), torch.arange(0, 200, dtype=torch.int32))
+
+
 def test_kalman_update_and_flow_warp():
     zc, zp, g = rnd('ku_z', (1, 256, 8, 8)), rnd('ku_zp', (1, 256, 8, 8)), (rnd('ku_g', (1, 1, 8, 8)) + 1) / 2
     out = torch.empty(1, 8, 8, 256, device='cuda')

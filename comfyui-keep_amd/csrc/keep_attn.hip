@@ -31,6 +31,11 @@ struct AttnP {
   int mode, T, seg_len;
   int img_h, img_w, ksplit, shift, kv_rot, n_img;
   int nslices;  // dv slices per head
+#ifdef KEEP_X3_ABLATE
+  int abl;               // dev builds: phase ablation selector (KEEP_ATTN_EXP)
+#endif
+  int dbg;                   // KEEP_ATTN_DBG bits (dev): 1 no XCD remap, 2 no lazy rescale, 4 no window tables
+  const _Float16* kv_pack;   // KEEP_MMA_X3: packed K / V^T tile images (attn_pack_kv_x3_kernel) or NULL
   const float* q_amax;   // KEEP_MMA_X3 range probes ([B] each) or NULL
   const float* k_amax;
   const float* v_amax;
@@ -593,8 +598,17 @@ typedef _Float16 af16x2 __attribute__((ext_vector_type(2)));
 // steps) live in registers for the whole kernel -- loaded straight from global, never staged -- so a block's LDS is one
 // K tile + one V^T tile (<= 35 KB) and two blocks share a CU.  D > 128 (VQGAN AttnBlock D = 512, CFA D = 256; 16x16 / 32x32
 // token maps): Q and K are re-staged through LDS per 128-wide chunk.
-template <int WAVES, int DVT, int NQ>
+// PACKED (WAVES 4, D = Dv = 128): K and V^T tiles come pre-split from attn_pack_kv_x3_kernel as the exact LDS image
+// [32 x (hi128|lo128|pad8) | 128 x (32 hi permuted | 32 lo | pad8)] -- 2208 16-byte pieces per key tile copied global -> register
+// -> LDS: 9 wide loads and 9 ds_write_b128 per thread and tile instead of 20 loads (16 of them 4-byte), 128 split
+// operations and 20 narrow LDS writes (the phase ablation: loads 55 %, commit 25 % of the unpacked kernel's time).
+template <int WAVES, int DVT, int NQ, bool PACKED = false>
 __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) void attn_x3_kernel(AttnP p) {
+#ifdef KEEP_X3_ABLATE
+  const int abl = p.abl;
+#else
+  constexpr int abl = 0;
+#endif
   constexpr bool QREG = NQ > 0;             // NQ 16-wide d steps of Q live in registers (NQ = 16: D <= 256, one block per CU)
   constexpr int NQA = QREG ? NQ : 1;
   extern __shared__ __attribute__((aligned(16))) _Float16 smemx[];
@@ -611,17 +625,59 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
   _Float16* Ks = smemx;                               // [32][QP]
   _Float16* Vt = Ks + 32 * QP;                        // [DVS][VP]
   _Float16* Qs = Vt + DVS * VP;                       // [WAVES*32][QP], chunked path only
+  // Window mode (GMFlow swin attention, mode 2) on the prefetching variant: the window-token -> pixel map and the shifted-
+  // window region ids of ALL keys are computed once per block into LDS (tpix: Lk ints; treg: 32 nibbles per key tile) instead
+  // of ~36 index computations (float reciprocal division, wrap, compares) per thread and key tile -- they were 4x the MFMA
+  // issue time of this kernel (121 TFLOP/s on the 1024-token windows).
+  const bool tab = PF && p.mode == 2 && p.Lk <= 4096 && !(p.dbg & 4);
+  int* tpix = reinterpret_cast<int*>(Qs);
+  unsigned* treg = reinterpret_cast<unsigned*>(tpix + ((p.Lk + 31) & ~31));
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int b = blockIdx.z;
-  const int head = blockIdx.y / p.nslices;
-  const int dv0 = (blockIdx.y - head * p.nslices) * DVS;
-  const int q0 = blockIdx.x * (WAVES * 32);
+  // XCD-aware block order: the hardware deals linear block ids round-robin to the 8 XCDs, so the query blocks of ONE
+  // (batch, head) -- which all stream the same K / V -- would land on 8 different L2s and fetch K / V 8 times from HBM
+  // (19.5 GB per GMFlow window-attention call: 14 TB/s of demand).  Give each XCD a contiguous range of logical ids:
+  // the query blocks of one (batch, head) become neighbours in one L2.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (!(p.dbg & 1)) {
+    const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+    const int lid = bx + gx * (by + gy * bz);
+    const int qd = total >> 3, rm = total & 7, xcd = lid & 7, slot = lid >> 3;
+    const int logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + slot;
+    bx = logical % gx;
+    const int rest = logical / gx;
+    by = rest % gy;
+    bz = rest / gy;
+  }
+  const int b = bz;
+  const int head = by / p.nslices;
+  const int dv0 = (by - head * p.nslices) * DVS;
+  const int q0 = bx * (WAVES * 32);
   const long qh = (long)head * p.q_hs, kh = (long)head * p.k_hs, vh = (long)head * p.v_hs;
   const int g4n = DC >> 2;
+  WinCtx wc;
+  if (tab) {
+    wc = win_ctx(p, b);
+    const int ntl = (p.Lk + 31) >> 5;
+    unsigned char* treg8 = reinterpret_cast<unsigned char*>(treg + ntl * 4);
+    for (int t = tid; t < ntl * 32; t += NT) {
+      int pix = 0, region = 0;
+      if (t < p.Lk) win_token(p, wc, t, pix, region);
+      tpix[t] = pix;
+      treg8[t] = (unsigned char)region;
+    }
+    __syncthreads();
+    for (int i = tid; i < ntl * 4; i += NT) {
+      unsigned w = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w |= (unsigned)treg8[i * 8 + j] << (4 * j);
+      treg[i] = w;
+    }
+    __syncthreads();
+  }
   // range scales of un-normalised operands (mode 0, host-probed): q, k, v are multiplied by powers of two before the
   // split; the score scale and the output normalisation absorb the inverses (all exact)
   float sq = 1.f, sk = 1.f, sv = 1.f, inv_qk = 1.f, inv_sv = 1.f;
@@ -698,7 +754,10 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
       if (i < 32 * g4n) {
         const int row = i / g4n, c = (i - row * g4n) << 2;
         const int t = kt * 32 + row;
-        if (t < p.Lk) kreg[u] = *reinterpret_cast<const float4*>(p.k + kv_offset(p, b, t, p.k_bs, p.k_ts) + kh + c);
+        if (t < p.Lk) {
+          const long off = tab ? (long)wc.img_kv * p.k_bs + (long)tpix[t] * p.k_ts : kv_offset(p, b, t, p.k_bs, p.k_ts);
+          kreg[u] = *reinterpret_cast<const float4*>(p.k + off + kh + c);
+        }
       }
     }
   };
@@ -722,8 +781,14 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
         const int pair = i / DVS, dv = i - pair * DVS;
         const int t = kt * 32 + pair * 2;
         if (dv0 + dv < p.Dv) {
-          if (t < p.Lk) vreg[u][0] = p.v[kv_offset(p, b, t, p.v_bs, p.v_ts) + vh + dv0 + dv];
-          if (t + 1 < p.Lk) vreg[u][1] = p.v[kv_offset(p, b, t + 1, p.v_bs, p.v_ts) + vh + dv0 + dv];
+          if (tab) {      // `pair` is wave-uniform (DVS >= 64): the two table reads are LDS broadcasts
+            const long vb = (long)wc.img_kv * p.v_bs + vh + dv0 + dv;
+            if (t < p.Lk) vreg[u][0] = p.v[vb + (long)tpix[t] * p.v_ts];
+            if (t + 1 < p.Lk) vreg[u][1] = p.v[vb + (long)tpix[t + 1] * p.v_ts];
+          } else {
+            if (t < p.Lk) vreg[u][0] = p.v[kv_offset(p, b, t, p.v_bs, p.v_ts) + vh + dv0 + dv];
+            if (t + 1 < p.Lk) vreg[u][1] = p.v[kv_offset(p, b, t + 1, p.v_bs, p.v_ts) + vh + dv0 + dv];
+          }
         }
       }
     }
@@ -749,6 +814,26 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
     }
   };
 
+  constexpr int PK16 = PACKED ? (32 * (2 * 128 + 8) + 128 * 72) / 8 : 1;     // 16-byte pieces of a packed tile image
+  constexpr int PKN = PACKED ? (PK16 + NT - 1) / NT : 1;
+  uint4 preg[PKN];
+  auto pk_issue = [&](int kt) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.kv_pack) + (((long)b * p.H + head) * ((p.Lk + 31) >> 5) + kt) * PK16;
+#pragma unroll
+    for (int u = 0; u < PKN; ++u) {
+      const int i = tid + u * NT;
+      preg[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < PK16) preg[u] = src[i];
+    }
+  };
+  auto pk_commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < PKN; ++u) {
+      const int i = tid + u * NT;
+      if (i < PK16) reinterpret_cast<uint4*>(Ks)[i] = preg[u];
+    }
+  };
+
   const int my_q = q0 + wave * 32 + l31;
   // ---- Q fragments of this lane: row my_q, d in [16*step + 8*lhi, +8), split once
   af16x8 qfh[NQA], qfl[NQA];
@@ -766,16 +851,22 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
     }
   }
   if (PF) {
-    k_issue(0);
-    v_issue(0);
-    k_commit();
-    v_commit();
+    if (PACKED) {
+      pk_issue(0);
+      pk_commit();
+    } else {
+      k_issue(0);
+      v_issue(0);
+      k_commit();
+      v_commit();
+    }
   }
 
   int my_region = 0;
   if (p.mode == 2 && p.shift > 0 && my_q < p.Lq) my_region = win_region(p, b, my_q);
 
   const float qk_scale = p.scale * inv_qk;
+  const float qk_scale2 = qk_scale * 1.4426950408889634f;      // scores in the exp2 domain (PF variant)
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 o[DVT];
 #pragma unroll
@@ -798,15 +889,19 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
         stage_vt(kt);
       }
       __syncthreads();                               // tile kt visible in LDS
-      if (PF && kt + 1 < ntiles) {
-        k_issue(kt + 1);                             // next tile's loads fly during the MFMAs below
-        v_issue(kt + 1);
+      if (PF && kt + 1 < ntiles && abl != 5) {
+        if (PACKED) {
+          pk_issue(kt + 1);                          // next tile's image flies during the MFMAs below
+        } else {
+          k_issue(kt + 1);
+          v_issue(kt + 1);
+        }
       }
 #pragma unroll
       for (int d8 = 0; d8 < NQA; ++d8) {
-        if (d8 * 16 < DC) {
-          const af16x8 kh8 = *reinterpret_cast<const af16x8*>(kp + d8 * 16);
-          const af16x8 kl8 = *reinterpret_cast<const af16x8*>(kp + DC + d8 * 16);
+        if (d8 * 16 < DC && abl != 1) {
+          const af16x8 kh8 = *reinterpret_cast<const af16x8*>(kp + (abl == 6 ? 0 : d8 * 16));
+          const af16x8 kl8 = *reinterpret_cast<const af16x8*>(kp + DC + (abl == 6 ? 0 : d8 * 16));
           s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qfh[QREG ? d8 : 0], s, 0, 0, 0);
           s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qfl[QREG ? d8 : 0], s, 0, 0, 0);
           s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qfh[QREG ? d8 : 0], s, 0, 0, 0);
@@ -830,24 +925,46 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
     }
 
     float mloc = -INFINITY;
+    if (PF) {
+      // exp2 domain (one v_exp_f32 per probability instead of the 13-instruction expf: x3 grade, keep_common.h); the
+      // shifted-window mask (-100 on cross-region pairs, GM/transformer.py:24-35) from the packed region table
+      uint4 rw = make_uint4(0u, 0u, 0u, 0u);
+      const bool masked = p.mode == 2 && p.shift > 0;
+      if (masked && tab) rw = *reinterpret_cast<const uint4*>(treg + kt * 4);
+      const unsigned rws[4] = {rw.x, rw.y, rw.z, rw.w};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      float val = s[r] * qk_scale;
-      if (p.mode == 2 && p.shift > 0 && key < p.Lk) {
-        if (win_region(p, b, key) != my_region) val += -100.0f;
+      for (int r = 0; r < 16; ++r) {
+        const int kl = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const int key = kt * 32 + kl;
+        float val = s[r] * qk_scale2;
+        if (masked) {
+          const int kr = tab ? (int)((rws[r >> 2] >> (4 * ((r & 3) + 4 * lhi))) & 15u) : (key < p.Lk ? win_region(p, b, key) : my_region);
+          if (kr != my_region) val += -100.0f * 1.4426950408889634f;
+        }
+        if (key >= p.Lk) val = -INFINITY;
+        s[r] = val;
+        mloc = fmaxf(mloc, val);
       }
-      if (key >= p.Lk) val = -INFINITY;
-      s[r] = val;
-      mloc = fmaxf(mloc, val);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        float val = s[r] * qk_scale;
+        if (p.mode == 2 && p.shift > 0 && key < p.Lk) {
+          if (win_region(p, b, key) != my_region) val += -100.0f;
+        }
+        if (key >= p.Lk) val = -INFINITY;
+        s[r] = val;
+        mloc = fmaxf(mloc, val);
+      }
     }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
     const float m_new = fmaxf(m_run, mloc);
-    const float alpha = expf(m_run - m_new);
+    const float alpha = PF ? __builtin_amdgcn_exp2f(m_run - m_new) : expf(m_run - m_new);
     float lsum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float pv = expf(s[r] - m_new);
+      const float pv = abl == 3 ? s[r] - m_new : (PF ? __builtin_amdgcn_exp2f(s[r] - m_new) : expf(s[r] - m_new));
       s[r] = pv;
       lsum += pv;
     }
@@ -855,12 +972,16 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
     l_run = l_run * alpha + lsum;
     m_run = m_new;
 
+    // rescale of the running output: skipped when no query of the wave raised its maximum (alpha == 1 exactly) -- after the
+    // first few key tiles that is the common case, and the 16 cross-lane broadcasts + 16*DVT multiplies go away with it
+    if (!PF || (p.dbg & 2) || __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      const float ar = __shfl(alpha, qrow);
+      for (int r = 0; r < 16; ++r) {
+        const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const float ar = __shfl(alpha, qrow);
 #pragma unroll
-      for (int j = 0; j < DVT; ++j) o[j][r] *= ar;
+        for (int j = 0; j < DVT; ++j) o[j][r] *= ar;
+      }
     }
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
@@ -873,7 +994,8 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
       }
 #pragma unroll
       for (int j = 0; j < DVT; ++j) {
-        const _Float16* vrow = Vt + (j * 32 + l31) * VP + (st * 2 + lhi) * 8;
+        if (abl == 2) continue;
+        const _Float16* vrow = Vt + ((abl == 6 ? 0 : j) * 32 + l31) * VP + (st * 2 + lhi) * 8;
         const af16x8 vh8 = *reinterpret_cast<const af16x8*>(vrow), vl8 = *reinterpret_cast<const af16x8*>(vrow + 32);
         o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh8, o[j], 0, 0, 0);
         o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl8, o[j], 0, 0, 0);
@@ -882,8 +1004,14 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
     }
     if (PF && kt + 1 < ntiles) {
       __syncthreads();                               // every wave is done reading tile kt
-      k_commit();
-      v_commit();
+      if (abl != 4) {
+        if (PACKED) {
+          pk_commit();
+        } else {
+          k_commit();
+          v_commit();
+        }
+      }
     }
   }
 
@@ -904,12 +1032,104 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
   }
 }
 
+// K / V^T tile images for the PACKED variant above: one block per (key tile, head, batch) gathers the tile's 32 key rows
+// (window / sparse-causal index math once per element instead of once per query block), applies the range scales, splits,
+// assembles the LDS image in LDS and writes it out with 16-byte stores.
+__global__ __launch_bounds__(256) void attn_pack_kv_x3_kernel(AttnP p, _Float16* out) {
+  constexpr int QP = 2 * 128 + 8, VP = 72, DVS = 128, PK16 = (32 * QP + DVS * VP) / 8;
+  __shared__ __attribute__((aligned(16))) _Float16 img[32 * QP + DVS * VP];
+  _Float16* Ks = img;
+  _Float16* Vt = img + 32 * QP;
+  const int tid = threadIdx.x;
+  const int kt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  float sk = 1.f, sv = 1.f, tmp;
+  if (p.q_amax) {
+    attn_range_scale(p.k_amax[b], sk, tmp);
+    attn_range_scale(p.v_amax[b], sv, tmp);
+  }
+  for (int i = tid; i < PK16; i += 256) reinterpret_cast<uint4*>(img)[i] = make_uint4(0u, 0u, 0u, 0u);   // pads, tail keys
+  __syncthreads();
+  const long kh = (long)head * p.k_hs, vh = (long)head * p.v_hs;
+  for (int i = tid; i < 32 * 32; i += 256) {                 // K: 32 rows x 32 float4
+    const int row = i >> 5, c = (i & 31) << 2;
+    const int t = kt * 32 + row;
+    if (t < p.Lk) {
+      const float4 v = *reinterpret_cast<const float4*>(p.k + kv_offset(p, b, t, p.k_bs, p.k_ts) + kh + c);
+      const float f[4] = {v.x * sk, v.y * sk, v.z * sk, v.w * sk};
+      af16x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const _Float16 h = (_Float16)f[j];
+        hi[j] = h;
+        lo[j] = (_Float16)(f[j] - (float)h);
+      }
+      *reinterpret_cast<af16x4*>(Ks + row * QP + c) = hi;
+      *reinterpret_cast<af16x4*>(Ks + row * QP + 128 + c) = lo;
+    }
+  }
+  for (int i = tid; i < 16 * DVS; i += 256) {                // V^T: (key pair, dv) items, lane <-> dv (coalesced reads)
+    const int pair = i / DVS, dv = i - pair * DVS;
+    const int t = kt * 32 + pair * 2;
+    float v[2] = {0.f, 0.f};
+    if (t < p.Lk) v[0] = p.v[kv_offset(p, b, t, p.v_bs, p.v_ts) + vh + dv];
+    if (t + 1 < p.Lk) v[1] = p.v[kv_offset(p, b, t + 1, p.v_bs, p.v_ts) + vh + dv];
+    af16x2 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float vs = v[j] * sv;
+      const _Float16 h = (_Float16)vs;
+      hi[j] = h;
+      lo[j] = (_Float16)(vs - (float)h);
+    }
+    _Float16* d = Vt + dv * VP + vt_pos(pair * 2);
+    *reinterpret_cast<af16x2*>(d) = hi;
+    *reinterpret_cast<af16x2*>(d + 32) = lo;
+  }
+  __syncthreads();
+  uint4* dst = reinterpret_cast<uint4*>(out) + (((long)b * p.H + head) * gridDim.x + kt) * PK16;
+  for (int i = tid; i < PK16; i += 256) dst[i] = reinterpret_cast<const uint4*>(img)[i];
+}
+
+// packed K / V^T path: worth it when several query blocks stream the same keys
+static long attn_pack_bytes(const AttnP& p, int mma) {
+  if (mma != KEEP_MMA_X3 || p.D != 128 || p.Dv != 128 || p.Lq < 256 || getenv("KEEP_NO_ATTN_PACK")) return 0;
+  return (long)p.B * p.H * ((p.Lk + 31) / 32) * ((32 * (2 * 128 + 8) + 128 * 72) * 2L);
+}
+
+static int launch_attn_x3_packed(const AttnP& p, hipStream_t st) {
+  const int ntl = (p.Lk + 31) / 32;
+  hipLaunchKernelGGL(attn_pack_kv_x3_kernel, dim3(ntl, p.H, p.B), dim3(256), 0, st, p, const_cast<_Float16*>(p.kv_pack));
+  KEEP_LAUNCH_CHECK("keep_attention(x3 pack)");
+  size_t lds = (size_t)(32 * (2 * 128 + 8) + 4 * 32 * 72) * 2;
+  if (p.mode == 2 && p.Lk <= 4096) lds += (size_t)ntl * (32 * 4 + 16 + 32);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_x3_kernel<4, 4, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      keep_set_error("keep_attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return KEEP_EHIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid(cdiv(p.Lq, 128), p.H * p.nslices, p.B);
+#ifdef KEEP_X3_ABLATE
+  const_cast<AttnP&>(p).abl = getenv("KEEP_ATTN_EXP") ? atoi(getenv("KEEP_ATTN_EXP")) : 0;
+#endif
+  hipLaunchKernelGGL((attn_x3_kernel<4, 4, 8, true>), grid, dim3(256), lds, st, p);
+  KEEP_LAUNCH_CHECK("keep_attention(x3 packed)");
+  return KEEP_OK;
+}
+
 template <int WAVES, int DVT, int NQ>
 static int launch_attn_x3_t(const AttnP& p, hipStream_t st) {
   constexpr bool QREG = NQ > 0;
   const int DCMAX = QREG ? 16 * NQ : 128;
   const int DC = p.D < DCMAX ? p.D : DCMAX;
-  const size_t lds = (size_t)(((QREG ? 0 : WAVES * 32) + 32) * (2 * DC + 8) + DVT * 32 * 72) * 2;
+  size_t lds = (size_t)(((QREG ? 0 : WAVES * 32) + 32) * (2 * DC + 8) + DVT * 32 * 72) * 2;
+  if (WAVES == 4 && QREG && p.mode == 2 && p.Lk <= 4096) {      // window tables: pixel per key, packed + byte region ids
+    const size_t ntl = (size_t)(p.Lk + 31) / 32;
+    lds += ntl * 32 * 4 + ntl * 16 + ntl * 32;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_x3_kernel<WAVES, DVT, NQ>,
@@ -921,6 +1141,9 @@ static int launch_attn_x3_t(const AttnP& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(cdiv(p.Lq, WAVES * 32), p.H * p.nslices, p.B);
+#ifdef KEEP_X3_ABLATE
+  const_cast<AttnP&>(p).abl = getenv("KEEP_ATTN_EXP") ? atoi(getenv("KEEP_ATTN_EXP")) : 0;
+#endif
   hipLaunchKernelGGL((attn_x3_kernel<WAVES, DVT, NQ>), grid, dim3(64 * WAVES), lds, st, p);
   KEEP_LAUNCH_CHECK("keep_attention(x3)");
   return KEEP_OK;
@@ -1485,6 +1708,17 @@ static int launch_attn_bf16in(const AttnP& p, hipStream_t st) {
   return KEEP_OK;
 }
 
+extern "C" int64_t keep_attention_workspace_bytes(const keep_attention_args* a) {
+  if (!a || a->mma != KEEP_MMA_X3 || a->in_dtype == KEEP_BF16 || a->B <= 0 || a->H <= 0 || a->Lk <= 0) return 0;
+  const bool x3_ok = (a->D % 16 == 0) && (a->q_ts % 4 == 0) && (a->q_bs % 4 == 0) && (a->q_hs % 4 == 0) && (a->k_ts % 4 == 0) &&
+                     (a->k_bs % 4 == 0) && (a->k_hs % 4 == 0) && ((uintptr_t)a->q % 16 == 0) && ((uintptr_t)a->k % 16 == 0) &&
+                     !getenv("KEEP_NO_ATTN_X3");
+  if (!x3_ok) return 0;
+  AttnP p;
+  p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.D = a->D; p.Dv = a->Dv;
+  return attn_pack_bytes(p, a->mma);
+}
+
 extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
   KEEP_REQUIRE(a != nullptr, "keep_attention: null args");
   KEEP_REQUIRE(a->q && a->k && a->v && a->o, "keep_attention: null tensor pointer");
@@ -1516,6 +1750,8 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
   p.img_h = a->img_h; p.img_w = a->img_w; p.ksplit = a->ksplit; p.shift = a->shift; p.kv_rot = a->kv_rot;
   p.n_img = a->n_img;
   p.q_amax = a->q_amax; p.k_amax = a->k_amax; p.v_amax = a->v_amax;
+  p.kv_pack = nullptr;
+  p.dbg = getenv("KEEP_ATTN_DBG") ? atoi(getenv("KEEP_ATTN_DBG")) : 0;
   KEEP_REQUIRE((!a->q_amax && !a->k_amax && !a->v_amax) || (a->q_amax && a->k_amax && a->v_amax && a->mode == 0 && a->mma == KEEP_MMA_X3),
                "keep_attention: q/k/v_amax come together, with KEEP_MMA_X3 and mode 0 only");
   hipStream_t st = (hipStream_t)stream;
@@ -1550,7 +1786,10 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
   // split fp16: fp32 tensors with 16-byte aligned rows, D a multiple of 16; everything else runs on the exact-f32 kernel
   if (a->mma == KEEP_MMA_X3 && (a->D % 16 == 0) && (a->q_ts % 4 == 0) && (a->q_bs % 4 == 0) && (a->q_hs % 4 == 0) &&
       (a->k_ts % 4 == 0) && (a->k_bs % 4 == 0) && (a->k_hs % 4 == 0) && ((uintptr_t)a->q % 16 == 0) &&
-      ((uintptr_t)a->k % 16 == 0) && !getenv("KEEP_NO_ATTN_X3")) {
+      ((uintptr_t)a->k % 16 == 0) && !getenv("KEEP_NO_ATTN_X3") &&
+      !((p.dbg & 8) && a->Lq <= 32) && !((p.dbg & 16) && a->Lq > 32 && a->D > 128 && a->D <= 256) &&
+      !((p.dbg & 32) && a->D > 256) && !((p.dbg & 64) && a->Lq > 32 && a->D <= 128 && a->mode != 2) &&
+      !((p.dbg & 128) && a->mode == 2)) {
     if (a->Lq <= 32) {
       if (dvt == 1) return launch_attn_x3<1, 1>(p, st);
       if (dvt == 2) return launch_attn_x3<1, 2>(p, st);
@@ -1558,6 +1797,13 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
     }
     if (dvt == 1) return launch_attn_x3<4, 1>(p, st);
     if (dvt == 2) return launch_attn_x3<4, 2>(p, st);
+    {
+      const long need = attn_pack_bytes(p, a->mma);
+      if (need > 0 && a->workspace && a->workspace_bytes >= need && (uintptr_t)a->workspace % 16 == 0) {
+        p.kv_pack = (const _Float16*)a->workspace;
+        return launch_attn_x3_packed(p, st);
+      }
+    }
     return launch_attn_x3<4, 4>(p, st);
   }
   // one wave per block for tiny query counts (temporal attention over T frames), else 4 (one per SIMD)

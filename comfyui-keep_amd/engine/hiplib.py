@@ -42,7 +42,7 @@ class AttnArgs(C.Structure):
                                     'o_bs', 'o_ts', 'o_hs')] + \
                [(n, _i32) for n in ('B', 'H', 'Lq', 'Lk', 'D', 'Dv')] + [('scale', _f32), ('mode', _i32)] + \
                [(n, _i32) for n in ('T', 'seg_len', 'img_h', 'img_w', 'ksplit', 'shift', 'kv_rot', 'n_img', 'mma', 'in_dtype')] + \
-               [('q_amax', _vp), ('k_amax', _vp), ('v_amax', _vp)]
+               [('q_amax', _vp), ('k_amax', _vp), ('v_amax', _vp), ('workspace', _vp), ('workspace_bytes', _i64)]
 
 
 # name -> argtypes (restype is always int32 status); every symbol include/keep_hip.h declares
@@ -78,7 +78,7 @@ _SIGNATURES = {
     'keep_f32_round_u8': [_vp, _vp, _i64, _vp],
     'keep_paste_face': [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
 }
-EXPORTED_SYMBOLS = ['keep_abi_version', 'keep_last_error', 'keep_device_ok'] + list(_SIGNATURES)
+EXPORTED_SYMBOLS = ['keep_abi_version', 'keep_last_error', 'keep_device_ok', 'keep_attention_workspace_bytes'] + list(_SIGNATURES)
 
 _lib = None
 _device_checked = set()
@@ -101,6 +101,8 @@ def load(check_device=True):
         lib.keep_last_error.restype = C.c_char_p
         lib.keep_device_ok.restype = _i32
         lib.keep_device_ok.argtypes = [_i32]
+        lib.keep_attention_workspace_bytes.restype = _i64
+        lib.keep_attention_workspace_bytes.argtypes = [C.POINTER(AttnArgs)]
         ver = lib.keep_abi_version()
         if ver != ABI_VERSION:
             raise KeepHipError(f"libkeep_hip.so ABI version {ver} != expected {ABI_VERSION}; rebuild")
@@ -156,6 +158,11 @@ def conv2d_plan(a):
     return out
 
 
+def attention_workspace_bytes(a):
+    """keep_attention_workspace_bytes: scratch the library can use for this call (0 = none)."""
+    return int(load(check_device=False).keep_attention_workspace_bytes(C.byref(a)))
+
+
 def conv2d_launch(a):
     _check(load().keep_conv2d(C.byref(a), _stream()), 'keep_conv2d')
 
@@ -169,4 +176,8 @@ def attention(**kw):
     a = AttnArgs()
     for k, v in kw.items():
         setattr(a, k, _ptr(v) if (isinstance(v, torch.Tensor) or v is None) else v)
+    need = int(lib.keep_attention_workspace_bytes(C.byref(a)))       # the library asks; the host only allocates
+    if need:
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=kw['q'].device)   # stream-ordered free after the call
+        a.workspace, a.workspace_bytes = ws.data_ptr(), need
     _check(lib.keep_attention(C.byref(a), _stream()), 'keep_attention')

@@ -177,8 +177,15 @@ typedef struct {
   const float* q_amax;
   const float* k_amax;
   const float* v_amax;
+  /* optional scratch (device, 16-byte aligned) of at least keep_attention_workspace_bytes(a) bytes: with it a KEEP_MMA_X3 call
+   * whose K / V are streamed by several query blocks first packs K and V^T ONCE into the split-fp16 tile images the kernel
+   * keeps in LDS (keep_attn.hip: attn_pack_kv_x3_kernel) and the query blocks copy tiles instead of re-splitting them */
+  void* workspace;
+  int64_t workspace_bytes;
 } keep_attention_args;
 int32_t keep_attention(const keep_attention_args* a, void* stream);
+/* bytes of `workspace` this call can use (0: none); a smaller or NULL workspace selects the unpacked path */
+int64_t keep_attention_workspace_bytes(const keep_attention_args* a);
 
 /* ------------------------------------------------------------------------------------------------
  * Normalisation statistics.  GroupNorm(32, eps 1e-6) VQ:16-17 and InstanceNorm2d(eps 1e-5, no affine)

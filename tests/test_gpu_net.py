@@ -245,13 +245,27 @@ def test_config3_config4_clip_mixes_equal_sequential(gpu_net, n_crops, faces):
     assert len(faces_out) == n_crops and all(f.shape == (512, 512, 3) and f.dtype == np.uint8 for f in faces_out)
     spans = split_clips(n_crops, 20)
     assert len(spans) == n_crops // 20 and all(e - s == 20 for s, e in spans)
+    # Equality with the sequential loop is checked on what is NOT chaotic: the recurrence (keep_arch.py:1062-1127) amplifies the
+    # batch-dependent fp32 re-association (split-K factors follow the batch) until one low-margin code index flips -- from
+    # that frame on two correct runs differ by whole codebook patches (tools/dev/batch_flip2.py: clip 0 flips at frame 12 of 20
+    # in a batch of 15, at no frame in a batch of 8).  So: frame 0 of EVERY clip (order / chunking: frame 0 depends on no other
+    # frame) and, for a spread of clips, every frame up to the first one with a flip -- at least the first four -- must agree
+    # with the solo run to one uint8 level on < 1 % of the pixels.
+    def close(a, b):
+        d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+        return d.max() <= 1 and (d > 0).mean() < 1e-2
+    firsts = gpu_net.run_clips_u8([torch.from_numpy(np.stack(crops[s:s + 1])) for s, _ in spans], max_b=16)
+    for ci, (s, e) in enumerate(spans):
+        assert close(firsts[ci].numpy()[0], faces_out[s]), ('frame 0 of clip', ci)
+    agree_frames = []
     for ci in sorted({0, len(spans) // 2, len(spans) - 1}):
         s, e = spans[ci]
         solo = gpu_net.run_clips_u8([torch.from_numpy(np.stack(crops[s:e]))], max_b=1)[0].numpy()
         got = np.stack(faces_out[s:e])
-        diff = np.abs(solo.astype(np.int16) - got.astype(np.int16))
-        # batch-mates change split-K factors (fp32 re-association, <= 5e-4 before rounding): at most a last-bit flip
-        assert diff.max() <= 1 and (diff > 0).mean() < 1e-2, (ci, int(diff.max()), float((diff > 0).mean()))
+        n_ok = next((t for t in range(e - s) if not close(solo[t], got[t])), e - s)
+        agree_frames.append(n_ok)
+        assert n_ok >= 4, (ci, n_ok)
+    print(f'config {n_crops}/{faces}: frames equal to the solo run before the first index flip, per checked clip: {agree_frames}')
 
 
 def test_full_forward_asian_T2_vs_reference_golden():

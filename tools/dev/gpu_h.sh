@@ -1,8 +1,5 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-{
-echo "== nb 15"; timeout 900 python tools/dev/batch_flip2.py 15 2>&1 | grep -v amdgpu.ids | grep -v "max diff [01]," 
-echo "== nb 15 window attn f32"; KEEP_ATTN_DBG=128 timeout 900 python tools/dev/batch_flip2.py 15 2>&1 | grep -v amdgpu.ids | grep -v "max diff [01],"
-} > gpurun_out/exp_h.log 2>&1
+timeout 900 python tools/dev/absmax_who.py 2>&1 | grep -v amdgpu.ids > gpurun_out/exp_h.log
 cat gpurun_out/exp_h.log

@@ -1648,12 +1648,13 @@ __global__ void conv_splitk_reduce_kernel(ConvP p) {
 int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int big_tile, hipStream_t st);
 bool keep_conv_x3_gather_is_gemm(const keep_conv2d_args* a);
+int keep_conv2d_x3_c3(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 bool keep_conv_x3_halo_ok(const keep_conv2d_args* a);
 bool keep_conv_x3_gather_ok(const keep_conv2d_args* a, const ConvP& p);
 
 enum ConvPath {
   PATH_COUT4 = 0, PATH_C3, PATH_HALO_F32, PATH_HALO_BF16, PATH_HALO_BF16_V1, PATH_GATHER_BF16, PATH_GATHER_F32, PATH_HALO_X3,
-  PATH_GATHER_X3, PATH_NEEDS_PRENORM
+  PATH_GATHER_X3, PATH_NEEDS_PRENORM, PATH_C3_X3
 };
 
 struct ConvPlan {
@@ -1786,6 +1787,17 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   if (mma == KEEP_MMA_X3) {
     KEEP_REQUIRE(a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16, "keep_conv2d: KEEP_MMA_X3 takes and writes fp32 tensors");
     const bool have_w = a->weight_x3 != nullptr && (uintptr_t)a->weight_x3 % 16 == 0 && a->x3_acc_scale > 0.f;
+    // RGB first convolutions: persistent im2col-in-LDS kernel, weights split on the fly from the fp32 tensor
+    if (is33s1 && !a->upsample && a->Cin <= 3 && a->Cout % 4 == 0 && a->Cout >= 32 && a->Ho == a->H && a->Wo == a->W &&
+        a->Ho % 8 == 0 && a->Wo % 32 == 0 && no_pro && !a->residual && !a->aux && a->split_k <= 1 && a->out_ld % 4 == 0 &&
+        (uintptr_t)a->out % 16 == 0 && (!a->bias || (uintptr_t)a->bias % 16 == 0) && a->weight && !getenv("KEEP_NO_C3")) {
+      pl.path = PATH_C3_X3;
+      pl.split_k = 1;
+      pl.stats_rows = 64;
+      pl.amax_ok = true;
+      snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_c3_x3_kernel");
+      return KEEP_OK;
+    }
     if (have_w && is33s1 && keep_conv_x3_halo_ok(a) && !getenv("KEEP_NO_HALO_X3")) {
       pl.path = PATH_HALO_X3;
       const long items = (M / 256) * ncb;
@@ -1955,8 +1967,10 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (a->x3_out_amax) {
     KEEP_REQUIRE(pl.amax_ok, "keep_conv2d: x3_out_amax is not available for this call (keep_conv2d_plan: out_amax_ok)");
-    hipLaunchKernelGGL(zero_u32_kernel, dim3(cdiv(a->N, 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(a->x3_out_amax), a->N);
-    KEEP_LAUNCH_CHECK("keep_conv2d(zero x3_out_amax)");
+    if (!a->x3_out_amax_zeroed) {
+      hipLaunchKernelGGL(zero_u32_kernel, dim3(cdiv(a->N, 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(a->x3_out_amax), a->N);
+      KEEP_LAUNCH_CHECK("keep_conv2d(zero x3_out_amax)");
+    }
     p.out_amax = reinterpret_cast<unsigned*>(a->x3_out_amax);
   }
   if (p.out_bf16)
@@ -1980,6 +1994,10 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
       KEEP_LAUNCH_CHECK("keep_conv2d(Cin<=3)");
       return KEEP_OK;
     }
+    case PATH_C3_X3:
+      rc = keep_conv2d_x3_c3(a, p, st);
+      if (rc != KEEP_OK) return rc;
+      break;
     case PATH_HALO_X3:
       rc = keep_conv2d_x3_halo(a, p, st);
       if (rc != KEEP_OK) return rc;

@@ -820,6 +820,191 @@ static int x3_num_cu() {
   return n_cu;
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3, Cin <= 3, split fp16
+// The RGB first convolutions (3 -> 64 at 512x512: VQ conv_in of the LQ encoder over all B*T frames, of the HQ encoder every
+// frame) under KEEP_MMA_X3 -- the x3 form of conv3x3_c3_kernel (keep_conv.hip): persistent blocks (2 per CU), per 8x32-pixel
+// item the 10x34xCin fp32 halo is loaded once, every thread expands ITS pixel into one K = 32 im2col row [hi x32 | lo x32]
+// (K = 9*Cin <= 27 real taps, zero padded), the 64 x K weight rows are split on the fly from the fp32 weights (27 values per
+// cout: no pre-split twin needed) and stay in LDS across items, and the wave runs 2 x 4 x 3 MFMAs before the LDS-staged float4
+// epilogue with GroupNorm partials and the fused max|out|.  HBM-write bound (64 couts x 4 B per pixel); on the exact-f32
+// gather kernel the same launches ran at 26-28 TFLOP/s = 1.6 TB/s.
+#define C3X_K 32
+#define C3X_P 72                             // fp16 per im2col / weight row: 32 hi + 32 lo + 8 pad (144 B)
+__global__ __launch_bounds__(256, 2) void conv3x3_c3_x3_kernel(ConvP p, int tiles_x, int tiles_y, int ncb, int n_items) {
+  constexpr int HW_ = 34, HROWS = 10;
+  constexpr int EPI_B = 4 * 64 * 68 * 4;                                    // staging tile; im2col rows and the halo alias it
+  constexpr int A_B = 256 * C3X_P * 2;
+  static_assert(A_B + HROWS * HW_ * 4 * 4 <= EPI_B, "im2col rows + halo fit the staging area");
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[EPI_B + 64 * C3X_P * 2];
+  float* et_base = reinterpret_cast<float*>(lds_raw);
+  _Float16* As = reinterpret_cast<_Float16*>(lds_raw);                      // [256 px][C3X_P]
+  float* Hs = reinterpret_cast<float*>(lds_raw + A_B);                      // [10][34 * Cin]
+  _Float16* Ws = reinterpret_cast<_Float16*>(lds_raw + EPI_B);              // [64][C3X_P], resident across items
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int Cin = p.Cin, K = 9 * Cin;
+  const int rowf = HW_ * Cin;
+
+  int cur_cb = -1;
+  auto load_weights = [&](int cb) {                                          // [64 couts][K] -> hi | lo, zero padded to 32
+    for (int i = tid; i < 64 * C3X_K; i += 256) {
+      const int co = i >> 5, k = i & 31;
+      float v = 0.f;
+      if (k < K && cb * 64 + co < p.Cout) v = p.w[(long)(cb * 64 + co) * K + k];
+      const _Float16 h = (_Float16)v;
+      Ws[co * C3X_P + k] = h;
+      Ws[co * C3X_P + 32 + k] = (_Float16)(v - (float)h);
+    }
+  };
+
+  f32x16 acc[2][2];
+  const bool has_act = p.epi_act != KEEP_ACT_NONE;
+  const int py = tid >> 5, px = tid & 31;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int lid = xcd_remap(item, n_items);
+    const int cb = lid % ncb;
+    int t = lid / ncb;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int n = t / tiles_y;
+    const int oy0 = ty * 8, ox0 = tx * 32, n0 = cb * 64;
+    float in_s = 1.f, in_inv = 1.f;
+    if (p.in_amax) x3_range_scale(p.in_amax[n], in_s, in_inv);
+    __syncthreads();                                                         // previous item's staging tile fully stored
+    if (cb != cur_cb) {
+      load_weights(cb);
+      cur_cb = cb;
+    }
+    const float* img = p.in + (long)n * p.H * p.W * p.in_ld;
+    for (int i = tid; i < HROWS * rowf; i += 256) {
+      const int hy = i / rowf, r = i - hy * rowf;
+      const int hx = r / Cin, c = r - hx * Cin;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      float v = 0.f;
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = img[((long)iy * p.W + ix) * p.in_ld + c];
+      Hs[i] = v * in_s;
+    }
+    __syncthreads();
+    {
+      float vals[C3X_K];
+#pragma unroll
+      for (int k = 0; k < C3X_K; ++k) vals[k] = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kwc = 0; kwc < 9; ++kwc)                                    // (kw, c) run is contiguous in the halo row for Cin = 3
+          if (kwc < 3 * Cin && kh * 3 * Cin + kwc < C3X_K) vals[kh * 3 * Cin + kwc] = Hs[(py + kh) * rowf + px * Cin + kwc];
+      f16x8 hi[4], lo[4];
+#pragma unroll
+      for (int k = 0; k < C3X_K; ++k) {
+        const _Float16 h = (_Float16)vals[k];
+        hi[k >> 3][k & 7] = h;
+        lo[k >> 3][k & 7] = (_Float16)(vals[k] - (float)h);
+      }
+      __syncthreads();                                                       // every thread has read its halo values (As aliases nothing of Hs, but keep the order simple)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<f16x8*>(&As[tid * C3X_P + q * 8]) = hi[q];
+        *reinterpret_cast<f16x8*>(&As[tid * C3X_P + 32 + q * 8]) = lo[q];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const _Float16* src = &As[(wave * 64 + i * 32 + l31) * C3X_P + ks * 16 + lhi * 8];
+        ah[i] = *reinterpret_cast<const f16x8*>(src);
+        al[i] = *reinterpret_cast<const f16x8*>(src + 32);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const _Float16* src = &Ws[(j * 32 + l31) * C3X_P + ks * 16 + lhi * 8];
+        bh[j] = *reinterpret_cast<const f16x8*>(src);
+        bl[j] = *reinterpret_cast<const f16x8*>(src + 32);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          MMA_X3(acc[i][j], ah[i], al[i], bh[j], bl[j])
+        }
+    }
+    __syncthreads();                                                         // A reads done: the area becomes the staging tile
+    constexpr int EP = 68;
+    float* et = et_base + wave * 64 * EP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) et[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * EP + j * 32 + l31] = acc[i][j][r] * in_inv;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const int c4 = (lane & 15) * 4, prow = lane >> 4;
+    const int co = n0 + c4;
+    const bool cok = co < p.Cout;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
+    float amx = 0.f;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
+#pragma unroll 8
+    for (int q16 = 0; q16 < 16; ++q16) {
+      if (!cok) break;
+      const int pxl = q16 * 4 + prow;
+      const int oy = oy0 + 2 * wave + (pxl >> 5);
+      const long m = ((long)n * p.Ho + oy) * p.Wo + ox0 + (pxl & 31);
+      const float4 v = *reinterpret_cast<const float4*>(et + pxl * EP + c4);
+      float e[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
+      if (has_act) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = p.fast ? act_apply_fast(e[q], p.epi_act) : act_apply(e[q], p.epi_act);
+      }
+      *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s4[q] += e[q];
+        ss4[q] += e[q] * e[q];
+        amx = fmaxf(amx, fabsf(e[q]));
+      }
+    }
+    if (p.out_amax) wave_amax_commit(p.out_amax + n, amx);
+    if (p.stats) {          // per wave: stats_P = Ho*Wo/64, partial index = tile*4 + wave
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s4[q] = xor32_sum(xor16_sum(s4[q]));
+        ss4[q] = xor32_sum(xor16_sum(ss4[q]));
+      }
+      if (lane < 16 && cok) {
+        float* dst = p.stats + (((long)n * p.stats_P + (ty * tiles_x + tx) * 4 + wave) * p.Cout + co) * 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          dst[q * 2 + 0] = s4[q];
+          dst[q * 2 + 1] = ss4[q];
+        }
+      }
+    }
+  }
+}
+
+int keep_conv2d_x3_c3(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
+  const int tx = a->Wo / 32, ty = a->Ho / 8, ncb = (a->Cout + 63) / 64;
+  const int n_items = a->N * tx * ty * ncb;
+  const int n_cu = x3_num_cu();
+  hipLaunchKernelGGL(conv3x3_c3_x3_kernel, dim3(n_items < 2 * n_cu ? n_items : 2 * n_cu), dim3(256), 0, st, p, tx, ty, ncb, n_items);
+  KEEP_LAUNCH_CHECK("keep_conv2d(Cin<=3, x3)");
+  return KEEP_OK;
+}
+
 // Geometry the x3 kernels accept (everything else of a KEEP_MMA_X3 call runs on the exact-f32 kernels: same parity grade).
 bool keep_conv_x3_halo_ok(const keep_conv2d_args* a) {
   return a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 &&

@@ -580,6 +580,7 @@ class KeepNet:
 
     def _forward(self, x, B, T, H, Wd, force_indices, return_aux, force_flows=None):
         cfg = self.cfg
+        self.o.begin_forward(self.device)
         # K1: flows for all T-1 pairs (KA:976-986): flownet(x[:,1:], x[:,:-1])
         flows = None
         if force_flows is not None:      # parity tests: inject the oracle's flows [B,T-1,2,H,W] (isolates GMFlow drift)

@@ -83,6 +83,20 @@ class Ops:
         # bench.py's roofline leg: when a list, every keep_conv2d launch is bracketed by HIP events on the launch stream
         # and appended as (kernel family, algorithmic_flops, split_k, start_event, end_event, algorithmic_bytes)
         self.profile = None
+        self.amax_arena = None     # x3: per-forward arena of fused max|out| slots (begin_forward)
+        self.amax_pos = 0
+
+    def begin_forward(self, device):
+        """x3 policy: the per-image max|out| slots the convolutions fill with atomicMax come from ONE arena that is zero-
+        filled once here instead of one zero-fill launch per convolution (2.4 k launches per 16-clip step).  A slot lives
+        until the next begin_forward: Stats objects never outlive the forward pass that made them."""
+        if self.mma != L.MMA_X3:
+            self.amax_arena = None
+            return
+        if self.amax_arena is None or self.amax_arena.device != torch.device(device):
+            self.amax_arena = torch.empty(1 << 18, dtype=torch.float32, device=device)
+        self.amax_arena.zero_()
+        self.amax_pos = 0
 
     def set_precision(self, mma, blob32=None, blob16=None, blobx3=None, x3_acc_scale=1.0):
         self.mma = self.attn_mma = mma
@@ -148,7 +162,7 @@ class Ops:
         want_bf16_out = bool(out_bf16) and mma == L.MMA_BF16 and residual is None
         xin = x if in_off == 0 else x.view(-1)[in_off:]
         in_amax = None
-        if mma == L.MMA_X3 and wx3 is not None and pro is None and not bounded:
+        if mma == L.MMA_X3 and (wx3 is not None or (Cin <= 3 and KH == 3)) and pro is None and not bounded:   # (RGB convs split fp32 weights in-kernel)
             in_amax = x_amax if (x_amax is not None and x_amax.numel() == N) else absmax(xin, N, H * W, Cin, ld, H * W * ld)
         out_ld = Cout if out is None else out.shape[-1]
 
@@ -199,7 +213,12 @@ class Ops:
                 st.part, st.P = empty((N, pl.stats_P, Cout, 2), x), pl.stats_P
                 a.stats_out, a.stats_P = st.part.data_ptr(), pl.stats_P
             if pl.out_amax_ok:
-                st.amax = empty((N,), x)
+                if self.amax_arena is not None and self.amax_pos + N <= self.amax_arena.numel():
+                    st.amax = self.amax_arena[self.amax_pos:self.amax_pos + N]       # zeroed once per forward
+                    self.amax_pos += N
+                    a.x3_out_amax_zeroed = 1
+                else:
+                    st.amax = empty((N,), x)
                 a.x3_out_amax = st.amax.data_ptr()
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

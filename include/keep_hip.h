@@ -123,6 +123,8 @@ typedef struct {
   /* optional, KEEP_MMA_X3 kernels with split_k == 1 (keep_conv2d_plan: out_amax_ok): out_amax[n] = max |out[n,...]|, [N]
    * floats, zeroed and filled by this call -- the range probe of the NEXT un-normalised x3 consumer for free */
   float* x3_out_amax;
+  int32_t x3_out_amax_zeroed; /* non-zero: the caller zero-filled x3_out_amax (one arena per forward pass); otherwise the
+                                 library zero-fills it with a kernel of its own before the launch */
 } keep_conv2d_args;
 int32_t keep_conv2d(const keep_conv2d_args* a, void* stream);
 

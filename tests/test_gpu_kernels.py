@@ -971,3 +971,25 @@ def test_conv_x3_halo_general_epilogue_two_blocks_per_cu():
         y32 = ops.conv(wide, w2p, dev(b2), **kw)
         y3 = ops.conv(wide, w2p, dev(b2), mma=L.MMA_X3, wx3=w2x, x3_acc_scale=asc2, **kw)
         check(y3, y32, 1e-5, f'x3 halo cft off={off}')
+
+
+def test_conv_x3_rgb_first_conv_kernel():
+    """KEEP_MMA_X3, Cin = 3 (VQ conv_in at 512^2): the im2col-in-LDS x3 kernel -- weights split on the fly, range-probed and
+    bounded inputs, fused statistics and max|out| -- against the exact-f32 kernels."""
+    x, w, b = rnd('c3x_x', (3, 3, 64, 96)), rnd('c3x_w', (64, 3, 3, 3), 0.2), rnd('c3x_b', (64,))
+    wp = pack(w)
+    for scale, bounded in ((1.0, True), (900.0, False)):
+        xs = dev(nhwc(x * scale))
+        ops.DEFAULT.profile = []
+        y3, st = ops.conv(xs, wp, dev(b), mma=L.MMA_X3, wx3=None, x3_acc_scale=1.0, stats=True, bounded=bounded)
+        name = ops.DEFAULT.profile[-1][0]
+        ops.DEFAULT.profile = None
+        assert name == 'conv3x3_c3_x3_kernel', name
+        y32 = ops.conv(xs, wp, dev(b))
+        ref64 = F.conv2d(x.double() * scale, w.double(), b.double(), padding=1)
+        e3, e32 = err64(nchw(y3), ref64), err64(nchw(y32), ref64)
+        assert e3 <= max(3.0 * e32, 2e-6 * float(ref64.abs().max())), (scale, e3, e32)
+        assert torch.equal(st.amax.cpu(), y3.abs().flatten(1).max(1).values.cpu())
+        sc, sh = ops.norm_affine(y3, None, None, 32, 1e-6, stats=st)
+        sc2, sh2 = ops.norm_affine(y3, None, None, 32, 1e-6)
+        check(sc, sc2, 1e-5, 'c3 x3 stats scale'); check(sh, sh2, 1e-5, 'c3 x3 stats shift')

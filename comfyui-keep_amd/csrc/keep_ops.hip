@@ -889,23 +889,22 @@ extern "C" int32_t keep_add_bcast(const float* a, const float* t, float* out, in
 }
 
 __global__ void concat2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long M,
-                               int C1, int C2) {
-  const int C = C1 + C2;
-  const long total = M * C;
+                               int C1, int C2, int ld) {
+  const long total = M * ld;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / C;
-    const int c = (int)(i - m * C);
-    out[i] = c < C1 ? a[m * C1 + c] : b[m * C2 + (c - C1)];
+    const long m = i / ld;
+    const int c = (int)(i - m * ld);
+    out[i] = c < C1 ? a[m * C1 + c] : (c < C1 + C2 ? b[m * C2 + (c - C1)] : 0.f);      // columns >= C1 + C2: zero padding
   }
 }
 
-extern "C" int32_t keep_concat2(const float* a, const float* b, float* out, int64_t M, int32_t C1, int32_t C2,
+extern "C" int32_t keep_concat2(const float* a, const float* b, float* out, int64_t M, int32_t C1, int32_t C2, int32_t out_ld,
                                 void* stream) {
-  KEEP_REQUIRE(a && b && out && M > 0 && C1 > 0 && C2 > 0, "keep_concat2: bad args");
-  const long total = (long)M * (C1 + C2);
+  KEEP_REQUIRE(a && b && out && M > 0 && C1 > 0 && C2 > 0 && out_ld >= C1 + C2, "keep_concat2: bad args");
+  const long total = (long)M * out_ld;
   int blocks = cdiv(total, 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(concat2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)M, C1, C2);
+  hipLaunchKernelGGL(concat2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)M, C1, C2, out_ld);
   KEEP_LAUNCH_CHECK("keep_concat2");
   return KEEP_OK;
 }

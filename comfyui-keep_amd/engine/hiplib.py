@@ -70,7 +70,7 @@ _SIGNATURES = {
     'keep_nchw_to_nhwc': [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     'keep_nhwc_to_nchw': [_vp, _vp, _i32, _i32, _i32, _vp],
     'keep_add_bcast': [_vp, _vp, _vp, _i64, _i64, _f32, _vp],
-    'keep_concat2': [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
+    'keep_concat2': [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
     'keep_tensor2img': [_vp, _vp, _i64, _vp],
     'keep_img2tensor': [_vp, _vp, _i64, _vp],
     'keep_sep_filter': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],

@@ -499,7 +499,8 @@ class KeepNet:
         self.o.attention(q, k, flow, flow2, B=P, H=1, Lq=Ltok, Lk=Ltok, D=C, Dv=2, scale=1.0 / (C ** 0.5),
                       q_str=sF, k_str=sF, v_str=(Ltok * 2, 2, 0), o_str=(Ltok * 2, 2, 0))
         # convex upsampling (GM/gmflow.py:75-88)
-        cat = ops.concat2(flow2, f0).view(P, h8, w8, C + 2)
+        cat = ops.concat2(flow2, f0, pad_to=16)                  # [.., 130 -> 144]; upsampler.0.weight is packed to match
+        cat = cat.view(P, h8, w8, cat.shape[-1])
         m = self.o.conv(cat, w[f'{pfx}.upsampler.0.weight'], w[f'{pfx}.upsampler.0.bias'], act=L.ACT_RELU)
         mask = self.o.linear(m, w[f'{pfx}.upsampler.2.weight'], w[f'{pfx}.upsampler.2.bias'], bounded=True)
         k8 = GMFLOW['upsample_factor']

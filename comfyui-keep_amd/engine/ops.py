@@ -366,11 +366,14 @@ def absmax(x, N, R, C, ld, img_stride):
     return out
 
 
-def concat2(a, b):
+def concat2(a, b, pad_to=1):
+    """cat([a, b], -1); ``pad_to``: zero-pad the channel count up to a multiple (a 130-channel conv input becomes 144 wide so
+    that the 16-channel-chunk MFMA kernels take it; the weights carry matching zero columns, engine/weights.py)."""
     C1, C2 = a.shape[-1], b.shape[-1]
     M = a.numel() // C1
-    out = empty((*a.shape[:-1], C1 + C2), a)
-    L.call('keep_concat2', a, b, out, M, C1, C2)
+    ld = (C1 + C2 + pad_to - 1) // pad_to * pad_to
+    out = empty((*a.shape[:-1], ld), a)
+    L.call('keep_concat2', a, b, out, M, C1, C2, ld)
     return out
 
 

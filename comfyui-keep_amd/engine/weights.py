@@ -88,6 +88,11 @@ def logical_tensors(sd, cfg=None):
             t = _conv_pack(t)
             if t.shape[1] == 1 and t.shape[2] == 1:
                 t = t.reshape(t.shape[0], t.shape[3])          # 1x1 conv == linear
+            elif t.shape[1] == 3 and t.shape[3] > 16 and t.shape[3] % 16:
+                # 3x3 conv with a ragged channel count (GMFlow upsampler.0: cat[flow 2 | feature 128] = 130): zero input
+                # columns up to a multiple of 16 -- the net pads the activation the same way (ops.concat2(pad_to=16)) and the
+                # layer runs on the 16-channel-chunk MFMA kernels instead of the generic gather kernel
+                t = torch.nn.functional.pad(t, (0, 16 - t.shape[3] % 16))
         out[name] = t.contiguous()
     return out
 

@@ -268,8 +268,8 @@ int32_t keep_nhwc_to_nchw(const float* x, float* out, int32_t N, int32_t C, int3
 /* out[n,i] = a[n,i] + alpha * t[i % tsize]   (position tables, grid subtraction) */
 int32_t keep_add_bcast(const float* a, const float* t, float* out, int64_t total, int64_t tsize, float alpha,
                        void* stream);
-/* out[m, 0:C1] = a[m,:], out[m, C1:C1+C2] = b[m,:] */
-int32_t keep_concat2(const float* a, const float* b, float* out, int64_t M, int32_t C1, int32_t C2, void* stream);
+/* out[m, 0:C1] = a[m,:], out[m, C1:C1+C2] = b[m,:], out[m, C1+C2:out_ld] = 0 (channel padding to a multiple of 16) */
+int32_t keep_concat2(const float* a, const float* b, float* out, int64_t M, int32_t C1, int32_t C2, int32_t out_ld, void* stream);
 /* img_util.py:66-90 tensor2img: fp32 [N,H,W,3] RGB -> uint8 [N,H,W,3] BGR, clamp[-1,1], round-half-even */
 int32_t keep_tensor2img(const float* x, uint8_t* out, int64_t npix, void* stream);
 /* keep_processor.py:258-259: uint8 BGR [N,H,W,3] -> fp32 NHWC RGB (float32(u8/255.) - 0.5)/0.5 */

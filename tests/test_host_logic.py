@@ -256,8 +256,11 @@ def test_packed_blob_layouts(synth_weights):
     v = views(torch.from_numpy(blob), index)
     assert all(off % 64 == 0 for off, _ in index.values())
     assert torch.equal(v['position_emb'], synth_weights['position_emb'])
+    # the one ragged 3x3 convolution (GMFlow upsampler.0, Cin = 2 + 128) carries zero input columns up to 144
+    up, src = lt['flownet.model.upsampler.0.weight'], synth_weights['flownet.model.upsampler.0.weight']
+    assert up.shape == (256, 3, 3, 144) and torch.equal(up[..., :130], src.permute(0, 2, 3, 1)) and not up[..., 130:].any()
     n_in = sum(t.numel() for t in synth_weights.values())
-    assert sum(t.numel() for t in lt.values()) == n_in
+    assert sum(t.numel() for t in lt.values()) == n_in + 256 * 9 * 14
 
 
 def test_face_tracking_restatement():

@@ -666,7 +666,8 @@ class KeepNet:
         """list of [1,T_i,3,H,W] -> list of restored clips.  Clips share no state (KA:1050,1064,1113), so equal-length
         clips are stacked on the batch axis (as many as free HBM allows, ``clips_per_call``).  A clip's result does not
         depend on its batch-mates beyond fp32 re-association: kernel choice and split-K factors follow the launch size
-        (<= 5e-4 on the output, tests/test_gpu_net.py::test_batched_clips_equal_sequential)."""
+        (<= 5e-4 on the output of a short clip, tests/test_gpu_net.py::test_batched_clips_equal_sequential; on long clips the
+        recurrence can amplify that into a low-margin code flip)."""
         order = {}
         for n, c in enumerate(clips):
             order.setdefault((c.shape[1], c.shape[3], c.shape[4]), []).append(n)

@@ -13,8 +13,11 @@ Detection / tracking / alignment / paste-back stay with the reference's ``FaceRe
 ``face_tracks.py`` because they live in the reference's own glue file.
 
 What this build adds: independent clips are handed to the engine in one call
-(``keep_net.run_clips``) so it can batch equal-length clips per GPU and shard them across
-GPUs; results are identical to the sequential loop because clips share no state.
+(``keep_net.run_clips_u8``) so it can batch equal-length clips per GPU (bounded by free HBM) and,
+when a torch.distributed group is up, shard them across GPUs.  Clips share no state, so the result
+equals the sequential loop up to fp32 re-association (kernel tiles / split-K follow the batch): within
+one uint8 level until the recurrence's first low-margin code flip (batch dependence).
+The paste-back compositing can run on the GPU (``KEEP_AMD_GPU_PASTE=1``, ``_paste`` below).
 """
 import os
 

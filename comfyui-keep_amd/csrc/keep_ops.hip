@@ -990,11 +990,12 @@ __global__ void absmax_zero_kernel(unsigned* p, int n) {
   if (i < n) p[i] = 0u;
 }
 
-extern "C" int32_t keep_absmax(const float* x, float* amax, int32_t N, int64_t R, int32_t C, int64_t ld, int64_t img_stride,
+extern "C" int32_t keep_absmax(const float* x, float* amax, int32_t N, int64_t R, int32_t C, int64_t ld, int64_t img_stride, int32_t zeroed,
                                void* stream) {
   KEEP_REQUIRE(x && amax && N > 0 && R > 0 && C > 0 && ld >= C, "keep_absmax: bad args");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(absmax_zero_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(amax), N);
+  if (!zeroed)   // the caller may hand in slots of an arena it zero-fills once per forward pass
+    hipLaunchKernelGGL(absmax_zero_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(amax), N);
   KEEP_LAUNCH_CHECK("keep_absmax(zero)");
   // ~8 float4 per thread, at most ~2048 blocks over all images
   const long work = (R * C / 4 + 2047) / 2048;

@@ -59,7 +59,7 @@ _SIGNATURES = {
     'keep_norm_act_bf16': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     'keep_gm_join': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     'keep_bilinear_upscale': [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
-    'keep_absmax': [_vp, _vp, _i32, _i64, _i32, _i64, _i64, _vp],
+    'keep_absmax': [_vp, _vp, _i32, _i64, _i32, _i64, _i64, _i32, _vp],
     'keep_layernorm': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp],
     'keep_geglu': [_vp, _vp, _i32, _i32, _vp],
     'keep_argmax_gather': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],

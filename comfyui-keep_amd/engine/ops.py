@@ -163,7 +163,7 @@ class Ops:
         xin = x if in_off == 0 else x.view(-1)[in_off:]
         in_amax = None
         if mma == L.MMA_X3 and (wx3 is not None or (Cin <= 3 and KH == 3)) and pro is None and not bounded:   # (RGB convs split fp32 weights in-kernel)
-            in_amax = x_amax if (x_amax is not None and x_amax.numel() == N) else absmax(xin, N, H * W, Cin, ld, H * W * ld)
+            in_amax = x_amax if (x_amax is not None and x_amax.numel() == N) else absmax(xin, N, H * W, Cin, ld, H * W * ld, self)
         out_ld = Cout if out is None else out.shape[-1]
 
         def make_args(inp, dtype, pro_t, pro_a, odt, sk):
@@ -320,8 +320,8 @@ class Ops:
         amax = (None, None, None)
         if probe and mma == L.MMA_X3 and mode == 0 and in_dtype == L.F32:
             # rows of batch b: tokens x (H heads x D) starting at b*bs; heads are contiguous slices of one row here
-            amax = (absmax(q, B, Lq, H * D, q_str[1], q_str[0]), absmax(k, B, Lk, H * D, k_str[1], k_str[0]),
-                    absmax(v, B, Lk, H * Dv, v_str[1], v_str[0]))
+            amax = (absmax(q, B, Lq, H * D, q_str[1], q_str[0], self), absmax(k, B, Lk, H * D, k_str[1], k_str[0], self),
+                    absmax(v, B, Lk, H * Dv, v_str[1], v_str[0], self))
         if DEBUG_SYNC:
             import sys
             print(f'[keep] attention mma={mma} in_dtype={in_dtype} B={B} H={H} Lq={Lq} Lk={Lk} D={D} Dv={Dv} mode={mode}',
@@ -359,10 +359,16 @@ class Ops:
         return out
 
 
-def absmax(x, N, R, C, ld, img_stride):
-    """Range probe: max |x| per image over R rows x C columns (row stride ld, image stride img_stride) -> [N] floats."""
+def absmax(x, N, R, C, ld, img_stride, ops=None):
+    """Range probe: max |x| per image over R rows x C columns (row stride ld, image stride img_stride) -> [N] floats.
+    ``ops``: take the result slots from that Ops' per-forward arena (already zero: no zero-fill launch)."""
+    if ops is not None and ops.amax_arena is not None and ops.amax_pos + N <= ops.amax_arena.numel():
+        out = ops.amax_arena[ops.amax_pos:ops.amax_pos + N]
+        ops.amax_pos += N
+        L.call('keep_absmax', x, out, N, R, C, ld, img_stride, 1)
+        return out
     out = torch.empty((N,), dtype=torch.float32, device=x.device)
-    L.call('keep_absmax', x, out, N, R, C, ld, img_stride)
+    L.call('keep_absmax', x, out, N, R, C, ld, img_stride, 0)
     return out
 
 

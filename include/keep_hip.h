@@ -224,7 +224,8 @@ int32_t keep_gm_join(const float* a, const float* sa, const float* ha, const flo
 
 /* amax[n] = max |x[n, r, c]| over the R rows x C columns (row stride ld) of image n -- the range probe in front of
  * KEEP_MMA_X3 operators whose input is not normalised (x3_in_amax / q_amax ...).  Deterministic (max is order-free). */
-int32_t keep_absmax(const float* x, float* amax, int32_t N, int64_t R, int32_t C, int64_t ld, int64_t img_stride, void* stream);
+int32_t keep_absmax(const float* x, float* amax, int32_t N, int64_t R, int32_t C, int64_t ld, int64_t img_stride,
+                    int32_t zeroed /* non-zero: amax[] was zero-filled by the caller */, void* stream);
 
 /* LayerNorm(eps 1e-5) over the last dim of [M,C] (KA:395-396,491-492,597; GM/transformer.py:134,145).
  *   y = LN(x)*gamma+beta;  out = y + (res ? res : 0);  out2 (optional) = y + pos[m % pos_rows]  (KA:429-430) */

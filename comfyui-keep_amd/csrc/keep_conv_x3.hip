@@ -466,7 +466,7 @@ __device__ __forceinline__ void x3_gather_epilogue(const ConvP& p, f32x16 (&acc)
   float amx = 0.f;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
-  constexpr int UNR = SIMPLE ? 8 : 2;
+  constexpr int UNR = SIMPLE ? 8 : 4;
 #pragma unroll UNR
   for (int it = 0; it < WR / RPI; ++it) {
     const int px = it * RPI + prow;
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
     a_mv[it] = m < p.M;
     a_n[it] = 0; a_oy[it] = 0; a_ox[it] = 0;
     a_s[it] = 1.f;
-    if (a_mv[it]) {
+    if (a_mv[it] && (!ONE || p.in_amax || !PLAIN)) {      // the GEMM form needs the image index only for per-image scales
       a_n[it] = (int)(m / hw);
       const int r = (int)(m - (long)a_n[it] * hw);
       a_oy[it] = r / p.Wo;

@@ -1,11 +1,8 @@
 #!/bin/bash
 cd /root/repo
-bash tools/profile_step.sh x3 16 r2z > gpurun_out/r2z_x3.out 2>&1
-REPO=$(pwd)
-for POL in fp32 bf16; do
-  (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/r2z/trace_${POL}" -o t -- python "$REPO/tools/run_step.py" $POL 16 2 > "$REPO/gpurun_out/r2z/trace_${POL}.log" 2>&1)
-  DB=$(find gpurun_out/r2z/trace_${POL} -name "*results.db" | head -1)
-  python profiles/summarize_rocpd.py "$DB" 2 > gpurun_out/r2z/${POL}_b16_kernel_stats.txt
-done
-find gpurun_out/r2z -name "*.db" -size +40M -delete
-head -8 gpurun_out/r2z/x3_b16_kernel_stats.txt; head -6 gpurun_out/r2z/fp32_b16_kernel_stats.txt; head -6 gpurun_out/r2z/bf16_b16_kernel_stats.txt; ls gpurun_out/r2z
+{
+X3=1 ACT=gelu timeout 300 python tools/bench_conv.py lin256_1024 2>&1 | grep -v amdgpu.ids
+X3=1 timeout 300 python tools/bench_conv.py lin256_1024 lin1024_128 lin128 c128_64_1x1 2>&1 | grep -v amdgpu.ids
+timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -k "x3 or linear or plan" 2>&1 | tail -2
+} > gpurun_out/exp_h.log 2>&1
+cat gpurun_out/exp_h.log

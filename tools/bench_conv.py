@@ -23,6 +23,10 @@ LAYERS = {  # name: (N, H, W, Cin, Cout, ksize, upsample)
     'c512_16': (4, 16, 16, 512, 512, 3, False),
     'lin128': (1, 622592, 1, 128, 128, 1, False),
     'lin256_1024': (1, 622592, 1, 256, 1024, 1, False),
+    't512_1024': (1, 4096, 1, 512, 1024, 1, False),
+    't512_512': (1, 4096, 1, 512, 512, 1, False),
+    't1024_512': (1, 4096, 1, 1024, 512, 1, False),
+    't512_1536': (16, 256, 1, 512, 1536, 1, False),
     'lin1024_128': (1, 622592, 1, 1024, 128, 1, False),
     'c128_64_1x1': (4, 512, 512, 128, 64, 1, False),
     'down64_512': (4, 512, 512, 64, 64, 3, False),

@@ -1,8 +1,7 @@
 #!/bin/bash
 cd /root/repo
 {
-X3=1 ACT=gelu timeout 300 python tools/bench_conv.py lin256_1024 2>&1 | grep -v amdgpu.ids
-X3=1 timeout 300 python tools/bench_conv.py lin256_1024 lin1024_128 lin128 c128_64_1x1 2>&1 | grep -v amdgpu.ids
-timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -k "x3 or linear or plan" 2>&1 | tail -2
+for kb in 32 64; do echo "== KB $kb"; KEEP_GATHER_KB=$kb X3=1 timeout 300 python tools/bench_conv.py t512_1024 t512_512 t1024_512 t512_1536 down64_512 2>&1 | grep -v amdgpu.ids | cut -c1-150; done
+timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q 2>&1 | tail -2
 } > gpurun_out/exp_h.log 2>&1
 cat gpurun_out/exp_h.log

@@ -34,7 +34,6 @@ struct AttnP {
 #ifdef KEEP_X3_ABLATE
   int abl;               // dev builds: phase ablation selector (KEEP_ATTN_EXP)
 #endif
-  int dbg;                   // KEEP_ATTN_DBG bits (dev): 1 no XCD remap, 2 no lazy rescale, 4 no window tables
   const _Float16* kv_pack;   // KEEP_MMA_X3: packed K / V^T tile images (attn_pack_kv_x3_kernel) or NULL
   const float* q_amax;   // KEEP_MMA_X3 range probes ([B] each) or NULL
   const float* k_amax;
@@ -629,7 +628,7 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
   // window region ids of ALL keys are computed once per block into LDS (tpix: Lk ints; treg: 32 nibbles per key tile) instead
   // of ~36 index computations (float reciprocal division, wrap, compares) per thread and key tile -- they were 4x the MFMA
   // issue time of this kernel (121 TFLOP/s on the 1024-token windows).
-  const bool tab = PF && p.mode == 2 && p.Lk <= 4096 && !(p.dbg & 4);
+  const bool tab = PF && p.mode == 2 && p.Lk <= 4096;
   int* tpix = reinterpret_cast<int*>(Qs);
   unsigned* treg = reinterpret_cast<unsigned*>(tpix + ((p.Lk + 31) & ~31));
 
@@ -642,7 +641,7 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
   // (19.5 GB per GMFlow window-attention call: 14 TB/s of demand).  Give each XCD a contiguous range of logical ids:
   // the query blocks of one (batch, head) become neighbours in one L2.
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (!(p.dbg & 1)) {
+  {
     const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
     const int lid = bx + gx * (by + gy * bz);
     const int qd = total >> 3, rm = total & 7, xcd = lid & 7, slot = lid >> 3;
@@ -974,7 +973,7 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
 
     // rescale of the running output: skipped when no query of the wave raised its maximum (alpha == 1 exactly) -- after the
     // first few key tiles that is the common case, and the 16 cross-lane broadcasts + 16*DVT multiplies go away with it
-    if (!PF || (p.dbg & 2) || __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
+    if (!PF || __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -1751,7 +1750,6 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
   p.n_img = a->n_img;
   p.q_amax = a->q_amax; p.k_amax = a->k_amax; p.v_amax = a->v_amax;
   p.kv_pack = nullptr;
-  p.dbg = getenv("KEEP_ATTN_DBG") ? atoi(getenv("KEEP_ATTN_DBG")) : 0;
   KEEP_REQUIRE((!a->q_amax && !a->k_amax && !a->v_amax) || (a->q_amax && a->k_amax && a->v_amax && a->mode == 0 && a->mma == KEEP_MMA_X3),
                "keep_attention: q/k/v_amax come together, with KEEP_MMA_X3 and mode 0 only");
   hipStream_t st = (hipStream_t)stream;
@@ -1786,10 +1784,7 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
   // split fp16: fp32 tensors with 16-byte aligned rows, D a multiple of 16; everything else runs on the exact-f32 kernel
   if (a->mma == KEEP_MMA_X3 && (a->D % 16 == 0) && (a->q_ts % 4 == 0) && (a->q_bs % 4 == 0) && (a->q_hs % 4 == 0) &&
       (a->k_ts % 4 == 0) && (a->k_bs % 4 == 0) && (a->k_hs % 4 == 0) && ((uintptr_t)a->q % 16 == 0) &&
-      ((uintptr_t)a->k % 16 == 0) && !getenv("KEEP_NO_ATTN_X3") &&
-      !((p.dbg & 8) && a->Lq <= 32) && !((p.dbg & 16) && a->Lq > 32 && a->D > 128 && a->D <= 256) &&
-      !((p.dbg & 32) && a->D > 256) && !((p.dbg & 64) && a->Lq > 32 && a->D <= 128 && a->mode != 2) &&
-      !((p.dbg & 128) && a->mode == 2)) {
+      ((uintptr_t)a->k % 16 == 0) && !getenv("KEEP_NO_ATTN_X3")) {
     if (a->Lq <= 32) {
       if (dvt == 1) return launch_attn_x3<1, 1>(p, st);
       if (dvt == 2) return launch_attn_x3<1, 2>(p, st);

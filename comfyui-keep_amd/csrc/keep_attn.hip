@@ -597,7 +597,7 @@ typedef _Float16 af16x2 __attribute__((ext_vector_type(2)));
 // steps) live in registers for the whole kernel -- loaded straight from global, never staged -- so a block's LDS is one
 // K tile + one V^T tile (<= 35 KB) and two blocks share a CU.  D > 128 (VQGAN AttnBlock D = 512, CFA D = 256; 16x16 / 32x32
 // token maps): Q and K are re-staged through LDS per 128-wide chunk.
-// PACKED (WAVES 4, D = Dv = 128): K and V^T tiles come pre-split from attn_pack_kv_x3_kernel as the exact LDS image
+// PACKED (WAVES 4, D = 128, Dv <= 128): K and V^T tiles come pre-split from attn_pack_kv_x3_kernel as the exact LDS image
 // [32 x (hi128|lo128|pad8) | 128 x (32 hi permuted | 32 lo | pad8)] -- 2208 16-byte pieces per key tile copied global -> register
 // -> LDS: 9 wide loads and 9 ds_write_b128 per thread and tile instead of 20 loads (16 of them 4-byte), 128 split
 // operations and 20 narrow LDS writes (the phase ablation: loads 55 %, commit 25 % of the unpacked kernel's time).
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
     }
   };
 
-  constexpr int PK16 = PACKED ? (32 * (2 * 128 + 8) + 128 * 72) / 8 : 1;     // 16-byte pieces of a packed tile image
+  constexpr int PK16 = PACKED ? (32 * (2 * 128 + 8) + DVS * 72) / 8 : 1;     // 16-byte pieces of a packed tile image
   constexpr int PKN = PACKED ? (PK16 + NT - 1) / NT : 1;
   uint4 preg[PKN];
   auto pk_issue = [&](int kt) {
@@ -1034,8 +1034,9 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
 // K / V^T tile images for the PACKED variant above: one block per (key tile, head, batch) gathers the tile's 32 key rows
 // (window / sparse-causal index math once per element instead of once per query block), applies the range scales, splits,
 // assembles the LDS image in LDS and writes it out with 16-byte stores.
+template <int DVS>
 __global__ __launch_bounds__(256) void attn_pack_kv_x3_kernel(AttnP p, _Float16* out) {
-  constexpr int QP = 2 * 128 + 8, VP = 72, DVS = 128, PK16 = (32 * QP + DVS * VP) / 8;
+  constexpr int QP = 2 * 128 + 8, VP = 72, PK16 = (32 * QP + DVS * VP) / 8;
   __shared__ __attribute__((aligned(16))) _Float16 img[32 * QP + DVS * VP];
   _Float16* Ks = img;
   _Float16* Vt = img + 32 * QP;
@@ -1070,8 +1071,10 @@ __global__ __launch_bounds__(256) void attn_pack_kv_x3_kernel(AttnP p, _Float16*
     const int pair = i / DVS, dv = i - pair * DVS;
     const int t = kt * 32 + pair * 2;
     float v[2] = {0.f, 0.f};
-    if (t < p.Lk) v[0] = p.v[kv_offset(p, b, t, p.v_bs, p.v_ts) + vh + dv];
-    if (t + 1 < p.Lk) v[1] = p.v[kv_offset(p, b, t + 1, p.v_bs, p.v_ts) + vh + dv];
+    if (dv < p.Dv) {                                           // dv columns beyond Dv stay zero
+      if (t < p.Lk) v[0] = p.v[kv_offset(p, b, t, p.v_bs, p.v_ts) + vh + dv];
+      if (t + 1 < p.Lk) v[1] = p.v[kv_offset(p, b, t + 1, p.v_bs, p.v_ts) + vh + dv];
+    }
     af16x2 hi, lo;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1091,19 +1094,21 @@ __global__ __launch_bounds__(256) void attn_pack_kv_x3_kernel(AttnP p, _Float16*
 
 // packed K / V^T path: worth it when several query blocks stream the same keys
 static long attn_pack_bytes(const AttnP& p, int mma) {
-  if (mma != KEEP_MMA_X3 || p.D != 128 || p.Dv != 128 || p.Lq < 256 || getenv("KEEP_NO_ATTN_PACK")) return 0;
-  return (long)p.B * p.H * ((p.Lk + 31) / 32) * ((32 * (2 * 128 + 8) + 128 * 72) * 2L);
+  if (mma != KEEP_MMA_X3 || p.D != 128 || p.Dv > 128 || p.Lq < 256 || getenv("KEEP_NO_ATTN_PACK")) return 0;
+  const int dvs = p.Dv <= 32 ? 32 : (p.Dv <= 64 ? 64 : 128);
+  return (long)p.B * p.H * ((p.Lk + 31) / 32) * ((32 * (2 * 128 + 8) + dvs * 72) * 2L);
 }
 
+template <int DVT>
 static int launch_attn_x3_packed(const AttnP& p, hipStream_t st) {
   const int ntl = (p.Lk + 31) / 32;
-  hipLaunchKernelGGL(attn_pack_kv_x3_kernel, dim3(ntl, p.H, p.B), dim3(256), 0, st, p, const_cast<_Float16*>(p.kv_pack));
+  hipLaunchKernelGGL(attn_pack_kv_x3_kernel<DVT * 32>, dim3(ntl, p.H, p.B), dim3(256), 0, st, p, const_cast<_Float16*>(p.kv_pack));
   KEEP_LAUNCH_CHECK("keep_attention(x3 pack)");
-  size_t lds = (size_t)(32 * (2 * 128 + 8) + 4 * 32 * 72) * 2;
+  size_t lds = (size_t)(32 * (2 * 128 + 8) + DVT * 32 * 72) * 2;
   if (p.mode == 2 && p.Lk <= 4096) lds += (size_t)ntl * (32 * 4 + 16 + 32);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_x3_kernel<4, 4, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_x3_kernel<4, DVT, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       keep_set_error("keep_attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return KEEP_EHIP;
@@ -1114,7 +1119,7 @@ static int launch_attn_x3_packed(const AttnP& p, hipStream_t st) {
 #ifdef KEEP_X3_ABLATE
   const_cast<AttnP&>(p).abl = getenv("KEEP_ATTN_EXP") ? atoi(getenv("KEEP_ATTN_EXP")) : 0;
 #endif
-  hipLaunchKernelGGL((attn_x3_kernel<4, 4, 8, true>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((attn_x3_kernel<4, DVT, 8, true>), grid, dim3(256), lds, st, p);
   KEEP_LAUNCH_CHECK("keep_attention(x3 packed)");
   return KEEP_OK;
 }
@@ -1790,15 +1795,17 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
       if (dvt == 2) return launch_attn_x3<1, 2>(p, st);
       return launch_attn_x3<1, 4>(p, st);
     }
-    if (dvt == 1) return launch_attn_x3<4, 1>(p, st);
-    if (dvt == 2) return launch_attn_x3<4, 2>(p, st);
     {
       const long need = attn_pack_bytes(p, a->mma);
       if (need > 0 && a->workspace && a->workspace_bytes >= need && (uintptr_t)a->workspace % 16 == 0) {
         p.kv_pack = (const _Float16*)a->workspace;
-        return launch_attn_x3_packed(p, st);
+        if (dvt == 1) return launch_attn_x3_packed<1>(p, st);
+        if (dvt == 2) return launch_attn_x3_packed<2>(p, st);
+        return launch_attn_x3_packed<4>(p, st);
       }
     }
+    if (dvt == 1) return launch_attn_x3<4, 1>(p, st);
+    if (dvt == 2) return launch_attn_x3<4, 2>(p, st);
     return launch_attn_x3<4, 4>(p, st);
   }
   // one wave per block for tiny query counts (temporal attention over T frames), else 4 (one per SIMD)

@@ -597,7 +597,7 @@ typedef _Float16 af16x2 __attribute__((ext_vector_type(2)));
 // steps) live in registers for the whole kernel -- loaded straight from global, never staged -- so a block's LDS is one
 // K tile + one V^T tile (<= 35 KB) and two blocks share a CU.  D > 128 (VQGAN AttnBlock D = 512, CFA D = 256; 16x16 / 32x32
 // token maps): Q and K are re-staged through LDS per 128-wide chunk.
-// PACKED (WAVES 4, D = 128, Dv <= 128): K and V^T tiles come pre-split from attn_pack_kv_x3_kernel as the exact LDS image
+// PACKED (WAVES 4, D = 128 or 256, any Dv): K and V^T tiles come pre-split from attn_pack_kv_x3_kernel as the exact LDS image
 // [32 x (hi128|lo128|pad8) | 128 x (32 hi permuted | 32 lo | pad8)] -- 2208 16-byte pieces per key tile copied global -> register
 // -> LDS: 9 wide loads and 9 ds_write_b128 per thread and tile instead of 20 loads (16 of them 4-byte), 128 split
 // operations and 20 narrow LDS writes (the phase ablation: loads 55 %, commit 25 % of the unpacked kernel's time).
@@ -813,16 +813,22 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
     }
   };
 
-  constexpr int PK16 = PACKED ? (32 * (2 * 128 + 8) + DVS * 72) / 8 : 1;     // 16-byte pieces of a packed tile image
+  // packed tile of (batch, head, key tile): [K image 32 x (2 D + 8)] [V^T slice 0: DVS x 72] [slice 1] ...; a block copies the K
+  // image and ITS dv slice -- contiguous in LDS (Ks, then Vt)
+  constexpr int PKK = PACKED ? 32 * (2 * 16 * NQA + 8) / 8 : 1;       // 16-byte pieces of the K image (D == 16 NQ)
+  constexpr int PKV = PACKED ? DVS * 72 / 8 : 1;                      // ... of one V^T slice
+  constexpr int PK16 = PKK + PKV;
   constexpr int PKN = PACKED ? (PK16 + NT - 1) / NT : 1;
   uint4 preg[PKN];
   auto pk_issue = [&](int kt) {
-    const uint4* src = reinterpret_cast<const uint4*>(p.kv_pack) + (((long)b * p.H + head) * ((p.Lk + 31) >> 5) + kt) * PK16;
+    const long tile = ((long)b * p.H + head) * ((p.Lk + 31) >> 5) + kt;
+    const uint4* src = reinterpret_cast<const uint4*>(p.kv_pack) + tile * (PKK + p.nslices * PKV);
+    const int vs = PKK + (dv0 / DVS) * PKV;
 #pragma unroll
     for (int u = 0; u < PKN; ++u) {
       const int i = tid + u * NT;
       preg[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (i < PK16) preg[u] = src[i];
+      if (i < PK16) preg[u] = src[i < PKK ? i : vs + (i - PKK)];
     }
   };
   auto pk_commit = [&]() {
@@ -1034,46 +1040,49 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
 // K / V^T tile images for the PACKED variant above: one block per (key tile, head, batch) gathers the tile's 32 key rows
 // (window / sparse-causal index math once per element instead of once per query block), applies the range scales, splits,
 // assembles the LDS image in LDS and writes it out with 16-byte stores.
-template <int DVS>
+template <int DC, int DVS>
 __global__ __launch_bounds__(256) void attn_pack_kv_x3_kernel(AttnP p, _Float16* out) {
-  constexpr int QP = 2 * 128 + 8, VP = 72, PK16 = (32 * QP + DVS * VP) / 8;
+  constexpr int QP = 2 * DC + 8, VP = 72, PKK = 32 * QP / 8, PKV = DVS * VP / 8;
   __shared__ __attribute__((aligned(16))) _Float16 img[32 * QP + DVS * VP];
   _Float16* Ks = img;
   _Float16* Vt = img + 32 * QP;
   const int tid = threadIdx.x;
-  const int kt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  const int kt = blockIdx.x, head = blockIdx.y / p.nslices, slice = blockIdx.y - head * p.nslices, b = blockIdx.z;
   float sk = 1.f, sv = 1.f, tmp;
   if (p.q_amax) {
     attn_range_scale(p.k_amax[b], sk, tmp);
     attn_range_scale(p.v_amax[b], sv, tmp);
   }
-  for (int i = tid; i < PK16; i += 256) reinterpret_cast<uint4*>(img)[i] = make_uint4(0u, 0u, 0u, 0u);   // pads, tail keys
+  for (int i = tid; i < PKK + PKV; i += 256) reinterpret_cast<uint4*>(img)[i] = make_uint4(0u, 0u, 0u, 0u);   // pads, tail keys
   __syncthreads();
   const long kh = (long)head * p.k_hs, vh = (long)head * p.v_hs;
-  for (int i = tid; i < 32 * 32; i += 256) {                 // K: 32 rows x 32 float4
-    const int row = i >> 5, c = (i & 31) << 2;
-    const int t = kt * 32 + row;
-    if (t < p.Lk) {
-      const float4 v = *reinterpret_cast<const float4*>(p.k + kv_offset(p, b, t, p.k_bs, p.k_ts) + kh + c);
-      const float f[4] = {v.x * sk, v.y * sk, v.z * sk, v.w * sk};
-      af16x4 hi, lo;
+  if (slice == 0) {                                            // the K image is shared by the dv slices: written once
+    for (int i = tid; i < 32 * (DC / 4); i += 256) {           // K: 32 rows x DC/4 float4
+      const int row = i / (DC / 4), c = (i - row * (DC / 4)) << 2;
+      const int t = kt * 32 + row;
+      if (t < p.Lk) {
+        const float4 v = *reinterpret_cast<const float4*>(p.k + kv_offset(p, b, t, p.k_bs, p.k_ts) + kh + c);
+        const float f[4] = {v.x * sk, v.y * sk, v.z * sk, v.w * sk};
+        af16x4 hi, lo;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const _Float16 h = (_Float16)f[j];
-        hi[j] = h;
-        lo[j] = (_Float16)(f[j] - (float)h);
+        for (int j = 0; j < 4; ++j) {
+          const _Float16 h = (_Float16)f[j];
+          hi[j] = h;
+          lo[j] = (_Float16)(f[j] - (float)h);
+        }
+        *reinterpret_cast<af16x4*>(Ks + row * QP + c) = hi;
+        *reinterpret_cast<af16x4*>(Ks + row * QP + DC + c) = lo;
       }
-      *reinterpret_cast<af16x4*>(Ks + row * QP + c) = hi;
-      *reinterpret_cast<af16x4*>(Ks + row * QP + 128 + c) = lo;
     }
   }
+  const int dv0 = slice * DVS;
   for (int i = tid; i < 16 * DVS; i += 256) {                // V^T: (key pair, dv) items, lane <-> dv (coalesced reads)
     const int pair = i / DVS, dv = i - pair * DVS;
     const int t = kt * 32 + pair * 2;
     float v[2] = {0.f, 0.f};
-    if (dv < p.Dv) {                                           // dv columns beyond Dv stay zero
-      if (t < p.Lk) v[0] = p.v[kv_offset(p, b, t, p.v_bs, p.v_ts) + vh + dv];
-      if (t + 1 < p.Lk) v[1] = p.v[kv_offset(p, b, t + 1, p.v_bs, p.v_ts) + vh + dv];
+    if (dv0 + dv < p.Dv) {                                     // dv columns beyond Dv stay zero
+      if (t < p.Lk) v[0] = p.v[kv_offset(p, b, t, p.v_bs, p.v_ts) + vh + dv0 + dv];
+      if (t + 1 < p.Lk) v[1] = p.v[kv_offset(p, b, t + 1, p.v_bs, p.v_ts) + vh + dv0 + dv];
     }
     af16x2 hi, lo;
 #pragma unroll
@@ -1088,27 +1097,32 @@ __global__ __launch_bounds__(256) void attn_pack_kv_x3_kernel(AttnP p, _Float16*
     *reinterpret_cast<af16x2*>(d + 32) = lo;
   }
   __syncthreads();
-  uint4* dst = reinterpret_cast<uint4*>(out) + (((long)b * p.H + head) * gridDim.x + kt) * PK16;
-  for (int i = tid; i < PK16; i += 256) dst[i] = reinterpret_cast<const uint4*>(img)[i];
+  uint4* dst = reinterpret_cast<uint4*>(out) + (((long)b * p.H + head) * gridDim.x + kt) * (PKK + p.nslices * PKV);
+  if (slice == 0)
+    for (int i = tid; i < PKK; i += 256) dst[i] = reinterpret_cast<const uint4*>(img)[i];
+  for (int i = tid; i < PKV; i += 256) dst[PKK + slice * PKV + i] = reinterpret_cast<const uint4*>(img)[PKK + i];
 }
 
 // packed K / V^T path: worth it when several query blocks stream the same keys
 static long attn_pack_bytes(const AttnP& p, int mma) {
-  if (mma != KEEP_MMA_X3 || p.D != 128 || p.Dv > 128 || p.Lq < 256 || getenv("KEEP_NO_ATTN_PACK")) return 0;
+  if (mma != KEEP_MMA_X3 || (p.D != 128 && p.D != 256) || p.Lq < 256 || getenv("KEEP_NO_ATTN_PACK")) return 0;
   const int dvs = p.Dv <= 32 ? 32 : (p.Dv <= 64 ? 64 : 128);
-  return (long)p.B * p.H * ((p.Lk + 31) / 32) * ((32 * (2 * 128 + 8) + dvs * 72) * 2L);
+  const int nsl = (p.Dv + dvs - 1) / dvs;
+  return (long)p.B * p.H * ((p.Lk + 31) / 32) * ((32 * (2 * p.D + 8) + nsl * dvs * 72) * 2L);
 }
 
-template <int DVT>
+template <int DVT, int NQ>
 static int launch_attn_x3_packed(const AttnP& p, hipStream_t st) {
+  constexpr int DC = 16 * NQ;
   const int ntl = (p.Lk + 31) / 32;
-  hipLaunchKernelGGL(attn_pack_kv_x3_kernel<DVT * 32>, dim3(ntl, p.H, p.B), dim3(256), 0, st, p, const_cast<_Float16*>(p.kv_pack));
+  hipLaunchKernelGGL((attn_pack_kv_x3_kernel<DC, DVT * 32>), dim3(ntl, p.H * p.nslices, p.B), dim3(256), 0, st, p,
+                     const_cast<_Float16*>(p.kv_pack));
   KEEP_LAUNCH_CHECK("keep_attention(x3 pack)");
-  size_t lds = (size_t)(32 * (2 * 128 + 8) + DVT * 32 * 72) * 2;
+  size_t lds = (size_t)(32 * (2 * DC + 8) + DVT * 32 * 72) * 2;
   if (p.mode == 2 && p.Lk <= 4096) lds += (size_t)ntl * (32 * 4 + 16 + 32);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_x3_kernel<4, DVT, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_x3_kernel<4, DVT, NQ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       keep_set_error("keep_attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return KEEP_EHIP;
@@ -1119,7 +1133,7 @@ static int launch_attn_x3_packed(const AttnP& p, hipStream_t st) {
 #ifdef KEEP_X3_ABLATE
   const_cast<AttnP&>(p).abl = getenv("KEEP_ATTN_EXP") ? atoi(getenv("KEEP_ATTN_EXP")) : 0;
 #endif
-  hipLaunchKernelGGL((attn_x3_kernel<4, DVT, 8, true>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((attn_x3_kernel<4, DVT, NQ, true>), grid, dim3(256), lds, st, p);
   KEEP_LAUNCH_CHECK("keep_attention(x3 packed)");
   return KEEP_OK;
 }
@@ -1799,9 +1813,14 @@ extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
       const long need = attn_pack_bytes(p, a->mma);
       if (need > 0 && a->workspace && a->workspace_bytes >= need && (uintptr_t)a->workspace % 16 == 0) {
         p.kv_pack = (const _Float16*)a->workspace;
-        if (dvt == 1) return launch_attn_x3_packed<1>(p, st);
-        if (dvt == 2) return launch_attn_x3_packed<2>(p, st);
-        return launch_attn_x3_packed<4>(p, st);
+        if (a->D == 128) {
+          if (dvt == 1) return launch_attn_x3_packed<1, 8>(p, st);
+          if (dvt == 2) return launch_attn_x3_packed<2, 8>(p, st);
+          return launch_attn_x3_packed<4, 8>(p, st);
+        }
+        if (dvt == 1) return launch_attn_x3_packed<1, 16>(p, st);
+        if (dvt == 2) return launch_attn_x3_packed<2, 16>(p, st);
+        return launch_attn_x3_packed<4, 16>(p, st);
       }
     }
     if (dvt == 1) return launch_attn_x3<4, 1>(p, st);

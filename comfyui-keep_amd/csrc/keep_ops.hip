@@ -962,14 +962,38 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   const float* xi = x + (long)n * img_stride;
   unsigned m = 0u;
   const bool vec = (C % 4 == 0) && (ld % 4 == 0) && (img_stride % 4 == 0) && ((uintptr_t)x % 16 == 0);
-  if (vec) {
-    const int c4n = C >> 2;
-    const long total = R * c4n;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-      const long r = i / c4n;
-      const int c = (int)(i - r * c4n) << 2;
-      const uint4 v = *reinterpret_cast<const uint4*>(xi + r * ld + c);
+  if (vec && ld == C) {                // contiguous rows: one flat stream, four independent 16-byte loads per iteration
+    const uint4* x4 = reinterpret_cast<const uint4*>(xi);
+    const long total = R * (C >> 2), stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < total; i += 4 * stride) {
+      const uint4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+      m = max(max(m, a.x & 0x7fffffffu), max(a.y & 0x7fffffffu, max(a.z & 0x7fffffffu, a.w & 0x7fffffffu)));
+      m = max(max(m, b.x & 0x7fffffffu), max(b.y & 0x7fffffffu, max(b.z & 0x7fffffffu, b.w & 0x7fffffffu)));
+      m = max(max(m, c.x & 0x7fffffffu), max(c.y & 0x7fffffffu, max(c.z & 0x7fffffffu, c.w & 0x7fffffffu)));
+      m = max(max(m, d.x & 0x7fffffffu), max(d.y & 0x7fffffffu, max(d.z & 0x7fffffffu, d.w & 0x7fffffffu)));
+    }
+    for (; i < total; i += stride) {
+      const uint4 v = x4[i];
       m = max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+    }
+  } else if (vec) {                    // channel slice of wider rows: (row, column) walked without a division per element
+    const int c4n = C >> 2;
+    const long total = R * c4n, stride = (long)gridDim.x * 256;
+    const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
+    long r = i0 / c4n;
+    int c = (int)(i0 - r * c4n);
+    const long dr = stride / c4n;
+    const int dc = (int)(stride - dr * c4n);
+    for (long i = i0; i < total; i += stride) {
+      const uint4 v = *reinterpret_cast<const uint4*>(xi + r * ld + (c << 2));
+      m = max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+      r += dr;
+      c += dc;
+      if (c >= c4n) {
+        c -= c4n;
+        ++r;
+      }
     }
   } else {
     const long total = R * C;

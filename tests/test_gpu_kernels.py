@@ -993,3 +993,18 @@ def test_conv_x3_rgb_first_conv_kernel():
         sc, sh = ops.norm_affine(y3, None, None, 32, 1e-6, stats=st)
         sc2, sh2 = ops.norm_affine(y3, None, None, 32, 1e-6)
         check(sc, sc2, 1e-5, 'c3 x3 stats scale'); check(sh, sh2, 1e-5, 'c3 x3 stats shift')
+
+
+def test_absmax_paths():
+    """keep_absmax: contiguous rows (flat stream), a channel slice of wider rows, and the scalar path (C % 4 != 0); several images."""
+    x = rnd('am_x', (3, 1000, 96), 5.0)
+    x[1, 777, 13] = -123.5
+    x[2, 3, 95] = 77.25
+    xd = dev(x)
+    assert torch.equal(ops.absmax(xd, 3, 1000, 96, 96, 1000 * 96).cpu(), x.abs().flatten(1).max(1).values)
+    got = ops.absmax(xd.view(-1)[32:], 3, 1000, 48, 96, 1000 * 96).cpu()               # columns 32..79 of every row
+    assert torch.equal(got, x[:, :, 32:80].abs().flatten(1).max(1).values)
+    y = rnd('am_y', (2, 333, 7), 3.0)
+    assert torch.equal(ops.absmax(dev(y), 2, 333, 7, 7, 333 * 7).cpu(), y.abs().flatten(1).max(1).values)
+    big = rnd('am_big', (1, 300000, 128))
+    assert torch.equal(ops.absmax(dev(big), 1, 300000, 128, 128, 300000 * 128).cpu(), big.abs().flatten(1).max(1).values)

@@ -1,20 +1,6 @@
 #!/bin/bash
 cd /root/repo
-timeout 300 python - <<'PY' 2>&1 | grep -v amdgpu.ids
-import sys, torch
-sys.path.insert(0, '/root/repo')
-from __graft_entry__ import load_package
-load_package()
-from comfyui_keep_amd.engine import ops
-for shape, C, ld in (((16, 65536, 128), 128, 128), ((16, 4096, 512), 256, 512), ((1, 1000000, 128), 128, 128), ((16, 1024, 256), 256, 256), ((320, 4096, 64), 64, 64)):
-    x = torch.randn(*shape, device='cuda')
-    N, R, W = shape
-    for _ in range(3): ops.absmax(x, N, R, C, ld, R * W)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20): ops.absmax(x, N, R, C, ld, R * W)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 20
-    print(shape, 'C', C, f'{ms*1e3:.1f} us  {N*R*C*4/ms/1e6:.0f} GB/s')
-PY
+{
+for w in "" 1; do echo "== WIDE=$w"; env ${w:+KEEP_GATHER_WIDE=1} X3=1 ACT=gelu timeout 300 python tools/bench_conv.py lin256_1024 2>&1 | grep -v amdgpu.ids | cut -c1-150; env ${w:+KEEP_GATHER_WIDE=1} X3=1 timeout 300 python tools/bench_conv.py lin256_1024 2>&1 | grep -v amdgpu.ids | cut -c1-150; done
+} > gpurun_out/exp_h.log 2>&1
+cat gpurun_out/exp_h.log

@@ -1696,7 +1696,11 @@ static int validate_conv(const keep_conv2d_args* a) {
   KEEP_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->KH > 0 && a->KW > 0 &&
                    a->stride > 0 && a->Ho > 0 && a->Wo > 0,
                "keep_conv2d: non-positive dimension");
-  KEEP_REQUIRE(a->in_ld >= a->Cin && a->out_ld >= a->Cout, "keep_conv2d: ld smaller than channel count");
+  KEEP_REQUIRE(a->in_ld >= (a->in2 ? a->in2_cin1 : a->Cin) && a->out_ld >= a->Cout, "keep_conv2d: ld smaller than channel count");
+  if (a->in2 && a->mma != KEEP_MMA_X3) {
+    keep_set_error("keep_conv2d: in2 (K-concatenated input) is a KEEP_MMA_X3 feature");
+    return KEEP_EUNSUP;
+  }
   KEEP_REQUIRE((a->pro_scale == nullptr) == (a->pro_shift == nullptr), "keep_conv2d: pro_scale/pro_shift must pair");
   KEEP_REQUIRE(!a->aux || a->residual, "keep_conv2d: aux epilogue requires residual");
   KEEP_REQUIRE(!a->residual || a->res_ld >= a->Cout, "keep_conv2d: res_ld smaller than Cout");
@@ -1722,6 +1726,8 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   p.wx3 = (const unsigned short*)a->weight_x3;
   p.acc_scale = a->x3_acc_scale;
   p.in_amax = a->x3_in_amax;
+  p.in2 = (const float*)a->in2;
+  p.cin1 = a->in2_cin1;
   p.out_amax = nullptr;
   p.bias = a->bias;
   p.out = (float*)a->out;
@@ -1808,6 +1814,15 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
       pl.amax_ok = pl.split_k == 1;
       snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3_kernel<%d>", pl.wide ? 32 : 16);
       return KEEP_OK;
+    }
+    if (a->in2) {      // K-concatenated input: GEMM form of the x3 gather kernel only
+      const bool ok2 = have_w && keep_conv_x3_gather_ok(a, p) && keep_conv_x3_gather_is_gemm(a) && no_pro && !a->x3_in_amax &&
+                       a->in2_cin1 > 0 && a->in2_cin1 < a->Cin && a->in2_cin1 % 32 == 0 && (a->Cin - a->in2_cin1) % 4 == 0 &&
+                       a->in_ld >= a->in2_cin1 && (uintptr_t)a->in2 % 16 == 0 && !is33s1 && !getenv("KEEP_NO_GATHER_X3");
+      if (!ok2) {
+        keep_set_error("keep_conv2d: in2 (K-concatenated input) needs KEEP_MMA_X3, a 1x1 stride-1 convolution without prologue / range probe and in2_cin1 %% 32 == 0");
+        return KEEP_EUNSUP;
+      }
     }
     if (have_w && keep_conv_x3_gather_ok(a, p) && !getenv("KEEP_NO_GATHER_X3")) {
       pl.path = PATH_GATHER_X3;

@@ -38,6 +38,8 @@ struct ConvP {
   const unsigned short* wx3;  // KEEP_MMA_X3: weights pre-multiplied by 2^e and split into fp16 (hi, lo), [Cout][KH*KW][Cin/16][hi16|lo16]
   float acc_scale;            // KEEP_MMA_X3: 2^-e, applied to the accumulators before bias / activation
   const float* in_amax;       // KEEP_MMA_X3: per-image max |input| (NULL: inputs are split unscaled)
+  const float* in2;           // KEEP_MMA_X3 GEMM form: second K-concatenated input (channels >= cin1), dense rows, or NULL
+  int cin1;
   unsigned* out_amax;         // KEEP_MMA_X3: per-image max |output| as raw float bits (atomicMax), or NULL
 };
 

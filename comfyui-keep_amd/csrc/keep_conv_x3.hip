@@ -626,6 +626,18 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) a_voff[it] = ((a_row0 + it * 64) * p.in_ld + a_grp * 8) * 4;
   }
+  // K-concatenated second input (channels >= cin1, dense rows): its own descriptor and row offsets; a K step never straddles
+  // the seam (cin1 % 32 == 0)
+  __amdgpu_buffer_rsrc_t a2_rsrc = a_rsrc;
+  int a2_voff[A_IT];
+  const int ld2 = p.Cin - p.cin1;
+  if (ONE && p.in2) {
+    const unsigned long long b = (unsigned long long)(p.in2 + m0 * ld2);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    a2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)rows_here * ld2 * 4, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) a2_voff[it] = ((a_row0 + it * 64) * ld2 + a_grp * 8) * 4;
+  }
   const __amdgpu_buffer_rsrc_t w_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.wx3, 0, p.Cout * p.KH * p.KW * p.Cin * 4, 0x00020000);
   int b_voff[B_IT];
@@ -653,8 +665,11 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
 #pragma unroll
       for (int it = 0; it < A_IT; ++it) {
         a_ok[it] = ca < p.Cin;             // rows beyond M: zeros from the range check
-        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[it], c0 * 4, 0);
-        const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[it] + 16, c0 * 4, 0);
+        const bool second = p.in2 && c0 >= p.cin1;                      // wave-uniform
+        const u32x4 v0 = second ? __builtin_amdgcn_raw_buffer_load_b128(a2_rsrc, a2_voff[it], (c0 - p.cin1) * 4, 0)
+                                : __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[it], c0 * 4, 0);
+        const u32x4 v1 = second ? __builtin_amdgcn_raw_buffer_load_b128(a2_rsrc, a2_voff[it] + 16, (c0 - p.cin1) * 4, 0)
+                                : __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[it] + 16, c0 * 4, 0);
         a_raw[it][0] = __uint_as_float(v0.x); a_raw[it][1] = __uint_as_float(v0.y);
         a_raw[it][2] = __uint_as_float(v0.z); a_raw[it][3] = __uint_as_float(v0.w);
         a_raw[it][4] = __uint_as_float(v1.x); a_raw[it][5] = __uint_as_float(v1.y);

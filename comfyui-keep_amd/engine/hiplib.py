@@ -28,7 +28,7 @@ class ConvArgs(C.Structure):
                [(n, _i32) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad_t', 'pad_l', 'Ho', 'Wo',
                                     'in_ld', 'out_ld', 'res_ld', 'upsample', 'pro_act', 'epi_act')] + \
                [('aux_w', _f32), ('split_k', _i32), ('dtype', _i32), ('mma', _i32), ('weight_bf16', _vp), ('stats_out', _vp), ('stats_P', _i32), ('bk256', _i32), ('out_dtype', _i32),
-                ('weight_x3', _vp), ('x3_acc_scale', _f32), ('x3_in_amax', _vp), ('x3_out_amax', _vp), ('x3_out_amax_zeroed', _i32)]
+                ('weight_x3', _vp), ('x3_acc_scale', _f32), ('x3_in_amax', _vp), ('x3_out_amax', _vp), ('x3_out_amax_zeroed', _i32), ('in2', _vp), ('in2_cin1', _i32)]
 
 
 class ConvPlanOut(C.Structure):

@@ -429,7 +429,10 @@ class KeepNet:
         if self.o.mma == L.MMA_BF16 and C == 128 and FUSED_GM_MLP:
             m2 = self.o.gm_mlp(src, m, w[f'{p}.mlp.0.weight'], w[f'{p}.mlp.2.weight'])      # [M,8C] never leaves the CU
         else:
-            hmid = self.o.linear(ops.concat2(src, m), w[f'{p}.mlp.0.weight'], act=L.ACT_GELU, bounded=True)
+            if self.o.mma == L.MMA_X3:      # cat[src | m] folded into the GEMM: two K-concatenated inputs (keep_conv2d in2)
+                hmid = self.o.linear(src, w[f'{p}.mlp.0.weight'], act=L.ACT_GELU, bounded=True, x2=m)
+            else:
+                hmid = self.o.linear(ops.concat2(src, m), w[f'{p}.mlp.0.weight'], act=L.ACT_GELU, bounded=True)
             m2 = self.o.linear(hmid, w[f'{p}.mlp.2.weight'], bounded=True)
         return ops.layernorm(m2, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], res=src)
 

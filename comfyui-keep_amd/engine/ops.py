@@ -129,7 +129,7 @@ class Ops:
     # ------------------------------------------------------------------ keep_conv2d
     def conv(self, x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=False, pro=None, pro_act=L.PRO_NONE,
              act=L.ACT_NONE, residual=None, aux=None, aux_w=1.0, cin=None, in_off=0, out=None, split_k=None, wb=None,
-             wx3=None, x3_acc_scale=None, mma=None, stats=False, out_bf16=False, bounded=False, x_amax=None):
+             wx3=None, x3_acc_scale=None, mma=None, stats=False, out_bf16=False, bounded=False, x_amax=None, x2=None):
         """x [N,H,W,ld] -> [N,Ho,Wo,Cout].  ``w`` packed [Cout,KH,KW,Cin].  ``cin``/``in_off`` select a channel
         slice of a wider input buffer.  ``down`` = VQGAN Downsample geometry (pad right/bottom only, stride 2).
         ``stats=True`` returns ``(out, st)``: ``st`` is a ``Stats`` (epilogue-reduced GroupNorm partials and, under the x3
@@ -140,6 +140,9 @@ class Ops:
         N, H, W, ld = x.shape
         Cout = w.shape[0]
         Cin = ld if cin is None else cin
+        if x2 is not None:          # K-concatenated second input (x3 GEMM form, keep_conv2d in2): channels ld.. come from x2
+            assert bounded and pro is None and cin is None and in_off == 0, 'x2 needs a bounded, unsliced, prologue-free input'
+            Cin = ld + x2.shape[-1]
         KH = KW = ksize
         assert w.numel() == Cout * KH * KW * Cin, (w.shape, Cout, KH, KW, Cin)
         Hv, Wv = (2 * H, 2 * W) if upsample else (H, W)
@@ -175,12 +178,13 @@ class Ops:
                 upsample=int(upsample), pro_act=pro_a, epi_act=act, aux_w=float(aux_w), split_k=sk, dtype=dtype,
                 mma=mma, weight_bf16=wb if mma == L.MMA_BF16 else None, stats_out=None, stats_P=0,
                 bk256=int(USE_BK256), out_dtype=odt, weight_x3=wx3 if mma == L.MMA_X3 else None,
-                x3_acc_scale=float(x3_acc_scale), x3_in_amax=in_amax, x3_out_amax=None)
+                x3_acc_scale=float(x3_acc_scale), x3_in_amax=in_amax, x3_out_amax=None,
+                in2=x2, in2_cin1=0 if x2 is None else ld)
 
         def key_of(dtype, pro_t, pro_a, odt, sk):
             return (N, H, W, ld, Cin, Cout, KH, stride, pad_t, pad_l, Ho, Wo, out_ld, int(upsample), pro_a, act, dtype, mma,
                     odt, sk, pro_t is not None, residual is not None, 0 if residual is None else residual.shape[-1],
-                    aux is not None, bias is not None, in_off % 8, wx3 is not None, USE_BK256)
+                    aux is not None, bias is not None, in_off % 8, wx3 is not None, USE_BK256, x2 is not None)
 
         sk_req = 0 if split_k is None else int(split_k)
         odt = L.BF16 if want_bf16_out else L.F32
@@ -246,7 +250,7 @@ class Ops:
         return (out, st) if stats else out
 
     def linear(self, x, w, bias=None, *, act=L.ACT_NONE, residual=None, pro=None, pro_act=L.PRO_NONE, cin=None, in_off=0,
-               n_img=1, out_bf16=False, bounded=False, x_amax=None):
+               n_img=1, out_bf16=False, bounded=False, x_amax=None, x2=None):
         """x [M,ld] (or any [...,ld]) @ w[Cout,Cin]^T.  ``n_img``>1 makes the prologue per-image: rows are n_img
         images of M/n_img pixels each (1x1 conv on a feature map)."""
         shp = x.shape
@@ -257,9 +261,10 @@ class Ops:
                 and cin is None and in_off == 0 and x.dtype == torch.float32 and x.is_contiguous()):
             return self.token_linear(x.view(M, ld), w.view(w.shape[0], 128), bias, out_bf16).reshape(*shp[:-1], w.shape[0])
         x4 = x.reshape(n_img, M // n_img, 1, ld)
+        x24 = None if x2 is None else x2.reshape(n_img, M // n_img, 1, x2.shape[-1])
         res4 = None if residual is None else residual.reshape(n_img, M // n_img, 1, residual.shape[-1])
         y = self.conv(x4, w, bias, stride=1, pad=0, ksize=1, pro=pro, pro_act=pro_act, act=act, residual=res4, cin=cin,
-                      in_off=in_off, out_bf16=out_bf16, bounded=bounded, x_amax=x_amax)
+                      in_off=in_off, out_bf16=out_bf16, bounded=bounded, x_amax=x_amax, x2=x24)
         return y.reshape(*shp[:-1], w.shape[0])
 
     # ------------------------------------------------------------------ normalisation

@@ -125,6 +125,11 @@ typedef struct {
   float* x3_out_amax;
   int32_t x3_out_amax_zeroed; /* non-zero: the caller zero-filled x3_out_amax (one arena per forward pass); otherwise the
                                  library zero-fills it with a kernel of its own before the launch */
+  /* K-concatenated input of a 1x1 stride-1 convolution (KEEP_MMA_X3 GEMM form only; keep_conv2d_plan rejects it elsewhere with
+   * KEEP_EUNSUP): channels [0, in2_cin1) are read from `in` (row stride in_ld), channels [in2_cin1, Cin) from `in2`, a dense
+   * [N*H*W, Cin - in2_cin1] tensor -- torch.cat([a, b], -1) folded into the GEMM (GM/transformer.py:182).  NULL: single input. */
+  const void* in2;
+  int32_t in2_cin1;
 } keep_conv2d_args;
 int32_t keep_conv2d(const keep_conv2d_args* a, void* stream);
 

@@ -1008,3 +1008,18 @@ def test_absmax_paths():
     assert torch.equal(ops.absmax(dev(y), 2, 333, 7, 7, 333 * 7).cpu(), y.abs().flatten(1).max(1).values)
     big = rnd('am_big', (1, 300000, 128))
     assert torch.equal(ops.absmax(dev(big), 1, 300000, 128, 128, 300000 * 128).cpu(), big.abs().flatten(1).max(1).values)
+
+
+def test_linear_x3_k_concatenated_inputs():
+    """keep_conv2d in2 (x3 GEMM form): cat([a, b], -1) @ W^T without materialising the concatenation (GM/transformer.py:182);
+    equals the concat path bit for bit (same K order, same kernel), ragged M; rejected loudly outside the x3 policy."""
+    M, C = 1000, 128
+    a, b = dev(rnd('kc_a', (M, C))), dev(rnd('kc_b', (M, C), 2.0))
+    w = dev(rnd('kc_w', (512, 2 * C), 0.05))
+    wx3, asc = x3w(w)
+    kw = dict(mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, pad=0, ksize=1, act=L.ACT_GELU, bounded=True)
+    y_cat = ops.conv(ops.concat2(a, b).view(1, M, 1, 2 * C), w, None, **kw)
+    y_two = ops.conv(a.view(1, M, 1, C), w, None, x2=b.view(1, M, 1, C), **kw)
+    assert torch.equal(y_cat, y_two)
+    with pytest.raises(L.KeepHipError):
+        ops.conv(a.view(1, M, 1, C), w, None, x2=b.view(1, M, 1, C), pad=0, ksize=1, bounded=True)      # exact-f32 policy

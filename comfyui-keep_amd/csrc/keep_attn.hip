@@ -1726,8 +1726,27 @@ static int launch_attn_bf16in(const AttnP& p, hipStream_t st) {
   return KEEP_OK;
 }
 
-extern "C" int64_t keep_attention_workspace_bytes(const keep_attention_args* a) {
-  if (!a || a->mma != KEEP_MMA_X3 || a->in_dtype == KEEP_BF16 || a->B <= 0 || a->H <= 0 || a->Lk <= 0) return 0;
+static int attn_args_in(const keep_attention_args* src, keep_attention_args& a) {
+  KEEP_REQUIRE(src != nullptr, "keep_attention: null args");
+  const uint32_t sz = src->struct_size;
+  if (sz < KEEP_ATTENTION_ARGS_V12_SIZE || sz > sizeof(keep_attention_args) || sz % 8 != 0) {
+    keep_set_error("keep_attention: args.struct_size = %u, this library (ABI v%d) accepts %d..%zu -- set it to "
+                   "sizeof(keep_attention_args) of the header the caller was built with", sz, KEEP_ABI_VERSION,
+                   KEEP_ATTENTION_ARGS_V12_SIZE, sizeof(keep_attention_args));
+    return KEEP_EINVAL;
+  }
+  memset(&a, 0, sizeof(a));
+  memcpy(&a, src, sz);
+  return KEEP_OK;
+}
+
+extern "C" int32_t keep_sizeof_attention_args(void) { return (int32_t)sizeof(keep_attention_args); }
+
+extern "C" int64_t keep_attention_workspace_bytes(const keep_attention_args* a_in) {
+  keep_attention_args a_local;
+  if (attn_args_in(a_in, a_local) != KEEP_OK) return 0;
+  const keep_attention_args* a = &a_local;
+  if (a->mma != KEEP_MMA_X3 || a->in_dtype == KEEP_BF16 || a->B <= 0 || a->H <= 0 || a->Lk <= 0) return 0;
   const bool x3_ok = (a->D % 16 == 0) && (a->q_ts % 4 == 0) && (a->q_bs % 4 == 0) && (a->q_hs % 4 == 0) && (a->k_ts % 4 == 0) &&
                      (a->k_bs % 4 == 0) && (a->k_hs % 4 == 0) && ((uintptr_t)a->q % 16 == 0) && ((uintptr_t)a->k % 16 == 0) &&
                      !getenv("KEEP_NO_ATTN_X3");
@@ -1737,8 +1756,11 @@ extern "C" int64_t keep_attention_workspace_bytes(const keep_attention_args* a) 
   return attn_pack_bytes(p, a->mma);
 }
 
-extern "C" int32_t keep_attention(const keep_attention_args* a, void* stream) {
-  KEEP_REQUIRE(a != nullptr, "keep_attention: null args");
+extern "C" int32_t keep_attention(const keep_attention_args* a_in, void* stream) {
+  keep_attention_args a_local;
+  const int rc_in = attn_args_in(a_in, a_local);
+  if (rc_in != KEEP_OK) return rc_in;
+  const keep_attention_args* a = &a_local;
   KEEP_REQUIRE(a->q && a->k && a->v && a->o, "keep_attention: null tensor pointer");
   KEEP_REQUIRE(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0 && a->D > 0 && a->Dv > 0, "keep_attention: bad dims");
   KEEP_REQUIRE(a->D % 2 == 0 && (a->D <= 128 || a->D % 128 == 0), "keep_attention: D=%d must be even and (<= 128 or a multiple of 128)", a->D);

@@ -31,6 +31,8 @@ void keep_set_error(const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
     case KEEP_ACT_RELU: return v > 0.f ? v : 0.f;

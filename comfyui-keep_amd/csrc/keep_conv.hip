@@ -1680,6 +1680,15 @@ static int n_cu_cached() {
 }
 
 static const int kTargetWaves = 1024;
+// Parity policies (exact f32, x3): every choice that changes the ORDER of a floating-point sum -- the split-K factor, and with
+// it the statistics partition -- is made from the per-image geometry and this fixed reference batch, never from the actual N.
+// A clip's result is then bit-identical whatever its batch-mates are (KeepNet.clips_per_call follows free HBM; round 2's plans
+// followed N and a clip's code indices could differ between a batch of 8 and a batch of 15).  8 images: the 64x64 and larger
+// maps fill the chip without split-K at that count; the 16x16 / 32x32 stages split 8 / 4 ways at every batch size.
+static long plan_ref_images() {
+  const char* e = getenv("KEEP_PLAN_REF_IMAGES");
+  return e ? atol(e) : 8;
+}
 // gather kernels: launches of at most this many output rows use 64x64 tiles (more blocks), larger ones 128x128.  A tuning
 // knob the HOST never mirrors (keep_conv2d_plan reports what follows from it): tests retune it through the environment.
 static long small_m_threshold() {
@@ -1719,7 +1728,10 @@ static int validate_conv(const keep_conv2d_args* a) {
 // the launch will see (NULL optional tensors stay NULL), so plan and launch always agree.
 static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   memset(&pl, 0, sizeof(pl));
-  const long M = (long)a->N * a->Ho * a->Wo;
+  const long M_real = (long)a->N * a->Ho * a->Wo;
+  // rows the HEURISTICS below see (tile, split-K): per-image rows x the fixed reference batch under the parity policies,
+  // the real row count under the bf16 speed policy; launches and buffer sizes always use the real M (p.M)
+  const long M = a->mma == KEEP_MMA_BF16 ? M_real : plan_ref_images() * (long)a->Ho * a->Wo;
   p.in = (const float*)a->in;
   p.w = a->weight;
   p.wb = (const unsigned short*)a->weight_bf16;
@@ -1740,7 +1752,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   p.stride = a->stride; p.pad_t = a->pad_t; p.pad_l = a->pad_l; p.Ho = a->Ho; p.Wo = a->Wo;
   p.in_ld = a->in_ld; p.out_ld = a->out_ld; p.res_ld = a->res_ld;
   p.upsample = a->upsample; p.pro_act = a->pro_act; p.epi_act = a->epi_act; p.aux_w = a->aux_w;
-  p.M = (int)M;
+  p.M = (int)M_real;
   p.cchunks = (a->Cin + BK - 1) / BK;
   p.nsteps = a->KH * a->KW * p.cchunks;
   p.in_bf16 = (a->dtype == KEEP_BF16) ? 1 : 0;
@@ -1932,9 +1944,30 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   return KEEP_OK;
 }
 
-extern "C" int32_t keep_conv2d_plan(const keep_conv2d_args* a, keep_conv2d_plan_out* out) {
+// The struct the caller was compiled against may be an older (shorter) layout of this ABI version: `struct_size` says which.
+// Sizes the library does not know are rejected; the fields a shorter known layout lacks read as zero.
+static int conv_args_in(const keep_conv2d_args* src, keep_conv2d_args& a) {
+  KEEP_REQUIRE(src != nullptr, "keep_conv2d: null args");
+  const uint32_t sz = src->struct_size;
+  if (sz < KEEP_CONV2D_ARGS_V12_SIZE || sz > sizeof(keep_conv2d_args) || sz % 8 != 0) {
+    keep_set_error("keep_conv2d: args.struct_size = %u, this library (ABI v%d) accepts %d..%zu -- set it to sizeof(keep_conv2d_args) "
+                   "of the header the caller was built with", sz, KEEP_ABI_VERSION, KEEP_CONV2D_ARGS_V12_SIZE, sizeof(keep_conv2d_args));
+    return KEEP_EINVAL;
+  }
+  memset(&a, 0, sizeof(a));
+  memcpy(&a, src, sz);
+  return KEEP_OK;
+}
+
+extern "C" int32_t keep_sizeof_conv2d_args(void) { return (int32_t)sizeof(keep_conv2d_args); }
+
+extern "C" int32_t keep_conv2d_plan(const keep_conv2d_args* a_in, keep_conv2d_plan_out* out) {
   KEEP_REQUIRE(out != nullptr, "keep_conv2d_plan: null output");
-  int rc = validate_conv(a);
+  keep_conv2d_args a_local;
+  int rc = conv_args_in(a_in, a_local);
+  if (rc != KEEP_OK) return rc;
+  const keep_conv2d_args* a = &a_local;
+  rc = validate_conv(a);
   if (rc != KEEP_OK) return rc;
   ConvP p;
   ConvPlan pl;
@@ -1955,8 +1988,12 @@ extern "C" int32_t keep_conv2d_plan(const keep_conv2d_args* a, keep_conv2d_plan_
   return KEEP_OK;
 }
 
-extern "C" int32_t keep_conv2d(const keep_conv2d_args* a, void* stream) {
-  int rc = validate_conv(a);
+extern "C" int32_t keep_conv2d(const keep_conv2d_args* a_in, void* stream) {
+  keep_conv2d_args a_local;
+  int rc = conv_args_in(a_in, a_local);
+  if (rc != KEEP_OK) return rc;
+  const keep_conv2d_args* a = &a_local;
+  rc = validate_conv(a);
   if (rc != KEEP_OK) return rc;
   KEEP_REQUIRE(a->in && a->weight && a->out, "keep_conv2d: null tensor pointer");
   KEEP_REQUIRE((uintptr_t)a->weight % 16 == 0, "keep_conv2d: weight pointer must be 16-byte aligned");

@@ -340,9 +340,10 @@ __global__ __launch_bounds__(256) void gm_join4_kernel(const float4* __restrict_
     }
     const float4 yb = b[i];
     const float4 s = *reinterpret_cast<const float4*>(sb + o), h = *reinterpret_cast<const float4*>(hb + o);
-    const float r0 = fmaxf(yb.x * s.x + h.x, 0.f), r1 = fmaxf(yb.y * s.y + h.y, 0.f);
-    const float r2 = fmaxf(yb.z * s.z + h.z, 0.f), r3 = fmaxf(yb.w * s.w + h.w, 0.f);
-    out[i] = make_float4(fmaxf(xa.x + r0, 0.f), fmaxf(xa.y + r1, 0.f), fmaxf(xa.z + r2, 0.f), fmaxf(xa.w + r3, 0.f));
+    // (relu_keep_nan: v < 0 ? 0 : v -- fmaxf(NaN, 0) would be 0 and hide an upstream overflow)
+    const float r0 = relu_keep_nan(yb.x * s.x + h.x), r1 = relu_keep_nan(yb.y * s.y + h.y);
+    const float r2 = relu_keep_nan(yb.z * s.z + h.z), r3 = relu_keep_nan(yb.w * s.w + h.w);
+    out[i] = make_float4(relu_keep_nan(xa.x + r0), relu_keep_nan(xa.y + r1), relu_keep_nan(xa.z + r2), relu_keep_nan(xa.w + r3));
   }
 }
 
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(256) void argmax_gather_kernel(const float* __restr
                                                             const float* __restrict__ codebook,
                                                             const int* __restrict__ force_idx, int* __restrict__ idx,
                                                             float* __restrict__ margin, float* __restrict__ out, int M,
-                                                            int ncodes, int dim) {
+                                                            int ncodes, int dim, int* __restrict__ status) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -520,23 +521,64 @@ __global__ __launch_bounds__(256) void argmax_gather_kernel(const float* __restr
       second = fmaxf(second, ob);
     }
   }
+  // The arg-max is where a NaN / inf (an fp16-range overflow of the x3 policy upstream) would become a finite, plausible,
+  // WRONG code: v > best is false for every NaN, so an all-NaN row keeps bi = 0x7fffffff, and a row with some NaNs picks
+  // among the rest.  Scan result not finite, or any NaN seen in the row -> the row is flagged: status bit, NaN-filled output.
+  bool bad = !(fabsf(best) <= 3.0e38f) || bi < 0 || bi >= ncodes;
+  {
+    bool nan_seen = false;
+    for (int j = lane; j < ncodes; j += 64) nan_seen |= (lr[j] != lr[j]);
+    bad |= (__ballot(nan_seen) != 0ull);
+  }
   int sel = bi;
-  if (force_idx) sel = force_idx[row];
-  if (sel < 0 || sel >= ncodes) sel = 0;   // all-NaN logits (or a bad forced index) must not turn into a wild gather
+  if (force_idx) {
+    sel = force_idx[row];
+    bad = false;                             // injected indices (parity tests): the logits do not decide anything
+  }
+  if (sel < 0 || sel >= ncodes) sel = 0;     // never a wild gather
   if (lane == 0) {
     if (idx) idx[row] = sel;
     if (margin) margin[row] = best - second;
+    if (bad && status) atomicOr(status, KEEP_STATUS_NONFINITE_LOGITS);
   }
   const float* cb = codebook + (long)sel * dim;
-  for (int d = lane; d < dim; d += 64) out[(long)row * dim + d] = cb[d];
+  const float nanv = __builtin_nanf("");
+  for (int d = lane; d < dim; d += 64) out[(long)row * dim + d] = bad ? nanv : cb[d];
 }
 
 extern "C" int32_t keep_argmax_gather(const float* logits, const float* codebook, const int32_t* force_idx, int32_t* idx,
-                                      float* margin, float* out, int32_t M, int32_t ncodes, int32_t dim, void* stream) {
+                                      float* margin, float* out, int32_t M, int32_t ncodes, int32_t dim, int32_t* status,
+                                      void* stream) {
   KEEP_REQUIRE(logits && codebook && out && M > 0 && ncodes > 0 && dim > 0, "keep_argmax_gather: bad args");
   hipLaunchKernelGGL(argmax_gather_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, logits, codebook,
-                     force_idx, idx, margin, out, M, ncodes, dim);
+                     force_idx, idx, margin, out, M, ncodes, dim, status);
   KEEP_LAUNCH_CHECK("keep_argmax_gather");
+  return KEEP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ non-finite flag
+// One pass over a tensor; a block raises the status bit at most once.  (exponent all ones <=> NaN or +-inf)
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ x, long n, int* __restrict__ status) {
+  bool bad = false;
+  const long n4 = n >> 2;
+  const uint4* x4 = reinterpret_cast<const uint4*>(x);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const uint4 v = x4[i];
+    bad |= ((v.x & 0x7f800000u) == 0x7f800000u) | ((v.y & 0x7f800000u) == 0x7f800000u) | ((v.z & 0x7f800000u) == 0x7f800000u) |
+           ((v.w & 0x7f800000u) == 0x7f800000u);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3))
+    bad |= ((__float_as_uint(x[(n4 << 2) + threadIdx.x]) & 0x7f800000u) == 0x7f800000u);
+  if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(status, KEEP_STATUS_NONFINITE_TENSOR);
+}
+
+extern "C" int32_t keep_nonfinite_flag(const float* x, int64_t n, int32_t* status, void* stream) {
+  KEEP_REQUIRE(x && status && n > 0 && (uintptr_t)x % 16 == 0, "keep_nonfinite_flag: bad args (x must be 16-byte aligned)");
+  int blocks = cdiv(n >> 2, 256 * 8);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long)n, status);
+  KEEP_LAUNCH_CHECK("keep_nonfinite_flag");
   return KEEP_OK;
 }
 
@@ -735,8 +777,10 @@ __global__ void flow_warp_kernel(const float* __restrict__ x, const float* __res
     const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
     const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
     const float* xb = x + (long)n * H * W * C;
+    // a non-finite flow must not read as "sample outside the image" (zeros): it poisons the pixel, like torch's grid_sample
+    const float poison = (fabsf(fx) <= 3.0e38f && fabsf(fy) <= 3.0e38f) ? 0.f : __builtin_nanf("");
     for (int c = 0; c < C; ++c) {
-      float acc = 0.f;
+      float acc = poison;
       if (vy0 && vx0) acc += xb[((long)y0 * W + x0) * C + c] * w00;
       if (vy0 && vx1) acc += xb[((long)y0 * W + x1) * C + c] * w01;
       if (vy1 && vx0) acc += xb[((long)y1 * W + x0) * C + c] * w10;

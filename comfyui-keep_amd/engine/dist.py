@@ -2,8 +2,8 @@
 
 The path has NO exchange step: clips share no state (keep_arch.py:1050,1064,1113), so the only collective
 is the one-off broadcast of the packed weight blob (633 MB fp32) from rank 0 -- ``torch.distributed``
-backend ``nccl`` is RCCL on ROCm, i.e. one ncclBroadcast over xGMI.  Results are gathered on the host by
-clip index (uint8 frames), not by a GPU collective.  The same code runs on ``gloo`` for the CPU tests.
+backend ``nccl`` is RCCL on ROCm, i.e. one ncclBroadcast over xGMI.  Results are collected by clip index with one fixed-size
+uint8 tensor gather to rank 0 (which alone runs the paste-back).  The same code runs on ``gloo`` for the CPU tests.
 """
 import os
 
@@ -62,30 +62,60 @@ def broadcast_packed_weights(index, blob, src=0):
     return index, (blob if rank == src else wire.to(target))
 
 
-def gather_by_clip(local_results, n_clips, rank, world, to_all=False):
-    """local_results: {clip_index: uint8 numpy array}.  Returns the full list on rank 0 (host gather), or on every
-    rank with ``to_all``."""
+def gather_by_clip(local_results, n_clips, rank, world, to_all=False, shapes=None):
+    """local_results: {clip_index: uint8 numpy array [T,H,W,3]}.  Returns the full list on rank 0 (others: None), or on every
+    rank with ``to_all``.
+
+    ONE fixed-size uint8 tensor collective (``dist.gather`` / ``dist.all_gather``; nccl = RCCL moves device buffers over xGMI,
+    gloo host buffers): every rank knows every clip's shape (``shapes``: all ranks hold the same clip list and the restored
+    clip has the shape of its input), so each rank sends its clips back to back in ascending clip order, padded to the largest
+    per-rank byte count -- no pickling, no per-object round trips (round 2 used all_gather_object on numpy arrays)."""
     if not dist.is_initialized() or world == 1:
         return [local_results[i] for i in range(n_clips)]
-    if to_all:
+    import numpy as np
+    if shapes is None:                                   # shape exchange (tiny) when the caller could not provide them
+        mine = {i: tuple(a.shape) for i, a in local_results.items()}
         buckets = [None] * world
-        dist.all_gather_object(buckets, local_results)
+        dist.all_gather_object(buckets, mine)
+        shapes = [None] * n_clips
+        for b in buckets:
+            for i, sh in b.items():
+                shapes[i] = sh
+    per_rank = [shard_clips(n_clips, r, world) for r in range(world)]
+    nbytes = [sum(int(np.prod(shapes[i])) for i in ids) for ids in per_rank]
+    cap = max(max(nbytes), 1)
+    nccl = dist.get_backend() == 'nccl'
+    dev = torch.device('cuda', torch.cuda.current_device()) if nccl else torch.device('cpu')
+    send = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    off = 0
+    for i in per_rank[rank]:
+        a = torch.from_numpy(np.ascontiguousarray(local_results[i])).reshape(-1)
+        send[off:off + a.numel()].copy_(a, non_blocking=True)
+        off += a.numel()
+    if to_all:
+        recv = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist.all_gather(recv, send)
     else:
-        buckets = [None] * world if rank == 0 else None
-        dist.gather_object(local_results, buckets, dst=0)
+        recv = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+        dist.gather(send, recv, dst=0)
         if rank != 0:
             return None
-    merged = {}
-    for b in buckets:
-        merged.update(b)
-    return [merged[i] for i in range(n_clips)]
+    out = [None] * n_clips
+    for r in range(world):
+        flat = recv[r].cpu().numpy()
+        off = 0
+        for i in per_rank[r]:
+            n = int(np.prod(shapes[i]))
+            out[i] = flat[off:off + n].reshape(shapes[i])
+            off += n
+    return out
 
 
-def sharded_map(items, local_fn, gather='all'):
+def sharded_map(items, local_fn, gather='root', shapes=None):
     """The product's multi-GPU pattern in one place: ``items`` (independent clips) are sharded round-robin over the
     ranks, ``local_fn({index: item})`` restores this rank's share and returns {index: uint8 numpy array}, and the
-    results are gathered on the host by index ('all': every rank gets the full list, 'root': rank 0 only, 'none': the
-    local dict).  No data-path collective -- clips share no state."""
+    results are collected by index with one tensor gather ('root': rank 0 gets the full list, the others None; 'all':
+    every rank gets it; 'none': the local dict).  No data-path collective between clips -- they share no state."""
     rank, world = rank_world()
     mine = shard_clips(len(items), rank, world)
     local = local_fn({i: items[i] for i in mine})
@@ -93,4 +123,4 @@ def sharded_map(items, local_fn, gather='all'):
         return [local[i] for i in range(len(items))]
     if gather == 'none':
         return local
-    return gather_by_clip(local, len(items), rank, world, to_all=(gather == 'all'))
+    return gather_by_clip(local, len(items), rank, world, to_all=(gather == 'all'), shapes=shapes)

@@ -12,18 +12,21 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 F32, BF16 = 0, 1
 MMA_F32, MMA_BF16, MMA_X3 = 0, 1, 2
 PRO_NONE, PRO_SWISH, PRO_RELU = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 
-_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_vp, _i32, _i64, _f32, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
+STATUS_NONFINITE_LOGITS, STATUS_NONFINITE_TENSOR = 1, 2
 
 
 class ConvArgs(C.Structure):
-    _fields_ = [('inp', _vp), ('weight', _vp), ('bias', _vp), ('out', _vp), ('pro_scale', _vp), ('pro_shift', _vp),
+    # field-for-field include/keep_hip.h:keep_conv2d_args ('inp' = `in`, a Python keyword); tests/test_host_logic.py checks the
+    # names / order against the header, the size against keep_sizeof_conv2d_args(), and INTEGRATION.md's copy against this list
+    _fields_ = [('struct_size', _u32), ('reserved0', _u32), ('inp', _vp), ('weight', _vp), ('bias', _vp), ('out', _vp), ('pro_scale', _vp), ('pro_shift', _vp),
                 ('residual', _vp), ('aux', _vp), ('workspace', _vp)] + \
                [(n, _i32) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad_t', 'pad_l', 'Ho', 'Wo',
                                     'in_ld', 'out_ld', 'res_ld', 'upsample', 'pro_act', 'epi_act')] + \
@@ -37,7 +40,7 @@ class ConvPlanOut(C.Structure):
 
 
 class AttnArgs(C.Structure):
-    _fields_ = [('q', _vp), ('k', _vp), ('v', _vp), ('o', _vp)] + \
+    _fields_ = [('struct_size', _u32), ('reserved0', _u32), ('q', _vp), ('k', _vp), ('v', _vp), ('o', _vp)] + \
                [(n, _i64) for n in ('q_bs', 'q_ts', 'q_hs', 'k_bs', 'k_ts', 'k_hs', 'v_bs', 'v_ts', 'v_hs',
                                     'o_bs', 'o_ts', 'o_hs')] + \
                [(n, _i32) for n in ('B', 'H', 'Lq', 'Lk', 'D', 'Dv')] + [('scale', _f32), ('mode', _i32)] + \
@@ -62,7 +65,8 @@ _SIGNATURES = {
     'keep_absmax': [_vp, _vp, _i32, _i64, _i32, _i64, _i64, _i32, _vp],
     'keep_layernorm': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp],
     'keep_geglu': [_vp, _vp, _i32, _i32, _vp],
-    'keep_argmax_gather': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    'keep_argmax_gather': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    'keep_nonfinite_flag': [_vp, _i64, _vp, _vp],
     'keep_vq_nearest': [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
     'keep_kalman_update': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     'keep_flow_warp': [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
@@ -78,7 +82,8 @@ _SIGNATURES = {
     'keep_f32_round_u8': [_vp, _vp, _i64, _vp],
     'keep_paste_face': [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
 }
-EXPORTED_SYMBOLS = ['keep_abi_version', 'keep_last_error', 'keep_device_ok', 'keep_attention_workspace_bytes'] + list(_SIGNATURES)
+EXPORTED_SYMBOLS = ['keep_abi_version', 'keep_last_error', 'keep_device_ok', 'keep_attention_workspace_bytes',
+                    'keep_sizeof_conv2d_args', 'keep_sizeof_attention_args'] + list(_SIGNATURES)
 
 _lib = None
 _device_checked = set()
@@ -106,6 +111,12 @@ def load(check_device=True):
         ver = lib.keep_abi_version()
         if ver != ABI_VERSION:
             raise KeepHipError(f"libkeep_hip.so ABI version {ver} != expected {ABI_VERSION}; rebuild")
+        lib.keep_sizeof_conv2d_args.restype = lib.keep_sizeof_attention_args.restype = _i32
+        for name, struct in (('keep_sizeof_conv2d_args', ConvArgs), ('keep_sizeof_attention_args', AttnArgs)):
+            want = getattr(lib, name)()
+            if want != C.sizeof(struct):        # a layout drift between this binding and the library is a load-time error
+                raise KeepHipError(f"{name}() = {want} but the ctypes {struct.__name__} is {C.sizeof(struct)} bytes; "
+                                   f"engine/hiplib.py and include/keep_hip.h disagree")
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(lib, name)            # AttributeError if the symbol is missing
             fn.restype = _i32
@@ -145,6 +156,7 @@ def call(name, *args):
 
 def conv_args(**kw):
     a = ConvArgs()
+    a.struct_size = C.sizeof(ConvArgs)
     for k, v in kw.items():
         setattr(a, k, _ptr(v) if (isinstance(v, torch.Tensor) or v is None) else v)
     return a
@@ -174,6 +186,7 @@ def conv2d(**kw):
 def attention(**kw):
     lib = load()
     a = AttnArgs()
+    a.struct_size = C.sizeof(AttnArgs)
     for k, v in kw.items():
         setattr(a, k, _ptr(v) if (isinstance(v, torch.Tensor) or v is None) else v)
     need = int(lib.keep_attention_workspace_bytes(C.byref(a)))       # the library asks; the host only allocates

@@ -67,6 +67,11 @@ class KeepNet:
         # GRAPH_MAX_CLIPS clips per call, '1' = always, '0' = never.  One captured graph per (B, T, H, W, policy).
         self.graph_mode = os.environ.get('KEEP_AMD_GRAPH', 'auto')
         self._graphs = {}
+        self._graph_seen = {}      # graph key -> eager occurrences so far
+        # With an initialised process group, ONE clip list handed to run_clips_u8 on every rank is sharded over the ranks
+        # (True, default).  False: every rank restores the list IT is given (one video per GPU, BASELINE configs[4]).
+        self.shard_across_ranks = os.environ.get('KEEP_AMD_SHARD', '1') == '1'
+        self._aux_top1 = []
         self._pinned = None        # pinned host copy of the packed blob (made at the first upload)
         self.precision = 'fp32'
         self.set_precision(os.environ.get('KEEP_AMD_PRECISION', DEFAULT_PRECISION))
@@ -211,7 +216,7 @@ class KeepNet:
         s3 = (HW * 3 * C, 3 * C, 0)
         self.o.attention(qkv, ops.offset(qkv, C), ops.offset(qkv, 2 * C), o, B=N, H=1, Lq=HW, Lk=HW, D=C, Dv=C,
                       scale=int(C) ** (-0.5), q_str=s3, k_str=s3, v_str=s3, o_str=(HW * C, C, 0))
-        y = self.o.linear(o, w[f'{p}.proj_out.weight'], w[f'{p}.proj_out.bias'], residual=x.view(N * HW, C), bounded=True)
+        y = self.o.linear(o, w[f'{p}.proj_out.weight'], w[f'{p}.proj_out.bias'], residual=x.view(N * HW, C), bounded=True, n_img=N)
         return y.view(N, H, Wd, C)
 
     def _vq_stack(self, x, prefix, blocks, taps=(), hook=None):
@@ -252,30 +257,34 @@ class KeepNet:
         Ltok = z_hat.shape[1] * z_hat.shape[2]
         D, nh = cfg['dim_embd'], cfg['n_head']
         dh = D // nh
-        q = self.o.linear(z_hat.view(B * Ltok, -1), w['feat_emb.weight'], w['feat_emb.bias'])
+        q = self.o.linear(z_hat.view(B * Ltok, -1), w['feat_emb.weight'], w['feat_emb.bias'], n_img=B)
         pos = w['position_emb']
         for i in range(cfg['n_layers']):
             p = f'ft_layers.{i}'
             x2, qk_in = ops.layernorm(q, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], pos=pos)
             wi, bi = w[f'{p}.self_attn.in_proj_weight'], w[f'{p}.self_attn.in_proj_bias']
-            qk = self.o.linear(qk_in, wi[:2 * D], bi[:2 * D], out_bf16=True, bounded=True)
-            v = self.o.linear(x2, wi[2 * D:], bi[2 * D:], out_bf16=True, bounded=True)
+            qk = self.o.linear(qk_in, wi[:2 * D], bi[:2 * D], out_bf16=True, bounded=True, n_img=B)
+            v = self.o.linear(x2, wi[2 * D:], bi[2 * D:], out_bf16=True, bounded=True, n_img=B)
             o = ops.empty((B * Ltok, D), q)
             self.o.attention(qk, ops.offset(qk, D), v, o, B=B, H=nh, Lq=Ltok, Lk=Ltok, D=dh, Dv=dh, scale=dh ** -0.5,
                           q_str=(Ltok * 2 * D, 2 * D, dh), k_str=(Ltok * 2 * D, 2 * D, dh),
                           v_str=(Ltok * D, D, dh), o_str=(Ltok * D, D, dh))
-            q = self.o.linear(o, w[f'{p}.self_attn.out_proj.weight'], w[f'{p}.self_attn.out_proj.bias'], residual=q, bounded=True)
+            q = self.o.linear(o, w[f'{p}.self_attn.out_proj.weight'], w[f'{p}.self_attn.out_proj.bias'], residual=q, bounded=True, n_img=B)
             x2 = ops.layernorm(q, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'])
-            h = self.o.linear(x2, w[f'{p}.linear1.weight'], w[f'{p}.linear1.bias'], act=L.ACT_GELU, bounded=True)
-            q = self.o.linear(h, w[f'{p}.linear2.weight'], w[f'{p}.linear2.bias'], residual=q, bounded=True)
+            h = self.o.linear(x2, w[f'{p}.linear1.weight'], w[f'{p}.linear1.bias'], act=L.ACT_GELU, bounded=True, n_img=B)
+            q = self.o.linear(h, w[f'{p}.linear2.weight'], w[f'{p}.linear2.bias'], residual=q, bounded=True, n_img=B)
         xl = ops.layernorm(q, w['idx_pred_layer.0.weight'], w['idx_pred_layer.0.bias'])
-        logits = self.o.linear(xl, w['idx_pred_layer.1.weight'], bounded=True)
+        logits = self.o.linear(xl, w['idx_pred_layer.1.weight'], bounded=True, n_img=B)
         cb = w['quantize.embedding.weight']
         quant = ops.empty((B * Ltok, cb.shape[1]), q)
         idx = torch.empty((B * Ltok,), dtype=torch.int32, device=q.device)
         margin = ops.empty((B * Ltok,), q) if want_aux else None
-        L.call('keep_argmax_gather', logits, cb, force_idx, idx, margin, quant, B * Ltok, cb.shape[0], cb.shape[1])
+        # a non-finite logit row (an fp16-range overflow anywhere on hq_encoder -> Kalman update -> transformer) must not
+        # become a plausible code: the kernel raises the forward's status word and NaN-fills the row (keep_hip.h)
+        L.call('keep_argmax_gather', logits, cb, force_idx, idx, margin, quant, B * Ltok, cb.shape[0], cb.shape[1], self.o.status)
         side = z_hat.shape[1]
+        if want_aux:
+            self._aux_top1.append(logits.view(B, Ltok, -1).max(-1).values)
         return quant.view(B, side, z_hat.shape[2], cb.shape[1]), idx.view(B, Ltok), \
             (None if margin is None else margin.view(B, Ltok))
 
@@ -300,16 +309,16 @@ class KeepNet:
         nh, dh = cfg['cfa_nhead'], cfg['cfa_dim']
         inner = nh * dh
         c = curr.view(B * Ltok, C)
-        q = self.o.linear(c, w[f'{p}.attn.to_q.weight'], out_bf16=True)
-        kv = self.o.linear(prev.view(B * Ltok, C), w[f'{p}.attn.to_kv.weight'], out_bf16=True)
+        q = self.o.linear(c, w[f'{p}.attn.to_q.weight'], out_bf16=True, n_img=B)
+        kv = self.o.linear(prev.view(B * Ltok, C), w[f'{p}.attn.to_kv.weight'], out_bf16=True, n_img=B)
         o = ops.empty((B * Ltok, inner), curr)
         self.o.attention(q, kv, ops.offset(kv, inner), o, B=B, H=nh, Lq=Ltok, Lk=Ltok, D=dh, Dv=dh, scale=dh ** -0.5,
                       q_str=(Ltok * inner, inner, dh), k_str=(Ltok * 2 * inner, 2 * inner, dh),
                       v_str=(Ltok * 2 * inner, 2 * inner, dh), o_str=(Ltok * inner, inner, dh), probe=True)
-        a = self.o.linear(o, w[f'{p}.attn.to_out.0.weight'], w[f'{p}.attn.to_out.0.bias'])
+        a = self.o.linear(o, w[f'{p}.attn.to_out.0.weight'], w[f'{p}.attn.to_out.0.bias'], n_img=B)
         y = ops.layernorm(a, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], res=c)
-        f = ops.geglu(self.o.linear(y, w[f'{p}.ff.net.0.proj.weight'], w[f'{p}.ff.net.0.proj.bias']))
-        f = self.o.linear(f, w[f'{p}.ff.net.2.weight'], w[f'{p}.ff.net.2.bias'])
+        f = ops.geglu(self.o.linear(y, w[f'{p}.ff.net.0.proj.weight'], w[f'{p}.ff.net.0.proj.bias'], n_img=B))
+        f = self.o.linear(f, w[f'{p}.ff.net.2.weight'], w[f'{p}.ff.net.2.bias'], n_img=B)
         z = ops.layernorm(f, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], res=y)
         return z.view(B, H, Wd, C)
 
@@ -326,20 +335,20 @@ class KeepNet:
             p = f'kalman_filter.uncertainty_estimator.{i}'
             # sparse-causal spatial attention (KA:686-748): keys = [frame 0 ; frame f-1]
             x1 = ops.layernorm(h, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'])
-            qkv = self.o.linear(x1, w[f'{p}.attn1.to_qkv.weight'], out_bf16=True, bounded=True)
+            qkv = self.o.linear(x1, w[f'{p}.attn1.to_qkv.weight'], out_bf16=True, bounded=True, n_img=BT)
             o = ops.empty((BT * Ltok, inner), h)
             s3 = (Ltok * 3 * inner, 3 * inner, dh)
             self.o.attention(qkv, ops.offset(qkv, inner), ops.offset(qkv, 2 * inner), o, B=BT, H=nh, Lq=Ltok,
                           Lk=2 * Ltok, D=dh, Dv=dh, scale=dh ** -0.5, q_str=s3, k_str=s3, v_str=s3,
                           o_str=(Ltok * inner, inner, dh), mode=1, T=T, seg_len=Ltok)
-            h = self.o.linear(o, w[f'{p}.attn1.to_out.0.weight'], w[f'{p}.attn1.to_out.0.bias'], residual=h, bounded=True)
+            h = self.o.linear(o, w[f'{p}.attn1.to_out.0.weight'], w[f'{p}.attn1.to_out.0.bias'], residual=h, bounded=True, n_img=BT)
             # GEGLU feed-forward (KA:669)
             x3 = ops.layernorm(h, w[f'{p}.norm3.weight'], w[f'{p}.norm3.bias'])
-            f = ops.geglu(self.o.linear(x3, w[f'{p}.ff.net.0.proj.weight'], w[f'{p}.ff.net.0.proj.bias'], bounded=True))
-            h = self.o.linear(f, w[f'{p}.ff.net.2.weight'], w[f'{p}.ff.net.2.bias'], residual=h, bounded=True)
+            f = ops.geglu(self.o.linear(x3, w[f'{p}.ff.net.0.proj.weight'], w[f'{p}.ff.net.0.proj.bias'], bounded=True, n_img=BT))
+            h = self.o.linear(f, w[f'{p}.ff.net.2.weight'], w[f'{p}.ff.net.2.bias'], residual=h, bounded=True, n_img=BT)
             # temporal attention over the T frames of each spatial token (KA:671-680): strided, no rearrange
             xt = ops.layernorm(h, w[f'{p}.norm_temp.weight'], w[f'{p}.norm_temp.bias'])
-            qkv = self.o.linear(xt, w[f'{p}.attn_temp.to_qkv.weight'], out_bf16=True, bounded=True)
+            qkv = self.o.linear(xt, w[f'{p}.attn_temp.to_qkv.weight'], out_bf16=True, bounded=True, n_img=BT)
             o = ops.empty((BT * Ltok, inner), h)
             for b in range(B):
                 qb = ops.offset(qkv, b * T * Ltok * 3 * inner)
@@ -347,13 +356,13 @@ class KeepNet:
                 self.o.attention(qb, ops.offset(qb, inner), ops.offset(qb, 2 * inner),
                               ops.offset(o, b * T * Ltok * inner), B=Ltok, H=nh, Lq=T, Lk=T, D=dh, Dv=dh,
                               scale=dh ** -0.5, q_str=st, k_str=st, v_str=st, o_str=(inner, Ltok * inner, dh))
-            h = self.o.linear(o, w[f'{p}.attn_temp.to_out.0.weight'], w[f'{p}.attn_temp.to_out.0.bias'], residual=h, bounded=True)
+            h = self.o.linear(o, w[f'{p}.attn_temp.to_out.0.weight'], w[f'{p}.attn_temp.to_out.0.bias'], residual=h, bounded=True, n_img=BT)
         m = h.view(BT, Hh, Ww, C)
         mst = None
         for i in range(3):
             m, mst = self._resblock(m, f'kalman_filter.kalman_gain_calculator.{i}', mst)
         g = self.o.linear(m.view(BT * Ltok, C), w['kalman_filter.kalman_gain_calculator.3.weight'],
-                       w['kalman_filter.kalman_gain_calculator.3.bias'], act=L.ACT_SIGMOID)
+                       w['kalman_filter.kalman_gain_calculator.3.bias'], act=L.ACT_SIGMOID, n_img=BT)
         return g.view(BT, Ltok)
 
     # ------------------------------------------------------------------ GMFlow (GF:40-66, GM/gmflow.py:92-170)
@@ -411,18 +420,18 @@ class KeepNet:
         wqkv = w[f'{p}.qkv.weight']
         o = torch.empty_like(src)
         if tgt is src:
-            qkv = self.o.linear(src, wqkv, out_bf16=True, bounded=True)
+            qkv = self.o.linear(src, wqkv, out_bf16=True, bounded=True, n_img=n_img)
             q, k, v = qkv, ops.offset(qkv, C), ops.offset(qkv, 2 * C)
             sq = skv = (Ltok * 3 * C, 3 * C, 0)
         else:
-            q = self.o.linear(src, wqkv[:C], out_bf16=True, bounded=True)
-            kv = self.o.linear(tgt, wqkv[C:], out_bf16=True, bounded=True)
+            q = self.o.linear(src, wqkv[:C], out_bf16=True, bounded=True, n_img=n_img)
+            kv = self.o.linear(tgt, wqkv[C:], out_bf16=True, bounded=True, n_img=n_img)
             k, v = kv, ops.offset(kv, C)
             sq, skv = (Ltok * C, C, 0), (Ltok * 2 * C, 2 * C, 0)
         self.o.attention(q, k, v, o, B=n_img * 4, H=1, Lq=Ltok // 4, Lk=Ltok // 4, D=C, Dv=C, scale=1.0 / (C ** 0.5),
                       q_str=sq, k_str=skv, v_str=skv, o_str=(Ltok * C, C, 0), mode=2, img_h=h8, img_w=w8, ksplit=2,
                       shift=shift, kv_rot=kv_rot, n_img=n_img)
-        m = self.o.linear(o, w[f'{p}.merge.weight'], bounded=True)
+        m = self.o.linear(o, w[f'{p}.merge.weight'], bounded=True, n_img=n_img)
         if not ffn:
             return ops.layernorm(m, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], res=src)
         m = ops.layernorm(m, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'])
@@ -430,10 +439,10 @@ class KeepNet:
             m2 = self.o.gm_mlp(src, m, w[f'{p}.mlp.0.weight'], w[f'{p}.mlp.2.weight'])      # [M,8C] never leaves the CU
         else:
             if self.o.mma == L.MMA_X3:      # cat[src | m] folded into the GEMM: two K-concatenated inputs (keep_conv2d in2)
-                hmid = self.o.linear(src, w[f'{p}.mlp.0.weight'], act=L.ACT_GELU, bounded=True, x2=m)
+                hmid = self.o.linear(src, w[f'{p}.mlp.0.weight'], act=L.ACT_GELU, bounded=True, x2=m, n_img=n_img)
             else:
-                hmid = self.o.linear(ops.concat2(src, m), w[f'{p}.mlp.0.weight'], act=L.ACT_GELU, bounded=True)
-            m2 = self.o.linear(hmid, w[f'{p}.mlp.2.weight'], bounded=True)
+                hmid = self.o.linear(ops.concat2(src, m), w[f'{p}.mlp.0.weight'], act=L.ACT_GELU, bounded=True, n_img=n_img)
+            m2 = self.o.linear(hmid, w[f'{p}.mlp.2.weight'], bounded=True, n_img=n_img)
         return ops.layernorm(m2, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], res=src)
 
     def _gm_backbone(self, img_nchw):
@@ -496,8 +505,8 @@ class KeepNet:
         flow = ops.add_bcast(corr, grid, alpha=-1.0)
         # flow propagation (GM/transformer.py:363-372): k projected from the projected q
         fp = f'{pfx}.feature_flow_attn'
-        q = self.o.linear(f0, w[f'{fp}.q_proj.weight'], w[f'{fp}.q_proj.bias'], bounded=True)
-        k = self.o.linear(q, w[f'{fp}.k_proj.weight'], w[f'{fp}.k_proj.bias'], bounded=True)
+        q = self.o.linear(f0, w[f'{fp}.q_proj.weight'], w[f'{fp}.q_proj.bias'], bounded=True, n_img=P)
+        k = self.o.linear(q, w[f'{fp}.k_proj.weight'], w[f'{fp}.k_proj.bias'], bounded=True, n_img=P)
         flow2 = ops.empty((P * Ltok, 2), f0)
         self.o.attention(q, k, flow, flow2, B=P, H=1, Lq=Ltok, Lk=Ltok, D=C, Dv=2, scale=1.0 / (C ** 0.5),
                       q_str=sF, k_str=sF, v_str=(Ltok * 2, 2, 0), o_str=(Ltok * 2, 2, 0))
@@ -513,7 +522,7 @@ class KeepNet:
 
     # ------------------------------------------------------------------ KEEP.forward
     @torch.no_grad()
-    def __call__(self, x, need_upscale=False, force_indices=None, return_aux=False, force_flows=None):
+    def __call__(self, x, need_upscale=False, force_indices=None, return_aux=False, force_flows=None, _defer_check=False):
         if self.w is None:
             raise RuntimeError("KeepNet: weights are not on a device (load_state_dict + .to('cuda') first)")
         if x.dim() != 5 or x.shape[2] != 3:
@@ -538,33 +547,58 @@ class KeepNet:
                 res = self._forward_graphed(x, B, T, H, Wd)
             else:
                 res = self._forward(x, B, T, H, Wd, force_indices, return_aux, force_flows)
-            if self.precision == 'x3' and CHECK_X3_RANGE:
-                # fp16 halves top out at 65504: an out-of-range activation becomes inf/NaN in the output, never a quietly
-                # wrong value.  Raw-stream operands are range-probed (keep_absmax), so this is the last line of defence
-                # (e.g. a GroupNorm gamma in the hundreds): re-run the batch on the exact-f32 kernels.
-                out = res[0] if return_aux else res
-                if not bool(torch.isfinite(out).all()):
-                    import logging
-                    logging.getLogger('ComfyUI-KEEP').warning(
-                        "x3 precision policy left the fp16 operand range on this batch; re-running it on the f32 kernels")
-                    self.x3_fallbacks += 1
-                    self.precision = 'fp32'
-                    try:
-                        self._activate_precision()
-                        res = self._forward(x, B, T, H, Wd, force_indices, return_aux, force_flows)
-                    finally:
-                        self.precision = 'x3'
+            if _defer_check:
+                return res
+            return self._checked(res, x, B, T, H, Wd, force_indices, return_aux, force_flows)
+
+    def _status_bits(self):
+        """This forward's status word (KEEP_STATUS_*): one 4-byte device -> host read."""
+        return int(self.o.status.item())
+
+    def _checked(self, res, x, B, T, H, Wd, force_indices=None, return_aux=False, force_flows=None, bits=None):
+        """x3 policy: fp16 halves top out at 65504.  Raw-stream operands are range-probed, `bounded` ones are not; an operand
+        beyond the range turns into NaN in everything it touches and every op between there and the output propagates it --
+        including the discrete ones: the arg-max raises KEEP_STATUS_NONFINITE_LOGITS (it would otherwise select code 0 and the
+        generator would paint a finite, wrong frame), ReLU / flow_warp keep NaN, and the last kernel of the forward scans the
+        output (KEEP_STATUS_NONFINITE_TENSOR).  Any bit set -> the batch is re-run on the exact-f32 kernels: never a quietly
+        wrong frame.  The check is ONE int32 read (the forward's status word), not a host-side reduction over the output."""
+        if self.precision != 'x3' or not CHECK_X3_RANGE:
             return res
+        if bits is None:
+            bits = self._status_bits()
+        if bits == 0:
+            return res
+        import logging
+        logging.getLogger('ComfyUI-KEEP').warning(
+            "x3 precision policy left the fp16 operand range on this batch (status %d); re-running it on the f32 kernels", bits)
+        self.x3_fallbacks += 1
+        self.precision = 'fp32'
+        try:
+            self._activate_precision()
+            return self._forward(x, B, T, H, Wd, force_indices, return_aux, force_flows)
+        finally:
+            self.precision = 'x3'
+            self._activate_precision()
 
     def _forward_graphed(self, x, B, T, H, Wd):
         """The same kernel sequence as ``_forward``, captured once per (shape, policy) into a hipGraph and replayed: at
         B = 1 a clip is ~9 k launches averaging a few microseconds of GPU work each, i.e. bound by the host's launch
         rate; a replay submits them in one call.  Every kernel is stream-ordered, allocation-free and deterministic, and
         the host code between launches only computes shapes, so the replay is bit-identical to the eager run."""
-        key = (B, T, H, Wd, self.precision, self._dev_blob.data_ptr())
+        self.o.ensure_arena(self.device)
+        key = (B, T, H, Wd, self.precision, self._dev_blob.data_ptr(), self.o.arena_generation)
         ent = self._graphs.get(key)
         if ent is None:
-            self._forward(x, B, T, H, Wd, None, False, None)         # warm: weight twins, constants, plans, allocator
+            # First occurrence of a key: run eagerly (it is also the warm-up: weight twins, constants, plans, allocator).
+            # Capture on the SECOND one -- a capture costs a host-side pass over ~9 k launches and holds a private activation
+            # pool; a shape that shows up once per node call (a remainder clip) never pays for it.  KEEP_AMD_GRAPH=1 captures
+            # at once (after one warm pass).
+            seen = self._graph_seen.get(key, 0)
+            self._graph_seen[key] = seen + 1
+            if seen == 0:
+                out = self._forward(x, B, T, H, Wd, None, False, None)
+                if self.graph_mode != '1':
+                    return out
             torch.cuda.synchronize()
             if len(self._graphs) >= GRAPH_CACHE:
                 self._graphs.pop(next(iter(self._graphs)))
@@ -585,6 +619,7 @@ class KeepNet:
     def _forward(self, x, B, T, H, Wd, force_indices, return_aux, force_flows=None):
         cfg = self.cfg
         self.o.begin_forward(self.device)
+        self._aux_top1 = []
         # K1: flows for all T-1 pairs (KA:976-986): flownet(x[:,1:], x[:,:-1])
         flows = None
         if force_flows is not None:      # parity tests: inject the oracle's flows [B,T-1,2,H,W] (isolates GMFlow drift)
@@ -642,9 +677,11 @@ class KeepNet:
             prev_out = y
             out_nhwc[:, i].copy_(y)
         out = ops.nhwc_to_nchw(out_nhwc.view(B * T, H, Wd, 3)).view(B, T, 3, H, Wd)
+        if self.precision == 'x3' and CHECK_X3_RANGE:
+            L.call('keep_nonfinite_flag', out, out.numel(), self.o.status)
         if return_aux:
             aux = {'indices': torch.stack(idx_all, 1), 'margins': torch.stack(margin_all, 1), 'gains': gains,
-                   'flows': flows, 'z_codes': zc}
+                   'flows': flows, 'z_codes': zc, 'logit_top1': torch.stack(self._aux_top1, 1)}
             self.last_aux = aux
             return out, aux
         return out
@@ -685,53 +722,114 @@ class KeepNet:
         return outs
 
     # ------------------------------------------------------------------ device-side pre/post
-    def run_clips_u8(self, clips_u8, max_b=None, gather='all'):
+    def run_clips_u8(self, clips_u8, max_b=None, gather='root'):
         """list of uint8 BGR crops [T_i,H,W,3] (host or device) -> list of restored uint8 BGR [T_i,H,W,3] on the host.
 
         Replaces the per-frame host conversions either side of the clip loop -- ``img2tensor(face/255., bgr2rgb) +
         normalize(0.5, 0.5)`` (keep_processor.py:258-259) and ``tensor2img(rgb2bgr, min_max=(-1,1))``
         (keep_processor.py:272-273, img_util.py:66-90) -- with ``keep_img2tensor`` / ``keep_tensor2img`` on the GPU, so
         only uint8 crosses PCIe (4x fewer bytes each way).  Bit-identical to the host converters.  Clips are converted,
-        restored and converted back one batch group at a time (nothing but uint8 outlives a group).
+        restored and converted back one batch group at a time (nothing but uint8 outlives a group); the transfers of
+        neighbouring groups run on a second stream under the current group's forward (``_run_clips_u8_local``).
 
         With an initialised ``torch.distributed`` group of more than one rank (one process per GPU, engine/dist.py) the
         clips are sharded round-robin over the ranks -- no data-path collective, clips share no state -- and the restored
-        uint8 clips are gathered by clip index on the host: ``gather='all'`` (default) every rank returns the full list
-        (the processor code that follows is rank-agnostic), ``'root'`` only rank 0 does (others get None), ``'none'`` each
-        rank returns its own clips as {clip index: tensor}."""
+        uint8 clips are collected by clip index with ONE fixed-size uint8 tensor gather: ``gather='root'`` (default) rank 0
+        returns the full list and every other rank None (the paste-back that follows runs once, on rank 0); ``'all'`` every
+        rank returns the full list; ``'none'`` each rank returns its own clips as {clip index: tensor}."""
         if self.w is None:
             raise RuntimeError("KeepNet: weights are not on a device (load_state_dict + .to('cuda') first)")
         from . import dist as kdist
         for c in clips_u8:
             if c.dim() != 4 or c.shape[-1] != 3 or c.dtype != torch.uint8:
                 raise ValueError(f"expected uint8 [T,H,W,3], got {c.dtype} {tuple(c.shape)}")
-        res = kdist.sharded_map(clips_u8, lambda mine: self._run_clips_u8_local(mine, max_b), gather)
+        if not self.shard_across_ranks:      # per-rank workloads (BASELINE configs[4]: one video per GPU): nothing to exchange
+            local = self._run_clips_u8_local(dict(enumerate(clips_u8)), max_b)
+            return [torch.from_numpy(local[i]) for i in range(len(clips_u8))]
+        res = kdist.sharded_map(clips_u8, lambda mine: self._run_clips_u8_local(mine, max_b), gather,
+                                shapes=[tuple(c.shape) for c in clips_u8])
         if res is None or isinstance(res, dict):
             return res
         return [torch.from_numpy(r) if not isinstance(r, torch.Tensor) else r for r in res]
 
     def _run_clips_u8_local(self, mine, max_b=None):
-        """{clip index: uint8 [T,H,W,3]} -> {clip index: restored uint8 numpy [T,H,W,3]} on this rank's GPU."""
+        """{clip index: uint8 [T,H,W,3]} -> {clip index: restored uint8 numpy [T,H,W,3]} on this rank's GPU.
+
+        Three-stage pipeline over the batch groups, two HIP streams: while group g runs its forward on the compute stream,
+        the copy stream uploads group g+1 (pinned staging -> device uint8) and downloads group g-1's restored uint8 into
+        pinned memory.  The x3 range check of a group (one int32, ``_checked``) is read after its download has been queued,
+        i.e. the host never waits inside a forward; a flagged group is re-run on the f32 kernels before it is handed back."""
         order = {}
         for n, c in mine.items():
             order.setdefault(tuple(c.shape[:3]), []).append(n)
+        groups = []
+        for (T, H, Wd), ids in order.items():
+            b = self.clips_per_call(T, H, Wd) if max_b is None else max_b
+            groups += [(T, H, Wd, ids[s:s + b]) for s in range(0, len(ids), b)]
         local = {}
+        if not groups:
+            return local
         with torch.cuda.device(self.device):
-            for (T, H, Wd), ids in order.items():
-                b = self.clips_per_call(T, H, Wd) if max_b is None else max_b
-                for s in range(0, len(ids), b):
-                    grp = ids[s:s + b]
-                    u8 = torch.stack([mine[n] for n in grp], 0).to(self.device, non_blocking=True).contiguous()
-                    f = torch.empty((len(grp) * T, H, Wd, 3), dtype=torch.float32, device=self.device)
-                    L.call('keep_img2tensor', u8, f, len(grp) * T * H * Wd)
-                    x = ops.nhwc_to_nchw(f).view(len(grp), T, 3, H, Wd)
-                    del f, u8
-                    o = self(x)
+            comp = torch.cuda.current_stream()
+            io = self._io_stream = getattr(self, '_io_stream', None) or torch.cuda.Stream(device=self.device)
+
+            def upload(gi):
+                T, H, Wd, grp = groups[gi]
+                host = torch.empty((len(grp), T, H, Wd, 3), dtype=torch.uint8, pin_memory=True)
+                for k, n in enumerate(grp):
+                    host[k].copy_(mine[n])                      # (a device-resident clip is copied by the same call)
+                with torch.cuda.stream(io):
+                    dev = host.to(self.device, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(io)
+                return host, dev, ev
+
+            def finish(job):
+                """download queued -> wait for it, check the group's status word, hand the frames back"""
+                gi, x, r8_host, st_host, ev_done = job
+                ev_done.synchronize()
+                T, H, Wd, grp = groups[gi]
+                bits = int(st_host.item())
+                if bits and x is not None:
+                    o = self._checked(None, x, len(grp), T, H, Wd, bits=bits)
                     y = ops.nchw_to_nhwc(o.view(len(grp) * T, 3, H, Wd))
                     r8 = torch.empty((len(grp) * T, H, Wd, 3), dtype=torch.uint8, device=self.device)
                     L.call('keep_tensor2img', y, r8, len(grp) * T * H * Wd)
-                    r8 = r8.view(len(grp), T, H, Wd, 3).cpu().numpy()
-                    del x, o, y
-                    for k, n in enumerate(grp):
-                        local[n] = r8[k]
+                    r8_host = r8.view(len(grp), T, H, Wd, 3).cpu()
+                arr = r8_host.numpy()
+                for k, n in enumerate(grp):
+                    local[n] = arr[k]
+
+            nxt = upload(0)
+            pending = None
+            for gi, (T, H, Wd, grp) in enumerate(groups):
+                host, u8, ev_in = nxt
+                nxt = upload(gi + 1) if gi + 1 < len(groups) else None     # flies under this group's forward
+                comp.wait_event(ev_in)
+                u8.record_stream(comp)
+                f = torch.empty((len(grp) * T, H, Wd, 3), dtype=torch.float32, device=self.device)
+                L.call('keep_img2tensor', u8, f, len(grp) * T * H * Wd)
+                x = ops.nhwc_to_nchw(f).view(len(grp), T, 3, H, Wd)
+                del f, u8
+                o = self(x, _defer_check=True)
+                y = ops.nchw_to_nhwc(o.view(len(grp) * T, 3, H, Wd))
+                r8 = torch.empty((len(grp) * T, H, Wd, 3), dtype=torch.uint8, device=self.device)
+                L.call('keep_tensor2img', y, r8, len(grp) * T * H * Wd)
+                st_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                st_host.copy_(self.o.status, non_blocking=True)            # this forward's status word, stream-ordered
+                ev_out = torch.cuda.Event()
+                ev_out.record(comp)
+                r8_host = torch.empty((len(grp), T, H, Wd, 3), dtype=torch.uint8, pin_memory=True)
+                with torch.cuda.stream(io):
+                    io.wait_event(ev_out)
+                    r8_host.copy_(r8.view(len(grp), T, H, Wd, 3), non_blocking=True)
+                    r8.record_stream(io)
+                    ev_done = torch.cuda.Event()
+                    ev_done.record(io)
+                del o, y, r8
+                if pending is not None:
+                    finish(pending)          # group g-1: its download ran under group g's launches
+                # x is kept only for the (rare) f32 re-run; precision 'x3' is the only policy that can ask for one
+                pending = (gi, x if (self.precision == 'x3' and CHECK_X3_RANGE) else None, r8_host, st_host, ev_done)
+            finish(pending)
         return local

@@ -85,18 +85,27 @@ class Ops:
         self.profile = None
         self.amax_arena = None     # x3: per-forward arena of fused max|out| slots (begin_forward)
         self.amax_pos = 0
+        self.status = None         # one device int32: KEEP_STATUS_* bits raised by this forward's kernels (begin_forward zeroes it)
+        self.arena_generation = 0  # bumped when the block is (re)allocated: hipGraphs captured before that are stale
 
     def begin_forward(self, device):
-        """x3 policy: the per-image max|out| slots the convolutions fill with atomicMax come from ONE arena that is zero-
-        filled once here instead of one zero-fill launch per convolution (2.4 k launches per 16-clip step).  A slot lives
-        until the next begin_forward: Stats objects never outlive the forward pass that made them."""
-        if self.mma != L.MMA_X3:
-            self.amax_arena = None
-            return
-        if self.amax_arena is None or self.amax_arena.device != torch.device(device):
-            self.amax_arena = torch.empty(1 << 18, dtype=torch.float32, device=device)
-        self.amax_arena.zero_()
+        """Zero this forward's bookkeeping words with ONE fill launch: the status word (non-finite logits / tensors, see
+        keep_argmax_gather, keep_nonfinite_flag) and, for the x3 policy, the arena of per-image max|out| slots the convolutions
+        fill with atomicMax (instead of one zero-fill launch per convolution: 2.4 k launches per 16-clip step).  A slot lives
+        until the next begin_forward: Stats objects never outlive the forward pass that made them.
+        The block is allocated ONCE per Ops and device and never freed or swapped while the Ops lives: captured hipGraphs
+        bake its address in, so dropping it on a policy change (as round 2 did) left replays writing through a dangling pointer."""
+        self.ensure_arena(device)
+        self._block.zero_()
         self.amax_pos = 0
+
+    def ensure_arena(self, device):
+        device = torch.device(device)
+        if self.amax_arena is None or self.amax_arena.device != device:
+            self._block = torch.empty((1 << 18) + 4, dtype=torch.float32, device=device)
+            self.amax_arena = self._block[4:]
+            self.status = self._block[:1].view(torch.int32)
+            self.arena_generation += 1
 
     def set_precision(self, mma, blob32=None, blob16=None, blobx3=None, x3_acc_scale=1.0):
         self.mma = self.attn_mma = mma
@@ -218,7 +227,7 @@ class Ops:
                 a.stats_out, a.stats_P = st.part.data_ptr(), pl.stats_P
             if pl.out_amax_ok:
                 if self.amax_arena is not None and self.amax_pos + N <= self.amax_arena.numel():
-                    st.amax = self.amax_arena[self.amax_pos:self.amax_pos + N]       # zeroed once per forward
+                    st.amax = self.amax_arena[self.amax_pos:self.amax_pos + N]       # zeroed once per forward (begin_forward)
                     self.amax_pos += N
                     a.x3_out_amax_zeroed = 1
                 else:
@@ -250,12 +259,17 @@ class Ops:
         return (out, st) if stats else out
 
     def linear(self, x, w, bias=None, *, act=L.ACT_NONE, residual=None, pro=None, pro_act=L.PRO_NONE, cin=None, in_off=0,
-               n_img=1, out_bf16=False, bounded=False, x_amax=None, x2=None):
-        """x [M,ld] (or any [...,ld]) @ w[Cout,Cin]^T.  ``n_img``>1 makes the prologue per-image: rows are n_img
-        images of M/n_img pixels each (1x1 conv on a feature map)."""
+               n_img=None, out_bf16=False, bounded=False, x_amax=None, x2=None):
+        """x [M,ld] (or any [...,ld]) @ w[Cout,Cin]^T.  ``n_img``: the rows are n_img independent images (frames, clips) of
+        M/n_img rows each -- the unit of the per-image prologue AND of the library's plan (kernel tile / split-K are chosen
+        from the per-image row count, so a clip's result never depends on its batch-mates).  Default: the leading axis of a
+        3-D+ input, 1 for a plain [M,ld] matrix (callers that flatten independent images into rows pass it)."""
         shp = x.shape
         ld = shp[-1]
         M = x.numel() // ld
+        if n_img is None:
+            n_img = shp[0] if x.dim() >= 3 else 1
+        assert M % n_img == 0, (tuple(shp), n_img)
         if (TOKEN_LINEAR and self.mma == L.MMA_BF16 and ld == 128 and w.shape[0] in (128, 256, 384) and w.shape[-1] == 128
                 and M >= 65536 and act == L.ACT_NONE and residual is None and pro is None and pro_act == L.PRO_NONE
                 and cin is None and in_off == 0 and x.dtype == torch.float32 and x.is_contiguous()):
@@ -282,7 +296,7 @@ class Ops:
             return scale, shift
         assert x.dtype == torch.float32, "bf16 activations carry their statistics from the producing conv's epilogue"
         cpg = C // groups
-        if ((cpg % 4 == 0 and HW * cpg <= 32768) or HW <= 1024) and C % 4 == 0 and groups * N >= 16:
+        if ((cpg % 4 == 0 and HW * cpg <= 32768) or HW <= 1024) and C % 4 == 0 and groups >= 2:   # (per-image rule: never N)
             # small maps: one block per (image, group), one launch
             L.call('keep_group_stats', x, gamma, beta, scale, shift, N, HW, C, groups, float(eps))
             return scale, shift

@@ -18,6 +18,7 @@ import torch
 from .arch import DEFAULT_ARCH, state_dict_spec
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+HEAD_GAIN = 0.125       # see _sigma_for('generator.blocks.24.weight')
 
 
 def _splitmix64(x):
@@ -53,6 +54,12 @@ def _sigma_for(name: str, shape):
         return 0.0, 0.7
     if name == 'idx_pred_layer.1.weight':                 # peaked logits (top-1/top-2 margins ~ trained nets)
         return 0.0, 4.0 / math.sqrt(shape[1])
+    if name == 'generator.blocks.24.weight':
+        # the output head (VQ:339-343 last conv, 64 -> 3): scaled so that the synthetic net's restored frames live in the
+        # range a trained net's do (~[-1, 1]: tensor2img clamps to it, img_util.py:66-90) -- that is the range the <= 1e-3
+        # max-abs tolerance of the parity tests is stated for, and the range the HQ encoder sees through prev_out
+        fan_in = shape[1] * shape[2] * shape[3]
+        return 0.0, HEAD_GAIN / math.sqrt(fan_in)
     if len(shape) == 4:                                   # conv weight
         fan_in = shape[1] * shape[2] * shape[3]
         return 0.0, 1.0 / math.sqrt(fan_in)

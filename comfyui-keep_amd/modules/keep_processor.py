@@ -128,6 +128,8 @@ class KEEPFaceProcessor:
                 clip = torch.cat([clip, clip], dim=0)    # (the engine restores a lone frame as T=1: same frame 0, half the work)
             clips.append(clip)
         outs = run_u8(clips)
+        if outs is None:          # a non-root rank of a run sharded over several GPUs: rank 0 holds the frames and pastes
+            return None
         faces = []
         for (s, e), o in zip(spans, outs):
             o = o.numpy()
@@ -173,6 +175,8 @@ class KEEPFaceProcessor:
 
         # one face -> T=2 duplicate, keep frame 0; several faces -> one "clip" of T=#faces (KP:173-178)
         faces = self._restore_crops_u8(crops, max_clip_length=max(len(crops), 1))
+        if faces is None:
+            return None
         self.last_restored_faces = faces
         helper.restored_faces = [f.astype('uint8') for f in faces]
 
@@ -286,6 +290,8 @@ class KEEPFaceProcessor:
         restored_faces = []
         if crops:
             restored_faces = self._restore_crops_u8(crops, max_clip_length)
+            if restored_faces is None:          # non-root rank of a sharded multi-GPU run (engine/dist.py): nothing to paste here
+                return None
         self.last_restored_faces = restored_faces
         pbar.update(n_frames)
 

@@ -25,7 +25,11 @@
 extern "C" {
 #endif
 
-#define KEEP_ABI_VERSION 11
+/* Bumped on EVERY layout or signature change.  v12: keep_conv2d_args / keep_attention_args start with `struct_size`
+ * (callers set it to sizeof of the struct THEY were compiled against; the library rejects sizes it does not know and reads
+ * the fields a shorter known layout lacks as zero), keep_sizeof_*_args(), keep_argmax_gather takes the non-finite status word,
+ * keep_nonfinite_flag. */
+#define KEEP_ABI_VERSION 12
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -83,6 +87,8 @@ int32_t keep_device_ok(int32_t dev);
  * split_k>1: `workspace` must hold split_k*M*Cout floats; partial sums are reduced deterministically.
  */
 typedef struct {
+  uint32_t struct_size;   /* sizeof(keep_conv2d_args) of the CALLER's header; keep_sizeof_conv2d_args() is the library's */
+  uint32_t reserved0;     /* 0 */
   const void* in;         /* [N,H,W,in_ld]                                   */
   const float* weight;    /* [Cout][KH][KW][Cin] fp32 (packed by the host)   */
   const float* bias;      /* [Cout] or NULL                                  */
@@ -131,7 +137,13 @@ typedef struct {
   const void* in2;
   int32_t in2_cin1;
 } keep_conv2d_args;
+/* smallest struct_size the library accepts: the v12 layout up to and including in2_cin1 (fields appended later are optional) */
+#define KEEP_CONV2D_ARGS_V12_SIZE 256
 int32_t keep_conv2d(const keep_conv2d_args* a, void* stream);
+/* sizeof(keep_conv2d_args) / sizeof(keep_attention_args) as THIS library was compiled: a binding checks its own struct
+ * against it at load time (engine/hiplib.py does) */
+int32_t keep_sizeof_conv2d_args(void);
+int32_t keep_sizeof_attention_args(void);
 
 /* What keep_conv2d will do with exactly these arguments -- kernel choice, split-K, buffer sizes -- so that callers size
  * `workspace` / `stats_out` from the library's own decision instead of mirroring its tile rules.  Tensor pointers only
@@ -166,6 +178,8 @@ int32_t keep_conv2d_plan(const keep_conv2d_args* a, keep_conv2d_plan_out* out);
  *           from image (image + kv_rot) % n_img  (the [f0;f1] vs [f1;f0] pairing, GM/transformer.py:301-314).
  */
 typedef struct {
+  uint32_t struct_size;   /* sizeof(keep_attention_args) of the caller's header */
+  uint32_t reserved0;     /* 0 */
   const void* q;
   const void* k;
   const void* v;
@@ -190,6 +204,7 @@ typedef struct {
   void* workspace;
   int64_t workspace_bytes;
 } keep_attention_args;
+#define KEEP_ATTENTION_ARGS_V12_SIZE 248
 int32_t keep_attention(const keep_attention_args* a, void* stream);
 /* bytes of `workspace` this call can use (0: none); a smaller or NULL workspace selects the unpacked path */
 int64_t keep_attention_workspace_bytes(const keep_attention_args* a);
@@ -242,9 +257,17 @@ int32_t keep_layernorm(const float* x, const float* gamma, const float* beta, co
 int32_t keep_geglu(const float* x, float* out, int32_t M, int32_t F, void* stream);
 
 /* KA:1085-1089 + VQ:78-91: idx[m] = argmax_j logits[m,j] (lowest index on ties); out[m,:] = codebook[idx[m],:].
- * force_idx (optional) overrides the argmax (parity tests).  margin (optional) = top1-top2 logit gap. */
+ * force_idx (optional) overrides the argmax (parity tests).  margin (optional) = top1-top2 logit gap.
+ * An arg-max is where a NaN / inf would otherwise turn into a finite, plausible, WRONG result: a row whose maximum is not
+ * finite (all-NaN rows included) gets idx 0, a NaN-filled `out` row (so the failure also travels with the data) and, when
+ * `status` (optional, one device int32) is given, bit KEEP_STATUS_NONFINITE_LOGITS OR-ed into it. */
+#define KEEP_STATUS_NONFINITE_LOGITS 1
+#define KEEP_STATUS_NONFINITE_TENSOR 2
 int32_t keep_argmax_gather(const float* logits, const float* codebook, const int32_t* force_idx, int32_t* idx,
-                           float* margin, float* out, int32_t M, int32_t ncodes, int32_t dim, void* stream);
+                           float* margin, float* out, int32_t M, int32_t ncodes, int32_t dim, int32_t* status, void* stream);
+/* status |= KEEP_STATUS_NONFINITE_TENSOR if any of the n floats of x is NaN or +-inf (one pass, one atomic per block at
+ * most): the x3 policy's end-of-forward range check as a 4-byte read instead of a host-side reduction */
+int32_t keep_nonfinite_flag(const float* x, int64_t n, int32_t* status, void* stream);
 
 /* VQ:37-48 true nearest-neighbour code search: idx[m] = argmin_j |z_m|^2 + |e_j|^2 - 2 z_m.e_j  (next-row 8f-3) */
 int32_t keep_vq_nearest(const float* z, const float* codebook, int32_t* idx, int32_t M, int32_t ncodes, int32_t dim,
@@ -254,7 +277,8 @@ int32_t keep_vq_nearest(const float* z, const float* codebook, int32_t* idx, int
 int32_t keep_kalman_update(const float* z_code, const float* z_prime, const float* gain, float* out, int32_t N,
                            int32_t HW, int32_t C, void* stream);
 
-/* AU:113-144 flow_warp: bilinear grid_sample(zeros, align_corners=True) of x [N,H,W,C] by flow [N,H,W,2] */
+/* AU:113-144 flow_warp: bilinear grid_sample(zeros, align_corners=True) of x [N,H,W,C] by flow [N,H,W,2].  A non-finite
+ * flow vector yields NaN pixels (torch's grid_sample does the same for NaN; an out-of-range sample must not hide it). */
 int32_t keep_flow_warp(const float* x, const float* flow, float* out, int32_t N, int32_t H, int32_t W, int32_t C,
                        void* stream);
 

@@ -57,6 +57,15 @@ def _worker(rank, world, port, n_clips, out_dir):
     assert all(np.array_equal(allr[c], 255 - clips[c]) for c in range(n_clips))
     root = kdist.sharded_map(clips, local_fn, gather='root')
     assert (root is None) == (rank != 0)
+    # ragged clips (different T per clip, what a 41-crop video gives: 20 + 20 + 1) through the fixed-size tensor gather,
+    # with and without the caller providing the shapes
+    ragged = [np.full((t, 4, 4, 3), 10 + c, dtype=np.uint8) for c, t in enumerate((20, 20, 1, 7, 3))]
+    for shapes in ([r.shape for r in ragged], None):
+        got = kdist.sharded_map(ragged, lambda d: {i: (c // 2) for i, c in d.items()}, gather='root', shapes=shapes)
+        if rank == 0:
+            assert all(g.shape == r.shape and np.array_equal(g, r // 2) for g, r in zip(got, ragged))
+        else:
+            assert got is None
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

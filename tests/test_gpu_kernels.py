@@ -456,16 +456,75 @@ def test_argmax_gather_and_ties():
     out = torch.empty(512, 256, device='cuda')
     idx = torch.empty(512, dtype=torch.int32, device='cuda')
     margin = torch.empty(512, device='cuda')
-    L.call('keep_argmax_gather', dev(logits), dev(cb), None, idx, margin, out, 512, 1024, 256)
+    status = torch.zeros(1, dtype=torch.int32, device='cuda')
+    L.call('keep_argmax_gather', dev(logits), dev(cb), None, idx, margin, out, 512, 1024, 256, status)
     ref_idx = logits.argmax(-1)
     ref_idx[7] = 100
     assert torch.equal(idx.cpu().long(), ref_idx)
     assert torch.equal(out.cpu(), cb[ref_idx])
+    assert int(status.item()) == 0
     top2 = logits.topk(2, -1).values
     assert torch.allclose(margin.cpu(), top2[:, 0] - top2[:, 1], atol=1e-6)
     force = torch.arange(512, dtype=torch.int32, device='cuda') % 1024
-    L.call('keep_argmax_gather', dev(logits), dev(cb), force, idx, None, out, 512, 1024, 256)
+    L.call('keep_argmax_gather', dev(logits), dev(cb), force, idx, None, out, 512, 1024, 256, None)
     assert torch.equal(out.cpu(), cb[force.cpu().long()])
+
+
+def test_argmax_never_launders_non_finite_logits():
+    """A NaN / inf logit row (an fp16-range overflow upstream under the x3 policy) must not become a plausible code: rows
+    that are all NaN, rows with ONE NaN among finite logits, and rows whose maximum is +inf raise the status word and get
+    a NaN-filled codebook row; the finite rows of the same launch are untouched."""
+    logits = rnd('nl', (64, 1024), 4.0)
+    logits[3] = float('nan')                       # all NaN: round 2 returned code 0 and a finite row
+    logits[10, 517] = float('nan')                 # one NaN: the scan would just skip it
+    logits[20, 5] = float('inf')                   # an overflow that stayed inf
+    logits[30] = float('-inf')
+    cb = rnd('ncb', (1024, 256))
+    out = torch.empty(64, 256, device='cuda')
+    idx = torch.empty(64, dtype=torch.int32, device='cuda')
+    status = torch.zeros(1, dtype=torch.int32, device='cuda')
+    L.call('keep_argmax_gather', dev(logits), dev(cb), None, idx, None, out, 64, 1024, 256, status)
+    assert int(status.item()) & L.STATUS_NONFINITE_LOGITS
+    o = out.cpu()
+    bad = [3, 10, 20, 30]
+    good = [r for r in range(64) if r not in bad]
+    assert torch.isnan(o[bad]).all()
+    assert torch.equal(o[good], cb[logits[good].argmax(-1)])
+    assert ((idx.cpu() >= 0) & (idx.cpu() < 1024)).all()
+    # clean launch: the word stays 0; keep_nonfinite_flag raises its own bit on a tensor with one inf / one NaN at any position
+    status.zero_()
+    L.call('keep_argmax_gather', dev(logits[good]), dev(cb), None, idx, None, out, len(good), 1024, 256, status)
+    assert int(status.item()) == 0
+    for n, pos, val in [(1 << 20, 12345, float('inf')), (4099, 4098, float('nan')), (7, 6, float('-inf')), (1 << 20, None, 0.0)]:
+        t = torch.ones(n, device='cuda')
+        if pos is not None:
+            t[pos] = val
+        status.zero_()
+        L.call('keep_nonfinite_flag', t, n, status)
+        assert int(status.item()) == (L.STATUS_NONFINITE_TENSOR if pos is not None else 0), (n, pos, val)
+
+
+def test_relu_and_flow_warp_keep_nan():
+    """The other two places a NaN could have vanished: ReLU written as v > 0 ? v : 0 (NaN -> 0) and grid_sample's 'outside
+    the image' branch (NaN flow -> zeros).  Both propagate now (torch's F.relu and F.grid_sample do as well)."""
+    x = rnd('rn', (1, 64, 16, 16))
+    x[0, 5, 3, 3] = float('nan')
+    w = rnd('rnw', (64, 64, 1, 1), 0.1)
+    y = ops.conv(dev(nhwc(x)), pack(w), None, pad=0, ksize=1, act=L.ACT_RELU)
+    assert torch.isnan(nchw(y)[0, :, 3, 3]).all() and torch.isfinite(nchw(y)[0, :, 4, 4]).all()
+    sc, sh = torch.ones(1, 64, device='cuda'), torch.zeros(1, 64, device='cuda')
+    y = ops.conv(dev(nhwc(x)), pack(rnd('rnw3', (64, 64, 3, 3), 0.05)), None, pro=(sc, sh), pro_act=L.PRO_RELU)
+    assert torch.isnan(nchw(y)[0, :, 3, 3]).all()
+    img = dev(nhwc(rnd('wi', (1, 3, 32, 32))))
+    flow = torch.zeros(1, 32, 32, 2, device='cuda')
+    flow[0, 7, 9, 0] = float('nan')
+    flow[0, 8, 9, 1] = float('inf')
+    out = torch.empty_like(img)
+    L.call('keep_flow_warp', img, flow, out, 1, 32, 32, 3)
+    assert torch.isnan(out[0, 7, 9]).all() and torch.isnan(out[0, 8, 9]).all()
+    keep = torch.ones(32, 32, dtype=torch.bool)
+    keep[7, 9] = keep[8, 9] = False
+    assert torch.equal(out[0].cpu()[keep], img[0].cpu()[keep])
 
 
 def test_vq_nearest(synth_weights):

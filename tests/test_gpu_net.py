@@ -18,6 +18,11 @@ from comfyui_keep_amd.engine import arch, ops, synth
 from comfyui_keep_amd.engine.arch import DEFAULT_ARCH, encoder_blocks, generator_blocks
 
 pytestmark = pytest.mark.gpu
+# Largest |top-1 logit - reference's| tolerated on frames before (and at) the first index flip of a free-running clip.  Frame 0
+# is held to 1e-3; later frames see the optical flow (a 4096-way soft-argmax whose fp32 re-association moves the warp by
+# ~1e-2 px, which the synthetic net's pixel-level texture turns into logit shifts of this size).  Measured: see the printed
+# `per_frame_top1_logit_err` of the T = 20 tests (DESIGN.md section 6 quotes them); tokens may only flip below twice this.
+LOGIT_ERR_BOUND = 4e-3
 OPS = np.load(os.path.join(GOLDEN, 'ops.npz'))
 
 
@@ -109,9 +114,8 @@ def _full_forward_check(net, gold_name, T):
     (~5e-5 relative, ~1e-2 px) moves a few logits by more than the smallest margins.  Short clips (T <= 3): agreement on
     confidently-decided tokens and >= 99 % overall.  Long clips: the recurrence is chaotic once ONE token flips (the next
     frame restores a different prev_out), so indices are compared frame by frame up to the first frame with a flip, and
-    the flipped tokens of that frame must be low-margin ones (<= 4e-3: the T=3 golden shows flips of margin 3.1e-3 at frame 2
-    for the exact-f32 policy and the x3 policy alike -- the size of the logit shift a 0.02 px flow
-    difference causes); beyond it only frame-independent quantities (gains, flows) are comparable.  The arithmetic is
+    the flipped tokens of that frame must be low-margin ones: at most twice the measured top-1 logit error, which is itself
+    asserted against LOGIT_ERR_BOUND (the size of the logit shift a 0.02 px flow difference causes); beyond it only frame-independent quantities (gains, flows) are comparable.  The arithmetic is
     pinned separately with the reference's indices injected.  The strict all-frames free-running check runs against the
     oracle with its flows injected (tests below)."""
     g = np.load(os.path.join(GOLDEN, gold_name))
@@ -120,8 +124,17 @@ def _full_forward_check(net, gold_name, T):
     idx = aux['indices'][0].cpu().numpy().astype(np.int16)
     agree = (idx == g['indices'])
     first_div = next((t for t in range(T) if not agree[t].all()), T)
+    # top-1 logit of every token against the reference's (golden `logit_top1`), frame by frame up to and including the first
+    # frame with a flip: THE quantity that decides whether an index can flip.  A token can only flip if its margin is below
+    # twice the logit error, so the flip rule is derived from the measured error instead of being a free constant.
+    top1 = aux['logit_top1'][0].cpu().numpy()
+    upto = min(first_div + 1, T)
+    dlogit = np.abs(top1[:upto] - g['logit_top1'][:upto])
+    dlogit_agree = float(dlogit[agree[:upto]].max())
     report = {'index_agreement': float(agree.mean()), 'frame0_agreement': float(agree[0].mean()),
               'first_frame_with_a_flip': first_div,
+              'max_top1_logit_err_up_to_first_flip': dlogit_agree,
+              'per_frame_top1_logit_err': [round(float(dlogit[t][agree[t]].max()), 6) for t in range(upto)],
               'gain_err': float(np.abs(aux['gains'][0].cpu().numpy() - g['gains']).max()),
               'flow_err_px': float(np.abs(_digest(aux['flows'][0].permute(0, 3, 1, 2).cpu()).numpy() - g['flow_grid']).max()),
               'flow_scale_px': float(np.abs(g['flow_grid']).max()),
@@ -130,10 +143,12 @@ def _full_forward_check(net, gold_name, T):
     assert report['flow_err_px'] <= 2e-4 * max(1.0, report['flow_scale_px']), report
     assert report['gain_err'] <= 2e-4, report
     assert agree[0][g['margins'][0] > 1e-3].all(), report
+    assert float(dlogit[0].max()) <= 1e-3, report                 # frame 0 sees no flow: fp32 re-association only
+    assert dlogit_agree <= LOGIT_ERR_BOUND, report
     if T <= 3:
         assert agree[g['margins'] > 0.1].all() and agree.mean() >= 0.99, report
     else:
-        assert first_div >= 1 and all(m <= 4e-3 for m in report['margins_of_first_flips']), report
+        assert first_div >= 1 and all(m <= 2 * LOGIT_ERR_BOUND for m in report['margins_of_first_flips']), report
     # arithmetic drift with the reference's indices injected (separates index flips from drift)
     forced = torch.from_numpy(g['indices'].astype(np.int32)).view(1, T, -1)
     out_f = net(x, need_upscale=False, force_indices=forced)
@@ -142,16 +157,13 @@ def _full_forward_check(net, gold_name, T):
     scale = float(np.abs(g['out_grid']).max())
     print(gold_name, f'[{net.precision}] max-abs pixel diff (reference indices injected): {err_f:.3e}; per frame:',
           [round(float(v), 6) for v in per_frame], f'; output scale {scale:.3g}')
-    # <= 1e-3 (north_star) on the short clips as an ABSOLUTE bound, although the synthetic net's outputs span +-6.
-    # Over T = 20 frames the error of the recurrence through the cross-frame attention (KA:1110-1121) grows: measured
-    # 1.9e-3 (x3) / 1.2e-3 (exact f32 vs the oracle) on outputs of magnitude 6.9-9.5, i.e. exact-f32 arithmetic in a
-    # different summation order already exceeds an absolute 1e-3 there.  The bound is therefore taken relative to the
-    # output scale (1e-3 of max |out|; equal to the absolute bound for [-1, 1] images).
-    tol = 1e-3 if T <= 3 else 1e-3 * max(1.0, scale)
+    # <= 1e-3 max-abs (north_star), ABSOLUTE, at every clip length incl. the metric's own T = 20: the synthetic net's frames
+    # live in the range the tolerance is stated for (engine/synth.py HEAD_GAIN; goldens: [-1.26, 0.97] over 20 frames)
+    tol = 1e-3
     assert err_f <= tol, (err_f, tol)
     st = out_f[0].cpu().reshape(T, 3, -1)
     stats = torch.stack([st.mean(-1), st.std(-1), st.min(-1).values, st.max(-1).values], -1).numpy()
-    assert np.abs(stats - g['out_stats']).max() <= 2e-3 * (1.0 if T <= 3 else max(1.0, scale))
+    assert np.abs(stats - g['out_stats']).max() <= 2e-3
     if agree.all():
         err = np.abs(_digest(out[0].cpu()).numpy() - g['out_grid']).max()
         print(gold_name, f'[{net.precision}] max-abs pixel diff (free running):', err)
@@ -214,9 +226,7 @@ def test_full_forward_T20_vs_oracle_drift_report(gpu_net, synth_weights):
     for t in range(min(first_div + 1, 20)):
         assert agree[t][margin[t] > 1e-3].all(), f'frame {t}: a token with margin > 1e-3 differs'
     assert first_div >= 1
-    # relative to the output scale, as in _full_forward_check (exact-f32 re-association alone reaches 1.2e-3 absolute here)
-    scale = max(1.0, float(ref.abs().max()))
-    assert float(per_frame[:first_div].max()) <= 1e-3 * scale, (per_frame[:first_div], scale)
+    assert float(per_frame[:first_div].max()) <= 1e-3, per_frame[:first_div]          # absolute, every pixel, every frame
 
 
 def _stub_helper_pack(net):
@@ -245,27 +255,15 @@ def test_config3_config4_clip_mixes_equal_sequential(gpu_net, n_crops, faces):
     assert len(faces_out) == n_crops and all(f.shape == (512, 512, 3) and f.dtype == np.uint8 for f in faces_out)
     spans = split_clips(n_crops, 20)
     assert len(spans) == n_crops // 20 and all(e - s == 20 for s, e in spans)
-    # Equality with the sequential loop is checked on what is NOT chaotic: the recurrence (keep_arch.py:1062-1127) amplifies the
-    # batch-dependent fp32 re-association (split-K factors follow the batch) until one low-margin code index flips -- from
-    # that frame on two correct runs differ by whole codebook patches (tools/dev/batch_flip2.py: clip 0 flips at frame 12 of 20
-    # in a batch of 15, at no frame in a batch of 8).  So: frame 0 of EVERY clip (order / chunking: frame 0 depends on no other
-    # frame) and, for a spread of clips, every frame up to the first one with a flip -- at least the first four -- must agree
-    # with the solo run to one uint8 level on < 1 % of the pixels.
-    def close(a, b):
-        d = np.abs(a.astype(np.int16) - b.astype(np.int16))
-        return d.max() <= 1 and (d > 0).mean() < 1e-2
+    # Kernel tile / split-K choices follow the per-image geometry only (keep_conv2d_plan), so a clip's
+    # frames do not depend on its batch-mates: every frame of every checked clip must equal the solo run BIT FOR BIT.
     firsts = gpu_net.run_clips_u8([torch.from_numpy(np.stack(crops[s:s + 1])) for s, _ in spans], max_b=16)
     for ci, (s, e) in enumerate(spans):
-        assert close(firsts[ci].numpy()[0], faces_out[s]), ('frame 0 of clip', ci)
-    agree_frames = []
+        assert np.array_equal(firsts[ci].numpy()[0], faces_out[s]), ('frame 0 of clip', ci)
     for ci in sorted({0, len(spans) // 2, len(spans) - 1}):
         s, e = spans[ci]
         solo = gpu_net.run_clips_u8([torch.from_numpy(np.stack(crops[s:e]))], max_b=1)[0].numpy()
-        got = np.stack(faces_out[s:e])
-        n_ok = next((t for t in range(e - s) if not close(solo[t], got[t])), e - s)
-        agree_frames.append(n_ok)
-        assert n_ok >= 4, (ci, n_ok)
-    print(f'config {n_crops}/{faces}: frames equal to the solo run before the first index flip, per checked clip: {agree_frames}')
+        assert np.array_equal(solo, np.stack(faces_out[s:e])), ('clip', ci)
 
 
 def test_full_forward_asian_T2_vs_reference_golden():
@@ -295,6 +293,128 @@ def test_hipgraph_replay_is_bit_identical_to_eager(gpu_net):
         gpu_net.graph_mode = mode
 
 
+def test_graph_survives_a_policy_switch_and_auto_captures_on_second_use(gpu_net):
+    """(a) The per-forward bookkeeping block (status word + max|out| arena) lives as long as the net's Ops: a captured x3
+    graph must replay correctly after forwards under another policy (round 2 freed the arena on a policy switch and the
+    replay wrote through the dangling pointer).  (b) graph mode 'auto' runs the first occurrence of a shape eagerly and
+    captures on the second, so a shape seen once never pays for a capture."""
+    if gpu_net.precision != 'x3':
+        pytest.skip('x3 bookkeeping')
+    x = synth.synth_clip(T=2, B=1, seed=11).cuda()
+    mode = gpu_net.graph_mode
+    try:
+        gpu_net.graph_mode = '0'
+        eager = gpu_net(x)
+        gpu_net.graph_mode = 'auto'
+        gpu_net._graphs.clear()
+        gpu_net._graph_seen.clear()
+        a = gpu_net(x)
+        assert not gpu_net._graphs                        # first occurrence: eager
+        b = gpu_net(x)
+        assert len(gpu_net._graphs) == 1                  # second: captured + replayed
+        gpu_net.set_precision('fp32')
+        f32 = gpu_net(x)                                  # another policy in between (own graph key, same Ops block)
+        junk = [torch.randn(1 << 16, device='cuda') for _ in range(64)]   # allocator churn where the arena used to be freed
+        gpu_net.set_precision('x3')
+        c = gpu_net(x)                                    # replay of the x3 graph
+        assert torch.equal(eager, a) and torch.equal(eager, b) and torch.equal(eager, c)
+        assert torch.isfinite(f32).all() and len(junk) == 64
+    finally:
+        gpu_net.set_precision('x3')
+        gpu_net.graph_mode = mode
+
+
+def test_x3_overflow_on_the_index_chain_falls_back_to_f32(synth_weights):
+    """an fp16-range overflow that reaches the output ONLY through the arg-max (hq_encoder / Kalman update
+    / code transformer: every linear there is an un-probed `bounded` operand) used to select code 0 and paint a finite, wrong
+    frame.  Here one transformer MLP weight is scaled so that gelu(linear1) leaves the fp16 range on the x3 kernels: the
+    arg-max raises the status word, the batch is re-run on the exact-f32 kernels, and the result equals the fp32 policy's."""
+    from comfyui_keep_amd.engine.net import KeepNet
+    W = dict(synth_weights)
+    W['ft_layers.4.linear1.weight'] = W['ft_layers.4.linear1.weight'] * 3.0e5
+    W['ft_layers.4.linear2.weight'] = W['ft_layers.4.linear2.weight'] / 3.0e5      # the fp32 net stays O(1) downstream
+    x = synth.synth_clip(T=2, B=1, seed=21).cuda()
+    nets = {}
+    for pol in ('x3', 'fp32'):
+        n = KeepNet(**DEFAULT_ARCH)
+        n.load_state_dict(W, strict=True)
+        nets[pol] = n.to('cuda').eval().set_precision(pol)
+    ref = nets['fp32'](x)
+    assert torch.isfinite(ref).all() and nets['fp32'].x3_fallbacks == 0
+    got = nets['x3'](x)
+    assert nets['x3'].x3_fallbacks == 1
+    assert torch.equal(got, ref)
+    # the uint8 entry point (deferred check, two streams) takes the same decision
+    u8 = [torch.randint(0, 256, (2, 512, 512, 3), dtype=torch.uint8)]
+    r_x3 = nets['x3'].run_clips_u8(u8)[0]
+    r_32 = nets['fp32'].run_clips_u8(u8)[0]
+    assert nets['x3'].x3_fallbacks == 2 and torch.equal(r_x3, r_32)
+
+
+def _nccl_worker(rank, world, port, out_dir, n_clips):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), KEEP_DIST_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from __graft_entry__ import load_package
+    load_package()
+    from comfyui_keep_amd.engine import dist as kdist, synth as S
+    from comfyui_keep_amd.engine.arch import DEFAULT_ARCH as ARCH
+    from comfyui_keep_amd.engine.net import KeepNet
+    kdist.init_from_env(backend='nccl')
+    net = KeepNet(**ARCH)
+    if rank == 0:
+        net.load_state_dict(S.synth_state_dict(seed=0), strict=True)
+        net.to('cuda')
+        index, blob = net._index, net.packed_blob()
+    else:
+        index, blob = None, None
+    torch.cuda.synchronize()
+    torch.distributed.barrier()
+    t0 = time.perf_counter()
+    index, blob = kdist.broadcast_packed_weights(index, blob, src=0)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    if rank != 0:
+        net.adopt_packed(index, blob)
+    net.eval()
+    g = torch.Generator().manual_seed(5)
+    clips = [torch.randint(0, 256, (2 if c % 3 else 1, 512, 512, 3), generator=g, dtype=torch.uint8) for c in range(n_clips)]
+    res = net.run_clips_u8(clips, max_b=2)                         # sharded round-robin, gather to rank 0
+    if rank == 0:
+        print(f'broadcast_ms {ms:.1f} for {blob.numel() * 4 / 1e6:.0f} MB over RCCL ({world} ranks on one device)', flush=True)
+        np.savez(os.path.join(out_dir, 'sharded.npz'), *[r.numpy() for r in res], broadcast_ms=ms)
+    else:
+        assert res is None
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_over_rccl(tmp_path, synth_weights):
+    """The N > 1 product path on the hardware that is reachable: 2 ranks share device 0 (KEEP_DIST_DEVICE=0), backend nccl
+    = RCCL.  The real 633 MB packed blob goes through broadcast_packed_weights + adopt_packed, 6 ragged clips are sharded
+    by run_clips_u8 and collected with the uint8 tensor gather; the result must equal the single-process run bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    from comfyui_keep_amd.engine.net import KeepNet
+    with socket.socket() as sck:
+        sck.bind(('127.0.0.1', 0))
+        port = sck.getsockname()[1]
+    n_clips = 6
+    mp.spawn(_nccl_worker, args=(2, port, str(tmp_path), n_clips), nprocs=2, join=True)
+    got = np.load(tmp_path / 'sharded.npz')
+    print('RCCL weight broadcast, 2 ranks on one device:', float(got['broadcast_ms']), 'ms')
+    net = KeepNet(**DEFAULT_ARCH)
+    net.load_state_dict(synth_weights, strict=True)
+    net.to('cuda').eval()
+    g = torch.Generator().manual_seed(5)
+    clips = [torch.randint(0, 256, (2 if c % 3 else 1, 512, 512, 3), generator=g, dtype=torch.uint8) for c in range(n_clips)]
+    solo = net.run_clips_u8(clips, max_b=2)
+    for c in range(n_clips):
+        assert np.array_equal(got[f'arr_{c}'], solo[c].numpy()), c
+
+
 def test_batched_clips_equal_sequential(gpu_net):
     """Independent clips on the batch axis give the same result as one at a time (hot loop #1 semantics)."""
     x = torch.cat([synth.synth_clip(T=2, B=1, seed=1234), synth.synth_clip(T=2, B=1, seed=77, phase=1.0)], 0).cuda()
@@ -302,9 +422,13 @@ def test_batched_clips_equal_sequential(gpu_net):
     for b in range(2):
         one, aux1 = gpu_net(x[b:b + 1], return_aux=True)
         assert torch.equal(aux1['indices'][0], aux['indices'][b])
-        assert (one[0] - both[b]).abs().max().item() <= 5e-4   # split-K factors depend on the batch size
+        assert torch.equal(one[0], both[b])        # plans follow the per-image geometry: no dependence on batch-mates
     outs = gpu_net.run_clips([x[0:1], x[1:2]])
-    assert (outs[1] - both[1:2]).abs().max().item() <= 5e-4
+    assert torch.equal(outs[1], both[1:2])
+    # ... also across a very different batch (5 clips, the two above among them) and under graph replay of the solo run
+    x5 = torch.cat([x, synth.synth_clip(T=2, B=3, seed=5, phase=0.3).cuda()], 0)
+    five = gpu_net(x5)
+    assert torch.equal(five[:2], both)
 
 
 def test_processor_runs_on_engine(gpu_net):
@@ -363,7 +487,7 @@ def test_single_frame_fast_path_equals_frame0_of_duplicate(gpu_net):
     one = gpu_net(x)
     two = gpu_net(torch.cat([x, x], dim=1))
     assert one.shape == (2, 1, 3, 512, 512)
-    assert (one[:, 0] - two[:, 0]).abs().max().item() <= 5e-4      # split-K factors depend on the batch size
+    assert torch.equal(one[:, 0], two[:, 0])          # same per-image plans at N = 2 and N = 4 frames
     import test_host_logic as H   # installs the ComfyUI stubs
     from comfyui_keep_amd.modules.keep_processor import KEEPFaceProcessor
     from comfyui_keep_amd.modules.keep_model_loader import KEEPModelPack
@@ -381,7 +505,7 @@ def test_single_frame_fast_path_equals_frame0_of_duplicate(gpu_net):
 
     proc.keep_net = NoT1(gpu_net)
     dup = proc._restore_crops_u8(crop, 20)
-    assert np.abs(fast[0].astype(np.int16) - dup[0].astype(np.int16)).max() <= 1     # uint8 rounding of <=5e-4 differences
+    assert np.array_equal(fast[0], dup[0])
 
 
 def test_bf16_policy_quality_report(gpu_net):
@@ -418,7 +542,7 @@ def test_need_upscale_runs_on_the_device(gpu_net):
     up = torch.nn.functional.interpolate(x.flatten(0, 1), scale_factor=4, mode='bilinear').unflatten(0, (1, 1))
     a = gpu_net(x, need_upscale=True)
     b = gpu_net(up.contiguous(), need_upscale=False)
-    assert a.shape == (1, 1, 3, 512, 512) and (a - b).abs().max().item() <= 5e-4
+    assert a.shape == (1, 1, 3, 512, 512) and (a - b).abs().max().item() <= 5e-4     # (keep_bilinear_upscale vs torch's interpolate)
 
 
 def test_weights_stay_resident_across_offload(monkeypatch, synth_weights):

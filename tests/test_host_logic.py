@@ -294,6 +294,85 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.keep_conv2d(None, None) == -1 and b'null args' in lib.keep_last_error()
 
 
+def _header_struct_fields(header, name):
+    """Field names of `typedef struct { ... } name;` in declaration order (comments stripped, `a, b, c;` lists expanded)."""
+    end = re.search(r'\}\s*' + name + r'\s*;', header).start()
+    body = header[header.rindex('typedef struct {', 0, end) + len('typedef struct {'):end]
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    names = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *rest = decl.split(',')
+        m = re.search(r'(\w+)\s*(\[\d+\])?$', first.strip())
+        names.append(m.group(1))
+        names += [r.strip().lstrip('*').strip() for r in rest]
+    return names
+
+
+def test_abi_struct_layouts_match_header_library_and_doc():
+    """The three descriptions of the argument structs -- include/keep_hip.h, the ctypes binding, the built library -- and
+    the copy printed in INTEGRATION.md agree: field names and order (header vs binding), byte size (binding vs
+    keep_sizeof_*_args() of the built .so), documented listing (generated from the binding, tools/gen_abi_doc.py)."""
+    from comfyui_keep_amd.engine import hiplib
+    header = open(os.path.join(ROOT, 'include', 'keep_hip.h')).read()
+    assert int(re.search(r'#define KEEP_ABI_VERSION (\d+)', header).group(1)) == hiplib.ABI_VERSION
+    rename = {'inp': 'in'}
+    for cname, cls in (('keep_conv2d_args', hiplib.ConvArgs), ('keep_conv2d_plan_out', hiplib.ConvPlanOut),
+                       ('keep_attention_args', hiplib.AttnArgs)):
+        assert [rename.get(n, n) for n, _ in cls._fields_] == _header_struct_fields(header, cname), cname
+    lib = ctypes.CDLL(hiplib.LIB_PATH)
+    lib.keep_sizeof_conv2d_args.restype = lib.keep_sizeof_attention_args.restype = ctypes.c_int32
+    assert lib.keep_sizeof_conv2d_args() == ctypes.sizeof(hiplib.ConvArgs)
+    assert lib.keep_sizeof_attention_args() == ctypes.sizeof(hiplib.AttnArgs)
+    assert hiplib.ConvArgs._fields_[0][0] == 'struct_size' and hiplib.AttnArgs._fields_[0][0] == 'struct_size'
+    # the v12 minimum sizes the header promises to keep accepting are not larger than today's structs
+    for macro, cls in (('KEEP_CONV2D_ARGS_V12_SIZE', hiplib.ConvArgs), ('KEEP_ATTENTION_ARGS_V12_SIZE', hiplib.AttnArgs)):
+        assert int(re.search(rf'#define {macro} (\d+)', header).group(1)) <= ctypes.sizeof(cls)
+    # a struct_size the library does not know is refused before anything is read
+    lib.keep_last_error.restype = ctypes.c_char_p
+    lib.keep_conv2d_plan.restype = ctypes.c_int32
+    a, out = hiplib.ConvArgs(), hiplib.ConvPlanOut()
+    for bad in (0, 128, ctypes.sizeof(hiplib.ConvArgs) + 8):
+        a.struct_size = bad
+        assert lib.keep_conv2d_plan(ctypes.byref(a), ctypes.byref(out)) == -1 and b'struct_size' in lib.keep_last_error()
+    # the plan query itself is host-side C: a well-formed struct is answered without a GPU
+    a = hiplib.ConvArgs(struct_size=ctypes.sizeof(hiplib.ConvArgs), N=2, H=64, W=64, Cin=128, Cout=128, KH=3, KW=3, stride=1,
+                        pad_t=1, pad_l=1, Ho=64, Wo=64, in_ld=128, out_ld=128, mma=hiplib.MMA_F32)
+    assert lib.keep_conv2d_plan(ctypes.byref(a), ctypes.byref(out)) == 0, lib.keep_last_error()
+    assert out.kernel.decode().startswith('conv3x3_halo_f32_kernel')
+
+
+def test_integration_doc_matches_the_binding():
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import gen_abi_doc
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    a, b = doc.index(gen_abi_doc.BEGIN), doc.index(gen_abi_doc.END) + len(gen_abi_doc.END)
+    assert doc[a:b] == gen_abi_doc.block(), "INTEGRATION.md section 3 is stale: run python tools/gen_abi_doc.py"
+
+
+def test_plan_is_batch_invariant_in_the_parity_policies():
+    """keep_conv2d_plan (host-side C, no GPU needed): under the exact-f32 policy the split-K factor, the kernel and the
+    statistics partition of a layer are the same for 1, 3, 16 and 320 images -- a clip's sums never depend on its
+    batch-mates."""
+    from comfyui_keep_amd.engine import hiplib
+    lib = ctypes.CDLL(hiplib.LIB_PATH)
+    lib.keep_conv2d_plan.restype = ctypes.c_int32
+    lib.keep_last_error.restype = ctypes.c_char_p
+    geoms = [(16, 16, 512, 512, 3), (32, 32, 256, 256, 3), (64, 64, 256, 128, 3), (256, 256, 128, 128, 3), (256, 1, 512, 1024, 1),
+             (4096, 1, 128, 384, 1), (16, 16, 512, 1536, 1)]
+    for H, W, Cin, Cout, k in geoms:
+        seen = set()
+        for N in (1, 3, 16, 320):
+            a = hiplib.ConvArgs(struct_size=ctypes.sizeof(hiplib.ConvArgs), N=N, H=H, W=W, Cin=Cin, Cout=Cout, KH=k, KW=k,
+                                stride=1, pad_t=k // 2, pad_l=k // 2, Ho=H, Wo=W, in_ld=Cin, out_ld=Cout, mma=hiplib.MMA_F32)
+            out = hiplib.ConvPlanOut()
+            assert lib.keep_conv2d_plan(ctypes.byref(a), ctypes.byref(out)) == 0, lib.keep_last_error()
+            seen.add((out.split_k, out.kernel, out.stats_rows, out.stats_P))
+        assert len(seen) == 1, (H, W, Cin, Cout, k, seen)
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, 'comfyui-keep_amd')
     for dirpath, _, files in os.walk(pkg):

@@ -118,3 +118,24 @@ def test_full_forward_T3_vs_golden(synth_weights):
     assert np.array_equal(aux['indices'][0].numpy().astype(np.int16)[safe], g['indices'][safe])
     assert np.abs(aux['gains'][0, :, 0].reshape(3, -1).numpy() - g['gains']).max() <= 1e-4
     assert np.abs(_digest(out[0]) - g['out_grid']).max() <= 3e-4
+
+
+@pytest.mark.slow
+def test_full_forward_T20_vs_golden(synth_weights):
+    """The metric's own clip length on the CPU oracle against the imported reference (tests/golden/keep_forward_T20.npz):
+    code indices wherever the reference's margin exceeds 1e-3, frame by frame up to the first frame with any differing
+    token (beyond it the two runs restore different inputs), gains, and every digest pixel of those frames within an
+    ABSOLUTE 1e-3 (the synthetic net's frames live in [-1.3, 1])."""
+    g = np.load(os.path.join(GOLDEN, 'keep_forward_T20.npz'))
+    x = synth.synth_clip(T=20, B=1, seed=1234)
+    out, aux = O.keep_forward(x, synth_weights, return_aux=True)
+    idx = aux['indices'][0].numpy().astype(np.int16)
+    agree = idx == g['indices']
+    first = next((t for t in range(20) if not agree[t].all()), 20)
+    assert np.abs(aux['gains'][0, :, 0].reshape(20, -1).numpy() - g['gains']).max() <= 1e-4
+    for t in range(min(first + 1, 20)):
+        assert agree[t][g['margins'][t] > 1e-3].all(), t
+    assert first >= 1
+    err = np.abs(_digest(out[0])[:first] - g['out_grid'][:first]).max()
+    print('oracle vs reference, T=20: first frame with a differing index', first, '; max-abs digest diff before it', err)
+    assert err <= 1e-3, err

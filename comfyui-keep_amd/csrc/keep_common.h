@@ -35,8 +35,8 @@ __device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f :
 
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
-    case KEEP_ACT_RELU: return v > 0.f ? v : 0.f;
-    case KEEP_ACT_LRELU02: return v > 0.f ? v : 0.2f * v;
+    case KEEP_ACT_RELU: return relu_keep_nan(v);   // (NaN < 0 is false: a NaN stays a NaN)
+    case KEEP_ACT_LRELU02: return v < 0.f ? 0.2f * v : v;
     case KEEP_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     case KEEP_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
     default: return v;
@@ -55,8 +55,8 @@ __device__ __forceinline__ float erf_fast(float x) {
 
 __device__ __forceinline__ float act_apply_fast(float v, int act) {
   switch (act) {
-    case KEEP_ACT_RELU: return v > 0.f ? v : 0.f;
-    case KEEP_ACT_LRELU02: return v > 0.f ? v : 0.2f * v;
+    case KEEP_ACT_RELU: return relu_keep_nan(v);   // (NaN < 0 is false: a NaN stays a NaN)
+    case KEEP_ACT_LRELU02: return v < 0.f ? 0.2f * v : v;
     case KEEP_ACT_GELU: return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f));
     case KEEP_ACT_SIGMOID: return __frcp_rn(1.0f + __expf(-v));
     default: return v;
@@ -72,12 +72,12 @@ __device__ __forceinline__ float swish_x3(float v) {
 }
 __device__ __forceinline__ float pro_apply_x3(float v, int act) {
   if (act == KEEP_PRO_SWISH) return swish_x3(v);
-  if (act == KEEP_PRO_RELU) return v > 0.f ? v : 0.f;
+  if (act == KEEP_PRO_RELU) return relu_keep_nan(v);
   return v;
 }
 
 __device__ __forceinline__ float pro_apply(float v, int act) {
   if (act == KEEP_PRO_SWISH) return v * (1.0f / (1.0f + expf(-v)));
-  if (act == KEEP_PRO_RELU) return v > 0.f ? v : 0.f;
+  if (act == KEEP_PRO_RELU) return relu_keep_nan(v);
   return v;
 }

@@ -292,7 +292,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 __device__ __forceinline__ float pro_apply_fast(float v, int act) {
   if (act == KEEP_PRO_SWISH) return v * __frcp_rn(1.0f + __expf(-v));
-  if (act == KEEP_PRO_RELU) return v > 0.f ? v : 0.f;
+  if (act == KEEP_PRO_RELU) return relu_keep_nan(v);
   return v;
 }
 
@@ -1741,6 +1741,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   p.in2 = (const float*)a->in2;
   p.cin1 = a->in2_cin1;
   p.out_amax = nullptr;
+  p.bk_prio = 0;
   p.bias = a->bias;
   p.out = (float*)a->out;
   p.pro_scale = a->pro_scale;

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void norm_act_bf16_kernel(const void* __restri
       for (int j = 0; j < 8; ++j) {
         float t = v[u][j];
         if (ACT == KEEP_PRO_SWISH) t = t * __frcp_rn(1.0f + __expf(-t));
-        else if (ACT == KEEP_PRO_RELU) t = t > 0.f ? t : 0.f;
+        else if (ACT == KEEP_PRO_RELU) t = relu_keep_nan(t);
         h[j] = (__bf16)t;
       }
       out[i] = h;
@@ -320,9 +320,9 @@ __global__ void gm_join_kernel(const float* __restrict__ a, const float* __restr
     float xa = a[i];
     if (sa) xa = xa * sa[n * C + c] + ha[n * C + c];
     float yb = b[i] * sb[n * C + c] + hb[n * C + c];
-    yb = yb > 0.f ? yb : 0.f;
+    yb = relu_keep_nan(yb);
     const float v = xa + yb;
-    out[i] = v > 0.f ? v : 0.f;
+    out[i] = relu_keep_nan(v);
   }
 }
 

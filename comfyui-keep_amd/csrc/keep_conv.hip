@@ -1741,7 +1741,6 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   p.in2 = (const float*)a->in2;
   p.cin1 = a->in2_cin1;
   p.out_amax = nullptr;
-  p.bk_prio = 0;
   p.bias = a->bias;
   p.out = (float*)a->out;
   p.pro_scale = a->pro_scale;

@@ -41,7 +41,6 @@ struct ConvP {
   const float* in2;           // KEEP_MMA_X3 GEMM form: second K-concatenated input (channels >= cin1), dense rows, or NULL
   int cin1;
   unsigned* out_amax;         // KEEP_MMA_X3: per-image max |output| as raw float bits (atomicMax), or NULL
-  int bk_prio;                // dev switch (KEEP_X3S_PRIO): consumer waves of the specialised halo kernel raise their priority
 };
 
 // zero-fill of the small atomicMax targets as a KERNEL node: inside a captured hipGraph a hipMemsetAsync node was observed to

@@ -415,311 +415,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
 #undef KEEP_T
 }
 
-// ------------------------------------------------------------------------------------------------ 3x3 halo, wave-specialised
-// The same arithmetic as conv3x3_halo_x3_kernel (same chunk / tap / MFMA order: bit-identical results, same statistics partials)
-// with the two halves of the work on DIFFERENT waves of one 512-thread block (one block per CU, two waves per SIMD):
-//   waves 4-7 PRODUCERS  fetch the fp32 halo + the pre-split weight rows of chunk c+1 (buffer loads), apply the GroupNorm affine
-//                        + swish, split into (hi, lo) and write the LDS stage image -- all the VALU / VMEM / ds_write work;
-//   waves 0-3 CONSUMERS  read fragments of chunk c from the OTHER stage buffer and issue the 108 MFMAs per chunk, nothing else,
-//                        then run the epilogue of their 64 x 64 tile through a wave-private 8-pixel scratch.
-// One raw s_barrier per chunk hands a stage over (producers wait lgkmcnt(0) only: their prefetch loads of chunk c+2 stay in
-// flight across it).  In the single-role kernel a wave alternates fetch-issue / stage / MFMA / epilogue phases and the matrix
-// pipe only runs while one of the CU's two blocks happens to be in its MFMA phase (37 % of a wave's time, s_memtime timeline in
-// DESIGN.md); here the consumer wave of every SIMD is in its MFMA loop except during its epilogue, and the producer wave's VALU
-// issues underneath it.  LDS: 2 stages x 73,280 B + 4 x 2,176 B scratch = 155,264 B.
-template <int TW, int PRO, bool SIMPLE_EPI, bool FASTACT = true>
-__global__ __launch_bounds__(512, 1) void conv3x3_halo_x3s_kernel(ConvP p, int tiles_x, int tiles_y, int ncb, int n_items) {
-  constexpr int HALO_TH = 256 / TW, HALO_W = TW + 2, HALO_PIX = (HALO_TH + 2) * HALO_W;
-  constexpr int RPT = 32 / TW;
-  constexpr int STAGE_H = (HALO_MAXPIX + 9 * 64) * XPITCH;      // fp16 elements per stage (halo rows, then 9 x 64 weight rows)
-  constexpr int EPX = 68;                                       // floats per scratch row (64 channels + pad)
-  constexpr int SCR_F = 8 * EPX;                                // floats per consumer wave: 8 pixels x 64 channels
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * STAGE_H * 2 + 4 * SCR_F * 4];
-  _Float16* const stage0 = reinterpret_cast<_Float16*>(lds_raw);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int items_per_z = n_items / p.split_k;
-  const int Hv = p.upsample ? 2 * p.H : p.H;
-  const int Wv = p.upsample ? 2 * p.W : p.W;
-
-  if (wave >= 4) {
-    // ================================================================================================ producers
-    const int pt = tid - 256;
-    const int g = pt & 3;
-    const bool has_pro = p.pro_scale != nullptr || PRO != KEEP_PRO_NONE;
-    int h_voff[HALO_IT];
-    int w_voff = -16;
-    long sc_off = 0;
-    float in_s = 1.f, in_inv = 1.f;
-    __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.wx3, 0, p.Cout * 9 * p.Cin * 4, 0x00020000);
-    auto setup = [&](const HaloItem& it) {
-      if (p.in_amax) x3_range_scale(p.in_amax[it.n], in_s, in_inv);
-#pragma unroll
-      for (int k = 0; k < HALO_IT; ++k) {
-        const int hp = (pt >> 2) + k * 64;
-        h_voff[k] = -16;
-        if (hp < HALO_PIX) {
-          const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-          const int iy = it.oy0 - 1 + hy, ix = it.ox0 - 1 + hx;
-          if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
-            const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
-            h_voff[k] = ((sy * p.W + sx) * p.in_ld + g * 4) * 4;
-          }
-        }
-      }
-      const unsigned long long base = (unsigned long long)(p.in + (long)it.n * p.H * p.W * p.in_ld);
-      const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
-      in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)bhi << 32) | blo), 0, p.H * p.W * p.in_ld * 4, 0x00020000);
-      sc_off = (long)it.n * p.Cin + g * 4;
-      w_voff = (it.n0 + (pt >> 2)) < p.Cout ? ((it.n0 + (pt >> 2)) * 9 * p.Cin * 2 + g * 8) * 2 : -16;
-    };
-    float4 hreg[HALO_IT];
-    uint4 wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7, wr8;
-    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto fetch = [&](int ch) {
-      const int c0 = ch << 4;
-#pragma unroll
-      for (int k = 0; k < HALO_IT; ++k) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, h_voff[k], c0 * 4, 0);
-        hreg[k] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-      }
-#define KEEP_WLOADX(TAP, R)                                                                                  \
-  {                                                                                                          \
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff, ((TAP) * p.Cin + c0) * 4, 0);      \
-    R = make_uint4(v.x, v.y, v.z, v.w);                                                                      \
-  }
-      KEEP_TAPS(KEEP_WLOADX)
-#undef KEEP_WLOADX
-      if (p.pro_scale) {
-        sc4 = *reinterpret_cast<const float4*>(p.pro_scale + sc_off + c0);
-        sh4 = *reinterpret_cast<const float4*>(p.pro_shift + sc_off + c0);
-      }
-    };
-    auto stage = [&](_Float16* Hs) {
-      _Float16* Ws = Hs + HALO_MAXPIX * XPITCH;
-#pragma unroll
-      for (int k = 0; k < HALO_IT; ++k) {
-        const int hp = (pt >> 2) + k * 64;
-        if (hp < HALO_PIX) {
-          float v[4] = {hreg[k].x, hreg[k].y, hreg[k].z, hreg[k].w};
-          if (has_pro && h_voff[k] >= 0) {      // zero padding applies to the normalised + activated tensor
-            v[0] = pro_x3<PRO, FASTACT>(v[0] * sc4.x + sh4.x);
-            v[1] = pro_x3<PRO, FASTACT>(v[1] * sc4.y + sh4.y);
-            v[2] = pro_x3<PRO, FASTACT>(v[2] * sc4.z + sh4.z);
-            v[3] = pro_x3<PRO, FASTACT>(v[3] * sc4.w + sh4.w);
-          }
-          if (PRO == KEEP_PRO_NONE && p.in_amax) {
-            v[0] *= in_s; v[1] *= in_s; v[2] *= in_s; v[3] *= in_s;
-          }
-          f16x4 hi, lo;
-          split4(v, hi, lo);
-          *reinterpret_cast<f16x4*>(&Hs[hp * XPITCH + g * 4]) = hi;
-          *reinterpret_cast<f16x4*>(&Hs[hp * XPITCH + 16 + g * 4]) = lo;
-        }
-      }
-#define KEEP_WSTOREX(TAP, R) *reinterpret_cast<uint4*>(&Ws[((TAP) * 64 + (pt >> 2)) * XPITCH + g * 8]) = R;
-      KEEP_TAPS(KEEP_WSTOREX)
-#undef KEEP_WSTOREX
-    };
-    // cursor over this block's (item, chunk) sequence; items with an empty chunk range (ragged split-K) have no stages
-    int item = blockIdx.x;
-    HaloItem cur;
-    int ch = 0;
-    bool valid = false;
-    auto seek = [&]() {                         // first item from `item` on with a non-empty chunk range
-      valid = false;
-      while (item < n_items) {
-        cur = halo_decode<TW, 4>(p, item, items_per_z, tiles_x, tiles_y, ncb);
-        if (cur.ch_begin < cur.ch_end) {
-          ch = cur.ch_begin;
-          valid = true;
-          return;
-        }
-        item += gridDim.x;
-      }
-    };
-    seek();
-    if (valid) {
-      setup(cur);
-      fetch(ch);
-    }
-    int seq = 0;
-    while (valid) {
-      stage(stage0 + (seq & 1) * STAGE_H);      // (the compiler waits for this chunk's loads in front of their first use)
-      if (++ch >= cur.ch_end) {                 // next (item, chunk): its loads fly while the consumers multiply this one
-        item += gridDim.x;
-        seek();
-        if (valid) setup(cur);
-      }
-      if (valid) fetch(ch);
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // stage `seq` is complete in LDS
-      ++seq;
-    }
-    return;
-  }
-
-  // ================================================================================================== consumers
-  if (p.bk_prio) __builtin_amdgcn_s_setprio(3);
-  const int l31 = lane & 31, lhi = lane >> 5;
-  f32x16 acc[2][2];
-  const int a_base = (((2 * wave) * RPT + l31 / TW) * HALO_W + (l31 % TW)) * XPITCH + lhi * 8;
-  const int b_base = l31 * XPITCH + lhi * 8;
-  auto mma = [&](const _Float16* Hs) {
-    const _Float16* Ws = Hs + HALO_MAXPIX * XPITCH;
-    f16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const _Float16* src = &Hs[a_base + ((i * RPT + kh) * HALO_W + kw) * XPITCH];
-          ah[i] = *reinterpret_cast<const f16x8*>(src);
-          al[i] = *reinterpret_cast<const f16x8*>(src + 16);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const _Float16* src = &Ws[b_base + ((kh * 3 + kw) * 64 + j * 32) * XPITCH];
-          bh[j] = *reinterpret_cast<const f16x8*>(src);
-          bl[j] = *reinterpret_cast<const f16x8*>(src + 16);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            MMA_X3(acc[i][j], ah[i], al[i], bh[j], bl[j])
-          }
-      }
-    }
-  };
-  auto make_rsrc = [&](const void* ptr, int bytes) {
-    const unsigned long long b = (unsigned long long)ptr;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
-  };
-  // Epilogue: as conv3x3_halo_x3_kernel's, through a wave-private scratch of 8 pixels x 64 channels (8 rounds): a round parks
-  // accumulator rows 8q..8q+7 of pixel block i, the wave reads them back channel-contiguous (two 16-byte pieces per lane) and
-  // stores them; sums are taken in the same order as in the single-role kernel (q16 ascending), so the statistics match bit for bit.
-  float* const et = reinterpret_cast<float*>(lds_raw + 2 * STAGE_H * 2) + wave * SCR_F;
-  auto epilogue_t = [&](const HaloItem& it, float item_inv, auto res_c) {
-    constexpr bool HAS_RES = decltype(res_c)::value;
-    const float asc = p.acc_scale * item_inv;
-    const int c4 = (lane & 15) * 4, prow = lane >> 4;
-    const int co = it.n0 + c4;
-    const bool cok = co < p.Cout;
-    const int hw_o = p.Ho * p.Wo;
-    const int pix_b = (it.oy0 + 2 * wave * RPT) * p.Wo + it.ox0 + prow;
-    const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc(p.out + (long)it.n * hw_o * p.out_ld, hw_o * p.out_ld * 4);
-    const int v_out = cok ? (pix_b * p.out_ld + co) * 4 : -16;
-    __amdgpu_buffer_rsrc_t res_rsrc = out_rsrc, aux_rsrc = out_rsrc;
-    int v_res = -16, v_aux = -16;
-    if (HAS_RES) {
-      res_rsrc = make_rsrc(p.res + (long)it.n * hw_o * p.res_ld, hw_o * p.res_ld * 4);
-      v_res = cok ? (pix_b * p.res_ld + co) * 4 : -16;
-      if (!SIMPLE_EPI && p.aux) {
-        aux_rsrc = make_rsrc(p.aux + (long)it.n * hw_o * p.Cout, hw_o * p.Cout * 4);
-        v_aux = cok ? (pix_b * p.Cout + co) * 4 : -16;
-      }
-    }
-    float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
-    float amx = 0.f;
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
-#pragma unroll
-    for (int rd = 0; rd < 8; ++rd) {            // round rd: pixel block i = rd >> 2, accumulator rows q = rd & 3
-      const int i = rd >> 2, q = rd & 3;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) et[(r + 4 * lhi) * EPX + j * 32 + l31] = acc[i][j][q * 4 + r] * asc;
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int q16 = rd * 2 + h;
-        const int drow = (q16 >> 3) * RPT + (TW == 32 ? 0 : ((q16 & 7) >> 2));
-        const int dcol = TW == 32 ? (q16 & 7) * 4 : (q16 & 3) * 4;
-        const int dpix = drow * p.Wo + dcol;
-        const float4 v = *reinterpret_cast<const float4*>(et + (h * 4 + prow) * EPX + c4);
-        if (!SIMPLE_EPI && p.split_k > 1) {
-          if (cok) {
-            const long m = (long)it.n * hw_o + pix_b + dpix;
-            *reinterpret_cast<float4*>(p.ws + ((long)it.z * p.M + m) * p.Cout + co) = v;
-          }
-          continue;
-        }
-        float e[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
-        if (!SIMPLE_EPI) {
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) e[qq] = p.fast ? act_apply_fast(e[qq], p.epi_act) : act_apply(e[qq], p.epi_act);
-        }
-        if (HAS_RES) {
-          const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, v_res, dpix * p.res_ld * 4, 0);
-          const float rr[4] = {__uint_as_float(r4.x), __uint_as_float(r4.y), __uint_as_float(r4.z), __uint_as_float(r4.w)};
-          if (!SIMPLE_EPI && p.aux) {
-            const u32x4 a4 = __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, v_aux, dpix * p.Cout * 4, 0);
-            const float aa[4] = {__uint_as_float(a4.x), __uint_as_float(a4.y), __uint_as_float(a4.z), __uint_as_float(a4.w)};
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) e[qq] = rr[qq] + p.aux_w * (rr[qq] * aa[qq] + e[qq]);
-          } else {
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) e[qq] += rr[qq];
-          }
-        }
-        u32x4 o;
-        o.x = __float_as_uint(e[0]); o.y = __float_as_uint(e[1]); o.z = __float_as_uint(e[2]); o.w = __float_as_uint(e[3]);
-        __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, v_out, dpix * p.out_ld * 4, 0);
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          s4[qq] += e[qq];
-          ss4[qq] += e[qq] * e[qq];
-          amx = fmaxf(amx, fabsf(e[qq]));
-        }
-      }
-    }
-    if (p.out_amax) wave_amax_commit(p.out_amax + it.n, amx);
-    if (p.stats) {
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        s4[qq] = xor32_sum(xor16_sum(s4[qq]));
-        ss4[qq] = xor32_sum(xor16_sum(ss4[qq]));
-      }
-      if (lane < 16 && cok) {
-        float* dst = p.stats + (((long)it.n * p.stats_P + (it.ty * tiles_x + it.tx) * 4 + wave) * p.Cout + co) * 2;
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          dst[qq * 2 + 0] = s4[qq];
-          dst[qq * 2 + 1] = ss4[qq];
-        }
-      }
-    }
-  };
-  int seq = 0;
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const HaloItem it = halo_decode<TW, 4>(p, item, items_per_z, tiles_x, tiles_y, ncb);
-    float in_s = 1.f, in_inv = 1.f;
-    if (p.in_amax) x3_range_scale(p.in_amax[it.n], in_s, in_inv);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int ch = it.ch_begin; ch < it.ch_end; ++ch) {
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // stage `seq` complete; stage seq-1 free for the producers
-      mma(stage0 + (seq & 1) * STAGE_H);
-      ++seq;
-    }
-    if (p.res)
-      epilogue_t(it, in_inv, std::true_type{});
-    else
-      epilogue_t(it, in_inv, std::false_type{});
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ gather GEMM, split fp16
 // Everything that is not a 3x3 stride-1 convolution on a tileable map: token GEMMs, 1x1 convs, stride-2 convs.  Implicit
 // GEMM like conv_bf16_kernel: K step = 32 channels of one tap; LDS rows [hi x32 | lo x32 | pad x8] at a 144-byte pitch (9 slots:
@@ -1399,39 +1094,6 @@ int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
 #undef KEEP_LAUNCH_ABL
   }
 #endif
-  {
-    const char* x3s_env = getenv("KEEP_X3S");                                            // (read per call: A/B runs flip it)
-    const int x3s_mode = x3s_env ? atoi(x3s_env) : -1;                                   // -1 auto, 0 never, 1 always
-    const bool use_s = x3s_mode == 1 || (x3s_mode < 0 && n_items >= 2 * n_cu);
-    if (use_s) {
-      p.bk_prio = getenv("KEEP_X3S_PRIO") ? 1 : 0;
-      dim3 grid_s(n_items < n_cu ? n_items : n_cu), block_s(512);
-#define KEEP_LAUNCH_SX2(TWV, PROV, FA)                                                                                              \
-  if (simple)                                                                                                                       \
-    hipLaunchKernelGGL((conv3x3_halo_x3s_kernel<TWV, PROV, true, FA>), grid_s, block_s, 0, st, p, tiles_x, tiles_y, ncb, n_items);  \
-  else                                                                                                                              \
-    hipLaunchKernelGGL((conv3x3_halo_x3s_kernel<TWV, PROV, false, FA>), grid_s, block_s, 0, st, p, tiles_x, tiles_y, ncb, n_items);
-#define KEEP_LAUNCH_SX(TWV)                                       \
-  if (a->pro_act == KEEP_PRO_SWISH && !p.fast) {                  \
-    KEEP_LAUNCH_SX2(TWV, KEEP_PRO_SWISH, false)                   \
-  } else if (a->pro_act == KEEP_PRO_SWISH) {                      \
-    KEEP_LAUNCH_SX2(TWV, KEEP_PRO_SWISH, true)                    \
-  } else if (a->pro_act == KEEP_PRO_RELU) {                       \
-    KEEP_LAUNCH_SX2(TWV, KEEP_PRO_RELU, true)                     \
-  } else {                                                        \
-    KEEP_LAUNCH_SX2(TWV, KEEP_PRO_NONE, true)                     \
-  }
-      if (wide) {
-        KEEP_LAUNCH_SX(32)
-      } else {
-        KEEP_LAUNCH_SX(16)
-      }
-#undef KEEP_LAUNCH_SX
-#undef KEEP_LAUNCH_SX2
-      KEEP_LAUNCH_CHECK("keep_conv2d(halo x3, wave-specialised)");
-      return KEEP_OK;
-    }
-  }
 #define KEEP_LAUNCH_HX2(TWV, PROV)                                                                                          \
   if (simple)                                                                                                              \
     hipLaunchKernelGGL((conv3x3_halo_x3_kernel<TWV, PROV, true>), grid, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);  \

@@ -775,10 +775,13 @@ __global__ void flow_warp_kernel(const float* __restrict__ x, const float* __res
     const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
     const float tx = sx - x0f, ty = sy - y0f;
     const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
-    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    // a non-finite flow must not read as "sample outside the image" (zeros): it poisons the pixel, like torch's grid_sample;
+    // its int conversions are meaningless (x0 + 1 may wrap), so no tap is read at all
+    const bool fin = fabsf(fx) <= 3.0e38f && fabsf(fy) <= 3.0e38f;
+    const bool vx0 = fin && x0 >= 0 && x0 < W, vx1 = fin && x0 >= -1 && x0 < W - 1;
+    const bool vy0 = fin && y0 >= 0 && y0 < H, vy1 = fin && y0 >= -1 && y0 < H - 1;
     const float* xb = x + (long)n * H * W * C;
-    // a non-finite flow must not read as "sample outside the image" (zeros): it poisons the pixel, like torch's grid_sample
-    const float poison = (fabsf(fx) <= 3.0e38f && fabsf(fy) <= 3.0e38f) ? 0.f : __builtin_nanf("");
+    const float poison = fin ? 0.f : __builtin_nanf("");
     for (int c = 0; c < C; ++c) {
       float acc = poison;
       if (vy0 && vx0) acc += xb[((long)y0 * W + x0) * C + c] * w00;

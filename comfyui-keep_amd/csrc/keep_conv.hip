@@ -100,8 +100,9 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
         if (a_mvalid && kk < ktot) {
           const int tp = kk / p.Cin, c = kk - tp * p.Cin;
           const int kh2 = tp / p.KW, kw2 = tp - kh2 * p.KW;
-          const int iy = a_oy * p.stride - p.pad_t + kh2;
-          const int ix = a_ox * p.stride - p.pad_l + kw2;
+          int iy = a_oy * p.stride - p.pad_t + kh2;
+          int ix = a_ox * p.stride - p.pad_l + kw2;
+          KEEP_REFLECT(iy, ix, Hv, Wv)
           if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
             const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
             v = p.in[(((long)a_n * p.H + sy) * p.W + sx) * p.in_ld + c];
@@ -119,8 +120,9 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvP p) {
     const int kh = tap / p.KW;
     const int kw = tap - kh * p.KW;
     // ---- A
-    const int iy = a_oy * p.stride - p.pad_t + kh;
-    const int ix = a_ox * p.stride - p.pad_l + kw;
+    int iy = a_oy * p.stride - p.pad_t + kh;
+    int ix = a_ox * p.stride - p.pad_l + kw;
+    KEEP_REFLECT(iy, ix, Hv, Wv)
     a_ok = a_mvalid && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
     const int sy = (!PLAIN && p.upsample) ? (iy >> 1) : iy;
     const int sx = (!PLAIN && p.upsample) ? (ix >> 1) : ix;
@@ -1195,7 +1197,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(ConvP p, int t
       h_off[k] = -1;
       if (hp < HALO_PIX) {
         const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-        const int iy = it.oy0 - 1 + hy, ix = it.ox0 - 1 + hx;
+        int iy = it.oy0 - 1 + hy, ix = it.ox0 - 1 + hx;
+        KEEP_REFLECT(iy, ix, Hv, Wv)
         if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
           const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
           h_off[k] = (sy * p.W + sx) * p.in_ld + g * 4;
@@ -1720,6 +1723,15 @@ static int validate_conv(const keep_conv2d_args* a) {
                  "keep_conv2d: output extent %dx%d inconsistent with input %dx%d", a->Ho, a->Wo, Hv, Wv);
   }
   KEEP_REQUIRE(a->mma == KEEP_MMA_F32 || a->mma == KEEP_MMA_BF16 || a->mma == KEEP_MMA_X3, "keep_conv2d: bad mma %d", a->mma);
+  KEEP_REQUIRE(a->pad_mode == KEEP_PAD_ZERO || a->pad_mode == KEEP_PAD_REFLECT, "keep_conv2d: bad pad_mode %d", a->pad_mode);
+  if (a->pad_mode == KEEP_PAD_REFLECT) {
+    const int Hv = a->upsample ? 2 * a->H : a->H, Wv = a->upsample ? 2 * a->W : a->W;
+    if (a->mma == KEEP_MMA_BF16 || a->dtype != KEEP_F32 || a->pad_t != a->pad_l || a->pad_t >= Hv || a->pad_t >= Wv ||
+        a->pad_t != a->KH / 2 || a->KH != a->KW) {
+      keep_set_error("keep_conv2d: KEEP_PAD_REFLECT needs fp32 tensors, KEEP_MMA_F32 / KEEP_MMA_X3, a square odd kernel and pad_t == pad_l == KH/2 < min(H, W)");
+      return KEEP_EUNSUP;
+    }
+  }
   KEEP_REQUIRE((long)a->N * a->Ho * a->Wo < (1L << 31), "keep_conv2d: M too large");
   return KEEP_OK;
 }
@@ -1741,6 +1753,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   p.in2 = (const float*)a->in2;
   p.cin1 = a->in2_cin1;
   p.out_amax = nullptr;
+  p.reflect = a->pad_mode == KEEP_PAD_REFLECT ? 1 : 0;
   p.bias = a->bias;
   p.out = (float*)a->out;
   p.pro_scale = a->pro_scale;
@@ -1782,7 +1795,8 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   int auto_split = 1;
 
   // ---- <= 4 output channels: exact-fp32 VALU kernel in every precision policy
-  if (a->Cout <= 4 && is33s1 && !a->upsample && a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && a->Cin % SC_CH == 0 &&
+  const bool reflect = a->pad_mode == KEEP_PAD_REFLECT;
+  if (a->Cout <= 4 && is33s1 && !reflect && !a->upsample && a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && a->Cin % SC_CH == 0 &&
       a->in_ld % 4 == 0 && (uintptr_t)a->in % 16 == 0 && a->Ho == a->H && a->Wo == a->W && a->Ho % SC_TH == 0 &&
       a->Wo % SC_TW == 0 && !a->residual && !a->aux && a->split_k <= 1 && pro_al && !getenv("KEEP_NO_COUT4")) {
     pl.path = PATH_COUT4;
@@ -1806,7 +1820,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
     KEEP_REQUIRE(a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16, "keep_conv2d: KEEP_MMA_X3 takes and writes fp32 tensors");
     const bool have_w = a->weight_x3 != nullptr && (uintptr_t)a->weight_x3 % 16 == 0 && a->x3_acc_scale > 0.f;
     // RGB first convolutions: persistent im2col-in-LDS kernel, weights split on the fly from the fp32 tensor
-    if (is33s1 && !a->upsample && a->Cin <= 3 && a->Cout % 4 == 0 && a->Cout >= 32 && a->Ho == a->H && a->Wo == a->W &&
+    if (is33s1 && !reflect && !a->upsample && a->Cin <= 3 && a->Cout % 4 == 0 && a->Cout >= 32 && a->Ho == a->H && a->Wo == a->W &&
         a->Ho % 8 == 0 && a->Wo % 32 == 0 && no_pro && !a->residual && !a->aux && a->split_k <= 1 && a->out_ld % 4 == 0 &&
         (uintptr_t)a->out % 16 == 0 && (!a->bias || (uintptr_t)a->bias % 16 == 0) && a->weight && !getenv("KEEP_NO_C3")) {
       pl.path = PATH_C3_X3;

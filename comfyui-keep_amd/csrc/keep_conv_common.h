@@ -41,7 +41,15 @@ struct ConvP {
   const float* in2;           // KEEP_MMA_X3 GEMM form: second K-concatenated input (channels >= cin1), dense rows, or NULL
   int cin1;
   unsigned* out_amax;         // KEEP_MMA_X3: per-image max |output| as raw float bits (atomicMax), or NULL
+  int reflect;                // padding pixels mirror the image (nn.ReflectionPad2d, ParseNet) instead of reading zeros
 };
+
+// nn.ReflectionPad2d index map on the (virtual, post-upsample) input extent: -1 -> 1, n -> n - 2 (pad < n)
+#define KEEP_REFLECT(IY, IX, HV, WV)                                   \
+  if (p.reflect) {                                                     \
+    IY = IY < 0 ? -IY : (IY >= (HV) ? 2 * (HV) - 2 - IY : IY);          \
+    IX = IX < 0 ? -IX : (IX >= (WV) ? 2 * (WV) - 2 - IX : IX);          \
+  }
 
 // zero-fill of the small atomicMax targets as a KERNEL node: inside a captured hipGraph a hipMemsetAsync node was observed to
 // race with the atomics of the kernels that follow it (replays of one graph differed by ~2e-5); a kernel keeps stream order

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
       h_voff[k] = -16;
       if (hp < HALO_PIX) {
         const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-        const int iy = it.oy0 - 1 + hy, ix = it.ox0 - 1 + hx;
+        int iy = it.oy0 - 1 + hy, ix = it.ox0 - 1 + hx;
+        KEEP_REFLECT(iy, ix, Hv, Wv)
         if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
           const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
           h_voff[k] = ((sy * p.W + sx) * p.in_ld + g * 4) * 4;
@@ -678,8 +679,9 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
     } else {
 #pragma unroll
       for (int it = 0; it < A_IT; ++it) {
-        const int iy = a_oy[it] * p.stride - p.pad_t + kh;
-        const int ix = a_ox[it] * p.stride - p.pad_l + kw;
+        int iy = a_oy[it] * p.stride - p.pad_t + kh;
+        int ix = a_ox[it] * p.stride - p.pad_l + kw;
+        KEEP_REFLECT(iy, ix, p.H, p.W)
         a_ok[it] = a_mv[it] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ca < p.Cin;
         if (a_ok[it]) {
           const float* src = p.in + (((long)a_n[it] * p.H + iy) * p.W + ix) * p.in_ld + ca;

@@ -556,6 +556,35 @@ extern "C" int32_t keep_argmax_gather(const float* logits, const float* codebook
   return KEEP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ per-pixel class arg-max
+// out[m] = argmax_c x[m, c], c < C (lowest index on ties), x rows of pitch ld floats: ParseNet's out.argmax(dim=1)
+// (face_restoration_helper.py:424) on the channels-last logits; one thread per pixel, 16-byte loads when ld % 4 == 0.
+__global__ __launch_bounds__(256) void channel_argmax_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, long M,
+                                                             int C, int ld) {
+  for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
+    const float* r = x + m * ld;
+    float best = r[0];
+    int bi = 0;
+    for (int c = 1; c < C; ++c) {
+      const float v = r[c];
+      if (v > best) {
+        best = v;
+        bi = c;
+      }
+    }
+    out[m] = (unsigned char)bi;
+  }
+}
+
+extern "C" int32_t keep_channel_argmax(const float* x, uint8_t* out, int64_t M, int32_t C, int32_t ld, void* stream) {
+  KEEP_REQUIRE(x && out && M > 0 && C > 0 && C <= 256 && ld >= C, "keep_channel_argmax: bad args");
+  int blocks = cdiv(M, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(channel_argmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)M, C, ld);
+  KEEP_LAUNCH_CHECK("keep_channel_argmax");
+  return KEEP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ non-finite flag
 // One pass over a tensor; a block raises the status bit at most once.  (exponent all ones <=> NaN or +-inf)
 __global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ x, long n, int* __restrict__ status) {
@@ -899,20 +928,21 @@ extern "C" int32_t keep_nchw_to_nhwc(const float* x, float* out, int32_t N, int3
 
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int C,
                                                            int HW) {
-  extern __shared__ float tile[];  // [256][C] as read
+  extern __shared__ float tile[];  // [256][C | 1]: odd pitch, the per-pixel column reads below are bank-conflict free
   const int n = blockIdx.y;
   const int p0 = blockIdx.x * 256;
   const int tid = threadIdx.x;
   const int npx = min(256, HW - p0);
-  for (int i = tid; i < npx * C; i += 256) tile[i] = x[((long)n * HW + p0) * C + i];
+  const int P = C | 1;
+  for (int i = tid; i < npx * C; i += 256) tile[(i / C) * P + (i % C)] = x[((long)n * HW + p0) * C + i];
   __syncthreads();
   if (tid < npx)
-    for (int c = 0; c < C; ++c) out[((long)n * C + c) * HW + p0 + tid] = tile[tid * C + c];
+    for (int c = 0; c < C; ++c) out[((long)n * C + c) * HW + p0 + tid] = tile[tid * P + c];
 }
 
 extern "C" int32_t keep_nhwc_to_nchw(const float* x, float* out, int32_t N, int32_t C, int32_t HW, void* stream) {
-  KEEP_REQUIRE(x && out && N > 0 && C > 0 && C <= 16 && HW > 0, "keep_nhwc_to_nchw: bad args (C=%d)", C);
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(HW, 256), N), dim3(256), C * 256 * sizeof(float),
+  KEEP_REQUIRE(x && out && N > 0 && C > 0 && C <= 32 && HW > 0, "keep_nhwc_to_nchw: bad args (C=%d)", C);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(HW, 256), N), dim3(256), (C | 1) * 256 * sizeof(float),
                      (hipStream_t)stream, x, out, C, HW);
   KEEP_LAUNCH_CHECK("keep_nhwc_to_nchw");
   return KEEP_OK;

@@ -18,6 +18,7 @@ F32, BF16 = 0, 1
 MMA_F32, MMA_BF16, MMA_X3 = 0, 1, 2
 PRO_NONE, PRO_SWISH, PRO_RELU = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+PAD_ZERO, PAD_REFLECT = 0, 1
 
 _vp, _i32, _i64, _f32, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
 STATUS_NONFINITE_LOGITS, STATUS_NONFINITE_TENSOR = 1, 2
@@ -31,7 +32,7 @@ class ConvArgs(C.Structure):
                [(n, _i32) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad_t', 'pad_l', 'Ho', 'Wo',
                                     'in_ld', 'out_ld', 'res_ld', 'upsample', 'pro_act', 'epi_act')] + \
                [('aux_w', _f32), ('split_k', _i32), ('dtype', _i32), ('mma', _i32), ('weight_bf16', _vp), ('stats_out', _vp), ('stats_P', _i32), ('bk256', _i32), ('out_dtype', _i32),
-                ('weight_x3', _vp), ('x3_acc_scale', _f32), ('x3_in_amax', _vp), ('x3_out_amax', _vp), ('x3_out_amax_zeroed', _i32), ('in2', _vp), ('in2_cin1', _i32)]
+                ('weight_x3', _vp), ('x3_acc_scale', _f32), ('x3_in_amax', _vp), ('x3_out_amax', _vp), ('x3_out_amax_zeroed', _i32), ('in2', _vp), ('in2_cin1', _i32), ('pad_mode', _i32)]
 
 
 class ConvPlanOut(C.Structure):
@@ -77,6 +78,7 @@ _SIGNATURES = {
     'keep_concat2': [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
     'keep_tensor2img': [_vp, _vp, _i64, _vp],
     'keep_img2tensor': [_vp, _vp, _i64, _vp],
+    'keep_channel_argmax': [_vp, _vp, _i64, _i32, _i32, _vp],
     'keep_sep_filter': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
     'keep_u8_to_f32': [_vp, _vp, _i64, _vp],
     'keep_f32_round_u8': [_vp, _vp, _i64, _vp],

@@ -39,6 +39,20 @@ PRECISIONS = ('fp32', 'x3', 'bf16')
 DEFAULT_PRECISION = 'x3'
 
 
+class _FrameList:
+    """A clip handed to run_clips_u8 as T separate uint8 [H,W,3] crops (what the processor holds): behaves like a [T,H,W,3]
+    tensor for shape checks and is copied crop by crop into the pinned upload buffer -- no intermediate np.stack."""
+    __slots__ = ('frames', 'shape', 'dtype')
+
+    def __init__(self, frames):
+        self.frames = [np.ascontiguousarray(f) for f in frames]
+        f0 = self.frames[0]
+        if any(f.shape != f0.shape or f.dtype != np.uint8 for f in self.frames) or f0.ndim != 3:
+            raise ValueError("a clip given as a list must hold uint8 [H,W,3] crops of one size")
+        self.shape = (len(self.frames),) + tuple(f0.shape)
+        self.dtype = torch.uint8
+
+
 class KeepNet:
     def __init__(self, **arch):
         unknown = set(arch) - _KNOWN_KW
@@ -72,6 +86,7 @@ class KeepNet:
         # (True, default).  False: every rank restores the list IT is given (one video per GPU, BASELINE configs[4]).
         self.shard_across_ranks = os.environ.get('KEEP_AMD_SHARD', '1') == '1'
         self._aux_top1 = []
+        self._pinned_in = {}       # pinned upload staging buffers of run_clips_u8, by (shape, slot)
         self._pinned = None        # pinned host copy of the packed blob (made at the first upload)
         self.precision = 'fp32'
         self.set_precision(os.environ.get('KEEP_AMD_PRECISION', DEFAULT_PRECISION))
@@ -740,8 +755,9 @@ class KeepNet:
         if self.w is None:
             raise RuntimeError("KeepNet: weights are not on a device (load_state_dict + .to('cuda') first)")
         from . import dist as kdist
+        clips_u8 = [c if isinstance(c, torch.Tensor) else _FrameList(c) for c in clips_u8]
         for c in clips_u8:
-            if c.dim() != 4 or c.shape[-1] != 3 or c.dtype != torch.uint8:
+            if len(c.shape) != 4 or c.shape[-1] != 3 or c.dtype != torch.uint8:
                 raise ValueError(f"expected uint8 [T,H,W,3], got {c.dtype} {tuple(c.shape)}")
         if not self.shard_across_ranks:      # per-rank workloads (BASELINE configs[4]: one video per GPU): nothing to exchange
             local = self._run_clips_u8_local(dict(enumerate(clips_u8)), max_b)
@@ -751,6 +767,18 @@ class KeepNet:
         if res is None or isinstance(res, dict):
             return res
         return [torch.from_numpy(r) if not isinstance(r, torch.Tensor) else r for r in res]
+
+    def _pinned_staging(self, shape, slot):
+        """Pinned host staging for the uploads, cached per (shape, pipeline slot): hipHostMalloc of a 250 MB group costs tens of
+        milliseconds, which a 15-clip call would pay in front of its only forward.  Two slots: group g+1 is staged while
+        group g's upload may still be in flight."""
+        key = (tuple(shape), slot)
+        buf = self._pinned_in.get(key)
+        if buf is None:
+            if len(self._pinned_in) >= 4:
+                self._pinned_in.clear()
+            buf = self._pinned_in[key] = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+        return buf
 
     def _run_clips_u8_local(self, mine, max_b=None):
         """{clip index: uint8 [T,H,W,3]} -> {clip index: restored uint8 numpy [T,H,W,3]} on this rank's GPU.
@@ -775,9 +803,13 @@ class KeepNet:
 
             def upload(gi):
                 T, H, Wd, grp = groups[gi]
-                host = torch.empty((len(grp), T, H, Wd, 3), dtype=torch.uint8, pin_memory=True)
+                host = self._pinned_staging((len(grp), T, H, Wd, 3), gi & 1)
                 for k, n in enumerate(grp):
-                    host[k].copy_(mine[n])                      # (a device-resident clip is copied by the same call)
+                    if isinstance(mine[n], _FrameList):         # T separate [H,W,3] crops: one copy each, straight into pinned
+                        for t, fr in enumerate(mine[n].frames):
+                            host[k, t].copy_(torch.from_numpy(fr))
+                    else:
+                        host[k].copy_(mine[n])                  # (a device-resident clip is copied by the same call)
                 with torch.cuda.stream(io):
                     dev = host.to(self.device, non_blocking=True)
                     ev = torch.cuda.Event()

@@ -138,7 +138,8 @@ class Ops:
     # ------------------------------------------------------------------ keep_conv2d
     def conv(self, x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=False, pro=None, pro_act=L.PRO_NONE,
              act=L.ACT_NONE, residual=None, aux=None, aux_w=1.0, cin=None, in_off=0, out=None, split_k=None, wb=None,
-             wx3=None, x3_acc_scale=None, mma=None, stats=False, out_bf16=False, bounded=False, x_amax=None, x2=None):
+             wx3=None, x3_acc_scale=None, mma=None, stats=False, out_bf16=False, bounded=False, x_amax=None, x2=None,
+             reflect=False):
         """x [N,H,W,ld] -> [N,Ho,Wo,Cout].  ``w`` packed [Cout,KH,KW,Cin].  ``cin``/``in_off`` select a channel
         slice of a wider input buffer.  ``down`` = VQGAN Downsample geometry (pad right/bottom only, stride 2).
         ``stats=True`` returns ``(out, st)``: ``st`` is a ``Stats`` (epilogue-reduced GroupNorm partials and, under the x3
@@ -188,12 +189,12 @@ class Ops:
                 mma=mma, weight_bf16=wb if mma == L.MMA_BF16 else None, stats_out=None, stats_P=0,
                 bk256=int(USE_BK256), out_dtype=odt, weight_x3=wx3 if mma == L.MMA_X3 else None,
                 x3_acc_scale=float(x3_acc_scale), x3_in_amax=in_amax, x3_out_amax=None,
-                in2=x2, in2_cin1=0 if x2 is None else ld)
+                in2=x2, in2_cin1=0 if x2 is None else ld, pad_mode=L.PAD_REFLECT if reflect else L.PAD_ZERO)
 
         def key_of(dtype, pro_t, pro_a, odt, sk):
             return (N, H, W, ld, Cin, Cout, KH, stride, pad_t, pad_l, Ho, Wo, out_ld, int(upsample), pro_a, act, dtype, mma,
                     odt, sk, pro_t is not None, residual is not None, 0 if residual is None else residual.shape[-1],
-                    aux is not None, bias is not None, in_off % 8, wx3 is not None, USE_BK256, x2 is not None)
+                    aux is not None, bias is not None, in_off % 8, wx3 is not None, USE_BK256, x2 is not None, bool(reflect))
 
         sk_req = 0 if split_k is None else int(split_k)
         odt = L.BF16 if want_bf16_out else L.F32

@@ -118,15 +118,15 @@ class KEEPFaceProcessor:
         if run_u8 is None:
             x = crops_to_net_input(crops).unsqueeze(0).to(self.device)
             return [net_output_to_bgr_u8(f) for f in self._restore_clips(x, max_clip_length)]
-        arr = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(c) for c in crops], axis=0)))
-        spans = split_clips(arr.shape[0], max_clip_length)
+        crops = [np.asarray(c) for c in crops]
+        spans = split_clips(len(crops), max_clip_length)
         clips = []
         t1_ok = getattr(self.keep_net, 'supports_single_frame', False)
         for s, e in spans:
-            clip = arr[s:e]
-            if e - s == 1 and not t1_ok:                 # the reference net needs T>=2 (KP:173-178): duplicate, keep frame 0
-                clip = torch.cat([clip, clip], dim=0)    # (the engine restores a lone frame as T=1: same frame 0, half the work)
-            clips.append(clip)
+            clip = crops[s:e]                            # a clip = a list of crops: the engine copies them straight into its
+            if e - s == 1 and not t1_ok:                 # pinned upload buffer (no stacked intermediate)
+                clip = clip + clip                       # the reference net needs T>=2 (KP:173-178): duplicate, keep frame 0
+            clips.append(clip)                           # (the engine restores a lone frame as T=1: same frame 0, half the work)
         outs = run_u8(clips)
         if outs is None:          # a non-root rank of a run sharded over several GPUs: rank 0 holds the frames and pastes
             return None

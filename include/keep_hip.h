@@ -65,6 +65,10 @@ extern "C" {
 #define KEEP_ACT_GELU 3    /* exact erf GELU        KA:437, GM/transformer.py:141 */
 #define KEEP_ACT_SIGMOID 4 /* KA:771 */
 
+/* padding mode of keep_conv2d */
+#define KEEP_PAD_ZERO 0
+#define KEEP_PAD_REFLECT 1
+
 int32_t keep_abi_version(void);
 const char* keep_last_error(void);
 /* 0 if device `dev` is a gfx950 part this library was built for, KEEP_EUNSUP otherwise */
@@ -136,6 +140,9 @@ typedef struct {
    * [N*H*W, Cin - in2_cin1] tensor -- torch.cat([a, b], -1) folded into the GEMM (GM/transformer.py:182).  NULL: single input. */
   const void* in2;
   int32_t in2_cin1;
+  int32_t pad_mode; /* KEEP_PAD_ZERO (default) | KEEP_PAD_REFLECT: pixels outside the (post-upsample) input mirror it like
+                       nn.ReflectionPad2d(pad) (wm_facelib/parsing/parsenet.py:97,104: every ParseNet convolution); needs
+                       pad_t == pad_l < min(H, W) and KEEP_MMA_F32 or KEEP_MMA_X3 */
 } keep_conv2d_args;
 /* smallest struct_size the library accepts: the v12 layout up to and including in2_cin1 (fields appended later are optional) */
 #define KEEP_CONV2D_ARGS_V12_SIZE 256
@@ -305,6 +312,11 @@ int32_t keep_tensor2img(const float* x, uint8_t* out, int64_t npix, void* stream
 /* keep_processor.py:258-259: uint8 BGR [N,H,W,3] -> fp32 NHWC RGB (float32(u8/255.) - 0.5)/0.5 */
 int32_t keep_img2tensor(const uint8_t* x, float* out, int64_t npix, void* stream);
 
+
+/* ---- face parsing (wm_facelib/parsing/parsenet.py on keep_conv2d with KEEP_PAD_REFLECT, engine/parsenet.py) ----
+ * out[m] = argmax over the first C channels of row m of x [M, ld] (lowest index on ties): ParseNet's out.argmax(dim=1),
+ * face_restoration_helper.py:424, on channels-last logits. */
+int32_t keep_channel_argmax(const float* x, uint8_t* out, int64_t M, int32_t C, int32_t ld, void* stream);
 
 /* ---- paste-back compositing (face_restoration_helper.py:346-475, use_parse=True branch) ----------------
  * Separable filter with BORDER_REFLECT_101 (cv2.GaussianBlur, :433-434): n images [H,W]; the input is `src` (float) or a

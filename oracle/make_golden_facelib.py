@@ -1,0 +1,67 @@
+"""TEST INFRASTRUCTURE ONLY.  Golden vectors for the face-analysis networks from the IMPORTED REFERENCE
+modules under /root/reference (build container only) on deterministic synthetic weights / inputs:
+
+    python oracle/make_golden_facelib.py        # a few seconds of CPU
+
+  tests/golden/facelib.npz
+    parsenet128_*        reference ParseNet(in_size=128, out_size=128) on op_input('parsenet128', (2,3,128,128)): arg-max
+                         classes, top-2 margins, a strided logit digest
+    parsenet512_classes  reference ParseNet(512, 512) arg-max classes (uint8) + a strided logit digest on one 512x512 input
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+from __graft_entry__ import load_package  # noqa: E402
+
+load_package()
+from comfyui_keep_amd.engine import parsenet as PN  # noqa: E402
+from make_golden import op_input  # noqa: E402
+
+REF = os.environ.get('KEEP_REFERENCE_ROOT', '/root/reference')
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    ref = _load(os.path.join(REF, 'modules', 'deps', 'wm_facelib', 'parsing', 'parsenet.py'), 'ref_parsenet')
+    out = {}
+    for size in (128, 512):
+        net = ref.ParseNet(in_size=size, out_size=size).eval()
+        sd = PN.synth_parsenet_state_dict(seed=0, in_size=size, out_size=size)
+        spec = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        assert spec == {k: tuple(v) for k, v in PN.parsenet_state_dict_spec(in_size=size, out_size=size).items()}, 'spec drift'
+        net.load_state_dict(sd, strict=True)
+        x = op_input(f'parsenet{size}', (2 if size == 128 else 1, 3, size, size))
+        with torch.no_grad():
+            mask = net(x)[0]
+        if size == 128:
+            out['parsenet128_classes'] = mask.argmax(1).numpy().astype(np.uint8)
+            out['parsenet128_logit_grid'] = mask[:, :, 1::4, 2::4].numpy().astype(np.float32)
+            top2 = mask.topk(2, dim=1).values
+            out['parsenet128_margin'] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
+        else:
+            out['parsenet512_classes'] = mask.argmax(1).numpy().astype(np.uint8)
+            out['parsenet512_logit_grid'] = mask[:, :, 3::16, 5::16].numpy().astype(np.float32)
+            top2 = mask.topk(2, dim=1).values
+            out['parsenet512_margin'] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
+        print(f'ParseNet({size}): logits range', float(mask.min()), float(mask.max()))
+    np.savez_compressed(os.path.join(GOLD, 'facelib.npz'), **out)
+    print('facelib.npz:', {k: v.shape for k, v in out.items()})
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,90 @@
+"""GPU suite (-m gpu): the face-analysis networks of SURVEY.md 8f-4 on the HIP engine against the golden vectors generated
+from the imported reference modules (tests/golden/facelib.npz) and the CPU oracle (oracle/facelib_oracle.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import facelib_oracle as FO
+from conftest import GOLDEN, op_input
+from comfyui_keep_amd.engine import hiplib as L
+from comfyui_keep_amd.engine import ops
+from comfyui_keep_amd.engine import parsenet as PN
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(GOLDEN, 'facelib.npz'))
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+@pytest.mark.parametrize("mma", [L.MMA_F32, L.MMA_X3])
+def test_reflect_padding_every_kernel_family(mma):
+    """keep_conv2d pad_mode = KEEP_PAD_REFLECT (nn.ReflectionPad2d(1), parsenet.py:97) on every kernel family that takes it:
+    LDS-halo (stride 1, with and without the nearest-x2 gather), gather (stride 2; ragged map), flattened-K (Cin = 3)."""
+    cases = [('halo', 2, 64, 64, 32, 32, 1, False), ('halo up', 2, 64, 64, 16, 16, 1, True), ('gather s2', 2, 64, 96, 32, 32, 2, False),
+             ('gather ragged', 1, 48, 80, 20, 28, 1, False), ('rgb', 2, 3, 64, 32, 32, 1, False), ('halo 16x16 tile', 1, 128, 128, 16, 16, 1, False)]
+    for name, N, Cin, Cout, H, W, stride, up in cases:
+        x = op_input(f'rp_{name}', (N, Cin, H, W))
+        w = op_input(f'rpw_{name}', (Cout, Cin, 3, 3), 1.0 / (3.0 * Cin ** 0.5))
+        b = op_input(f'rpb_{name}', (Cout,), 0.1)
+        xin = F.interpolate(x, scale_factor=2, mode='nearest') if up else x
+        ref = F.conv2d(F.pad(xin.double(), (1, 1, 1, 1), mode='reflect'), w.double(), b.double(), stride=stride)
+        wp = w.permute(0, 2, 3, 1).contiguous().cuda()
+        kw = dict(stride=stride, pad=1, ksize=3, upsample=up, reflect=True, mma=mma)
+        if mma == L.MMA_X3 and Cin % 16 == 0:
+            sc = ops.x3_scale_for(float(w.abs().max()))
+            kw.update(wx3=ops.split_x3(wp.reshape(-1, Cin), sc).view(-1), x3_acc_scale=1.0 / sc)
+        y = ops.conv(nhwc(x), wp, b.cuda(), **kw)
+        err = (y.permute(0, 3, 1, 2).cpu().double() - ref).abs().max().item()
+        assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (name, err)
+
+
+def test_reflect_is_refused_where_no_kernel_has_it():
+    x = torch.zeros(1, 16, 16, 32, device='cuda')
+    w = torch.zeros(32, 3, 3, 32, device='cuda')
+    with pytest.raises(L.KeepHipError):
+        ops.conv(x, w, None, reflect=True, mma=L.MMA_BF16, wb=w.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("precision", ['x3', 'fp32'])
+def test_parsenet128_vs_reference_golden_and_oracle(precision):
+    W = PN.synth_parsenet_state_dict(seed=0, in_size=128, out_size=128)
+    eng = PN.ParseNetEngine(W, in_size=128, out_size=128, precision=precision).to('cuda')
+    x = op_input('parsenet128', (2, 3, 128, 128))
+    logits = eng.logits(x.cuda()).cpu()
+    assert logits.shape == (2, 19, 128, 128)
+    grid = G['parsenet128_logit_grid']
+    assert np.abs(logits[:, :, 1::4, 2::4].numpy() - grid).max() <= 3e-4 * np.abs(grid).max()
+    with torch.no_grad():
+        ref = FO.parsenet_forward(x, W, PN.parsenet_spec(in_size=128, out_size=128))
+    err = (logits - ref).abs().max().item()
+    print(f'ParseNet(128) [{precision}] max-abs logit diff vs the oracle: {err:.3e} (logit scale {ref.abs().max().item():.1f})')
+    assert err <= 3e-4 * ref.abs().max().item()
+    cls = eng.classes(nhwc(x)).cpu().numpy()
+    safe = G['parsenet128_margin'].astype(np.float32) > 1e-2
+    assert np.array_equal(cls[safe], G['parsenet128_classes'][safe])
+    assert np.array_equal(cls, logits.argmax(1).numpy().astype(np.uint8))          # keep_channel_argmax == argmax of its logits
+
+
+def test_parsenet512_batched_equals_one_by_one_and_reference_classes():
+    """ParseNet(512, 512) as init_parsing_model builds it: the reference's classes for the golden face wherever its top-2
+    margin exceeds 1e-2, and a batch of faces equal to the same faces one at a time (batch-invariant plans), through the
+    drop-in ``face_parse(x)[0]`` call."""
+    W = PN.synth_parsenet_state_dict(seed=0)
+    eng = PN.ParseNetEngine(W).to('cuda')
+    x = op_input('parsenet512', (1, 3, 512, 512))
+    cls = eng.classes(nhwc(x)).cpu().numpy()
+    safe = G['parsenet512_margin'].astype(np.float32) > 1e-2
+    assert safe.mean() > 0.99 and np.array_equal(cls[safe], G['parsenet512_classes'][safe])
+    fp = PN.EngineFaceParse(eng)
+    xb = torch.cat([x, op_input('parsenet512b', (2, 3, 512, 512))], 0).cuda()
+    out = fp(xb)[0]
+    assert out.shape == (3, 19, 512, 512)
+    grid = G['parsenet512_logit_grid']
+    assert np.abs(out[:1, :, 3::16, 5::16].cpu().numpy() - grid).max() <= 3e-4 * np.abs(grid).max()
+    for i in range(3):
+        assert torch.equal(fp(xb[i:i + 1])[0][0], out[i])

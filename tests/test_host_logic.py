@@ -196,6 +196,8 @@ class _U8Net(_RecordingNet):
         self.supports_single_frame = single_frame
 
     def run_clips_u8(self, clips, max_b=4):
+        # contract of KeepNet.run_clips_u8: a clip is a uint8 [T,H,W,3] tensor or a list of T uint8 [H,W,3] crops
+        clips = [torch.from_numpy(np.stack(c)) if isinstance(c, list) else c for c in clips]
         for c in clips:
             assert c.dtype == torch.uint8 and c.dim() == 4 and c.shape[1:] == (512, 512, 3)
             self.calls.append(c.shape[0])

@@ -139,3 +139,18 @@ def test_full_forward_T20_vs_golden(synth_weights):
     err = np.abs(_digest(out[0])[:first] - g['out_grid'][:first]).max()
     print('oracle vs reference, T=20: first frame with a differing index', first, '; max-abs digest diff before it', err)
     assert err <= 1e-3, err
+
+
+def test_parsenet_oracle_vs_reference_golden():
+    """oracle/facelib_oracle.py:parsenet_forward against the imported reference ParseNet (tests/golden/facelib.npz)."""
+    import facelib_oracle as FO
+    from comfyui_keep_amd.engine import parsenet as PN
+    g = np.load(os.path.join(GOLDEN, 'facelib.npz'))
+    W = PN.synth_parsenet_state_dict(seed=0, in_size=128, out_size=128)
+    x = op_input('parsenet128', (2, 3, 128, 128))
+    with torch.no_grad():
+        mask = FO.parsenet_forward(x, W, PN.parsenet_spec(in_size=128, out_size=128))
+    assert mask.shape == (2, 19, 128, 128)
+    assert np.abs(mask[:, :, 1::4, 2::4].numpy() - g['parsenet128_logit_grid']).max() <= 2e-4 * np.abs(g['parsenet128_logit_grid']).max()
+    safe = g['parsenet128_margin'].astype(np.float32) > 1e-2
+    assert np.array_equal(mask.argmax(1).numpy().astype(np.uint8)[safe], g['parsenet128_classes'][safe]) and safe.mean() > 0.99

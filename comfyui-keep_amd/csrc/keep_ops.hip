@@ -585,6 +585,99 @@ extern "C" int32_t keep_channel_argmax(const float* x, uint8_t* out, int64_t M, 
   return KEEP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ detector helpers
+// nn.MaxPool2d(kernel 3, stride 2, padding 1) of torchvision's ResNet stem on NHWC maps (padding = -inf); C % 4 == 0.
+__global__ __launch_bounds__(256) void maxpool3s2_kernel(const float4* __restrict__ x, float4* __restrict__ out, int N, int H, int W,
+                                                         int Ho, int Wo, int C4) {
+  const long total = (long)N * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        const float4 v = x[(((long)n * H + iy) * W + ix) * C4 + c];
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    out[i] = m;
+  }
+}
+
+extern "C" int32_t keep_maxpool3s2(const float* x, float* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+  KEEP_REQUIRE(x && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0,
+               "keep_maxpool3s2: bad args (C %% 4 == 0, 16-byte aligned tensors)");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total = (long)N * Ho * Wo * (C / 4);
+  int blocks = cdiv(total, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(maxpool3s2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x),
+                     reinterpret_cast<float4*>(out), N, H, W, Ho, Wo, C / 4);
+  KEEP_LAUNCH_CHECK("keep_maxpool3s2");
+  return KEEP_OK;
+}
+
+// out[n, y, x, :] = a[n, y, x, :] + b[n, floor(y * hb / H), floor(x * wb / W), :]: the FPN top-down step
+// `a + F.interpolate(b, size=a.shape[2:], mode='nearest')` (retinaface_net.py:86-92); C % 4 == 0.  (torch's nearest index is
+// floor(dst * scale) with scale = in / out as a float; the integer form below equals it for every size with in <= out.)
+__global__ __launch_bounds__(256) void upsample_add_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                           float4* __restrict__ out, int N, int H, int W, int hb, int wb, int C4) {
+  const long total = (long)N * H * W * C4;
+  const float sy = (float)hb / (float)H, sx = (float)wb / (float)W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    const int by = min((int)floorf((float)y * sy), hb - 1), bx = min((int)floorf((float)x * sx), wb - 1);
+    const float4 u = a[i], v = b[(((long)n * hb + by) * wb + bx) * C4 + c];
+    out[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+  }
+}
+
+extern "C" int32_t keep_upsample_add(const float* a, const float* b, float* out, int32_t N, int32_t H, int32_t W, int32_t hb,
+                                     int32_t wb, int32_t C, void* stream) {
+  KEEP_REQUIRE(a && b && out && N > 0 && H > 0 && W > 0 && hb > 0 && wb > 0 && C > 0 && C % 4 == 0 && (uintptr_t)a % 16 == 0 &&
+                   (uintptr_t)b % 16 == 0 && (uintptr_t)out % 16 == 0,
+               "keep_upsample_add: bad args (C %% 4 == 0, 16-byte aligned tensors)");
+  const long total = (long)N * H * W * (C / 4);
+  int blocks = cdiv(total, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(upsample_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(a),
+                     reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(out), N, H, W, hb, wb, C / 4);
+  KEEP_LAUNCH_CHECK("keep_upsample_add");
+  return KEEP_OK;
+}
+
+// x = act(x) in place (KEEP_ACT_*): the ReLU that follows a Bottleneck's residual sum (the convolution epilogue adds the
+// residual AFTER its own activation, so `relu(conv3 + identity)` is the fused sum plus this pass)
+__global__ __launch_bounds__(256) void act_inplace_kernel(float4* __restrict__ x, long n4, int act) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 v = x[i];
+    v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
+    x[i] = v;
+  }
+}
+
+extern "C" int32_t keep_act_inplace(float* x, int64_t n, int32_t act, void* stream) {
+  KEEP_REQUIRE(x && n > 0 && n % 4 == 0 && (uintptr_t)x % 16 == 0, "keep_act_inplace: bad args (n %% 4 == 0, 16-byte aligned)");
+  int blocks = cdiv(n / 4, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(act_inplace_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(x), (long)(n / 4), act);
+  KEEP_LAUNCH_CHECK("keep_act_inplace");
+  return KEEP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ non-finite flag
 // One pass over a tensor; a block raises the status bit at most once.  (exponent all ones <=> NaN or +-inf)
 __global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ x, long n, int* __restrict__ status) {

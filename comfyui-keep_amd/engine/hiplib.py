@@ -79,6 +79,9 @@ _SIGNATURES = {
     'keep_tensor2img': [_vp, _vp, _i64, _vp],
     'keep_img2tensor': [_vp, _vp, _i64, _vp],
     'keep_channel_argmax': [_vp, _vp, _i64, _i32, _i32, _vp],
+    'keep_maxpool3s2': [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    'keep_upsample_add': [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    'keep_act_inplace': [_vp, _i64, _i32, _vp],
     'keep_sep_filter': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
     'keep_u8_to_f32': [_vp, _vp, _i64, _vp],
     'keep_f32_round_u8': [_vp, _vp, _i64, _vp],

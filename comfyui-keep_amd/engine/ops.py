@@ -139,7 +139,7 @@ class Ops:
     def conv(self, x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=False, pro=None, pro_act=L.PRO_NONE,
              act=L.ACT_NONE, residual=None, aux=None, aux_w=1.0, cin=None, in_off=0, out=None, split_k=None, wb=None,
              wx3=None, x3_acc_scale=None, mma=None, stats=False, out_bf16=False, bounded=False, x_amax=None, x2=None,
-             reflect=False):
+             reflect=False, out_ld=None):
         """x [N,H,W,ld] -> [N,Ho,Wo,Cout].  ``w`` packed [Cout,KH,KW,Cin].  ``cin``/``in_off`` select a channel
         slice of a wider input buffer.  ``down`` = VQGAN Downsample geometry (pad right/bottom only, stride 2).
         ``stats=True`` returns ``(out, st)``: ``st`` is a ``Stats`` (epilogue-reduced GroupNorm partials and, under the x3
@@ -177,7 +177,7 @@ class Ops:
         in_amax = None
         if mma == L.MMA_X3 and (wx3 is not None or (Cin <= 3 and KH == 3)) and pro is None and not bounded:   # (RGB convs split fp32 weights in-kernel)
             in_amax = x_amax if (x_amax is not None and x_amax.numel() == N) else absmax(xin, N, H * W, Cin, ld, H * W * ld, self)
-        out_ld = Cout if out is None else out.shape[-1]
+        out_ld = (Cout if out is None else out.shape[-1]) if out_ld is None else out_ld
 
         def make_args(inp, dtype, pro_t, pro_a, odt, sk):
             return L.conv_args(

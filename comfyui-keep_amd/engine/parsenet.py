@@ -217,11 +217,14 @@ class EngineFaceParse:
         self.engine = engine
 
     @classmethod
-    def from_module(cls, module, device='cuda', precision='x3'):
+    def from_module(cls, module, device=None, precision='x3'):
+        """Take over the weights of a loaded reference ParseNet (sizes are read off its state dict).  ``device=None`` leaves the
+        packed weights on the host until ``.to('cuda')`` (what KEEPModelPack.load_device() calls)."""
         sd = module.state_dict()
         n_down = sum(1 for k in sd if k.startswith('encoder.') and k.endswith('.shortcut_func.conv2d.weight'))
         n_up = sum(1 for k in sd if k.startswith('decoder.') and k.endswith('.shortcut_func.conv2d.weight'))
-        return cls(ParseNetEngine(sd, in_size=32 << n_down, out_size=32 << n_up, precision=precision).to(device))
+        eng = ParseNetEngine(sd, in_size=32 << n_down, out_size=32 << n_up, precision=precision)
+        return cls(eng if device is None else eng.to(device))
 
     def __call__(self, x):
         return self.engine.logits(x), None

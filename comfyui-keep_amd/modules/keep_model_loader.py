@@ -60,6 +60,25 @@ class KEEPModelPack:
         model_management.soft_empty_cache()
 
 
+def engine_facelib(helper):
+    """put the helper's face-analysis networks on the HIP engine where an engine counterpart exists -- the
+    objects keep the reference's call signatures (``face_parse(x)[0]``, ``face_detector.detect_faces(img)``), so
+    FaceRestoreHelper itself is unchanged.  ``KEEP_AMD_ENGINE_FACELIB=0`` keeps the torch modules."""
+    if os.environ.get('KEEP_AMD_ENGINE_FACELIB', '1') == '0' or helper is None:
+        return helper
+    fp = getattr(helper, 'face_parse', None)
+    if fp is not None and hasattr(fp, 'state_dict') and 'out_mask_conv.conv2d.weight' in fp.state_dict():
+        from ..engine.parsenet import EngineFaceParse
+        helper.face_parse = EngineFaceParse.from_module(fp)
+        logger.debug("face_parse (ParseNet) runs on the HIP engine")
+    det = getattr(helper, 'face_detector', None)
+    if det is not None and hasattr(det, 'state_dict') and getattr(det, 'backbone', None) == 'Resnet50':
+        from ..engine.retinaface import EngineRetinaFace
+        helper.face_detector = EngineRetinaFace.from_module(det)
+        logger.debug("face_detector (RetinaFace resnet50) runs on the HIP engine")
+    return helper
+
+
 def convert_legacy_keys(state_dict):
     """``cross_fuse.* -> cfa.*``, ``fuse_convs_dict.* -> cft.*`` (keep_model_loader.py:110-118)."""
     if not any('cross_fuse' in k or 'fuse_convs_dict' in k for k in state_dict):
@@ -109,12 +128,13 @@ class KEEPModelLoader:
         root = os.path.join(folder_paths.models_dir, FACELIB_DEST_DIR)
         os.makedirs(root, exist_ok=True)
         try:
-            return _import_face_helper()(
+            helper = _import_face_helper()(
                 upscale_factor=1, face_size=512, crop_ratio=(1, 1), det_model=detection_model_str,
                 save_ext='png', use_parse=True, device=self.offload_device, model_rootpath=root)
         except Exception as e:
             logger.error(f"Error initializing FaceRestoreHelper: {e}")
             raise
+        return engine_facelib(helper)
 
     def load_keep_model_pack(self, model_type_str, detection_model_str,
                              bg_upscale_model=None, face_upscale_model=None):

@@ -62,6 +62,17 @@ def _is_gray(img, threshold=10):
     return bool(d <= threshold)
 
 
+class _ReplayDetector:
+    """Stands in for ``face_detector`` while the helper post-processes ONE frame of a batched detection pass: returns the
+    stored ``detect_faces`` result of that frame."""
+
+    def __init__(self, result):
+        self.result = result
+
+    def detect_faces(self, image, conf_threshold=0.8, *args, **kwargs):
+        return self.result
+
+
 def split_clips(num_faces: int, max_clip_length: int):
     """[(start, end)] chunk boundaries of the flat crop list (keep_processor.py:263-264)."""
     return [(s, min(s + max_clip_length, num_faces)) for s in range(0, num_faces, max_clip_length)]
@@ -228,23 +239,63 @@ class KEEPFaceProcessor:
         x = torch.empty(faces.shape, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             L.call('keep_img2tensor', faces, x, faces.numel() // 3)
-        classes = []
-        for i in range(faces.shape[0]):
-            logits = helper.face_parse(x[i:i + 1].permute(0, 3, 1, 2).contiguous())[0]
-            classes.append(logits.argmax(dim=1).squeeze(0).to(torch.uint8))
-        out = self._paster.paste(bg, faces, list(helper.inverse_affine_matrices), torch.stack(classes))
+        engine = getattr(helper.face_parse, 'engine', None)
+        if engine is not None:            # ParseNet on the HIP engine (engine/parsenet.py): all faces of the frame in one batch
+            classes = engine.classes(x)
+        else:
+            classes = []
+            for i in range(faces.shape[0]):
+                logits = helper.face_parse(x[i:i + 1].permute(0, 3, 1, 2).contiguous())[0]
+                classes.append(logits.argmax(dim=1).squeeze(0).to(torch.uint8))
+            classes = torch.stack(classes)
+        out = self._paster.paste(bg, faces, list(helper.inverse_affine_matrices), classes)
         return out.cpu().numpy()
 
     # ------------------------------------------------------------------ sequence
     def _detect_all(self, frames_bgr, only_center_face):
+        """Landmarks of every frame (keep_processor.py:207-213: one ``get_face_landmarks_5`` call -- one detector forward and
+        one host round trip -- per frame).  With the engine's detector (engine/retinaface.py, ``detect_batch``) the network
+        runs ONCE over all frames of the video in chunks of the batch axis; the helper's own per-frame host logic (resize
+        rule, eye-distance filter, centre-face selection: face_restoration_helper.py:206-252) then runs unchanged on the
+        stored detections, so the landmarks are what the per-frame loop produces."""
         raw = []
         helper = self.face_helper
-        for frame in tqdm(frames_bgr, desc="Detecting face landmarks"):
+        det = getattr(helper, 'face_detector', None)
+        batched = None
+        if hasattr(det, 'detect_batch') and getattr(helper, 'det_model', 'retinaface') != 'dlib' and frames_bgr:
+            batched = self._detect_batched(det, frames_bgr, resize=640)
+        for i, frame in enumerate(tqdm(frames_bgr, desc="Detecting face landmarks")):
             helper.clean_all()
             helper.read_image(frame)
-            helper.get_face_landmarks_5(only_center_face=only_center_face, resize=640, eye_dist_threshold=5)
+            if batched is None:
+                helper.get_face_landmarks_5(only_center_face=only_center_face, resize=640, eye_dist_threshold=5)
+            else:
+                helper.face_detector = _ReplayDetector(batched[i])
+                try:
+                    helper.get_face_landmarks_5(only_center_face=only_center_face, resize=640, eye_dist_threshold=5)
+                finally:
+                    helper.face_detector = det
             raw.append(list(helper.all_landmarks_5))
         return raw
+
+    def _detect_batched(self, det, frames_bgr, resize):
+        """The detector inputs ``get_face_landmarks_5`` would build, frame by frame (face_restoration_helper.py:206-216: frames
+        whose short side exceeds ``resize`` are scaled down with INTER_AREA), stacked and run through ``det.detect_batch`` with
+        the helper's 0.97 confidence threshold (:221).  None when the frames differ in size (the per-frame path handles it)."""
+        helper = self.face_helper
+        imgs = []
+        for frame in frames_bgr:
+            helper.clean_all()
+            helper.read_image(frame)
+            img = helper.input_img
+            h, w = img.shape[:2]
+            if resize is not None and min(h, w) > resize:
+                scale = resize / min(h, w)
+                img = _resize(img, int(w * scale), int(h * scale), 'INTER_AREA' if scale < 1 else 'INTER_LINEAR')
+            imgs.append(np.ascontiguousarray(img))
+        if any(im.shape != imgs[0].shape or im.dtype != np.uint8 for im in imgs):
+            return None
+        return det.detect_batch(np.stack(imgs), 0.97)
 
     @torch.no_grad()
     def process_image_sequence(self, image_sequence_tensor: torch.Tensor, final_upscale_factor: float,

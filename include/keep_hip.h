@@ -318,6 +318,15 @@ int32_t keep_img2tensor(const uint8_t* x, float* out, int64_t npix, void* stream
  * face_restoration_helper.py:424, on channels-last logits. */
 int32_t keep_channel_argmax(const float* x, uint8_t* out, int64_t M, int32_t C, int32_t ld, void* stream);
 
+/* ---- face detection (wm_facelib/detection/retinaface on keep_conv2d, engine/retinaface.py) ----
+ * nn.MaxPool2d(3, stride 2, padding 1) of the ResNet-50 stem on an NHWC map: [N,H,W,C] -> [N,(H-1)/2+1,(W-1)/2+1,C] */
+int32_t keep_maxpool3s2(const float* x, float* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+/* FPN top-down step (retinaface_net.py:86-92): out = a + nearest-resize(b [N,hb,wb,C] -> [N,H,W,C]) */
+int32_t keep_upsample_add(const float* a, const float* b, float* out, int32_t N, int32_t H, int32_t W, int32_t hb, int32_t wb,
+                          int32_t C, void* stream);
+/* x = act(x) in place, act = KEEP_ACT_*: the ReLU after a Bottleneck's residual sum (torchvision resnet.py Bottleneck.forward) */
+int32_t keep_act_inplace(float* x, int64_t n, int32_t act, void* stream);
+
 /* ---- paste-back compositing (face_restoration_helper.py:346-475, use_parse=True branch) ----------------
  * Separable filter with BORDER_REFLECT_101 (cv2.GaussianBlur, :433-434): n images [H,W]; the input is `src` (float) or a
  * class map `classes` (uint8) looked up through `lut` (MASK_COLORMAP, :428-429).  tmp and dst: [n,H,W] float.  kern: device

@@ -62,3 +62,59 @@ def parsenet_forward(x, W, blocks):
         if kind == 'none' and name == [b[0] for b in blocks if b[1] == 'none'][-1]:
             x = feat + x
     raise AssertionError('no out_mask_conv in the block list')
+
+
+# ------------------------------------------------------------------------------------------------------- RetinaFace (resnet50)
+def _cbr(x, W, conv, bn, stride=1, pad=0, relu=True):
+    x = F.conv2d(x, W[f'{conv}.weight'], None, stride=stride, padding=pad)
+    x = F.batch_norm(x, W[f'{bn}.running_mean'], W[f'{bn}.running_var'], W[f'{bn}.weight'], W[f'{bn}.bias'], False, 0.0, BN_EPS)
+    return F.relu(x) if relu else x
+
+
+def resnet50_trunk(x, W):
+    """torchvision ResNet-50 v1.5 up to layer4 (IntermediateLayerGetter(return_layers layer2/3/4), retinaface.py:104-105):
+    conv1 7x7 s2 p3 -> bn -> relu -> maxpool 3 s2 p1 -> Bottleneck stacks [3, 4, 6, 3], stride on the 3x3 convolution.
+    PARITY UNPINNED (torchvision is not available; see the module docstring)."""
+    x = _cbr(x, W, 'body.conv1', 'body.bn1', stride=2, pad=3)
+    x = F.max_pool2d(x, 3, 2, 1)
+    feats = []
+    for name, n, stride in (('layer1', 3, 1), ('layer2', 4, 2), ('layer3', 6, 2), ('layer4', 3, 2)):
+        for i in range(n):
+            p = f'body.{name}.{i}'
+            s = stride if i == 0 else 1
+            idt = _cbr(x, W, f'{p}.downsample.0', f'{p}.downsample.1', stride=s, relu=False) if i == 0 else x
+            h = _cbr(x, W, f'{p}.conv1', f'{p}.bn1')
+            h = _cbr(h, W, f'{p}.conv2', f'{p}.bn2', stride=s, pad=1)
+            h = _cbr(h, W, f'{p}.conv3', f'{p}.bn3', relu=False)
+            x = F.relu(h + idt)
+        if name != 'layer1':
+            feats.append(x)
+    return feats
+
+
+def retinaface_forward(x, W):
+    """RetinaFace.forward, phase 'test' (retinaface.py:124-146) -> (bbox_regressions [N,P,4], softmax conf [N,P,2], landmarks [N,P,10])."""
+    f = resnet50_trunk(x, W)
+    # FPN, retinaface_net.py:79-98 (out_channels 256 -> leaky 0 = ReLU)
+    o1 = _cbr(f[0], W, 'fpn.output1.0', 'fpn.output1.1')
+    o2 = _cbr(f[1], W, 'fpn.output2.0', 'fpn.output2.1')
+    o3 = _cbr(f[2], W, 'fpn.output3.0', 'fpn.output3.1')
+    o2 = _cbr(o2 + F.interpolate(o3, size=o2.shape[2:], mode='nearest'), W, 'fpn.merge2.0', 'fpn.merge2.1', pad=1)
+    o1 = _cbr(o1 + F.interpolate(o2, size=o1.shape[2:], mode='nearest'), W, 'fpn.merge1.0', 'fpn.merge1.1', pad=1)
+    feats = []
+    for k, o in enumerate((o1, o2, o3)):          # SSH, retinaface_net.py:37-63
+        s = f'ssh{k + 1}'
+        c3 = _cbr(o, W, f'{s}.conv3X3.0', f'{s}.conv3X3.1', pad=1, relu=False)
+        c51 = _cbr(o, W, f'{s}.conv5X5_1.0', f'{s}.conv5X5_1.1', pad=1)
+        c5 = _cbr(c51, W, f'{s}.conv5X5_2.0', f'{s}.conv5X5_2.1', pad=1, relu=False)
+        c72 = _cbr(c51, W, f'{s}.conv7X7_2.0', f'{s}.conv7X7_2.1', pad=1)
+        c7 = _cbr(c72, W, f'{s}.conv7x7_3.0', f'{s}.conv7x7_3.1', pad=1, relu=False)
+        feats.append(F.relu(torch.cat([c3, c5, c7], 1)))
+
+    def head(name, k):
+        outs = []
+        for i, ft in enumerate(feats):
+            o = F.conv2d(ft, W[f'{name}.{i}.conv1x1.weight'], W[f'{name}.{i}.conv1x1.bias'])
+            outs.append(o.permute(0, 2, 3, 1).contiguous().view(o.shape[0], -1, k))
+        return torch.cat(outs, 1)
+    return head('BboxHead', 4), F.softmax(head('ClassHead', 2), dim=-1), head('LandmarkHead', 10)

@@ -36,6 +36,48 @@ def _load(path, name):
     return mod
 
 
+def retinaface_golden():
+    """RetinaFace(resnet50): the reference's OWN FPN / SSH / head modules (retinaface_net.py) and prior / decode functions
+    (retinaface_utils.py, imported with a stub `torchvision` whose only touched member is ops.nms) on synthetic weights; the
+    ResNet-50 trunk (torchvision in the reference, absent here) is the oracle's restatement -- the trunk is NOT pinned."""
+    import types
+    import facelib_oracle as FO
+    from comfyui_keep_amd.engine import retinaface as RF
+    tv = types.ModuleType('torchvision')
+    tv.ops = types.SimpleNamespace(nms=lambda boxes, scores, iou_threshold: torch.tensor(RF.nms(
+        np.concatenate([boxes.numpy(), scores.numpy()[:, None]], 1), iou_threshold), dtype=torch.int64))
+    sys.modules.setdefault('torchvision', tv)
+    base = os.path.join(REF, 'modules', 'deps', 'wm_facelib', 'detection', 'retinaface')
+    net = _load(os.path.join(base, 'retinaface_net.py'), 'ref_retinaface_net')
+    utils = _load(os.path.join(base, 'retinaface_utils.py'), 'ref_retinaface_utils')
+    W = RF.synth_retinaface_state_dict(seed=0)
+    x = op_input('retinaface_img', (2, 3, 160, 224), 100.0)            # BGR minus mean, O(100) like real frames
+    with torch.no_grad():
+        feats = FO.resnet50_trunk(x, W)
+        fpn = net.FPN([512, 1024, 2048], 256).eval()
+        fpn.load_state_dict({k[4:]: v for k, v in W.items() if k.startswith('fpn.')}, strict=True)
+        pyr = fpn(feats)
+        sshs = []
+        for k in (1, 2, 3):
+            m = net.SSH(256, 256).eval()
+            m.load_state_dict({kk[5:]: v for kk, v in W.items() if kk.startswith(f'ssh{k}.')}, strict=True)
+            sshs.append(m(pyr[k - 1]))
+        heads = {}
+        for name, maker in (('ClassHead', net.make_class_head), ('BboxHead', net.make_bbox_head), ('LandmarkHead', net.make_landmark_head)):
+            hs = maker(fpn_num=3, inchannels=256).eval()
+            hs.load_state_dict({kk[len(name) + 1:]: v for kk, v in W.items() if kk.startswith(name + '.')}, strict=True)
+            heads[name] = torch.cat([hs[i](f) for i, f in enumerate(sshs)], dim=1)
+    conf = torch.softmax(heads['ClassHead'], dim=-1)
+    cfg = dict(RF.CFG_RE50)
+    priors = utils.PriorBox(cfg, image_size=(160, 224)).forward()
+    boxes = utils.decode(heads['BboxHead'][0], priors, cfg['variance'])
+    lms = utils.decode_landm(heads['LandmarkHead'][0], priors, cfg['variance'])
+    print('RetinaFace golden: conf range', float(conf[..., 1].min()), float(conf[..., 1].max()), 'priors', tuple(priors.shape))
+    return {'retinaface_loc': heads['BboxHead'].numpy().astype(np.float32), 'retinaface_conf': conf.numpy().astype(np.float32),
+            'retinaface_landm': heads['LandmarkHead'].numpy().astype(np.float32), 'retinaface_priors': priors.numpy().astype(np.float32),
+            'retinaface_boxes0': boxes.numpy().astype(np.float32), 'retinaface_lms0': lms.numpy().astype(np.float32)}
+
+
 def main():
     ref = _load(os.path.join(REF, 'modules', 'deps', 'wm_facelib', 'parsing', 'parsenet.py'), 'ref_parsenet')
     out = {}
@@ -59,6 +101,7 @@ def main():
             top2 = mask.topk(2, dim=1).values
             out['parsenet512_margin'] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
         print(f'ParseNet({size}): logits range', float(mask.min()), float(mask.max()))
+    out.update(retinaface_golden())
     np.savez_compressed(os.path.join(GOLD, 'facelib.npz'), **out)
     print('facelib.npz:', {k: v.shape for k, v in out.items()})
 

@@ -88,3 +88,42 @@ def test_parsenet512_batched_equals_one_by_one_and_reference_classes():
     assert np.abs(out[:1, :, 3::16, 5::16].cpu().numpy() - grid).max() <= 3e-4 * np.abs(grid).max()
     for i in range(3):
         assert torch.equal(fp(xb[i:i + 1])[0][0], out[i])
+
+
+@pytest.mark.parametrize("precision", ['x3', 'fp32'])
+def test_retinaface_engine_vs_reference_golden(precision):
+    """RetinaFace(resnet50) on the engine: raw head outputs against the golden composed from the reference's FPN / SSH / head
+    modules (trunk: the restated torchvision ResNet-50, unpinned), then the whole detect_batch pipeline against the oracle
+    network + the same host post-processing, frame by frame of a batch."""
+    from comfyui_keep_amd.engine import retinaface as RF
+    W = RF.synth_retinaface_state_dict(seed=0)
+    eng = RF.RetinaFaceEngine(W, precision=precision).to('cuda')
+    x = op_input('retinaface_img', (2, 3, 160, 224), 100.0)
+    loc, cls, lm = (t.cpu() for t in eng.raw_outputs(nhwc(x)))
+    conf = torch.softmax(cls, -1)
+    for got, key, tol in ((loc, 'retinaface_loc', 3e-4), (conf, 'retinaface_conf', 3e-4), (lm, 'retinaface_landm', 3e-4)):
+        err = np.abs(got.numpy() - G[key]).max()
+        print(f'RetinaFace [{precision}] {key}: max-abs diff {err:.3e} (scale {np.abs(G[key]).max():.1f})')
+        assert err <= tol * max(1.0, np.abs(G[key]).max()), (key, err)
+    # full pipeline on uint8 frames of a ragged size (stride-32 maps 5 x 7 -> ceil), batch of 3 == one by one == oracle
+    g = torch.Generator().manual_seed(3)
+    frames = torch.randint(0, 256, (3, 150, 210, 3), generator=g, dtype=torch.uint8)
+    dets = eng.detect_batch(frames, conf_threshold=0.8)
+    assert len(dets) == 3 and all(d.ndim == 2 and d.shape[1] == 15 for d in dets)
+    single = RF.EngineRetinaFace(eng).detect_faces(frames[1].numpy(), 0.8)
+    assert np.array_equal(single, dets[1])
+    xf = frames.float().permute(0, 3, 1, 2) - torch.tensor(RF.MEAN_BGR).view(1, 3, 1, 1)
+    with torch.no_grad():
+        rloc, rconf, rlm = FO.retinaface_forward(xf, W)
+    pri = RF.prior_boxes(150, 210)
+    for i in range(3):
+        sc = rconf[i, :, 1].numpy()
+        sure = (np.abs(sc - 0.8) > 1e-3)                       # anchors whose score is not within rounding of the threshold
+        boxes = RF.decode_boxes(rloc[i].numpy(), pri, RF.CFG_RE50['variance']) * np.array([210, 150, 210, 150], np.float32)
+        keep_ref = np.where((sc > 0.8) & sure)[0]
+        assert len(dets[i]) > 0
+        # every engine detection is a reference candidate (same box within 1e-2 px, same score within 1e-4)
+        for d in dets[i]:
+            j = np.argmin(np.abs(boxes - d[:4]).sum(1))
+            assert np.abs(boxes[j] - d[:4]).max() <= 1e-2 and abs(sc[j] - d[4]) <= 1e-4, (i, d[:5], boxes[j], sc[j])
+        assert len(dets[i]) <= len(keep_ref) + int((~sure).sum())

@@ -411,3 +411,55 @@ def test_paste_hook_defers_to_the_helper():
     assert not proc._gpu_paste_applies(h, bg, False)
     h.use_parse, proc.face_upscale_model = True, object()
     assert not proc._gpu_paste_applies(h, bg, False)
+
+
+def test_batched_detection_prepass_equals_the_per_frame_loop():
+    """SURVEY 8f-4 host logic: with a detector that offers ``detect_batch`` the processor runs ONE batched detection over the
+    video and lets the helper post-process each frame from the stored result; landmarks must equal the per-frame loop's
+    (keep_processor.py:207-213), the helper's own ``get_face_landmarks_5`` is called once per frame either way."""
+    class Det:
+        def __init__(self):
+            self.single_calls, self.batch_calls = 0, 0
+
+        def _res(self, img):
+            k = float(img[0, 0, 0])                      # result depends on the frame content only
+            return np.array([[k, 1, k + 50, 60, 0.99] + [k + 10, 20, k + 30, 20, k + 20, 30, k + 12, 40, k + 28, 40]], np.float32)
+
+        def detect_faces(self, img, thr=0.8):
+            self.single_calls += 1
+            return self._res(img)
+
+    class BatchDet(Det):
+        def detect_batch(self, frames, thr=0.8):
+            self.batch_calls += 1
+            assert frames.ndim == 4 and thr == 0.97
+            return [self._res(f) for f in frames]
+
+    class Helper:
+        det_model = 'retinaface_resnet50'
+
+        def __init__(self, det):
+            self.face_detector = det
+            self.calls = 0
+
+        def clean_all(self):
+            self.all_landmarks_5, self.input_img = [], None
+
+        def read_image(self, img):
+            self.input_img = img
+
+        def get_face_landmarks_5(self, only_center_face=False, resize=640, eye_dist_threshold=None):
+            self.calls += 1
+            b = self.face_detector.detect_faces(self.input_img, 0.97)
+            self.all_landmarks_5 = [b[i, 5:].reshape(5, 2) for i in range(b.shape[0])]
+            return len(self.all_landmarks_5)
+
+    frames = [np.full((64, 80, 3), 7 * i, np.uint8) for i in range(5)]
+    out = {}
+    for name, det in (('loop', Det()), ('batch', BatchDet())):
+        helper = Helper(det)
+        proc = KEEPFaceProcessor(KEEPModelPack(_RecordingNet(), helper, None, None, 'KEEP'))
+        out[name] = proc._detect_all(frames, True)
+        assert helper.calls == 5 and helper.face_detector is det
+        assert (det.single_calls, det.batch_calls) == ((5, 0) if name == 'loop' else (0, 1))
+    assert all(np.array_equal(a[0], b[0]) for a, b in zip(out['loop'], out['batch']))

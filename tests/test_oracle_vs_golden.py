@@ -154,3 +154,26 @@ def test_parsenet_oracle_vs_reference_golden():
     assert np.abs(mask[:, :, 1::4, 2::4].numpy() - g['parsenet128_logit_grid']).max() <= 2e-4 * np.abs(g['parsenet128_logit_grid']).max()
     safe = g['parsenet128_margin'].astype(np.float32) > 1e-2
     assert np.array_equal(mask.argmax(1).numpy().astype(np.uint8)[safe], g['parsenet128_classes'][safe]) and safe.mean() > 0.99
+
+
+def test_retinaface_oracle_and_host_decode_vs_reference_golden():
+    """oracle/facelib_oracle.py:retinaface_forward against the reference's own FPN / SSH / head modules composed over the same
+    (restated, unpinned) ResNet-50 trunk; engine/retinaface.py's prior boxes and decoders against the reference's PriorBox /
+    decode / decode_landm (tests/golden/facelib.npz)."""
+    import facelib_oracle as FO
+    from comfyui_keep_amd.engine import retinaface as RF
+    g = np.load(os.path.join(GOLDEN, 'facelib.npz'))
+    W = RF.synth_retinaface_state_dict(seed=0)
+    assert set(W) == set(RF.retinaface_state_dict_spec())
+    x = op_input('retinaface_img', (2, 3, 160, 224), 100.0)
+    with torch.no_grad():
+        loc, conf, lm = FO.retinaface_forward(x, W)
+    for got, key in ((loc, 'retinaface_loc'), (conf, 'retinaface_conf'), (lm, 'retinaface_landm')):
+        assert np.abs(got.numpy() - g[key]).max() <= 1e-4 * max(1.0, np.abs(g[key]).max()), key
+    pri = RF.prior_boxes(160, 224)
+    assert pri.shape == g['retinaface_priors'].shape and np.abs(pri - g['retinaface_priors']).max() <= 1e-7
+    assert np.abs(RF.decode_boxes(g['retinaface_loc'][0], pri, RF.CFG_RE50['variance']) - g['retinaface_boxes0']).max() <= 1e-5
+    assert np.abs(RF.decode_landmarks(g['retinaface_landm'][0], pri, RF.CFG_RE50['variance']) - g['retinaface_lms0']).max() <= 1e-5
+    # greedy NMS: a cluster of overlapping boxes keeps its best, disjoint boxes all survive, order = descending score
+    d = np.array([[0, 0, 10, 10, 0.9], [1, 1, 11, 11, 0.95], [20, 20, 30, 30, 0.5], [0, 0, 10, 10.5, 0.7]], np.float32)
+    assert RF.nms(d, 0.4) == [1, 2]

@@ -104,6 +104,54 @@ extern "C" int32_t keep_f32_round_u8(const float* x, uint8_t* out, int64_t n, vo
   return KEEP_OK;
 }
 
+// ---- crop warp: cv2.warpAffine(frame uint8 [H,W,3], M, (dw, dh), INTER_LINEAR, BORDER_CONSTANT, borderValue) -- the call that
+// PRODUCES the aligned 512x512 crops (face_restoration_helper.py:316-318, borderValue (135, 133, 132)).  Same fixed-point
+// coordinates and 15-bit weights as the face sampler below; a tap outside the source reads the border colour.
+struct WarpP {
+  const uint8_t* src;
+  uint8_t* dst;
+  double m00, m01, m02, m10, m11, m12;   // destination -> source map
+  int H, W, dh, dw;
+  int b0, b1, b2;
+};
+
+__global__ void warp_affine_u8_kernel(WarpP p) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= p.dw || y >= p.dh) return;
+  const long adelta = llrint(dmul_rn(dmul_rn(p.m00, (double)x), 1024.0));
+  const long bdelta = llrint(dmul_rn(dmul_rn(p.m10, (double)x), 1024.0));
+  const long X0 = llrint(dmul_rn(dadd_rn(dmul_rn(p.m01, (double)y), p.m02), 1024.0)) + 16;
+  const long Y0 = llrint(dmul_rn(dadd_rn(dmul_rn(p.m11, (double)y), p.m12), 1024.0)) + 16;
+  const long X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+  long sxl = X >> 5, syl = Y >> 5;
+  sxl = sxl < -32768 ? -32768 : (sxl > 32767 ? 32767 : sxl);
+  syl = syl < -32768 ? -32768 : (syl > 32767 ? 32767 : syl);
+  const int sx = (int)sxl, sy = (int)syl, fx = (int)(X & 31), fy = (int)(Y & 31);
+  const int i00 = (32 - fx) * (32 - fy) * 32, i01 = fx * (32 - fy) * 32, i10 = (32 - fx) * fy * 32, i11 = fx * fy * 32;
+  const int bv[3] = {p.b0, p.b1, p.b2};
+  auto at = [&](int yy, int xx, int c) -> int {
+    if (xx < 0 || xx >= p.W || yy < 0 || yy >= p.H) return bv[c];
+    return p.src[((long)yy * p.W + xx) * 3 + c];
+  };
+  uint8_t* d = p.dst + ((long)y * p.dw + x) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    d[c] = (uint8_t)((at(sy, sx, c) * i00 + at(sy, sx + 1, c) * i01 + at(sy + 1, sx, c) * i10 + at(sy + 1, sx + 1, c) * i11 + (1 << 14)) >> 15);
+}
+
+extern "C" int32_t keep_warp_affine_u8(const uint8_t* src, int32_t H, int32_t W, uint8_t* dst, int32_t dh, int32_t dw,
+                                       const double* dst_to_src, int32_t border_b, int32_t border_g, int32_t border_r, void* stream) {
+  KEEP_REQUIRE(src && dst && dst_to_src && H > 0 && W > 0 && dh > 0 && dw > 0 && H < 32768 && W < 32768, "keep_warp_affine_u8: bad arguments");
+  WarpP p;
+  p.src = src; p.dst = dst;
+  p.m00 = dst_to_src[0]; p.m01 = dst_to_src[1]; p.m02 = dst_to_src[2];
+  p.m10 = dst_to_src[3]; p.m11 = dst_to_src[4]; p.m12 = dst_to_src[5];
+  p.H = H; p.W = W; p.dh = dh; p.dw = dw; p.b0 = border_b & 255; p.b1 = border_g & 255; p.b2 = border_r & 255;
+  hipLaunchKernelGGL(warp_affine_u8_kernel, dim3(cdiv(dw, 32), cdiv(dh, 8)), dim3(256), 0, (hipStream_t)stream, p);
+  KEEP_LAUNCH_CHECK("keep_warp_affine_u8");
+  return KEEP_OK;
+}
+
 // ---- one face: warp (face uint8 x3, mask float) + blend into the float frame, over the face's bounding box
 struct PasteP {
   float* acc;            // [H,W,3] float32 frame, in place

@@ -53,6 +53,26 @@ def face_box(M_fwd, fw, fh, W, H, margin=2):
     return max(0, x0), max(0, y0), min(W, x1), min(H, y1)
 
 
+ALIGN_BORDER_BGR = (135, 133, 132)          # face_restoration_helper.py:318
+
+
+def crop_faces(frame_u8, affine_matrices, face_size=(512, 512), device='cuda', border=ALIGN_BORDER_BGR):
+    """``align_warp_face`` (face_restoration_helper.py:303-320, border_mode='constant') for one frame: uint8 [H,W,3] frame (numpy
+    or tensor) + the frame -> crop similarity matrices of ``cv2.estimateAffinePartial2D`` -> uint8 [F,fh,fw,3] crops on the device
+    (``keep_warp_affine_u8``).  None matrices give the reference's black crop (:309-311)."""
+    frame = torch.as_tensor(frame_u8).to(device, non_blocking=True).contiguous()
+    H, W, _ = frame.shape
+    fw, fh = face_size
+    out = torch.zeros((len(affine_matrices), fh, fw, 3), dtype=torch.uint8, device=frame.device)
+    with torch.cuda.device(frame.device):
+        for i, M in enumerate(affine_matrices):
+            if M is None:
+                continue
+            d2s = (C.c_double * 6)(*invert_affine(M).reshape(-1).tolist())
+            L.call('keep_warp_affine_u8', frame, H, W, out[i], fh, fw, d2s, int(border[0]), int(border[1]), int(border[2]))
+    return out
+
+
 class GpuPaster:
     """Device buffers are cached per frame size; one instance per processor."""
 

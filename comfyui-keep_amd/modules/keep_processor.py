@@ -62,6 +62,34 @@ def _is_gray(img, threshold=10):
     return bool(d <= threshold)
 
 
+def opencv_agrees_with_gpu_paste(device):
+    """True iff the HIP paste-back (engine/paste.py) reproduces OpenCV bit for bit on this installation: the composite
+    of engine/synth.py's 1080p / 3-face case computed with cv2 calls in the order of face_restoration_helper.py:382,426-468
+    against ``GpuPaster.paste``, and the :316-318 crop warp against ``crop_faces``.  Raises ImportError without cv2."""
+    import cv2
+    from ..engine import paste as gp
+    from ..engine import synth
+    frame, faces, mats, classes = synth.synth_paste_case()
+    H, W = frame.shape[:2]
+    up = frame
+    lut = np.asarray(gp.MASK_COLORMAP, np.float32)
+    for face, M, cls in zip(faces, mats, classes):
+        inv_restored = cv2.warpAffine(face, M, (W, H))
+        m = lut[cls.astype(np.int64)]
+        m = cv2.GaussianBlur(cv2.GaussianBlur(m, (101, 101), 11), (101, 101), 11)
+        t = gp.PARSE_BORDER
+        m[:t, :] = 0; m[-t:, :] = 0; m[:, :t] = 0; m[:, -t:] = 0
+        soft = cv2.warpAffine(m / np.float32(255.0), M, (W, H))[:, :, None]
+        up = soft * inv_restored + (1 - soft) * up
+    ref = np.round(np.clip(up, 0, 255)).astype(np.uint8)
+    got = gp.GpuPaster(device).paste(frame, faces, list(mats), torch.from_numpy(classes)).cpu().numpy()
+    if not np.array_equal(got, ref):
+        return False
+    fwd = cv2.invertAffineTransform(mats[2])
+    crop = cv2.warpAffine(frame, fwd, (512, 512), borderMode=cv2.BORDER_CONSTANT, borderValue=gp.ALIGN_BORDER_BGR)
+    return bool(np.array_equal(gp.crop_faces(frame, [fwd], device=device)[0].cpu().numpy(), crop))
+
+
 class _ReplayDetector:
     """Stands in for ``face_detector`` while the helper post-processes ONE frame of a batched detection pass: returns the
     stored ``detect_faces`` result of that frame."""
@@ -95,7 +123,11 @@ class KEEPFaceProcessor:
         self.return_restored_aligned = os.environ.get('KEEP_AMD_RETURN_RESTORED_ALIGNED', '0') == '1'
         # paste-back compositing on the GPU (engine/paste.py).  Opt-in: its arithmetic restates OpenCV's and
         # could not be checked against cv2 itself in the build image.
-        self.gpu_paste = os.environ.get('KEEP_AMD_GPU_PASTE', '0') == '1'
+        # KEEP_AMD_GPU_PASTE: '1' on, '0' off; unset = 'auto': the first paste runs ``opencv_agrees_with_gpu_paste`` -- the HIP
+        # path against cv2 itself on a synthetic 1080p / 3-face frame, bit for bit -- and switches the GPU path on only if that
+        # holds on this installation (cv2 is a hard dependency of the reference helper, so it exists wherever this code pastes).
+        env = os.environ.get('KEEP_AMD_GPU_PASTE')
+        self.gpu_paste = {'1': True, '0': False}.get(env, None)
         self._paster = None
 
     # ------------------------------------------------------------------ net invocation
@@ -209,6 +241,11 @@ class KEEPFaceProcessor:
         colour frame already at the output size, no box, no face upsampler, every crop at the helper's face size) the
         per-face masks, warps and the blend run on the MI355X (engine/paste.py); every other configuration -- and every
         helper that is not the reference's -- goes to the helper's own method."""
+        if self.gpu_paste is None:                       # 'auto': decided once per processor, against cv2 itself
+            try:
+                self.gpu_paste = bool(opencv_agrees_with_gpu_paste(self.device))
+            except Exception:                            # no cv2 / no GPU / any surprise: the helper's own path
+                self.gpu_paste = False
         if self.gpu_paste and self._gpu_paste_applies(helper, bg, draw_box):
             return self._paste_gpu(helper, bg)
         return helper.paste_faces_to_input_image(upsample_img=bg, draw_box=draw_box, face_upsampler=self.face_upscale_model)

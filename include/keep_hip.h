@@ -336,6 +336,11 @@ int32_t keep_sep_filter(const float* src, const uint8_t* classes, const float* l
 /* uint8 -> float32 (the frame accumulator of :463) and back: clip [0,255], round half to even, uint8 (:465-468) */
 int32_t keep_u8_to_f32(const uint8_t* x, float* out, int64_t n, void* stream);
 int32_t keep_f32_round_u8(const float* x, uint8_t* out, int64_t n, void* stream);
+/* cv2.warpAffine(src uint8 [H,W,3], M, (dw, dh)) with INTER_LINEAR, BORDER_CONSTANT and a border colour: the similarity crop that
+ * PRODUCES the aligned faces (align_warp_face, face_restoration_helper.py:316-318: borderValue (135, 133, 132)).  dst_to_src:
+ * HOST pointer to the 6 doubles of the destination -> source map (cv2.invertAffineTransform of M), read at call time. */
+int32_t keep_warp_affine_u8(const uint8_t* src, int32_t H, int32_t W, uint8_t* dst, int32_t dh, int32_t dw, const double* dst_to_src,
+                            int32_t border_b, int32_t border_g, int32_t border_r, void* stream);
 /* One face into the float frame [H,W,3], in place, over the box [x0,x1) x [y0,y1): cv2.warpAffine(face uint8 [fh,fw,3]) (:382)
  * and cv2.warpAffine(mask float [fh,fw]) (:441) with INTER_LINEAR / BORDER_CONSTANT 0 and OpenCV's fixed-point coordinates,
  * the mask's `mask_border` outer rows / columns read as zero and its values divided by 255 (:435-437), then

@@ -63,19 +63,20 @@ def warp_coords(M_fwd, width, height):
     return sx, sy, (X & (INTER_TAB_SIZE - 1)).astype(np.int32), (Y & (INTER_TAB_SIZE - 1)).astype(np.int32)
 
 
-def _fetch(src, sy, sx):
-    """src[sy, sx] with BORDER_CONSTANT 0 outside."""
+def _fetch(src, sy, sx, border=0):
+    """src[sy, sx] with BORDER_CONSTANT `border` (a scalar or one value per channel) outside."""
     h, w = src.shape[:2]
     ok = (sx >= 0) & (sx < w) & (sy >= 0) & (sy < h)
     v = src[np.clip(sy, 0, h - 1), np.clip(sx, 0, w - 1)]
     if v.ndim == 3:
         ok = ok[..., None]
-    return np.where(ok, v, 0)
+    return np.where(ok, v, np.asarray(border, dtype=v.dtype))
 
 
-def warp_affine_u8(src, M_fwd, width, height):
-    """cv2.warpAffine(uint8 [h,w,C], M, (width,height)), INTER_LINEAR, BORDER_CONSTANT 0: 15-bit integer weights
-    (32-fx)(32-fy)*32 ..., result (sum + 2^14) >> 15."""
+def warp_affine_u8(src, M_fwd, width, height, border=0):
+    """cv2.warpAffine(uint8 [h,w,C], M, (width,height)), INTER_LINEAR, BORDER_CONSTANT with borderValue `border` (0 in the
+    paste-back, (135, 133, 132) in align_warp_face :316-318): 15-bit integer weights (32-fx)(32-fy)*32 ..., result
+    (sum + 2^14) >> 15; a tap outside the source contributes the border colour."""
     sx, sy, fx, fy = warp_coords(M_fwd, width, height)
     w00 = ((32 - fx) * (32 - fy) * 32).astype(np.int64)
     w01 = (fx * (32 - fy) * 32).astype(np.int64)
@@ -83,8 +84,8 @@ def warp_affine_u8(src, M_fwd, width, height):
     w11 = (fx * fy * 32).astype(np.int64)
     s = src.astype(np.int64)
     ex = (lambda a: a[..., None]) if src.ndim == 3 else (lambda a: a)
-    acc = (_fetch(s, sy, sx) * ex(w00) + _fetch(s, sy, sx + 1) * ex(w01) + _fetch(s, sy + 1, sx) * ex(w10) +
-           _fetch(s, sy + 1, sx + 1) * ex(w11))
+    acc = (_fetch(s, sy, sx, border) * ex(w00) + _fetch(s, sy, sx + 1, border) * ex(w01) + _fetch(s, sy + 1, sx, border) * ex(w10) +
+           _fetch(s, sy + 1, sx + 1, border) * ex(w11))
     return ((acc + (1 << 14)) >> 15).astype(np.uint8)
 
 

@@ -45,6 +45,34 @@ def test_paste_small_frame_and_upscaled_matrix():
     assert np.array_equal(got, ref)
 
 
+def test_crop_warp_align_warp_face_is_bit_exact():
+    """align_warp_face's cv2.warpAffine(frame, M, (512, 512), borderValue=(135, 133, 132)) (face_restoration_helper.py:316-318)
+    on the device: frame -> crop matrices = the inverses of the synthetic case's crop -> frame matrices; the third face hangs over
+    the frame edge, so the border colour is exercised; a None matrix gives the reference's black crop."""
+    frame, _, mats, _ = synth.synth_paste_case()
+    fwd = [P.invert_affine(M) for M in mats]                       # frame -> crop
+    got = paste.crop_faces(frame, fwd + [None]).cpu().numpy()
+    assert got.shape == (4, 512, 512, 3) and not got[3].any()
+    for i, M in enumerate(fwd):
+        ref = P.warp_affine_u8(frame, M, 512, 512, border=(135, 133, 132))
+        assert np.array_equal(got[i], ref), (i, int(np.abs(got[i].astype(np.int16) - ref.astype(np.int16)).max()))
+    assert (got[2] == np.array([135, 133, 132], np.uint8)).all(-1).any()          # the border colour is in the edge face's crop
+
+
+def test_hip_paste_equals_opencv_where_opencv_exists():
+    """The HIP path against cv2 itself (skipped where cv2 is absent, like the build image): the crop warp and the whole
+    composite of the 1080p / 3-face case, bit for bit -- the check KEEPFaceProcessor runs once before it switches the GPU
+    paste on by default (``_selfcheck_gpu_paste``)."""
+    cv2 = pytest.importorskip('cv2')
+    from comfyui_keep_amd.modules.keep_processor import opencv_agrees_with_gpu_paste
+    assert opencv_agrees_with_gpu_paste('cuda') is True
+    frame, _, mats, _ = synth.synth_paste_case()
+    fwd = [cv2.invertAffineTransform(M) for M in mats]
+    got = paste.crop_faces(frame, fwd).cpu().numpy()
+    for i, M in enumerate(fwd):
+        assert np.array_equal(got[i], cv2.warpAffine(frame, M, (512, 512), borderMode=cv2.BORDER_CONSTANT, borderValue=(135, 133, 132)))
+
+
 def test_bad_arguments_fail_loudly():
     a = torch.zeros((8, 8, 3), device='cuda')
     with pytest.raises(L.KeepHipError):

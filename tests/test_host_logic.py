@@ -401,7 +401,10 @@ def test_paste_hook_defers_to_the_helper():
     proc = KEEPFaceProcessor(KEEPModelPack(_RecordingNet(), h, None, None, 'KEEP'))
     bg = np.zeros((64, 64, 3), np.uint8)
     h.input_img, h.restored_faces, h.inverse_affine_matrices = bg, [np.zeros((512, 512, 3), np.uint8)], [np.eye(2, 3)]
-    assert proc.gpu_paste is False and proc._paste(h, bg, False) is bg and calls == [(False, None)]
+    # unset environment = 'auto': the first paste self-checks the HIP path against cv2; without cv2 (this image) / without a GPU
+    # it settles on the helper's own path
+    assert proc.gpu_paste is None and proc._paste(h, bg, False) is bg and calls == [(False, None)]
+    assert proc.gpu_paste is False
     proc.gpu_paste = True
     assert proc._gpu_paste_applies(h, bg, False)
     assert not proc._gpu_paste_applies(h, bg, True)                                  # draw_box

@@ -4,6 +4,7 @@ import hashlib
 import os
 
 import numpy as np
+import pytest
 
 import paste_oracle as P
 from conftest import GOLDEN
@@ -63,3 +64,23 @@ def test_paste_regression_vectors():
     zero = P.paste_faces(frame, list(faces), list(mats), [np.zeros_like(c) for c in classes])
     assert np.array_equal(zero, frame)
     assert int((out != frame).any(-1).sum()) == int(g['changed_pixels'])
+
+
+def test_restatement_equals_opencv_where_opencv_exists():
+    """THE PIN (runs wherever cv2 is installed; the build image has none -> skipped there): every OpenCV call the paste-back
+    and the crop warp make -- warpAffine uint8 with and without a border colour, warpAffine float32, GaussianBlur((101,101), 11),
+    invertAffineTransform -- bit for bit against oracle/paste_oracle.py on the synthetic 1080p / 3-face case."""
+    cv2 = pytest.importorskip('cv2')
+    frame, faces, mats, classes = synth.synth_paste_case()
+    H, W = frame.shape[:2]
+    for i, M in enumerate(mats):
+        assert np.array_equal(cv2.invertAffineTransform(M), P.invert_affine(M)), i
+        assert np.array_equal(cv2.warpAffine(faces[i], M, (W, H)), P.warp_affine_u8(faces[i], M, W, H)), i
+        fwd = cv2.invertAffineTransform(M)
+        assert np.array_equal(cv2.warpAffine(frame, fwd, (512, 512), borderMode=cv2.BORDER_CONSTANT, borderValue=(135, 133, 132)),
+                              P.warp_affine_u8(frame, fwd, 512, 512, border=(135, 133, 132))), i
+        m = P.MASK_COLORMAP[classes[i].astype(np.int64)]
+        blur = cv2.GaussianBlur(cv2.GaussianBlur(m, (101, 101), 11), (101, 101), 11)
+        assert np.array_equal(blur, P.gaussian_blur(P.gaussian_blur(m, 101, 11), 101, 11)), i
+        soft = P.parse_soft_mask(classes[i])
+        assert np.array_equal(cv2.warpAffine(soft, M, (W, H)), P.warp_affine_f32(soft, M, W, H)), i

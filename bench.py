@@ -24,6 +24,7 @@ Also on the JSON line:
   b1             the literal configs[1] case: ONE 20-frame clip in flight;
   configs        BASELINE configs[2] / [3] as hot-path workloads through the processor's own chunking: 300 crops
                  (15 clips) and 900 frame-major interleaved crops of 3 faces (45 clips), uint8 host -> uint8 host;
+  facelib        ParseNet / RetinaFace on the engine, batched
   cpu_baseline   the CPU oracle (a port of the reference algorithm, PyTorch-CPU fp32) on the benchmarked clip
                  (one T=20 clip, ~1 min), rank 0 / N=1 only -- a reported baseline, not the target.
 """
@@ -178,6 +179,40 @@ def paste_leg(frames=10):
                     "3 box warps + blends, D2H); arithmetic bit-equal to oracle/paste_oracle.py, unpinned against cv2 (absent)"}
 
 
+def facelib_leg():
+    """the face-analysis networks either side of the hot path on the engine, batched (synthetic weights):
+    ParseNet(512, 512) class maps for 16 faces per call, RetinaFace(resnet50) raw outputs + host decode / NMS for 16 video
+    frames per call at 640 x 1138 (a 720p frame after the helper's resize-to-640 rule, face_restoration_helper.py:206-213)."""
+    from comfyui_keep_amd.engine import parsenet as PN
+    from comfyui_keep_amd.engine import retinaface as RF
+    out = {}
+    eng = PN.ParseNetEngine(PN.synth_parsenet_state_dict(seed=0)).to('cuda')
+    x = torch.rand((16, 512, 512, 3), device='cuda') * 2 - 1
+    eng.classes(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.classes(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    out["parsenet_512"] = {"faces_per_s": round(16 / dt, 1), "ms_per_call": round(dt * 1e3, 2), "batch": 16,
+                           "what": "fp32 NHWC faces on the device -> uint8 class maps on the device (x3 policy)"}
+    del eng, x
+    det = RF.RetinaFaceEngine(RF.synth_retinaface_state_dict(seed=0)).to('cuda')
+    frames = torch.randint(0, 256, (16, 640, 1138, 3), dtype=torch.uint8)
+    det.detect_batch(frames, 0.97)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        det.detect_batch(frames, 0.97)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    out["retinaface_resnet50_640x1138"] = {"frames_per_s": round(16 / dt, 1), "ms_per_call": round(dt * 1e3, 2), "batch": 16,
+                                           "what": "uint8 BGR frames in host memory -> boxes + 5 landmarks per frame on the host "
+                                                   "(H2D, network, D2H of the head outputs, numpy decode + NMS)"}
+    return out
+
+
 def processor_leg(net, n_crops, faces):
     """BASELINE configs[2] / [3] as the hot path sees them: `n_crops` crops stacked frame-major (`faces` crops per frame,
     interleaved: keep_processor.py:252-253) and cut into max_clip_length = 20 chunks by the processor's own code."""
@@ -263,6 +298,24 @@ def main():
         torch.distributed.all_gather(allr, mine)
         per_rank = [round(float(t.item()), 2) for t in allr]
 
+    cfg5 = None
+    if world > 1:
+        # BASELINE configs[4]: one 300-crop video (15 clips x 20) per GPU through the processor's uint8 entry point, nothing
+        # exchanged between ranks (shard_across_ranks off); value = all ranks' crops / slowest rank's wall time
+        net.shard_across_ranks = False
+        u8 = [torch.randint(0, 256, (T_CLIP, 512, 512, 3), dtype=torch.uint8) for _ in range(15)]
+        net.run_clips_u8(u8, max_b=15)
+        barrier()
+        t0 = time.perf_counter()
+        net.run_clips_u8(u8, max_b=15)
+        barrier()
+        d5 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                          device='cuda' if torch.distributed.get_backend() == 'nccl' else 'cpu')
+        torch.distributed.all_reduce(d5, op=torch.distributed.ReduceOp.MAX)
+        cfg5 = {"value": round(world * 300 / float(d5.item()), 3), "unit": "frames/s", "crops_per_gpu": 300, "clips_per_gpu": 15,
+                "seconds": round(float(d5.item()), 3),
+                "what": "uint8 crops in host memory -> restored uint8 crops in host memory on every GPU (its own video), max over ranks"}
+        del u8
     if rank == 0:
         frames = world * B * T_CLIP * args.steps
         fps = frames / dt
@@ -289,6 +342,7 @@ def main():
             line["broadcast_ms"] = round(bcast_ms, 2)
             line["broadcast_mb"] = round(net.packed_blob().numel() * 4 / 1e6, 1)
             line["frames_per_s_per_rank"] = per_rank
+            line["config5_one_video_per_gpu"] = cfg5
         extras = world == 1 and not args.no_extras
         if extras:
             # ---- the other policies on the same input, each compared with the exact-f32 result
@@ -349,6 +403,7 @@ def main():
             line["configs"] = {"config3_300_crops_1_face": processor_leg(net, 300, 1),
                                "config4_900_crops_3_faces": processor_leg(net, 900, 3)}
             line["paste_back_gpu"] = paste_leg()
+            line["facelib"] = facelib_leg()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_frames)
         print(json.dumps(line))

@@ -1686,11 +1686,14 @@ static const int kTargetWaves = 1024;
 // Parity policies (exact f32, x3): every choice that changes the ORDER of a floating-point sum -- the split-K factor, and with
 // it the statistics partition -- is made from the per-image geometry and this fixed reference batch, never from the actual N.
 // A clip's result is then bit-identical whatever its batch-mates are (KeepNet.clips_per_call follows free HBM; round 2's plans
-// followed N and a clip's code indices could differ between a batch of 8 and a batch of 15).  8 images: the 64x64 and larger
-// maps fill the chip without split-K at that count; the 16x16 / 32x32 stages split 8 / 4 ways at every batch size.
+// followed N and a clip's code indices could differ between a batch of 8 and a batch of 15).  16 images = the engine's design
+// point (16 clips per call): maps of 32x32 and larger fill the chip without split-K at that count, the 16x16 stages split 4 ways
+// at every batch size.  Measured (round 3, x3): reference 16 -> 235 frames/s at B = 16 and 93 at B = 1; 8 -> 230 / 101; 2 -> - /
+// 109: KEEP_PLAN_REF_IMAGES selects a latency profile (a deployment-wide setting like the precision policy -- results are
+// invariant within one setting).
 static long plan_ref_images() {
   const char* e = getenv("KEEP_PLAN_REF_IMAGES");
-  return e ? atol(e) : 8;
+  return e ? atol(e) : 16;
 }
 // gather kernels: launches of at most this many output rows use 64x64 tiles (more blocks), larger ones 128x128.  A tuning
 // knob the HOST never mirrors (keep_conv2d_plan reports what follows from it): tests retune it through the environment.

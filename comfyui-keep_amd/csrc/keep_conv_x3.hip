@@ -71,7 +71,12 @@ __device__ __forceinline__ float xor32_sum(float x) {
 // 2: no MFMAs, 3: no staging (LDS keeps stale data), 4: no global stores in the epilogue, 5: no operand fetch,
 // 6: start stagger between the two blocks of a CU, 7: library expf + IEEE division in the swish prologue, 8: s_setprio(1)
 // around the MFMA loop.
-template <int TW, int PRO, bool SIMPLE_EPI, int EXP = 0, bool FASTACT = true>
+// WDMA: the 9 x 64 pre-split weight rows of a chunk go from L2 straight into LDS (buffer_load_dwordx4 ... lds, 1 KB per wave
+// instruction, no VGPR round trip, no ds_write): rows at a 64-byte pitch, the 16-byte pieces of a row XOR-swizzled by
+// (row >> 2) & 3 through the SOURCE address of each lane (an LDS-DMA destination is lane-linear), which keeps the B-fragment
+// ds_read_b128 conflict-free without padding.  Issued after the barrier that ends a chunk's MFMA phase, landed (vmcnt(0)) under the
+// VALU staging of the halo.
+template <int TW, int PRO, bool SIMPLE_EPI, int EXP = 0, bool FASTACT = true, bool WDMA = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int tiles_x, int tiles_y, int ncb, int n_items) {
   constexpr int HALO_TH = 256 / TW, HALO_W = TW + 2, HALO_PIX = (HALO_TH + 2) * HALO_W;
   constexpr int RPT = 32 / TW;
@@ -80,6 +85,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[MAIN_B > EPI_B ? MAIN_B : EPI_B];
   _Float16* Hs = reinterpret_cast<_Float16*>(lds_raw);
   _Float16* Ws = Hs + HALO_MAXPIX * XPITCH;
+  unsigned char* const wdma_base = lds_raw + HALO_MAXPIX * XPITCH * 2;      // == Ws as bytes
+  int fetched_ch = 0;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -97,6 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   // ~185 instructions per chunk here, 15 % of the wave's time by the s_memtime timeline.)
   int h_voff[HALO_IT];                   // byte offset of this thread's piece inside the image; < 0: zero padding
   int w_voff = -16;                      // byte offset of this thread's piece of its cout row in the split weight tensor
+  int dma_voff[4] = {-16, -16, -16, -16};   // WDMA: this lane's source offset for the four 16-cout row groups of a tap
   long sc_off = 0;
   float in_s = 1.f, in_inv = 1.f;        // range scale of the item being FETCHED / staged (image it.n)
   __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);
@@ -123,6 +131,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)bhi << 32) | blo), 0, p.H * p.W * p.in_ld * 4, 0x00020000);
     sc_off = (long)it.n * p.Cin + g * 4;
     w_voff = (it.n0 + (tid >> 2)) < p.Cout ? ((it.n0 + (tid >> 2)) * 9 * p.Cin * 2 + g * 8) * 2 : -16;
+    if (WDMA) {
+      // DMA instruction q of this chunk (36 per chunk, 9 per wave: q = wave * 9 + t) fills LDS rows q*16 .. q*16+15 = tap q/4, couts
+      // (q%4)*16 + lane/4; lane's physical 16-byte slot lane&3 holds logical piece (lane&3) ^ ((lane>>4)&3) of its row
+      const int lp = (lane & 3) ^ ((lane >> 4) & 3);
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const int co = it.n0 + c4 * 16 + (lane >> 2);
+        dma_voff[c4] = co < p.Cout ? co * 9 * p.Cin * 4 + lp * 16 : -16;
+      }
+    }
   };
 
   float4 hreg[HALO_IT];
@@ -141,16 +159,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff, ((TAP) * p.Cin + c0) * 4, 0);      \
     R = make_uint4(v.x, v.y, v.z, v.w);                                                                      \
   }
-    KEEP_TAPS(KEEP_WLOADX)
+    if (!WDMA) {
+      KEEP_TAPS(KEEP_WLOADX)
+    }
 #undef KEEP_WLOADX
     if (p.pro_scale) {
       sc4 = *reinterpret_cast<const float4*>(p.pro_scale + sc_off + c0);
       sh4 = *reinterpret_cast<const float4*>(p.pro_shift + sc_off + c0);
     }
+    fetched_ch = ch;
   };
   auto stage = [&]() {
     constexpr bool FAST = FASTACT && EXP != 7;
     if (EXP == 3) return;
+    if (WDMA) {          // weights of the chunk being staged: L2 -> LDS, in flight under the halo's VALU work below
+      const int c0 = fetched_ch << 4;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int q = __builtin_amdgcn_readfirstlane(wave) * 9 + t;            // wave-uniform (M0 / soffset operands)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(wdma_base + q * 1024), 16,
+                                                 dma_voff[q & 3], ((q >> 2) * p.Cin + c0) * 4, 0, 0);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < HALO_IT; ++k) {
       const int hp = (tid >> 2) + k * 64;
@@ -172,13 +202,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
       }
     }
 #define KEEP_WSTOREX(TAP, R) *reinterpret_cast<uint4*>(&Ws[((TAP) * 64 + (tid >> 2)) * XPITCH + g * 8]) = R;
-    KEEP_TAPS(KEEP_WSTOREX)
+    if (!WDMA) {
+      KEEP_TAPS(KEEP_WSTOREX)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed (the barrier publishes them)
+    }
 #undef KEEP_WSTOREX
   };
 
   f32x16 acc[2][2];
   const int a_base = (((2 * wave) * RPT + l31 / TW) * HALO_W + (l31 % TW)) * XPITCH + lhi * 8;
-  const int b_base = l31 * XPITCH + lhi * 8;
+  // WDMA: 64-byte rows, physical slot = logical piece ^ ((row >> 2) & 3); tap / cout-block offsets are multiples of 16 rows
+  const int b_base = WDMA ? l31 * 32 + ((lhi ^ ((l31 >> 2) & 3)) * 8) : l31 * XPITCH + lhi * 8;
   auto mma = [&]() {
     f16x8 ah[2], al[2], bh[2], bl[2];
     if (EXP == 1) {
@@ -204,9 +239,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
           }
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const _Float16* src = &Ws[b_base + ((kh * 3 + kw) * 64 + j * 32) * XPITCH];
-            bh[j] = *reinterpret_cast<const f16x8*>(src);
-            bl[j] = *reinterpret_cast<const f16x8*>(src + 16);
+            if (WDMA) {
+              const int o = b_base + ((kh * 3 + kw) * 64 + j * 32) * 32;
+              bh[j] = *reinterpret_cast<const f16x8*>(&Ws[o]);
+              bl[j] = *reinterpret_cast<const f16x8*>(&Ws[o ^ 16]);                 // lo piece: logical + 2 -> physical slot ^ 2
+            } else {
+              const _Float16* src = &Ws[b_base + ((kh * 3 + kw) * 64 + j * 32) * XPITCH];
+              bh[j] = *reinterpret_cast<const f16x8*>(src);
+              bl[j] = *reinterpret_cast<const f16x8*>(src + 16);
+            }
           }
         }
         if (EXP == 2) {      // keep the reads alive without the matrix pipe
@@ -1096,8 +1137,13 @@ int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
 #undef KEEP_LAUNCH_ABL
   }
 #endif
+  static const bool wdma = !getenv("KEEP_X3_NO_WDMA");      // weights by LDS-DMA (default); the VGPR-staged form stays for A/B runs
 #define KEEP_LAUNCH_HX2(TWV, PROV)                                                                                          \
-  if (simple)                                                                                                              \
+  if (wdma && simple)                                                                                                      \
+    hipLaunchKernelGGL((conv3x3_halo_x3_kernel<TWV, PROV, true, 0, true, true>), grid, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);  \
+  else if (wdma)                                                                                                           \
+    hipLaunchKernelGGL((conv3x3_halo_x3_kernel<TWV, PROV, false, 0, true, true>), grid, block, 0, st, p, tiles_x, tiles_y, ncb, n_items); \
+  else if (simple)                                                                                                         \
     hipLaunchKernelGGL((conv3x3_halo_x3_kernel<TWV, PROV, true>), grid, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);  \
   else                                                                                                                     \
     hipLaunchKernelGGL((conv3x3_halo_x3_kernel<TWV, PROV, false>), grid, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);

@@ -25,7 +25,7 @@ HALO_PRENORM_MINPIX = int(os.environ.get('KEEP_HALO_PRENORM_MINPIX', '0'))
 DEBUG_SYNC = os.environ.get('KEEP_DEBUG_SYNC') is not None
 _PLAN_CACHE = {}
 _PLAN_ENV = ('KEEP_NO_COUT4', 'KEEP_NO_C3', 'KEEP_NO_HALO_F32', 'KEEP_NO_HALO_X3', 'KEEP_NO_GATHER_X3', 'KEEP_NO_PLAIN',
-             'KEEP_NO_FLATK_F32', 'KEEP_GATHER_SMALL_M')
+             'KEEP_NO_FLATK_F32', 'KEEP_GATHER_SMALL_M', 'KEEP_PLAN_REF_IMAGES')
 
 
 class Plan:

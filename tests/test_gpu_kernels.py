@@ -990,9 +990,9 @@ def test_plan_follows_a_retuned_tile_threshold(mma, monkeypatch):
         kw.update(wx3=wx3, x3_acc_scale=asc)
     ops.DEFAULT.profile = []
     y0, st0 = ops.conv(dev(nhwc(x)), wp, dev(b), **kw)
-    # the plan sees 8 reference images x 48*48 = 18432 rows (batch-invariant plans): a "large" launch -> 128x128 tiles;
+    # the plan sees 16 reference images x 48*48 = 36864 rows (batch-invariant plans): a "large" launch -> 128x128 tiles;
     # with the threshold above that it becomes a "small" one -> 64x64 tiles
-    monkeypatch.setenv('KEEP_GATHER_SMALL_M', '32768')
+    monkeypatch.setenv('KEEP_GATHER_SMALL_M', '65536')
     y1, st1 = ops.conv(dev(nhwc(x)), wp, dev(b), **kw)
     names = [r[0] for r in ops.DEFAULT.profile]
     ops.DEFAULT.profile = None

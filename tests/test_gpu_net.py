@@ -184,9 +184,18 @@ def test_full_forward_T3_vs_oracle_flows_injected(gpu_net, synth_weights):
     top2 = raux['logits'].topk(2, -1).values
     safe = (top2[..., 0] - top2[..., 1]) > 1e-3
     agree = aux['indices'].cpu().long() == raux['indices']
-    print('safe fraction', safe.float().mean().item(), 'agreement', agree.float().mean().item())
-    assert agree[safe].all()
+    # frame by frame up to and including the first frame with ANY differing token (a sub-1e-3-margin flip there makes the
+    # next frame restore a different prev_out: beyond it the two runs are not comparable token by token)
+    first_div = next((t for t in range(3) if not bool(agree[0, t].all())), 3)
+    print('safe fraction', safe.float().mean().item(), 'agreement', agree.float().mean().item(), 'first frame with a flip', first_div)
+    for t in range(min(first_div + 1, 3)):
+        assert agree[0, t][safe[0, t]].all(), f'frame {t}: a token with margin > 1e-3 differs'
+    assert first_div >= 1
     assert (aux['gains'].cpu() - raux['gains'].view(1, 3, -1)).abs().max().item() <= 2e-4
+    if first_div > 0:
+        err0 = (out.cpu() - ref)[0, :first_div].abs().max().item()
+        print('max-abs pixel diff, all pixels, frames before the first flip:', err0)
+        assert err0 <= 1e-3
     if agree.all():
         err = (out.cpu() - ref).abs().max().item()
         print('max-abs pixel diff, all pixels, free running:', err)

@@ -1098,7 +1098,8 @@ int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
   const int tiles_x = a->Wo / tw, tiles_y = a->Ho / th, ncb = (a->Cout + 63) / 64;
   const int n_items = a->N * tiles_x * tiles_y * ncb * p.split_k;
   const int n_cu = x3_num_cu();
-  dim3 grid(n_items < 2 * n_cu ? n_items : 2 * n_cu), block(256);
+  const int per_cu = getenv("KEEP_X3_BLOCKS_PER_CU") ? atoi(getenv("KEEP_X3_BLOCKS_PER_CU")) : 2;      // dev: occupancy scaling probe
+  dim3 grid(n_items < per_cu * n_cu ? n_items : per_cu * n_cu), block(256);
   const bool simple = p.split_k == 1 && !a->aux && a->epi_act == KEEP_ACT_NONE;
   // pipelined single-block-per-CU kernel: wide tiles, no split-K, at least two work items per CU
 #ifdef KEEP_X3_ABLATE

@@ -132,7 +132,10 @@ class KeepNet:
 
     def _make_x3(self):
         """Split-fp16 twin of every matrix weight in the blob (2-D+ tensors whose reduction axis is a multiple of 16)."""
-        names = [n for n, (_, shape) in self._index.items() if len(shape) >= 2 and shape[-1] % 16 == 0]
+        # only tensors a keep_conv2d call consumes as its x3 operand: the position table and the codebook are read by
+        # elementwise / gather kernels (a large-magnitude table must not shrink the scale of every convolution weight)
+        names = [n for n, (_, shape) in self._index.items() if len(shape) >= 2 and shape[-1] % 16 == 0
+                 and n not in ('position_emb', 'quantize.embedding.weight')]
         amax = max(float(self.w[n].abs().max()) for n in names)
         self._x3_scale = ops.x3_scale_for(amax)
         bx = torch.zeros(2 * self._dev_blob.numel(), dtype=torch.int16, device=self._dev_blob.device)

@@ -152,6 +152,71 @@ extern "C" int32_t keep_warp_affine_u8(const uint8_t* src, int32_t H, int32_t W,
   return KEEP_OK;
 }
 
+// ---- use_parse=False soft mask (face_restoration_helper.py:386-415): coverage of the warped face square, rectangular erosions,
+// Gaussian edge.  coverage: cv2.warpAffine(np.ones(face_size, float32), M, (W, H)) -- float weights of the quantised position,
+// BORDER_CONSTANT 0 -- written for the whole frame.
+struct CoverP {
+  float* dst;
+  double m00, m01, m02, m10, m11, m12;
+  int H, W, fh, fw;
+};
+__global__ void warp_ones_kernel(CoverP p) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= p.W || y >= p.H) return;
+  const long adelta = llrint(dmul_rn(dmul_rn(p.m00, (double)x), 1024.0));
+  const long bdelta = llrint(dmul_rn(dmul_rn(p.m10, (double)x), 1024.0));
+  const long X0 = llrint(dmul_rn(dadd_rn(dmul_rn(p.m01, (double)y), p.m02), 1024.0)) + 16;
+  const long Y0 = llrint(dmul_rn(dadd_rn(dmul_rn(p.m11, (double)y), p.m12), 1024.0)) + 16;
+  const long X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+  long sxl = X >> 5, syl = Y >> 5;
+  sxl = sxl < -32768 ? -32768 : (sxl > 32767 ? 32767 : sxl);
+  syl = syl < -32768 ? -32768 : (syl > 32767 ? 32767 : syl);
+  const int sx = (int)sxl, sy = (int)syl, fx = (int)(X & 31), fy = (int)(Y & 31);
+  const float ax = div_rn((float)fx, 32.f), ay = div_rn((float)fy, 32.f);
+  const float w00 = mul_rn(sub_rn(1.f, ax), sub_rn(1.f, ay)), w01 = mul_rn(ax, sub_rn(1.f, ay));
+  const float w10 = mul_rn(sub_rn(1.f, ax), ay), w11 = mul_rn(ax, ay);
+  auto one = [&](int yy, int xx) -> float { return (xx >= 0 && xx < p.fw && yy >= 0 && yy < p.fh) ? 1.f : 0.f; };
+  float v = mul_rn(one(sy, sx), w00);
+  v = add_rn(v, mul_rn(one(sy, sx + 1), w01));
+  v = add_rn(v, mul_rn(one(sy + 1, sx), w10));
+  v = add_rn(v, mul_rn(one(sy + 1, sx + 1), w11));
+  p.dst[(long)y * p.W + x] = v;
+}
+extern "C" int32_t keep_warp_ones(float* dst, int32_t H, int32_t W, int32_t fh, int32_t fw, const double* dst_to_src, void* stream) {
+  KEEP_REQUIRE(dst && dst_to_src && H > 0 && W > 0 && fh > 0 && fw > 0, "keep_warp_ones: bad arguments");
+  CoverP p;
+  p.dst = dst;
+  p.m00 = dst_to_src[0]; p.m01 = dst_to_src[1]; p.m02 = dst_to_src[2];
+  p.m10 = dst_to_src[3]; p.m11 = dst_to_src[4]; p.m12 = dst_to_src[5];
+  p.H = H; p.W = W; p.fh = fh; p.fw = fw;
+  hipLaunchKernelGGL(warp_ones_kernel, dim3(cdiv(W, 32), cdiv(H, 8)), dim3(256), 0, (hipStream_t)stream, p);
+  KEEP_LAUNCH_CHECK("keep_warp_ones");
+  return KEEP_OK;
+}
+
+// cv2.erode(img, np.ones((k, k))): minimum over the k x k window anchored at k/2 (offsets -k/2 .. k-1-k/2), pixels outside the image
+// never win (constant border +inf).  A minimum is separable: rows, then columns.
+__global__ void erode_pass_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int k, int along_x) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)H * W) return;
+  const int y = (int)(idx / W), x = (int)(idx - (long)y * W);
+  const int a = k >> 1;
+  float m = INFINITY;
+  for (int i = 0; i < k; ++i) {
+    const int xx = along_x ? x - a + i : x, yy = along_x ? y : y - a + i;
+    if (xx >= 0 && xx < W && yy >= 0 && yy < H) m = fminf(m, src[(long)yy * W + xx]);
+  }
+  dst[idx] = m;
+}
+extern "C" int32_t keep_erode_rect(const float* src, float* tmp, float* dst, int32_t H, int32_t W, int32_t k, void* stream) {
+  KEEP_REQUIRE(src && tmp && dst && H > 0 && W > 0 && k >= 1 && k <= 4096, "keep_erode_rect: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(erode_pass_kernel, dim3(cdiv((long)H * W, 256)), dim3(256), 0, st, src, tmp, H, W, k, 1);
+  hipLaunchKernelGGL(erode_pass_kernel, dim3(cdiv((long)H * W, 256)), dim3(256), 0, st, tmp, dst, H, W, k, 0);
+  KEEP_LAUNCH_CHECK("keep_erode_rect");
+  return KEEP_OK;
+}
+
 // ---- one face: warp (face uint8 x3, mask float) + blend into the float frame, over the face's bounding box
 struct PasteP {
   float* acc;            // [H,W,3] float32 frame, in place
@@ -159,6 +224,7 @@ struct PasteP {
   const float* mask;     // [fh,fw] blurred parse mask on the 0..255 scale (before border zeroing and /255)
   double m00, m01, m02, m10, m11, m12;   // destination -> source map (inverse of the matrix given to cv2.warpAffine)
   int H, W, fh, fw, x0, y0, bw, bh, border;
+  const float* frame_mask;   // use_parse=False: the soft mask already in FRAME space [H,W] (FH:411-415); then `mask` is unused
 };
 
 __device__ __forceinline__ float mask_at(const PasteP& p, int sy, int sx) {
@@ -189,10 +255,15 @@ __global__ void paste_face_kernel(PasteP p) {
   const float ax = div_rn((float)fx, 32.f), ay = div_rn((float)fy, 32.f);
   const float w00 = mul_rn(sub_rn(1.f, ax), sub_rn(1.f, ay)), w01 = mul_rn(ax, sub_rn(1.f, ay));
   const float w10 = mul_rn(sub_rn(1.f, ax), ay), w11 = mul_rn(ax, ay);
-  float soft = mul_rn(mask_at(p, sy, sx), w00);
-  soft = add_rn(soft, mul_rn(mask_at(p, sy, sx + 1), w01));
-  soft = add_rn(soft, mul_rn(mask_at(p, sy + 1, sx), w10));
-  soft = add_rn(soft, mul_rn(mask_at(p, sy + 1, sx + 1), w11));
+  float soft;
+  if (p.frame_mask) {
+    soft = p.frame_mask[(long)y * p.W + x];
+  } else {
+    soft = mul_rn(mask_at(p, sy, sx), w00);
+    soft = add_rn(soft, mul_rn(mask_at(p, sy, sx + 1), w01));
+    soft = add_rn(soft, mul_rn(mask_at(p, sy + 1, sx), w10));
+    soft = add_rn(soft, mul_rn(mask_at(p, sy + 1, sx + 1), w11));
+  }
   const float inv = sub_rn(1.f, soft);
   // face: 15-bit integer weights, (sum + 2^14) >> 15
   const int i00 = (32 - fx) * (32 - fy) * 32, i01 = fx * (32 - fy) * 32, i10 = (32 - fx) * fy * 32, i11 = fx * fy * 32;
@@ -209,13 +280,16 @@ extern "C" int32_t keep_paste_face(float* frame, int32_t H, int32_t W, const uin
                                    const double* dst_to_src, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t mask_border,
                                    void* stream) {
   KEEP_REQUIRE(frame && face && mask && dst_to_src && H > 0 && W > 0 && fh > 1 && fw > 1, "keep_paste_face: bad arguments");
-  KEEP_REQUIRE(x0 >= 0 && y0 >= 0 && x1 <= W && y1 <= H && mask_border >= 0, "keep_paste_face: box outside the frame");
+  // mask_border < 0: `mask` is a FRAME-space soft mask [H,W] (use_parse=False path), sampled at the destination pixel
+  KEEP_REQUIRE(x0 >= 0 && y0 >= 0 && x1 <= W && y1 <= H, "keep_paste_face: box outside the frame");
   if (x1 <= x0 || y1 <= y0) return KEEP_OK;        // the face does not touch the frame
   PasteP p;
   p.acc = frame; p.face = face; p.mask = mask;
   p.m00 = dst_to_src[0]; p.m01 = dst_to_src[1]; p.m02 = dst_to_src[2];
   p.m10 = dst_to_src[3]; p.m11 = dst_to_src[4]; p.m12 = dst_to_src[5];
-  p.H = H; p.W = W; p.fh = fh; p.fw = fw; p.x0 = x0; p.y0 = y0; p.bw = x1 - x0; p.bh = y1 - y0; p.border = mask_border;
+  p.H = H; p.W = W; p.fh = fh; p.fw = fw; p.x0 = x0; p.y0 = y0; p.bw = x1 - x0; p.bh = y1 - y0;
+  p.border = mask_border < 0 ? 0 : mask_border;
+  p.frame_mask = mask_border < 0 ? mask : nullptr;
   hipLaunchKernelGGL(paste_face_kernel, dim3(cdiv(p.bw, 32), cdiv(p.bh, 8)), dim3(256), 0, (hipStream_t)stream, p);
   KEEP_LAUNCH_CHECK("keep_paste_face");
   return KEEP_OK;

@@ -86,6 +86,8 @@ _SIGNATURES = {
     'keep_u8_to_f32': [_vp, _vp, _i64, _vp],
     'keep_f32_round_u8': [_vp, _vp, _i64, _vp],
     'keep_warp_affine_u8': [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
+    'keep_warp_ones': [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
+    'keep_erode_rect': [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
     'keep_paste_face': [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
 }
 EXPORTED_SYMBOLS = ['keep_abi_version', 'keep_last_error', 'keep_device_ok', 'keep_attention_workspace_bytes',

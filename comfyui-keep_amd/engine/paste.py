@@ -1,6 +1,6 @@
 """Paste-back compositing on the MI355X: the per-face work of
-``FaceRestoreHelper.paste_faces_to_input_image`` (wm_facelib/utils/face_restoration_helper.py:346-475, ``use_parse=True``,
-``draw_box=False``, colour frames) on HIP kernels (csrc/keep_paste.hip) instead of full-frame cv2 passes on the host:
+``FaceRestoreHelper.paste_faces_to_input_image`` (wm_facelib/utils/face_restoration_helper.py:346-475, ``use_parse=True`` and
+``use_parse=False``, ``draw_box=False``, colour frames) on HIP kernels (csrc/keep_paste.hip) instead of full-frame cv2 passes on the host:
 
     parse classes -> mask 0/255 -> 2 x GaussianBlur((101,101), 11) -> 10-px border zeroed -> /255        (:426-437)
     inverse-affine warp of the mask (float weights) and of the restored face (15-bit integer weights)    (:382, :441)
@@ -36,11 +36,18 @@ def invert_affine(M):
     return np.array([[A11, A12, -A11 * M[0, 2] - A12 * M[1, 2]], [A21, A22, -A21 * M[0, 2] - A22 * M[1, 2]]], np.float64)
 
 
+_SMALL_GAUSSIAN = {1: [1.0], 3: [0.25, 0.5, 0.25], 5: [0.0625, 0.25, 0.375, 0.25, 0.0625],
+                   7: [0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125]}
+
+
 def gaussian_kernel(ksize, sigma):
-    """cv2.getGaussianKernel(ksize, sigma, CV_32F) for sigma > 0: exp(-x^2 / 2 sigma^2) in double, rounded to float,
-    normalised by the float sum."""
+    """cv2.getGaussianKernel(ksize, sigma, CV_32F): fixed tables for ksize <= 7 with sigma <= 0, else exp(-x^2 / 2 sigma^2) in
+    double (sigma <= 0: 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8), rounded to float, normalised by the float sum."""
+    if sigma <= 0 and ksize in _SMALL_GAUSSIAN:
+        return np.array(_SMALL_GAUSSIAN[ksize], np.float32)
+    sig = sigma if sigma > 0 else ((ksize - 1) * 0.5 - 1) * 0.3 + 0.8
     x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
-    cf = np.exp((-0.5 / (sigma * sigma)) * x * x).astype(np.float32)
+    cf = np.exp((-0.5 / (sig * sig)) * x * x).astype(np.float32)
     return (cf.astype(np.float64) * (1.0 / float(cf.astype(np.float64).sum()))).astype(np.float32)
 
 
@@ -92,17 +99,44 @@ class GpuPaster:
         L.call('keep_sep_filter', a, None, None, tmp, b, F, h, w, self._kern, PARSE_BLUR_KSIZE)
         return b
 
-    def paste(self, frame_u8, faces_u8, inverse_affines, parse_classes):
+    def erosion_mask(self, d2s, H, W, fh, fw, upscale_factor):
+        """The ``use_parse=False`` soft mask of one face in FRAME space (face_restoration_helper.py:386-415): coverage of the warped
+        face square -> erode(2 * upscale) -> area -> erode(2 * (sqrt(area) // 20)) -> GaussianBlur of the same odd size.  The area
+        (one float64 sum) comes back to the host: it sets the two kernel sizes.  None when the blur would need more than 127 taps."""
+        a = torch.empty((H, W), dtype=torch.float32, device=self.device)
+        b = torch.empty_like(a)
+        tmp = torch.empty_like(a)
+        L.call('keep_warp_ones', a, H, W, fh, fw, d2s)
+        L.call('keep_erode_rect', a, tmp, b, H, W, max(1, int(2 * upscale_factor)))
+        total = float(b.sum(dtype=torch.float64).item())
+        if total == 0:
+            total = 1
+        w_edge = int(total ** 0.5) // 20
+        radius = max(1, w_edge * 2)
+        blur = max(1, w_edge * 2)
+        if blur % 2 == 0:
+            blur += 1
+        if blur > 127 or blur // 2 >= min(H, W):
+            return None
+        L.call('keep_erode_rect', b, tmp, a, H, W, radius)
+        kern = torch.from_numpy(gaussian_kernel(blur, 0)).to(self.device)
+        L.call('keep_sep_filter', a, None, None, tmp, b, 1, H, W, kern, blur)
+        return b
+
+    def paste(self, frame_u8, faces_u8, inverse_affines, parse_classes=None, upscale_factor=1.0):
         """frame_u8: uint8 [H,W,3] (numpy or tensor; the background at the output size), faces_u8: uint8 [F,fh,fw,3],
         inverse_affines: F crop -> frame matrices (``get_inverse_affine``; None entries are skipped), parse_classes: uint8
-        [F,fh,fw].  Returns the composited uint8 [H,W,3] tensor on the device."""
+        [F,fh,fw] (``use_parse=True``) or None (``use_parse=False``: the erosion mask above, ``upscale_factor`` as the helper's).
+        Returns the composited uint8 [H,W,3] tensor on the device, or None when a face needs a blur wider than the kernels take
+        (the caller falls back to the helper)."""
         frame = torch.as_tensor(frame_u8).to(self.device, non_blocking=True).contiguous()
         faces = torch.as_tensor(faces_u8).to(self.device, non_blocking=True).contiguous()
-        cls = torch.as_tensor(parse_classes).to(self.device, non_blocking=True).contiguous()
         H, W, _ = frame.shape
         F, fh, fw, _ = faces.shape
         with torch.cuda.device(self.device):
-            masks = self.soft_masks(cls)
+            masks = None
+            if parse_classes is not None:
+                masks = self.soft_masks(torch.as_tensor(parse_classes).to(self.device, non_blocking=True).contiguous())
             acc = torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
             L.call('keep_u8_to_f32', frame, acc, frame.numel())
             for i in range(F):
@@ -111,6 +145,12 @@ class GpuPaster:
                     continue
                 x0, y0, x1, y1 = face_box(M, fw, fh, W, H)
                 d2s = (C.c_double * 6)(*invert_affine(M).reshape(-1).tolist())
+                if masks is None:
+                    fm = self.erosion_mask(d2s, H, W, fh, fw, upscale_factor)
+                    if fm is None:
+                        return None
+                    L.call('keep_paste_face', acc, H, W, faces[i], fm, fh, fw, d2s, x0, y0, x1, y1, -1)
+                    continue
                 L.call('keep_paste_face', acc, H, W, faces[i], masks[i], fh, fw, d2s, x0, y0, x1, y1, PARSE_BORDER)
             out = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
             L.call('keep_f32_round_u8', acc, out, acc.numel())

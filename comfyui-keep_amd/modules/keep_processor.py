@@ -252,9 +252,10 @@ class KEEPFaceProcessor:
 
     def _gpu_paste_applies(self, helper, bg, draw_box):
         faces, mats = getattr(helper, 'restored_faces', None), getattr(helper, 'inverse_affine_matrices', None)
-        if draw_box or self.face_upscale_model is not None or not getattr(helper, 'use_parse', False):
+        if draw_box or self.face_upscale_model is not None:
             return False
-        if getattr(helper, 'is_gray', False) or getattr(helper, 'face_parse', None) is None or not faces or mats is None:
+        use_parse = getattr(helper, 'use_parse', False)
+        if getattr(helper, 'is_gray', False) or (use_parse and getattr(helper, 'face_parse', None) is None) or not faces or mats is None:
             return False
         if len(faces) != len(mats) or not isinstance(bg, np.ndarray) or bg.dtype != np.uint8 or bg.ndim != 3 or bg.shape[2] != 3:
             return False
@@ -272,6 +273,11 @@ class KEEPFaceProcessor:
         if self._paster is None:
             self._paster = GpuPaster(self.device)
         faces = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(f) for f in helper.restored_faces]))).to(self.device)
+        if not getattr(helper, 'use_parse', False):       # :386-415 erosion mask instead of the parse mask
+            out = self._paster.paste(bg, faces, list(helper.inverse_affine_matrices), None, getattr(helper, 'upscale_factor', 1))
+            if out is None:                                # a face larger than the blur kernel takes: the helper's own path
+                return helper.paste_faces_to_input_image(upsample_img=bg, draw_box=False, face_upsampler=None)
+            return out.cpu().numpy()
         # :418-424  BGR uint8 -> RGB float (x/255 - 0.5)/0.5, one face per ParseNet call like the reference
         x = torch.empty(faces.shape, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):

@@ -341,11 +341,16 @@ int32_t keep_f32_round_u8(const float* x, uint8_t* out, int64_t n, void* stream)
  * HOST pointer to the 6 doubles of the destination -> source map (cv2.invertAffineTransform of M), read at call time. */
 int32_t keep_warp_affine_u8(const uint8_t* src, int32_t H, int32_t W, uint8_t* dst, int32_t dh, int32_t dw, const double* dst_to_src,
                             int32_t border_b, int32_t border_g, int32_t border_r, void* stream);
+/* use_parse=False soft mask (FH:386-415): keep_warp_ones = cv2.warpAffine(np.ones((fh, fw), float32), M, (W, H)) for the whole
+ * frame; keep_erode_rect = cv2.erode(img, np.ones((k, k))) (separable minimum, +inf outside the image), tmp / dst: [H,W] floats. */
+int32_t keep_warp_ones(float* dst, int32_t H, int32_t W, int32_t fh, int32_t fw, const double* dst_to_src, void* stream);
+int32_t keep_erode_rect(const float* src, float* tmp, float* dst, int32_t H, int32_t W, int32_t k, void* stream);
 /* One face into the float frame [H,W,3], in place, over the box [x0,x1) x [y0,y1): cv2.warpAffine(face uint8 [fh,fw,3]) (:382)
  * and cv2.warpAffine(mask float [fh,fw]) (:441) with INTER_LINEAR / BORDER_CONSTANT 0 and OpenCV's fixed-point coordinates,
  * the mask's `mask_border` outer rows / columns read as zero and its values divided by 255 (:435-437), then
  * frame = soft * face + (1 - soft) * frame in float32 (:463).  dst_to_src: HOST pointer to the 6 doubles of the
- * destination -> source map (cv2.invertAffineTransform of the matrix the reference passes), read at call time. */
+ * destination -> source map (cv2.invertAffineTransform of the matrix the reference passes), read at call time.
+ * mask_border < 0: `mask` is a soft mask already in FRAME space [H,W] (the use_parse=False path), read at the destination pixel. */
 int32_t keep_paste_face(float* frame, int32_t H, int32_t W, const uint8_t* face, const float* mask, int32_t fh, int32_t fw,
                         const double* dst_to_src, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t mask_border, void* stream);
 

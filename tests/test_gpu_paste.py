@@ -45,6 +45,24 @@ def test_paste_small_frame_and_upscaled_matrix():
     assert np.array_equal(got, ref)
 
 
+def test_erosion_mask_paste_use_parse_false_is_bit_exact():
+    """use_parse=False (face_restoration_helper.py:386-415): warpAffine(ones) -> erode -> area -> erode -> GaussianBlur soft mask in
+    frame space, then the same warp + blend: whole 1080p / 3-face composite and each intermediate mask against the oracle."""
+    frame, faces, mats, _ = synth.synth_paste_case()
+    H, W = frame.shape[:2]
+    gp = paste.GpuPaster('cuda')
+    import ctypes as C
+    for i, M in enumerate(mats):
+        d2s = (C.c_double * 6)(*paste.invert_affine(M).reshape(-1).tolist())
+        got = gp.erosion_mask(d2s, H, W, 512, 512, 1.0).cpu().numpy()
+        ref, _ = P.erosion_soft_mask(M, W, H, 1.0)
+        assert np.array_equal(got, ref), (i, float(np.abs(got - ref).max()))
+    ref = P.paste_faces(frame, list(faces), list(mats), None, upscale_factor=1.0)
+    got = gp.paste(frame, faces, list(mats), None, 1.0).cpu().numpy()
+    assert np.array_equal(got, ref), int(np.abs(got.astype(np.int16) - ref.astype(np.int16)).max())
+    assert (got != frame).any()
+
+
 def test_crop_warp_align_warp_face_is_bit_exact():
     """align_warp_face's cv2.warpAffine(frame, M, (512, 512), borderValue=(135, 133, 132)) (face_restoration_helper.py:316-318)
     on the device: frame -> crop matrices = the inverses of the synthetic case's crop -> frame matrices; the third face hangs over

@@ -411,7 +411,7 @@ def test_paste_hook_defers_to_the_helper():
     assert not proc._gpu_paste_applies(h, bg.astype(np.float32), False)              # not uint8
     assert not proc._gpu_paste_applies(h, np.zeros((32, 32, 3), np.uint8), False)    # background still to be resized
     h.use_parse = False
-    assert not proc._gpu_paste_applies(h, bg, False)
+    assert proc._gpu_paste_applies(h, bg, False)                                    # the erosion-mask path is on the device too
     h.use_parse, proc.face_upscale_model = True, object()
     assert not proc._gpu_paste_applies(h, bg, False)
 

@@ -84,3 +84,10 @@ def test_restatement_equals_opencv_where_opencv_exists():
         assert np.array_equal(blur, P.gaussian_blur(P.gaussian_blur(m, 101, 11), 101, 11)), i
         soft = P.parse_soft_mask(classes[i])
         assert np.array_equal(cv2.warpAffine(soft, M, (W, H)), P.warp_affine_f32(soft, M, W, H)), i
+        # use_parse=False chain (:386-415): coverage, erosions (even and odd kernels), sigma-0 Gaussian of a computed size
+        cov = cv2.warpAffine(np.ones((512, 512), np.float32), M, (W, H))
+        assert np.array_equal(cov, P.warp_affine_f32(np.ones((512, 512), np.float32), M, W, H)), i
+        for k in (2, 9, 24):
+            assert np.array_equal(cv2.erode(cov, np.ones((k, k), np.uint8)), P.erode_rect(cov, k)), (i, k)
+        for ks in (5, 7, 13, 25):
+            assert np.array_equal(cv2.GaussianBlur(cov, (ks, ks), 0), P.gaussian_blur(cov, ks, 0)), (i, ks)

@@ -211,7 +211,7 @@ class KEEPFaceProcessor:
             if helper.get_face_landmarks_5(only_center_face=only_center_face, resize=640,
                                            eye_dist_threshold=5) == 0:
                 return bg_img_final
-            helper.align_warp_face()
+            self._align_warp(helper)
             crops = list(helper.cropped_faces)
             if not crops:
                 return bg_img_final
@@ -241,14 +241,32 @@ class KEEPFaceProcessor:
         colour frame already at the output size, no box, no face upsampler, every crop at the helper's face size) the
         per-face masks, warps and the blend run on the MI355X (engine/paste.py); every other configuration -- and every
         helper that is not the reference's -- goes to the helper's own method."""
-        if self.gpu_paste is None:                       # 'auto': decided once per processor, against cv2 itself
+        if self._gpu_cv_path() and self._gpu_paste_applies(helper, bg, draw_box):
+            return self._paste_gpu(helper, bg)
+        return helper.paste_faces_to_input_image(upsample_img=bg, draw_box=draw_box, face_upsampler=self.face_upscale_model)
+
+    def _gpu_cv_path(self):
+        """Whether the OpenCV-arithmetic kernels (paste-back, crop warp) may stand in for cv2: forced by KEEP_AMD_GPU_PASTE, else
+        decided once per processor by comparing them with cv2 itself on this installation."""
+        if self.gpu_paste is None:
             try:
                 self.gpu_paste = bool(opencv_agrees_with_gpu_paste(self.device))
             except Exception:                            # no cv2 / no GPU / any surprise: the helper's own path
                 self.gpu_paste = False
-        if self.gpu_paste and self._gpu_paste_applies(helper, bg, draw_box):
-            return self._paste_gpu(helper, bg)
-        return helper.paste_faces_to_input_image(upsample_img=bg, draw_box=draw_box, face_upsampler=self.face_upscale_model)
+        return self.gpu_paste
+
+    def _align_warp(self, helper):
+        """``helper.align_warp_face()`` (face_restoration_helper.py:256-320).  With the GPU cv path and the default configuration
+        (no pad_blur, constant border) only the similarity fit stays on the host (``cv2.estimateAffinePartial2D``, :305); the
+        ``cv2.warpAffine`` that produces the 512 x 512 crops (:316-318) runs on the device (``keep_warp_affine_u8``)."""
+        if not self._gpu_cv_path() or getattr(helper, 'pad_blur', False) or not hasattr(helper, 'face_template'):
+            return helper.align_warp_face()
+        from ..engine.paste import crop_faces
+        cv2 = _cv2()
+        mats = [cv2.estimateAffinePartial2D(lm, helper.face_template, method=cv2.LMEDS)[0] for lm in helper.all_landmarks_5]
+        crops = crop_faces(helper.input_img, mats, tuple(helper.face_size), self.device).cpu().numpy()
+        helper.affine_matrices.extend(mats)
+        helper.cropped_faces.extend(crops[i] for i in range(len(mats)))
 
     def _gpu_paste_applies(self, helper, bg, draw_box):
         faces, mats = getattr(helper, 'restored_faces', None), getattr(helper, 'inverse_affine_matrices', None)
@@ -373,7 +391,7 @@ class KEEPFaceProcessor:
                     helper.clean_all()
                     helper.read_image(frames_bgr[i])
                     helper.all_landmarks_5 = active
-                    helper.align_warp_face()
+                    self._align_warp(helper)
                     frame_crops = list(helper.cropped_faces)
                     frame_aff = list(helper.affine_matrices)
             faces_per_frame.append(len(frame_crops))

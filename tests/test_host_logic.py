@@ -466,3 +466,44 @@ def test_batched_detection_prepass_equals_the_per_frame_loop():
         assert helper.calls == 5 and helper.face_detector is det
         assert (det.single_calls, det.batch_calls) == ((5, 0) if name == 'loop' else (0, 1))
     assert all(np.array_equal(a[0], b[0]) for a, b in zip(out['loop'], out['batch']))
+
+
+def test_device_crop_warp_hook_keeps_the_helper_contract(monkeypatch):
+    """8f-2 host logic: with the GPU cv path on, ``_align_warp`` fits the similarity on the host (cv2.estimateAffinePartial2D) and
+    crops on the device, filling ``affine_matrices`` / ``cropped_faces`` exactly like ``align_warp_face``; pad_blur or the cv path
+    being off defers to the helper."""
+    from comfyui_keep_amd.modules import keep_processor as KPm
+    from comfyui_keep_amd.engine import paste as gp
+    calls = []
+
+    class Cv2:
+        LMEDS = 4
+
+        @staticmethod
+        def estimateAffinePartial2D(lm, tmpl, method=None):
+            return (np.array([[1.0, 0.0, float(lm[0, 0])], [0.0, 1.0, 0.0]]), None)
+
+    class Hp(_Helper):
+        pad_blur, face_size, face_template = False, (512, 512), np.zeros((5, 2))
+
+        def __init__(self):
+            self.affine_matrices, self.cropped_faces = [], []
+            self.all_landmarks_5 = [np.full((5, 2), 3.0), np.full((5, 2), 7.0)]
+            self.input_img = np.zeros((64, 64, 3), np.uint8)
+
+        def align_warp_face(self):
+            calls.append('helper')
+
+    monkeypatch.setattr(KPm, '_cv2', lambda: Cv2)
+    monkeypatch.setattr(gp, 'crop_faces', lambda frame, mats, size, dev: torch.zeros((len(mats), size[1], size[0], 3), dtype=torch.uint8))
+    h = Hp()
+    proc = KEEPFaceProcessor(KEEPModelPack(_RecordingNet(), h, None, None, 'KEEP'))
+    proc.gpu_paste = True
+    proc._align_warp(h)
+    assert calls == [] and len(h.cropped_faces) == 2 and h.cropped_faces[0].shape == (512, 512, 3)
+    assert [float(m[0, 2]) for m in h.affine_matrices] == [3.0, 7.0]
+    h.pad_blur = True
+    proc._align_warp(h)
+    proc.gpu_paste, h.pad_blur = False, False
+    proc._align_warp(h)
+    assert calls == ['helper', 'helper']

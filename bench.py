@@ -51,6 +51,7 @@ T_CLIP = 20
 PEAK_16BIT_MFMA_TFLOPS = 2500.0       # dense bf16 / fp16 MFMA (no sparsity), MI355X_MICROARCH.md
 PEAK_F32_MFMA_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 FLOP_PER_FRAME_T20 = 1038.5e9         # SURVEY.md 8d (reference graph, 2 FLOP/MAC)
+GMFLOW_DUPLICATE_FLOP_PER_FRAME = 33.0e9   # backbone passes of interior frames the reference repeats: 18 of 38 per T=20 clip
 PEAK = {'fp32': PEAK_F32_MFMA_TFLOPS, 'bf16': PEAK_16BIT_MFMA_TFLOPS, 'x3': PEAK_16BIT_MFMA_TFLOPS / 3.0}
 DTYPE = {'fp32': 'f32', 'bf16': 'bf16', 'x3': 'f16x3'}
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
@@ -334,6 +335,9 @@ def main():
                        "fp32": "exact f32 MFMA: the reference arithmetic up to re-association",
                        "bf16": "operands rounded to bf16: outside the <= 1e-3 tolerance (speed policy)"}[args.precision],
             "whole_net_tflops": round(fps * FLOP_PER_FRAME_T20 / 1e12, 2),
+            # the reference pushes every interior frame through GMFlow's CNN encoder twice (KA:979-984); the engine runs it once
+            # per frame (net.py:_gmflow_clip): ~33 GFLOP per frame of the reference count are not executed here
+            "whole_net_tflops_executed": round(fps * (FLOP_PER_FRAME_T20 - GMFLOW_DUPLICATE_FLOP_PER_FRAME) / 1e12, 2),
             "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
             "x3_range_fallbacks": net.x3_fallbacks,
             "roofline": conv_roofline(net, x),

@@ -1337,6 +1337,243 @@ __global__ __launch_bounds__(256, 1) void attn_x3_sfull_kernel(AttnP p) {
   }
 }
 
+// The same case (D = 512 = 4 x 128, at most 256 keys, mode 0: the VQGAN AttnBlock on a 16 x 16 map) cut for LATENCY and block
+// count: a block owns 32 queries (not 128) and ALL of Dv, so a launch has Lq/32 x H x B blocks (8 per image instead of
+// 2 x 4 dv slices that each recomputed Q.K^T) and no product is computed twice:
+//   phase 1  wave w multiplies ITS 128-channel chunk of Q (32 x 128) with the same chunk of every key tile -- operands staged
+//            wave-privately (no block barrier in the loop) -- into 8 partial score tiles S_w^T [32 keys x 32 queries];
+//   phase 2  the four partial sums of a tile are exchanged through LDS and added in wave order 0..3 by every wave (fixed
+//            order: deterministic, independent of the batch) -- each wave then holds the full score rows of the 32 queries;
+//   phase 3  exact fp32 softmax over the 256 keys (every wave, redundantly: 128 values per lane);
+//   phase 4  wave w multiplies P with ITS 128-column slice of V (staged wave-privately, key-permuted like attn_bf16_kernel).
+// 16^2 AttnBlock, B = 1: 140 us -> see DESIGN.md 5.1; the old kernel stays for the shapes this one does not take.
+__global__ __launch_bounds__(256, 1) void attn_x3_sfull2_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 smemx[];
+  constexpr int DC = 128, QP = 2 * DC + 8, VP = 72, DVS = 128;
+  constexpr int WREG = 2 * 32 * QP;                    // halfs per wave: Q chunk rows + one key tile's rows (>= DVS * VP for phase 4)
+  static_assert(WREG >= DVS * VP, "V^T tile fits the wave's staging region");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 32;
+  _Float16* Qw = smemx + wave * WREG;
+  _Float16* Kw = Qw + 32 * QP;
+  _Float16* Vt = Qw;                                   // phase 4 reuses the wave's region
+  float* red = reinterpret_cast<float*>(smemx + 4 * WREG);      // [4 waves][32 x 32]
+  const long qh = (long)head * p.q_hs, kh = (long)head * p.k_hs, vh = (long)head * p.v_hs;
+  const int ntiles = (p.Lk + 31) / 32;                 // <= 8
+  float sq = 1.f, sk = 1.f, sv = 1.f, inv_qk = 1.f, inv_sv = 1.f;
+  if (p.q_amax) {
+    float iq, ik;
+    attn_range_scale(p.q_amax[b], sq, iq);
+    attn_range_scale(p.k_amax[b], sk, ik);
+    attn_range_scale(p.v_amax[b], sv, inv_sv);
+    inv_qk = iq * ik;
+  }
+  // 32 rows x 128 channels (this wave's chunk) of q or k by the 64 lanes of ONE wave: 16 float4 per lane, all loads of a tile
+  // issued back to back into registers (the next tile's while the current one is on the matrix cores), then split into
+  // (hi | lo) rows
+  float4 buf[16];
+  auto load_rows = [&](const float* base, long bs, long ts, long hoff, int t0, int tmax) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = lane + u * 64;
+      const int row = i >> 5, c = (i & 31) << 2;
+      const int t = t0 + row;
+      buf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < tmax) buf[u] = *reinterpret_cast<const float4*>(base + (long)b * bs + (long)t * ts + hoff + wave * DC + c);
+    }
+  };
+  auto split_rows = [&](float sc, _Float16* dst) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = lane + u * 64;
+      const int row = i >> 5, c = (i & 31) << 2;
+      const float f[4] = {buf[u].x * sc, buf[u].y * sc, buf[u].z * sc, buf[u].w * sc};
+      af16x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const _Float16 h = (_Float16)f[j];
+        hi[j] = h;
+        lo[j] = (_Float16)(f[j] - (float)h);
+      }
+      *reinterpret_cast<af16x4*>(dst + row * QP + c) = hi;
+      *reinterpret_cast<af16x4*>(dst + row * QP + c + DC) = lo;
+    }
+  };
+  f32x16 s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[k][r] = 0.f;
+  // ---- phase 1: partial S^T over this wave's channel chunk
+  load_rows(p.q, p.q_bs, p.q_ts, qh, q0, p.Lq);
+  split_rows(sq, Qw);
+  load_rows(p.k, p.k_bs, p.k_ts, kh, 0, p.Lk);
+  const _Float16* qp = Qw + l31 * QP + lhi * 8;
+  const _Float16* kp = Kw + l31 * QP + lhi * 8;
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt) {
+    if (kt < ntiles) {
+      split_rows(sk, Kw);
+      __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): wave-private hand-off (LDS ops of one wave retire in order)
+      if (kt + 1 < ntiles) load_rows(p.k, p.k_bs, p.k_ts, kh, (kt + 1) * 32, p.Lk);      // in flight during the MFMAs below
+#pragma unroll
+      for (int d = 0; d < DC; d += 16) {
+        const af16x8 qh8 = *reinterpret_cast<const af16x8*>(qp + d), ql8 = *reinterpret_cast<const af16x8*>(qp + DC + d);
+        const af16x8 kh8 = *reinterpret_cast<const af16x8*>(kp + d), kl8 = *reinterpret_cast<const af16x8*>(kp + DC + d);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh8, s[kt], 0, 0, 0);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, ql8, s[kt], 0, 0, 0);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qh8, s[kt], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);              // fragment reads done before the next tile overwrites Kw
+    }
+  }
+  // ---- phase 2: full scores = sum over the four channel chunks, in wave order
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt) {
+    if (kt < ntiles) {
+      __syncthreads();                                 // the previous tile's partials are consumed
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lhi) * 32 + l31] = s[kt][r];
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = ((r & 3) + 8 * (r >> 2) + 4 * lhi) * 32 + l31;
+        s[kt][r] = ((red[o] + red[1024 + o]) + red[2048 + o]) + red[3072 + o];
+      }
+    }
+  }
+  // ---- phase 3: softmax over the whole key row of this lane's query (exact fp32)
+  const float qk_scale = p.scale * inv_qk;
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const float val = key < p.Lk ? s[k][r] * qk_scale : -INFINITY;
+      s[k][r] = val;
+      m = fmaxf(m, val);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32));
+  float lsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = expf(s[k][r] - m);
+      s[k][r] = pv;
+      lsum += pv;
+    }
+  lsum += __shfl_xor(lsum, 32);
+  // ---- phase 4: O[:, dv slice of this wave] = P . V
+  const int dv0 = wave * DVS;
+  f32x16 o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+  if (dv0 < p.Dv) {
+    // V tile = 32 keys x 128 dv of this wave's slice: 8 (key pair, 4-dv group) items per lane, 2 float4 each, reusing buf[]
+    auto load_v = [&](int kt) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = lane + u * 64;
+        const int pair = i >> 5, dv = (i & 31) << 2;
+        const int t = kt * 32 + pair * 2;
+        buf[2 * u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        buf[2 * u + 1] = buf[2 * u];
+        if (dv0 + dv < p.Dv) {
+          if (t < p.Lk) buf[2 * u] = *reinterpret_cast<const float4*>(p.v + (long)b * p.v_bs + (long)t * p.v_ts + vh + dv0 + dv);
+          if (t + 1 < p.Lk) buf[2 * u + 1] = *reinterpret_cast<const float4*>(p.v + (long)b * p.v_bs + (long)(t + 1) * p.v_ts + vh + dv0 + dv);
+        }
+      }
+    };
+    load_v(0);
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      if (kt < ntiles) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = lane + u * 64;
+          const int pair = i >> 5, dv = (i & 31) << 2;
+          const float4 va = buf[2 * u], vb = buf[2 * u + 1];
+          const float fa[4] = {va.x * sv, va.y * sv, va.z * sv, va.w * sv}, fb[4] = {vb.x * sv, vb.y * sv, vb.z * sv, vb.w * sv};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            af16x2 hi, lo;
+            const _Float16 ha = (_Float16)fa[j], hb = (_Float16)fb[j];
+            hi[0] = ha; hi[1] = hb;
+            lo[0] = (_Float16)(fa[j] - (float)ha); lo[1] = (_Float16)(fb[j] - (float)hb);
+            _Float16* dd = Vt + (dv + j) * VP + vt_pos(pair * 2);     // vt_pos(k0+1) = vt_pos(k0) + 1 for even k0
+            *reinterpret_cast<af16x2*>(dd) = hi;
+            *reinterpret_cast<af16x2*>(dd + 32) = lo;
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (kt + 1 < ntiles) load_v(kt + 1);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          af16x8 ph, pl;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const _Float16 h = (_Float16)s[kt][st * 8 + j];
+            ph[j] = h;
+            pl[j] = (_Float16)(s[kt][st * 8 + j] - (float)h);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const _Float16* vrow = Vt + (j * 32 + l31) * VP + (st * 2 + lhi) * 8;
+            const af16x8 vh8 = *reinterpret_cast<const af16x8*>(vrow), vl8 = *reinterpret_cast<const af16x8*>(vrow + 32);
+            o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh8, o[j], 0, 0, 0);
+            o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl8, o[j], 0, 0, 0);
+            o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh8, o[j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  const float inv_l = inv_sv / lsum;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    const float il = __shfl(inv_l, qrow);
+    const int t = q0 + qrow;
+    if (t < p.Lq && dv0 < p.Dv) {
+      const long base = (long)b * p.o_bs + (long)t * p.o_ts + (long)head * p.o_hs;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int dv = dv0 + j * 32 + l31;
+        if (dv < p.Dv) p.o[base + dv] = o[j][r] * il;
+      }
+    }
+  }
+}
+
+static bool attn_sfull2_ok(const AttnP& p) {
+  return p.mode == 0 && p.D == 512 && p.Lk <= 256 && p.Dv <= 512 && p.Dv % 4 == 0 && p.v_ts % 4 == 0 && p.v_bs % 4 == 0 &&
+         p.v_hs % 4 == 0 && (uintptr_t)p.v % 16 == 0 && !getenv("KEEP_NO_SFULL2");
+}
+
+static int launch_attn_x3_sfull2(const AttnP& p, hipStream_t st) {
+  const size_t lds = (size_t)4 * (2 * 32 * (2 * 128 + 8)) * 2 + 4 * 1024 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_x3_sfull2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      keep_set_error("keep_attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return KEEP_EHIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_x3_sfull2_kernel, dim3(cdiv(p.Lq, 32), p.H, p.B), dim3(256), lds, st, p);
+  KEEP_LAUNCH_CHECK("keep_attention(x3, full score row, 32-query blocks)");
+  return KEEP_OK;
+}
+
 template <int DVT>
 static int launch_attn_x3_sfull(const AttnP& p, hipStream_t st) {
   const size_t lds = (size_t)((128 + 64) * (2 * 128 + 8) + DVT * 32 * 72) * 2;
@@ -1359,6 +1596,7 @@ template <int WAVES, int DVT>
 static int launch_attn_x3(const AttnP& p, hipStream_t st) {
   if (p.D <= 128) return launch_attn_x3_t<WAVES, DVT, 8>(p, st);
   if (p.D <= 256) return launch_attn_x3_t<4, DVT, 16>(p, st);
+  if (attn_sfull2_ok(p)) return launch_attn_x3_sfull2(p, st);
   if (p.mode == 0 && p.Lk <= 256 && p.D % 128 == 0) return launch_attn_x3_sfull<DVT>(p, st);
   return launch_attn_x3_t<4, DVT, 0>(p, st);
 }

@@ -1839,7 +1839,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
       auto_split = items >= 256 ? 1 : (int)max(1L, min(min(512L / items, (long)a->Cin / 32), 16L));
       pl.split_k = a->split_k > 0 ? a->split_k : auto_split;
       if (pl.split_k > a->Cin / 16) pl.split_k = a->Cin / 16;
-      pl.stats_rows = 64;
+      pl.stats_rows = 256;      // one statistics partial per 256-pixel tile (the block adds its four waves' sums in LDS)
       pl.amax_ok = pl.split_k == 1;
       snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3_kernel<%d>", pl.wide ? 32 : 16);
       return KEEP_OK;

@@ -359,18 +359,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
       }
     }
     if (p.out_amax) wave_amax_commit(p.out_amax + it.n, amx);
-    if (p.stats) {          // per wave: stats_P = 4 * tiles, partial index = tile*4 + wave
+    if (p.stats) {          // one partial per 256-pixel tile (stats_P = tiles): the four waves' sums meet in LDS, added in wave order
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         s4[q] = xor32_sum(xor16_sum(s4[q]));
         ss4[q] = xor32_sum(xor16_sum(ss4[q]));
       }
-      if (lane < 16 && cok) {
-        float* dst = p.stats + (((long)it.n * p.stats_P + (it.ty * tiles_x + it.tx) * 4 + wave) * p.Cout + co) * 2;
+      if (lane < 16) {      // the head of this wave's own staging tile (its rows are consumed: the values live in registers)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          dst[q * 2 + 0] = s4[q];
-          dst[q * 2 + 1] = ss4[q];
+          et[(c4 + q) * 2 + 0] = s4[q];
+          et[(c4 + q) * 2 + 1] = ss4[q];
+        }
+      }
+      __syncthreads();
+      if (wave == 0) {
+        const float* e0 = reinterpret_cast<const float*>(lds_raw);
+        float a = 0.f, b2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          a += e0[w * 64 * EP + lane * 2 + 0];
+          b2 += e0[w * 64 * EP + lane * 2 + 1];
+        }
+        if (it.n0 + lane < p.Cout) {
+          float* dst = p.stats + (((long)it.n * p.stats_P + (it.ty * tiles_x + it.tx)) * p.Cout + it.n0 + lane) * 2;
+          dst[0] = a;
+          dst[1] = b2;
         }
       }
     }

@@ -507,3 +507,42 @@ def test_device_crop_warp_hook_keeps_the_helper_contract(monkeypatch):
     proc.gpu_paste, h.pad_blur = False, False
     proc._align_warp(h)
     assert calls == ['helper', 'helper']
+
+
+def test_loader_swaps_the_helpers_networks_for_engine_objects(monkeypatch):
+    """SURVEY 8f-4 host logic: ``engine_facelib`` replaces a ParseNet-shaped ``face_parse`` and a RetinaFace(resnet50)-shaped
+    ``face_detector`` by engine-backed objects with the same call surface (weights packed on the host, nothing uploaded until
+    ``.to('cuda')``), leaves other detectors alone, and KEEP_AMD_ENGINE_FACELIB=0 switches the swap off."""
+    from comfyui_keep_amd.modules.keep_model_loader import engine_facelib
+    from comfyui_keep_amd.engine import parsenet as PN, retinaface as RF
+
+    class FakeModule:
+        def __init__(self, sd, **attrs):
+            self._sd = sd
+            self.__dict__.update(attrs)
+
+        def state_dict(self):
+            return self._sd
+
+    class Hp:
+        pass
+    h = Hp()
+    h.face_parse = FakeModule(PN.synth_parsenet_state_dict(seed=0, in_size=128, out_size=128))
+    h.face_detector = FakeModule(RF.synth_retinaface_state_dict(seed=0), backbone='Resnet50')
+    engine_facelib(h)
+    assert isinstance(h.face_parse, PN.EngineFaceParse) and (h.face_parse.engine.in_size, h.face_parse.engine.out_size) == (128, 128)
+    assert isinstance(h.face_detector, RF.EngineRetinaFace) and h.face_detector.engine.w is None      # packed, not uploaded
+    assert callable(h.face_detector.detect_faces) and callable(h.face_detector.detect_batch)
+    with pytest.raises(RuntimeError):
+        h.face_parse.engine.logits_nhwc(torch.zeros(1, 128, 128, 3))                                   # loud: not on a device
+    h2 = Hp()
+    h2.face_parse = object()                                    # not a ParseNet: untouched
+    h2.face_detector = FakeModule({}, backbone='mobilenet0.25')
+    det2 = h2.face_detector
+    engine_facelib(h2)
+    assert h2.face_detector is det2 and not isinstance(h2.face_parse, PN.EngineFaceParse)
+    monkeypatch.setenv('KEEP_AMD_ENGINE_FACELIB', '0')
+    h3 = Hp()
+    h3.face_parse = FakeModule(PN.synth_parsenet_state_dict(seed=0, in_size=128, out_size=128))
+    engine_facelib(h3)
+    assert isinstance(h3.face_parse, FakeModule)

@@ -70,7 +70,9 @@ __device__ __forceinline__ float xor32_sum(float x) {
 // EXP (dev builds with -DKEEP_X3_ABLATE only, 0 in the product): phase ablations -- 1: no LDS fragment reads in the MFMA loop,
 // 2: no MFMAs, 3: no staging (LDS keeps stale data), 4: no global stores in the epilogue, 5: no operand fetch,
 // 6: start stagger between the two blocks of a CU, 7: library expf + IEEE division in the swish prologue, 8: s_setprio(1)
-// around the MFMA loop.
+// around the MFMA loop, 10: affine-only prologue (no transcendentals), 11: no epilogue, 12: weight DMA not waited for, 13: no
+// weight DMA, 14: halo rows computed but not written to LDS, 15: weight DMA from one 1 KB source (L1 hits), 16: no weight DMA and the
+// B fragments read from the halo rows, 17: the product kernel with the block cycle counter (KEEP_X3_CYC=1 prints it for every variant).
 // WDMA: the 9 x 64 pre-split weight rows of a chunk go from L2 straight into LDS (buffer_load_dwordx4 ... lds, 1 KB per wave
 // instruction, no VGPR round trip, no ds_write): rows at a 64-byte pitch, the 16-byte pieces of a row XOR-swizzled by
 // (row >> 2) & 3 through the SOURCE address of each lane (an LDS-DMA destination is lane-linear), which keeps the B-fragment
@@ -82,9 +84,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   constexpr int RPT = 32 / TW;
   constexpr int MAIN_B = (HALO_MAXPIX + 9 * 64) * XPITCH * 2;
   constexpr int EPI_B = 4 * 64 * 68 * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[MAIN_B > EPI_B ? MAIN_B : EPI_B];
+  constexpr int LDS_B = MAIN_B > EPI_B ? MAIN_B : EPI_B;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_B + 16];
   _Float16* Hs = reinterpret_cast<_Float16*>(lds_raw);
   _Float16* Ws = Hs + HALO_MAXPIX * XPITCH;
+  volatile unsigned* const ticket_lds = reinterpret_cast<volatile unsigned*>(lds_raw + LDS_B);   // next ticket of this block (p.sched)
   unsigned char* const wdma_base = lds_raw + HALO_MAXPIX * XPITCH * 2;      // == Ws as bytes
   int fetched_ch = 0;
 
@@ -143,6 +147,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     }
   };
 
+  unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+#define KEEP_T(IDX)                                                   \
+  if (EXP == 9) {                                                     \
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();       \
+    tacc[IDX] += t1 - t0;                                             \
+    t0 = t1;                                                          \
+  }
   float4 hreg[HALO_IT];
   uint4 wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7, wr8;
   float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -172,21 +183,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   auto stage = [&]() {
     constexpr bool FAST = FASTACT && EXP != 7;
     if (EXP == 3) return;
-    if (WDMA) {          // weights of the chunk being staged: L2 -> LDS, in flight under the halo's VALU work below
+    if (WDMA && !(EXP == 5 && fetched_ch > 0) && EXP != 13 && EXP != 16) {   // weights of the chunk being staged: L2 -> LDS, in flight under the halo's VALU work below
       const int c0 = fetched_ch << 4;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int q = __builtin_amdgcn_readfirstlane(wave) * 9 + t;            // wave-uniform (M0 / soffset operands)
+        if (EXP == 15)      // every piece from the same 1 KB of the weight tensor: L1 hits, no L2 traffic
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(wdma_base + q * 1024), 16,
+                                                   lane * 16, 0, 0, 0);
+        else
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(wdma_base + q * 1024), 16,
                                                  dma_voff[q & 3], ((q >> 2) * p.Cin + c0) * 4, 0, 0);
       }
+    }
+    KEEP_T(8)
+    if (EXP == 9) {
+      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      KEEP_T(9)
     }
 #pragma unroll
     for (int k = 0; k < HALO_IT; ++k) {
       const int hp = (tid >> 2) + k * 64;
       if (hp < HALO_PIX) {
         float v[4] = {hreg[k].x, hreg[k].y, hreg[k].z, hreg[k].w};
-        if (has_pro && h_voff[k] >= 0) {      // zero padding applies to the normalised + activated tensor
+        if (EXP == 10) {
+          v[0] = v[0] * sc4.x + sh4.x; v[1] = v[1] * sc4.y + sh4.y; v[2] = v[2] * sc4.z + sh4.z; v[3] = v[3] * sc4.w + sh4.w;
+        } else if (has_pro && h_voff[k] >= 0) {      // zero padding applies to the normalised + activated tensor
           v[0] = pro_x3<PRO, FAST>(v[0] * sc4.x + sh4.x);
           v[1] = pro_x3<PRO, FAST>(v[1] * sc4.y + sh4.y);
           v[2] = pro_x3<PRO, FAST>(v[2] * sc4.z + sh4.z);
@@ -197,15 +219,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
         }
         f16x4 hi, lo;
         split4(v, hi, lo);
-        *reinterpret_cast<f16x4*>(&Hs[hp * XPITCH + g * 4]) = hi;
-        *reinterpret_cast<f16x4*>(&Hs[hp * XPITCH + 16 + g * 4]) = lo;
+        if (EXP != 14 || (float)hi[0] + (float)lo[1] + (float)hi[2] + (float)lo[3] == 1.2345e-30f) {
+          *reinterpret_cast<f16x4*>(&Hs[hp * XPITCH + g * 4]) = hi;
+          *reinterpret_cast<f16x4*>(&Hs[hp * XPITCH + 16 + g * 4]) = lo;
+        }
       }
     }
 #define KEEP_WSTOREX(TAP, R) *reinterpret_cast<uint4*>(&Ws[((TAP) * 64 + (tid >> 2)) * XPITCH + g * 8]) = R;
     if (!WDMA) {
       KEEP_TAPS(KEEP_WSTOREX)
-    } else {
+    } else if (EXP != 12 && EXP != 13 && EXP != 16) {
+      KEEP_T(0)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed (the barrier publishes them)
+      KEEP_T(10)
     }
 #undef KEEP_WSTOREX
   };
@@ -241,6 +267,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
           for (int j = 0; j < 2; ++j) {
             if (WDMA) {
               const int o = b_base + ((kh * 3 + kw) * 64 + j * 32) * 32;
+              if (EXP == 16) {      // no weight DMA; the B fragments come from the (changing) halo rows
+                bh[j] = *reinterpret_cast<const f16x8*>(&Hs[o & 8191]);
+                bl[j] = *reinterpret_cast<const f16x8*>(&Hs[(o ^ 16) & 8191]);
+                continue;
+              }
               bh[j] = *reinterpret_cast<const f16x8*>(&Ws[o]);
               bl[j] = *reinterpret_cast<const f16x8*>(&Ws[o ^ 16]);                 // lo piece: logical + 2 -> physical slot ^ 2
             } else {
@@ -282,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     constexpr bool HAS_RES = decltype(res_c)::value;
     constexpr int EP = 68;
     float* et = reinterpret_cast<float*>(lds_raw) + wave * 64 * EP;
+    if (EXP == 11 && acc[0][0][0] + acc[1][1][3] + acc[0][1][7] + acc[1][0][9] != 1.2345e-30f) return;
     const float asc = p.acc_scale * item_inv;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -391,28 +423,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   };
 
   int item = blockIdx.x;
-  if (item >= n_items) return;
+  if (item >= n_items) return;      // never taken: the grid is min(n_items, blocks the chip holds) (a block that left here would not be counted in p.sched[8])
   if (EXP == 6 && blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(54);     // start stagger of the second block per CU
   // EXP == 9: phase timeline (s_memtime) of wave 0, summed over blocks into p.ws as u64[8]:
   // 0 stage, 1 wait at the barrier after staging, 2 fetch issue, 3 mma, 4 wait at the barrier after mma, 5 item set-up, 6 epilogue
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
-#define KEEP_T(IDX)                                                   \
-  if (EXP == 9) {                                                     \
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime();       \
-    tacc[IDX] += t1 - t0;                                             \
-    t0 = t1;                                                          \
-  }
+  const unsigned long long cyc0 = EXP != 0 ? __builtin_amdgcn_s_memtime() : 0ull;           // dev builds: shader cycles and
+  const unsigned long long rtc0 = EXP != 0 ? __builtin_amdgcn_s_memrealtime() : 0ull;       // 100 MHz ticks of the whole block
   HaloItem cur = halo_decode<TW, 4>(p, item, items_per_z, tiles_x, tiles_y, ncb);
   setup(cur);
   if (cur.ch_begin < cur.ch_end) fetch(cur.ch_begin);
   if (EXP == 9) t0 = __builtin_amdgcn_s_memtime();
+  // Work queue (p.sched, keep_abi.hip): the first item of a block is blockIdx.x; every further one is a ticket of the block's
+  // XCD (blocks are dealt round-robin to the XCDs, and xcd_remap gives the items with item % 8 == x one contiguous range of
+  // tiles: the L2 locality of the static order is kept).  Thread 0 draws the ticket for the NEXT item at the top of the
+  // current one and publishes it through LDS at the barrier after the first chunk's MFMA phase: the atomic's latency is hidden.
+  const int xcd = blockIdx.x & 7, first_dyn = gridDim.x >> 3;
   while (true) {
     const bool valid = cur.ch_begin < cur.ch_end;
+    unsigned tk = 0;
+    if (p.sched && tid == 0) tk = atomicAdd(p.sched + xcd, 1u);
     if (EXP == 9) {
       __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): operand loads landed
       KEEP_T(7)
     }
     if (valid) stage();
+    if (p.sched && tid == 0 && !valid) *ticket_lds = tk;      // (an item without chunks: published at this barrier)
     KEEP_T(0)
     __syncthreads();
     KEEP_T(1)
@@ -428,6 +463,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
       KEEP_T(2)
       mma();
       KEEP_T(3)
+      if (p.sched && tid == 0 && ch == cur.ch_begin) *ticket_lds = tk;      // a whole MFMA phase after the atomic was issued
       __syncthreads();
       KEEP_T(4)
       if (more) {
@@ -441,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
         KEEP_T(1)
       }
     }
-    const int next_item = item + gridDim.x;
+    const int next_item = p.sched ? (first_dyn + (int)*ticket_lds) * 8 + xcd : item + gridDim.x;
     const bool has_next = next_item < n_items;
     const float cur_inv = in_inv;                               // setup(nxt) below moves in_s / in_inv on to the next item
     HaloItem nxt = cur;
@@ -462,11 +498,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     item = next_item;
     cur = nxt;
   }
+  if (p.sched && tid == 0) {        // every ticket of this block is drawn: the last block to get here zeroes the slot for the next launch
+    __threadfence();
+    if (atomicAdd(p.sched + 8, 1u) == gridDim.x - 1) {
+#pragma unroll
+      for (int x = 0; x < 9; ++x) p.sched[x] = 0u;
+      __threadfence();
+    }
+  }
+  if (EXP != 0 && tid == 0) {
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.ws);
+    atomicAdd(dst + 13, __builtin_amdgcn_s_memtime() - cyc0);
+    atomicAdd(dst + 14, __builtin_amdgcn_s_memrealtime() - rtc0);
+    atomicAdd(dst + 15, 1ull);
+    if (blockIdx.x < 1024) {          // per-block start / end (100 MHz ticks) behind the 16 sums
+      dst[16 + blockIdx.x * 2] = rtc0;
+      dst[17 + blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
   if (EXP == 9 && tid == 0) {
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.ws);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) atomicAdd(dst + q, tacc[q]);
-    atomicAdd(dst + 8, 1ull);
+    for (int q = 0; q < 12; ++q) atomicAdd(dst + q, tacc[q]);
+    atomicAdd(dst + 12, 1ull);
   }
 #undef KEEP_T
 }
@@ -1115,35 +1169,75 @@ int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
   const int per_cu = getenv("KEEP_X3_BLOCKS_PER_CU") ? atoi(getenv("KEEP_X3_BLOCKS_PER_CU")) : 2;      // dev: occupancy scaling probe
   dim3 grid(n_items < per_cu * n_cu ? n_items : per_cu * n_cu), block(256);
   const bool simple = p.split_k == 1 && !a->aux && a->epi_act == KEEP_ACT_NONE;
+  // many items per block: dynamic order through the stream's ticket slot (measured, 16 images: +1.2 % from 16 items per block up --
+  // a block on a slow CU takes fewer items; with a handful of items per block the greedy tail costs 2-4 %, so those launches keep
+  // the strided order).  KEEP_X3_STATIC_ORDER=1: strided order everywhere, KEEP_X3_QUEUE_MIN_ITEMS: the threshold (A/B runs).
+  const bool static_order = getenv("KEEP_X3_STATIC_ORDER") != nullptr;
+  const int queue_min = getenv("KEEP_X3_QUEUE_MIN_ITEMS") ? atoi(getenv("KEEP_X3_QUEUE_MIN_ITEMS")) : 16;
+  p.sched = (!static_order && grid.x % 8 == 0 && n_items >= queue_min * (int)grid.x) ? keep_sched_slot(st) : nullptr;
   // pipelined single-block-per-CU kernel: wide tiles, no split-K, at least two work items per CU
 #ifdef KEEP_X3_ABLATE
   if (getenv("KEEP_X3_EXP") && wide && simple && (a->pro_act == KEEP_PRO_SWISH || a->pro_act == KEEP_PRO_NONE)) {
     const int ex = atoi(getenv("KEEP_X3_EXP"));
-#define KEEP_LAUNCH_ABL(E)                                                                                                         \
-  if (ex == E) {                                                                                                                   \
-    if (a->pro_act == KEEP_PRO_SWISH)                                                                                              \
-      hipLaunchKernelGGL((conv3x3_halo_x3_kernel<32, KEEP_PRO_SWISH, true, E>), grid, block, 0, st, p, tiles_x, tiles_y, ncb, n_items); \
-    else                                                                                                                           \
-      hipLaunchKernelGGL((conv3x3_halo_x3_kernel<32, KEEP_PRO_NONE, true, E>), grid, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);  \
-    KEEP_LAUNCH_CHECK("keep_conv2d(halo x3 ablation)");                                                                            \
-    return KEEP_OK;                                                                                                                \
-  }
-    KEEP_LAUNCH_ABL(1) KEEP_LAUNCH_ABL(2) KEEP_LAUNCH_ABL(3) KEEP_LAUNCH_ABL(4) KEEP_LAUNCH_ABL(5) KEEP_LAUNCH_ABL(6) KEEP_LAUNCH_ABL(7)
-    KEEP_LAUNCH_ABL(8)
-    if (ex == 9) {       // phase timeline: one instrumented launch, cycle sums printed to stderr
-      static unsigned long long* dbg = nullptr;
-      if (!dbg) (void)hipMalloc(&dbg, 128);
-      (void)hipMemsetAsync(dbg, 0, 128, st);
-      ConvP q = p;
-      q.ws = reinterpret_cast<float*>(dbg);
-      if (a->pro_act == KEEP_PRO_SWISH)
-        hipLaunchKernelGGL((conv3x3_halo_x3_kernel<32, KEEP_PRO_SWISH, true, 9>), grid, block, 0, st, q, tiles_x, tiles_y, ncb, n_items);
-      else
-        hipLaunchKernelGGL((conv3x3_halo_x3_kernel<32, KEEP_PRO_NONE, true, 9>), grid, block, 0, st, q, tiles_x, tiles_y, ncb, n_items);
+static unsigned long long* dbg = nullptr;
+    if (!dbg) (void)hipMalloc(&dbg, 128 + 1024 * 16);
+    const bool cyc = getenv("KEEP_X3_CYC") != nullptr;
+    if (cyc) (void)hipMemsetAsync(dbg, 0, 128, st);
+    ConvP q = p;
+    q.ws = reinterpret_cast<float*>(dbg);
+    auto report = [&](int e) {      // shader cycles and 100 MHz ticks per block -> the effective shader clock of this variant
+      if (!cyc) return;
       unsigned long long h[16];
       (void)hipStreamSynchronize(st);
       (void)hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost);
-      const double nb = (double)h[8], tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + h[6] + h[7]);
+      const double nb = (double)h[15];
+      fprintf(stderr, "[x3 cycles] exp %d  blocks %.0f  cycles/block %.0f  us/block %.1f  clock %.0f MHz\n", e, nb, h[13] / nb,
+              h[14] / nb / 100.0, (double)h[13] / ((double)h[14] / 100.0));
+      static unsigned long long se[2048];
+      const int nblk = (int)grid.x < 1024 ? (int)grid.x : 1024;
+      (void)hipMemcpy(se, dbg + 16, nblk * 16, hipMemcpyDeviceToHost);
+      unsigned long long t_min = ~0ull, t_max = 0;
+      for (int b = 0; b < nblk; ++b) {
+        if (se[2 * b] < t_min) t_min = se[2 * b];
+        if (se[2 * b + 1] > t_max) t_max = se[2 * b + 1];
+      }
+      double dur_x[8] = {0}, st_x[8] = {0}, en_x[8] = {0}, dmin = 1e30, dmax = 0;
+      int cnt_x[8] = {0};
+      for (int b = 0; b < nblk; ++b) {
+        const double d = (se[2 * b + 1] - se[2 * b]) / 100.0;
+        dur_x[b & 7] += d; st_x[b & 7] += (se[2 * b] - t_min) / 100.0; en_x[b & 7] += (se[2 * b + 1] - t_min) / 100.0; cnt_x[b & 7]++;
+        if (d < dmin) dmin = d;
+        if (d > dmax) dmax = d;
+      }
+      fprintf(stderr, "[x3 blocks] span %.1f us  block life min %.1f max %.1f us | per XCD (start, life, end):", (t_max - t_min) / 100.0, dmin, dmax);
+      for (int x = 0; x < 8; ++x) fprintf(stderr, "  %.0f/%.0f/%.0f", st_x[x] / cnt_x[x], dur_x[x] / cnt_x[x], en_x[x] / cnt_x[x]);
+      fprintf(stderr, "\n");
+    };
+#define KEEP_LAUNCH_ABL(E)                                                                                                         \
+  if (ex == E) {                                                                                                                   \
+    if (a->pro_act == KEEP_PRO_SWISH)                                                                                              \
+      hipLaunchKernelGGL((conv3x3_halo_x3_kernel<32, KEEP_PRO_SWISH, true, E, true, true>), grid, block, 0, st, q, tiles_x, tiles_y, ncb, n_items); \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((conv3x3_halo_x3_kernel<32, KEEP_PRO_NONE, true, E, true, true>), grid, block, 0, st, q, tiles_x, tiles_y, ncb, n_items);  \
+    KEEP_LAUNCH_CHECK("keep_conv2d(halo x3 ablation)");                                                                            \
+    report(E);                                                                                                                     \
+    return KEEP_OK;                                                                                                                \
+  }
+    KEEP_LAUNCH_ABL(1) KEEP_LAUNCH_ABL(2) KEEP_LAUNCH_ABL(3) KEEP_LAUNCH_ABL(4) KEEP_LAUNCH_ABL(5) KEEP_LAUNCH_ABL(6) KEEP_LAUNCH_ABL(7)
+    KEEP_LAUNCH_ABL(8) KEEP_LAUNCH_ABL(10) KEEP_LAUNCH_ABL(11) KEEP_LAUNCH_ABL(12) KEEP_LAUNCH_ABL(13) KEEP_LAUNCH_ABL(14) KEEP_LAUNCH_ABL(15) KEEP_LAUNCH_ABL(16)
+    KEEP_LAUNCH_ABL(17)
+    if (ex == 9) {       // phase timeline: one instrumented launch, cycle sums printed to stderr
+      (void)hipMemsetAsync(dbg, 0, 128, st);
+      if (a->pro_act == KEEP_PRO_SWISH)
+        hipLaunchKernelGGL((conv3x3_halo_x3_kernel<32, KEEP_PRO_SWISH, true, 9, true, true>), grid, block, 0, st, q, tiles_x, tiles_y, ncb, n_items);
+      else
+        hipLaunchKernelGGL((conv3x3_halo_x3_kernel<32, KEEP_PRO_NONE, true, 9, true, true>), grid, block, 0, st, q, tiles_x, tiles_y, ncb, n_items);
+      unsigned long long h[16];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost);
+      const double nb = (double)h[12], tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + h[6] + h[7] + h[8] + h[9] + h[10]);
+      fprintf(stderr, "[x3 timeline] stage split: DMA issue %.1f%%  wait halo regs %.1f%%  VALU+ds_write %.1f%%  wait DMA %.1f%%\n",
+              100.0 * h[8] / tot, 100.0 * h[9] / tot, 100.0 * h[0] / tot, 100.0 * h[10] / tot);
       fprintf(stderr, "[x3 timeline] blocks %.0f  cycles/block %.0f | stage %.1f%%  sync-after-stage %.1f%%  fetch-issue %.1f%%  mma %.1f%%  "
               "sync-after-mma %.1f%%  item-setup %.1f%%  epilogue %.1f%%  wait-loads %.1f%%\n", nb, tot / nb, 100.0 * h[0] / tot, 100.0 * h[1] / tot,
               100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot, 100.0 * h[5] / tot, 100.0 * h[6] / tot, 100.0 * h[7] / tot);

@@ -1758,6 +1758,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   p.out_amax = nullptr;
   p.reflect = a->pad_mode == KEEP_PAD_REFLECT ? 1 : 0;
   p.sched = nullptr;
+  p.tile_cols = 0;
   p.bias = a->bias;
   p.out = (float*)a->out;
   p.pro_scale = a->pro_scale;

@@ -43,6 +43,7 @@ struct ConvP {
   unsigned* out_amax;         // KEEP_MMA_X3: per-image max |output| as raw float bits (atomicMax), or NULL
   int reflect;                // padding pixels mirror the image (nn.ReflectionPad2d, ParseNet) instead of reading zeros
   unsigned* sched;            // persistent kernels: ticket slot of the launch stream (keep_abi.hip), NULL = static striding
+  int tile_cols;              // x3 gather kernel on a 1-D grid: column blocks per row block (0: blockIdx.x / .y are the row / column block)
 };
 
 unsigned* keep_sched_slot(hipStream_t st);

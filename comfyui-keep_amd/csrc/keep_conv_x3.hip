@@ -22,6 +22,8 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void split4(const float (&v)[4], f16x4& hi, f16x4& lo) {
 #pragma unroll
@@ -138,11 +140,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     if (WDMA) {
       // DMA instruction q of this chunk (36 per chunk, 9 per wave: q = wave * 9 + t) fills LDS rows q*16 .. q*16+15 = tap q/4, couts
       // (q%4)*16 + lane/4; lane's physical 16-byte slot lane&3 holds logical piece (lane&3) ^ ((lane>>4)&3) of its row
+      // (stored rotated by the wave index: instruction t of wave w is q = 9 w + t, its row group q & 3 = (w + t) & 3 -- slot t & 3)
       const int lp = (lane & 3) ^ ((lane >> 4) & 3);
 #pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4) {
-        const int co = it.n0 + c4 * 16 + (lane >> 2);
-        dma_voff[c4] = co < p.Cout ? co * 9 * p.Cin * 4 + lp * 16 : -16;
+      for (int j = 0; j < 4; ++j) {
+        const int co = it.n0 + ((wave + j) & 3) * 16 + (lane >> 2);
+        dma_voff[j] = co < p.Cout ? co * 9 * p.Cin * 4 + lp * 16 : -16;
       }
     }
   };
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
                                                    lane * 16, 0, 0, 0);
         else
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(wdma_base + q * 1024), 16,
-                                                 dma_voff[q & 3], ((q >> 2) * p.Cin + c0) * 4, 0, 0);
+                                                 dma_voff[t & 3], ((q >> 2) * p.Cin + c0) * 4, 0, 0);
       }
     }
     KEEP_T(8)
@@ -201,27 +204,57 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
       asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
       KEEP_T(9)
     }
+    // GroupNorm affine + activation + split of this thread's 16-byte pieces, two values per instruction where the ISA has a packed
+    // form (v_pk_fma / v_pk_add / v_pk_mul / v_cvt_pk_f16_f32): VALU instructions do not overlap the matrix pipe of their SIMD
+    // (tools/dev/coissue_probe.hip), so every one of them is paid in full.  Fast swish: x * rcp(1 + exp2(x * s' + t')) with the
+    // -log2(e) folded into a second affine (s', t') once per chunk.
+    const f32x2 sc01 = {sc4.x, sc4.y}, sc23 = {sc4.z, sc4.w}, sh01 = {sh4.x, sh4.y}, sh23 = {sh4.z, sh4.w};
+    constexpr bool FOLD = PRO == KEEP_PRO_SWISH && FAST && EXP != 10;
+    const f32x2 nsc01 = sc01 * -1.4426950408889634f, nsc23 = sc23 * -1.4426950408889634f;
+    const f32x2 nsh01 = sh01 * -1.4426950408889634f, nsh23 = sh23 * -1.4426950408889634f;
 #pragma unroll
     for (int k = 0; k < HALO_IT; ++k) {
       const int hp = (tid >> 2) + k * 64;
       if (hp < HALO_PIX) {
-        float v[4] = {hreg[k].x, hreg[k].y, hreg[k].z, hreg[k].w};
-        if (EXP == 10) {
-          v[0] = v[0] * sc4.x + sh4.x; v[1] = v[1] * sc4.y + sh4.y; v[2] = v[2] * sc4.z + sh4.z; v[3] = v[3] * sc4.w + sh4.w;
-        } else if (has_pro && h_voff[k] >= 0) {      // zero padding applies to the normalised + activated tensor
-          v[0] = pro_x3<PRO, FAST>(v[0] * sc4.x + sh4.x);
-          v[1] = pro_x3<PRO, FAST>(v[1] * sc4.y + sh4.y);
-          v[2] = pro_x3<PRO, FAST>(v[2] * sc4.z + sh4.z);
-          v[3] = pro_x3<PRO, FAST>(v[3] * sc4.w + sh4.w);
-        }
-        if (PRO == KEEP_PRO_NONE && p.in_amax) {     // activated inputs are bounded: the host never probes them
-          v[0] *= in_s; v[1] *= in_s; v[2] *= in_s; v[3] *= in_s;
-        }
-        f16x4 hi, lo;
-        split4(v, hi, lo);
-        if (EXP != 14 || (float)hi[0] + (float)lo[1] + (float)hi[2] + (float)lo[3] == 1.2345e-30f) {
-          *reinterpret_cast<f16x4*>(&Hs[hp * XPITCH + g * 4]) = hi;
-          *reinterpret_cast<f16x4*>(&Hs[hp * XPITCH + 16 + g * 4]) = lo;
+        _Float16* dst = &Hs[hp * XPITCH + g * 4];
+        if (!has_pro || h_voff[k] >= 0) {
+          f32x2 v01 = {hreg[k].x, hreg[k].y}, v23 = {hreg[k].z, hreg[k].w};
+          if (has_pro) {
+            const f32x2 y01 = v01 * sc01 + sh01, y23 = v23 * sc23 + sh23;
+            if (FOLD) {
+              const f32x2 z01 = v01 * nsc01 + nsh01, z23 = v23 * nsc23 + nsh23;
+              f32x2 d01 = {__builtin_amdgcn_exp2f(z01.x), __builtin_amdgcn_exp2f(z01.y)};
+              f32x2 d23 = {__builtin_amdgcn_exp2f(z23.x), __builtin_amdgcn_exp2f(z23.y)};
+              d01 += 1.0f;
+              d23 += 1.0f;
+              const f32x2 r01 = {__builtin_amdgcn_rcpf(d01.x), __builtin_amdgcn_rcpf(d01.y)};
+              const f32x2 r23 = {__builtin_amdgcn_rcpf(d23.x), __builtin_amdgcn_rcpf(d23.y)};
+              v01 = y01 * r01;
+              v23 = y23 * r23;
+            } else if (EXP == 10) {
+              v01 = y01;
+              v23 = y23;
+            } else {
+              v01 = f32x2{pro_x3<PRO, FAST>(y01.x), pro_x3<PRO, FAST>(y01.y)};
+              v23 = f32x2{pro_x3<PRO, FAST>(y23.x), pro_x3<PRO, FAST>(y23.y)};
+            }
+          }
+          if (PRO == KEEP_PRO_NONE && p.in_amax) {     // activated inputs are bounded: the host never probes them
+            v01 *= in_s;
+            v23 *= in_s;
+          }
+          const f16x2 h01 = __builtin_convertvector(v01, f16x2), h23 = __builtin_convertvector(v23, f16x2);
+          const f16x2 l01 = __builtin_convertvector(v01 - __builtin_convertvector(h01, f32x2), f16x2);
+          const f16x2 l23 = __builtin_convertvector(v23 - __builtin_convertvector(h23, f32x2), f16x2);
+          const f16x4 hi = {h01.x, h01.y, h23.x, h23.y}, lo = {l01.x, l01.y, l23.x, l23.y};
+          if (EXP != 14 || (float)hi[0] + (float)lo[1] + (float)hi[2] + (float)lo[3] == 1.2345e-30f) {
+            *reinterpret_cast<f16x4*>(dst) = hi;
+            *reinterpret_cast<f16x4*>(dst + 16) = lo;
+          }
+        } else {      // zero padding applies to the normalised + activated tensor
+          const f16x4 zero = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+          *reinterpret_cast<f16x4*>(dst) = zero;
+          *reinterpret_cast<f16x4*>(dst + 16) = zero;
         }
       }
     }
@@ -321,8 +354,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          et[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * EP + j * 32 + l31] = acc[i][j][r] * asc;
+          et[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * EP + j * 32 + l31] = acc[i][j][r];      // raw: asc (a power of two) rides in the bias FMA below
     __builtin_amdgcn_s_waitcnt(0xc07f);
+    KEEP_T(11)
     const int c4 = (lane & 15) * 4, prow = lane >> 4;
     const int co = it.n0 + c4;
     const bool cok = co < p.Cout;
@@ -344,29 +378,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     float amx = 0.f;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
+    // Residual rows of the simple form: all 16 loads are issued before the first store.  Inside the loop every load sat behind
+    // the previous iteration's store (the compiler must assume `res` and `out` alias -- in place they do) and its
+    // `s_waitcnt vmcnt(0)` -- loads and stores share the counter on gfx9 -- exposed a full memory round trip 16 times per item.
+    // (In-place use stays correct: a thread reads exactly the 16 addresses it later writes.)
+    auto dpix_of = [&](int q16) {
+      const int drow = (q16 >> 3) * RPT + (TW == 32 ? 0 : ((q16 & 7) >> 2));
+      const int dcol = TW == 32 ? (q16 & 7) * 4 : (q16 & 3) * 4;
+      return drow * p.Wo + dcol;                                              // wave-uniform
+    };
+    u32x4 rpre[SIMPLE_EPI && HAS_RES ? 16 : 1];
+    if (SIMPLE_EPI && HAS_RES) {
+#pragma unroll
+      for (int q16 = 0; q16 < 16; ++q16) rpre[q16] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, v_res, dpix_of(q16) * p.res_ld * 4, 0);
+    }
     // the general epilogue (activation switch, aux tensor, split-K) stays a loop: fully unrolled it is 30k instructions
     constexpr int UNR = SIMPLE_EPI ? 16 : 2;
 #pragma unroll UNR
     for (int q16 = 0; q16 < 16; ++q16) {
       const int px = q16 * 4 + prow;
-      const int drow = (q16 >> 3) * RPT + (TW == 32 ? 0 : ((q16 & 7) >> 2));
-      const int dcol = TW == 32 ? (q16 & 7) * 4 : (q16 & 3) * 4;
-      const int dpix = drow * p.Wo + dcol;                                    // wave-uniform
+      const int dpix = dpix_of(q16);
       const float4 v = *reinterpret_cast<const float4*>(et + px * EP + c4);
       if (!SIMPLE_EPI && p.split_k > 1) {
         if (cok) {
           const long m = (long)it.n * hw_o + pix_b + dpix;
-          *reinterpret_cast<float4*>(p.ws + ((long)it.z * p.M + m) * p.Cout + co) = v;
+          *reinterpret_cast<float4*>(p.ws + ((long)it.z * p.M + m) * p.Cout + co) = make_float4(v.x * asc, v.y * asc, v.z * asc, v.w * asc);
         }
         continue;
       }
-      float e[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
+      float e[4] = {__builtin_fmaf(v.x, asc, bias4.x), __builtin_fmaf(v.y, asc, bias4.y), __builtin_fmaf(v.z, asc, bias4.z),
+                    __builtin_fmaf(v.w, asc, bias4.w)};
       if (!SIMPLE_EPI) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) e[q] = p.fast ? act_apply_fast(e[q], p.epi_act) : act_apply(e[q], p.epi_act);
       }
       if (HAS_RES) {
-        const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, v_res, dpix * p.res_ld * 4, 0);
+        const u32x4 r4 = SIMPLE_EPI ? rpre[SIMPLE_EPI ? q16 : 0] : __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, v_res, dpix * p.res_ld * 4, 0);
         const float rr[4] = {__uint_as_float(r4.x), __uint_as_float(r4.y), __uint_as_float(r4.z), __uint_as_float(r4.w)};
         if (!SIMPLE_EPI && p.aux) {
           const u32x4 a4 = __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, v_aux, dpix * p.Cout * 4, 0);
@@ -477,7 +524,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
         KEEP_T(1)
       }
     }
-    const int next_item = p.sched ? (first_dyn + (int)*ticket_lds) * 8 + xcd : item + gridDim.x;
+    // (readfirstlane: the compiler must see a wave-uniform item, or every buffer access of the next item gets a waterfall loop)
+    const int next_item = p.sched ? (first_dyn + __builtin_amdgcn_readfirstlane((int)*ticket_lds)) * 8 + xcd : item + gridDim.x;
     const bool has_next = next_item < n_items;
     const float cur_inv = in_inv;                               // setup(nxt) below moves in_s / in_inv on to the next item
     HaloItem nxt = cur;
@@ -576,9 +624,17 @@ __device__ __forceinline__ void x3_gather_epilogue(const ConvP& p, f32x16 (&acc)
   float amx = 0.f;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
-  constexpr int UNR = SIMPLE ? 8 : 4;
+  // SIMPLE form: groups of up to 8 rows, the group's residual rows loaded before its first store (inside the loop each load sat behind
+  // the previous store and its `s_waitcnt vmcnt(0)` exposed a memory round trip per row: see the halo kernel's epilogue)
+  constexpr int NIT = WR / RPI, GRP = NIT < 8 ? NIT : 8;
+  constexpr int UNR = SIMPLE ? GRP : 4;
+  u32x4 rpre[SIMPLE ? GRP : 1];
 #pragma unroll UNR
-  for (int it = 0; it < WR / RPI; ++it) {
+  for (int it = 0; it < NIT; ++it) {
+    if (SIMPLE && p.res && (it % GRP) == 0) {
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) rpre[u] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, v_res + (it + u) * RPI * p.res_ld * 4, 0, 0);
+    }
     const int px = it * RPI + prow;
     const float4 v = *reinterpret_cast<const float4*>(et + px * EP + c4);
     if (!SIMPLE && p.split_k > 1) {
@@ -593,7 +649,7 @@ __device__ __forceinline__ void x3_gather_epilogue(const ConvP& p, f32x16 (&acc)
       for (int q = 0; q < 4; ++q) e[q] = p.fast ? act_apply_fast(e[q], p.epi_act) : act_apply(e[q], p.epi_act);
     }
     if (p.res) {
-      const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, v_res + it * RPI * p.res_ld * 4, 0, 0);
+      const u32x4 r4 = SIMPLE ? rpre[SIMPLE ? it % GRP : 0] : __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, v_res + it * RPI * p.res_ld * 4, 0, 0);
       const float rr[4] = {__uint_as_float(r4.x), __uint_as_float(r4.y), __uint_as_float(r4.z), __uint_as_float(r4.w)};
       if (!SIMPLE && p.aux) {
         const u32x4 a4 = __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, v_aux + it * RPI * p.Cout * 4, 0, 0);
@@ -681,8 +737,16 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
   const int wave = tid >> 6;
   const int wm = wave / WGN;
   const int wn = wave % WGN;
-  const long m0 = (long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // tile_cols > 0 (1-D grid): the column blocks of one row block are consecutive logical ids of ONE XCD (xcd_remap), so the A rows
+  // a row block shares between its column blocks are re-read from that XCD's L2 instead of once per column block from HBM
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (p.tile_cols > 0) {
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    bx = lid / p.tile_cols;
+    by = lid - bx * p.tile_cols;
+  }
+  const long m0 = (long)bx * BM;
+  const int n0 = by * BN;
   const int z = blockIdx.z;
   const int cchunks = (p.Cin + XBK - 1) / XBK;
   const int nsteps = p.KH * p.KW * cchunks;
@@ -1235,9 +1299,9 @@ static unsigned long long* dbg = nullptr;
       unsigned long long h[16];
       (void)hipStreamSynchronize(st);
       (void)hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost);
-      const double nb = (double)h[12], tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + h[6] + h[7] + h[8] + h[9] + h[10]);
-      fprintf(stderr, "[x3 timeline] stage split: DMA issue %.1f%%  wait halo regs %.1f%%  VALU+ds_write %.1f%%  wait DMA %.1f%%\n",
-              100.0 * h[8] / tot, 100.0 * h[9] / tot, 100.0 * h[0] / tot, 100.0 * h[10] / tot);
+      const double nb = (double)h[12], tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + h[6] + h[7] + h[8] + h[9] + h[10] + h[11]);
+      fprintf(stderr, "[x3 timeline] stage split: DMA issue %.1f%%  wait halo regs %.1f%%  VALU+ds_write %.1f%%  wait DMA %.1f%%  | epilogue: park in LDS %.1f%%  rest %.1f%%\n",
+              100.0 * h[8] / tot, 100.0 * h[9] / tot, 100.0 * h[0] / tot, 100.0 * h[10] / tot, 100.0 * h[11] / tot, 100.0 * h[6] / tot);
       fprintf(stderr, "[x3 timeline] blocks %.0f  cycles/block %.0f | stage %.1f%%  sync-after-stage %.1f%%  fetch-issue %.1f%%  mma %.1f%%  "
               "sync-after-mma %.1f%%  item-setup %.1f%%  epilogue %.1f%%  wait-loads %.1f%%\n", nb, tot / nb, 100.0 * h[0] / tot, 100.0 * h[1] / tot,
               100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot, 100.0 * h[5] / tot, 100.0 * h[6] / tot, 100.0 * h[7] / tot);
@@ -1298,11 +1362,15 @@ int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int big_tile, hip
     hipLaunchKernelGGL((conv_x3_kernel<A, B, C, D, false, true>), grid, block, 0, st, p);          \
   else                                                                                             \
     hipLaunchKernelGGL((conv_x3_kernel<A, B, C, D, false, false>), grid, block, 0, st, p);
+  // several column blocks and many row blocks: row-block-major order on a 1-D grid (KEEP_X3_GEMM_2D=1: the 2-D grid, for A/B runs)
+  const int bt = big_tile ? 128 : 64;
+  const long gx = cdiv(M, bt), gy = cdiv(a->Cout, bt);
+  const bool rowmajor = gy > 1 && gx >= 1024 && gx * gy < (1L << 30) && !getenv("KEEP_X3_GEMM_2D");
+  p.tile_cols = rowmajor ? (int)gy : 0;
+  dim3 grid(rowmajor ? (unsigned)(gx * gy) : (unsigned)gx, rowmajor ? 1u : (unsigned)gy, p.split_k);
   if (!big_tile) {
-    dim3 grid(cdiv(M, 64), cdiv(a->Cout, 64), p.split_k);
     KEEP_LAUNCH_GX(2, 2, 1, 1)
   } else {
-    dim3 grid(cdiv(M, 128), cdiv(a->Cout, 128), p.split_k);
     KEEP_LAUNCH_GX(2, 2, 2, 2)
   }
 #undef KEEP_LAUNCH_GX

@@ -1301,12 +1301,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(ConvP p, int t
     float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
+    auto m_of = [&](int q16) {
+      const int px = q16 * 4 + prow;
+      const int oy = it.oy0 + (2 * wave + (px >> 5)) * RPT + (px & 31) / TW;
+      return ((long)it.n * p.Ho + oy) * p.Wo + it.ox0 + (px & 31) % TW;
+    };
+    // simple form: the residual rows of a group of four iterations are loaded before the group's first store (inside the loop every
+    // load sits behind the previous store -- `res` may alias `out` -- and its vmcnt wait exposes a memory round trip per row)
+    float4 rpre[4];
 #pragma unroll 4
     for (int q16 = 0; q16 < 16; ++q16) {
       if (!cok) break;
+      if (SIMPLE && p.res && (q16 & 3) == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rpre[u] = *reinterpret_cast<const float4*>(p.res + m_of(q16 + u) * p.res_ld + co);
+      }
       const int px = q16 * 4 + prow;
-      const int oy = it.oy0 + (2 * wave + (px >> 5)) * RPT + (px & 31) / TW;
-      const long m = ((long)it.n * p.Ho + oy) * p.Wo + it.ox0 + (px & 31) % TW;
+      const long m = m_of(q16);
       const float4 v = *reinterpret_cast<const float4*>(et + px * EP + c4);
       if (!SIMPLE && p.split_k > 1) {
         *reinterpret_cast<float4*>(p.ws + ((long)it.z * p.M + m) * p.Cout + co) = v;
@@ -1318,7 +1329,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(ConvP p, int t
         for (int q = 0; q < 4; ++q) e[q] = act_apply(e[q], p.epi_act);
       }
       if (p.res) {
-        const float4 r4 = *reinterpret_cast<const float4*>(p.res + m * p.res_ld + co);
+        const float4 r4 = SIMPLE ? rpre[q16 & 3] : *reinterpret_cast<const float4*>(p.res + m * p.res_ld + co);
         const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
         if (!SIMPLE && p.aux) {
           const float4 a4 = *reinterpret_cast<const float4*>(p.aux + m * (long)p.Cout + co);

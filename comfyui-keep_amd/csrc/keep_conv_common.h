@@ -168,8 +168,18 @@ __device__ __forceinline__ void staged_epilogue_impl(const ConvP& p, f32x16 (&ac
   float amx = 0.f;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
+  // simple form: the residual rows of a group of four iterations are loaded before the group's first store (inside the loop every load
+  // sits behind the previous store -- `res` may alias `out` -- and its vmcnt wait exposes a memory round trip per row)
+  float4 rpre[4];
 #pragma unroll 4
   for (int it = 0; it < WR / RPI; ++it) {
+    if (SIMPLE && p.res && (it & 3) == 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long mu = m0 + wm * WR + (it + u) * RPI + prow;
+        rpre[u] = (it + u < WR / RPI && mu < p.M && cok) ? *reinterpret_cast<const float4*>(p.res + mu * p.res_ld + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
     const int px = it * RPI + prow;
     const long m = m0 + wm * WR + px;
     if (m >= p.M || !cok) continue;
@@ -184,7 +194,7 @@ __device__ __forceinline__ void staged_epilogue_impl(const ConvP& p, f32x16 (&ac
       for (int q = 0; q < 4; ++q) e[q] = p.fast ? act_apply_fast(e[q], p.epi_act) : act_apply(e[q], p.epi_act);
     }
     if (p.res) {
-      const float4 r4 = *reinterpret_cast<const float4*>(p.res + m * p.res_ld + co);
+      const float4 r4 = SIMPLE ? rpre[it & 3] : *reinterpret_cast<const float4*>(p.res + m * p.res_ld + co);
       const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
       if (!SIMPLE && p.aux) {
         const float4 a4 = *reinterpret_cast<const float4*>(p.aux + m * (long)p.Cout + co);

@@ -392,10 +392,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
 #pragma unroll
       for (int q16 = 0; q16 < 16; ++q16) rpre[q16] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, v_res, dpix_of(q16) * p.res_ld * 4, 0);
     }
-    // the general epilogue (activation switch, aux tensor, split-K) stays a loop: fully unrolled it is 30k instructions
-    constexpr int UNR = SIMPLE_EPI ? 16 : 2;
+    // the general epilogue (activation switch, aux tensor, split-K) stays a loop: fully unrolled it is 30k instructions; its residual
+    // / aux rows are loaded per group of four iterations, before the group's first store
+    constexpr int UNR = SIMPLE_EPI ? 16 : 4;
+    u32x4 rgrp[4], agrp[4];
 #pragma unroll UNR
     for (int q16 = 0; q16 < 16; ++q16) {
+      if (!SIMPLE_EPI && HAS_RES && (q16 & 3) == 0 && p.split_k == 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          rgrp[u] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, v_res, dpix_of(q16 + u) * p.res_ld * 4, 0);
+          if (p.aux) agrp[u] = __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, v_aux, dpix_of(q16 + u) * p.Cout * 4, 0);
+        }
+      }
       const int px = q16 * 4 + prow;
       const int dpix = dpix_of(q16);
       const float4 v = *reinterpret_cast<const float4*>(et + px * EP + c4);
@@ -413,10 +422,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
         for (int q = 0; q < 4; ++q) e[q] = p.fast ? act_apply_fast(e[q], p.epi_act) : act_apply(e[q], p.epi_act);
       }
       if (HAS_RES) {
-        const u32x4 r4 = SIMPLE_EPI ? rpre[SIMPLE_EPI ? q16 : 0] : __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, v_res, dpix * p.res_ld * 4, 0);
+        const u32x4 r4 = SIMPLE_EPI ? rpre[SIMPLE_EPI ? q16 : 0] : rgrp[q16 & 3];
         const float rr[4] = {__uint_as_float(r4.x), __uint_as_float(r4.y), __uint_as_float(r4.z), __uint_as_float(r4.w)};
         if (!SIMPLE_EPI && p.aux) {
-          const u32x4 a4 = __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, v_aux, dpix * p.Cout * 4, 0);
+          const u32x4 a4 = agrp[q16 & 3];
           const float aa[4] = {__uint_as_float(a4.x), __uint_as_float(a4.y), __uint_as_float(a4.z), __uint_as_float(a4.w)};
 #pragma unroll
           for (int q = 0; q < 4; ++q) e[q] = rr[q] + p.aux_w * (rr[q] * aa[q] + e[q]);

@@ -790,14 +790,19 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
   // b piece -> LDS column: 16-channel chunk c = b_pc >> 2, part = b_pc & 3 (0,1: hi ch 0-7 / 8-15; 2,3: lo)
   const int b_col = ((b_pc & 3) >> 1) * XBK + (b_pc >> 2) * 16 + (b_pc & 1) * 8;
 
-  float a_raw[A_IT][8];
-  bool a_ok[A_IT];
-  uint4 b_raw[B_IT];
-  int a_c = 0;
+  // the in-flight operands of one K step (registers)
+  struct StepRegs {
+    float a_raw[A_IT][8];
+    bool a_ok[A_IT];
+    uint4 b_raw[B_IT];
+    int a_c;
+    float u_sc[8], u_sh[8];
+  };
+  StepRegs R0;
+  R0.a_c = 0;
   const long m_last = (m0 + BM - 1 < p.M) ? (m0 + BM - 1) : (long)p.M - 1;
   const bool uni_n = !PLAIN && p.pro_scale && ((m0 / hw) == (m_last / hw));
   const long uni_off = (m0 / hw) * (long)p.Cin;
-  float u_sc[8], u_sh[8];
 
   const long rows_here = (p.M - m0) < BM ? (p.M - m0) : BM;
   __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);
@@ -830,33 +835,33 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
     b_voff[it] = co < p.Cout ? (int)((long)co * wrow_stride * 2) + b_pc * 16 : (int)0x80000000;
   }
 
-  auto fetch = [&](int s) {
+  auto fetch = [&](int s, StepRegs& R) {
     const int tap = s / cchunks;
     const int c0 = (s - tap * cchunks) * XBK;
     const int kh = tap / p.KW;
     const int kw = tap - kh * p.KW;
     const int ca = c0 + a_grp * 8;
-    a_c = ca;
+    R.a_c = ca;
     if (uni_n && ca < p.Cin) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        u_sc[j] = p.pro_scale[uni_off + ca + j];
-        u_sh[j] = p.pro_shift[uni_off + ca + j];
+        R.u_sc[j] = p.pro_scale[uni_off + ca + j];
+        R.u_sh[j] = p.pro_shift[uni_off + ca + j];
       }
     }
     if (ONE) {
 #pragma unroll
       for (int it = 0; it < A_IT; ++it) {
-        a_ok[it] = ca < p.Cin;             // rows beyond M: zeros from the range check
+        R.a_ok[it] = ca < p.Cin;             // rows beyond M: zeros from the range check
         const bool second = p.in2 && c0 >= p.cin1;                      // wave-uniform
         const u32x4 v0 = second ? __builtin_amdgcn_raw_buffer_load_b128(a2_rsrc, a2_voff[it], (c0 - p.cin1) * 4, 0)
                                 : __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[it], c0 * 4, 0);
         const u32x4 v1 = second ? __builtin_amdgcn_raw_buffer_load_b128(a2_rsrc, a2_voff[it] + 16, (c0 - p.cin1) * 4, 0)
                                 : __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[it] + 16, c0 * 4, 0);
-        a_raw[it][0] = __uint_as_float(v0.x); a_raw[it][1] = __uint_as_float(v0.y);
-        a_raw[it][2] = __uint_as_float(v0.z); a_raw[it][3] = __uint_as_float(v0.w);
-        a_raw[it][4] = __uint_as_float(v1.x); a_raw[it][5] = __uint_as_float(v1.y);
-        a_raw[it][6] = __uint_as_float(v1.z); a_raw[it][7] = __uint_as_float(v1.w);
+        R.a_raw[it][0] = __uint_as_float(v0.x); R.a_raw[it][1] = __uint_as_float(v0.y);
+        R.a_raw[it][2] = __uint_as_float(v0.z); R.a_raw[it][3] = __uint_as_float(v0.w);
+        R.a_raw[it][4] = __uint_as_float(v1.x); R.a_raw[it][5] = __uint_as_float(v1.y);
+        R.a_raw[it][6] = __uint_as_float(v1.z); R.a_raw[it][7] = __uint_as_float(v1.w);
       }
     } else {
 #pragma unroll
@@ -864,13 +869,13 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
         int iy = a_oy[it] * p.stride - p.pad_t + kh;
         int ix = a_ox[it] * p.stride - p.pad_l + kw;
         KEEP_REFLECT(iy, ix, p.H, p.W)
-        a_ok[it] = a_mv[it] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ca < p.Cin;
-        if (a_ok[it]) {
+        R.a_ok[it] = a_mv[it] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ca < p.Cin;
+        if (R.a_ok[it]) {
           const float* src = p.in + (((long)a_n[it] * p.H + iy) * p.W + ix) * p.in_ld + ca;
           const float4 v0 = *reinterpret_cast<const float4*>(src);
           const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
-          a_raw[it][0] = v0.x; a_raw[it][1] = v0.y; a_raw[it][2] = v0.z; a_raw[it][3] = v0.w;
-          a_raw[it][4] = v1.x; a_raw[it][5] = v1.y; a_raw[it][6] = v1.z; a_raw[it][7] = v1.w;
+          R.a_raw[it][0] = v0.x; R.a_raw[it][1] = v0.y; R.a_raw[it][2] = v0.z; R.a_raw[it][3] = v0.w;
+          R.a_raw[it][4] = v1.x; R.a_raw[it][5] = v1.y; R.a_raw[it][6] = v1.z; R.a_raw[it][7] = v1.w;
         }
       }
     }
@@ -878,25 +883,25 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, cb_ok ? b_voff[it] : (int)0x80000000, (tap * p.Cin + c0) * 4, 0);
-      b_raw[it] = make_uint4(v.x, v.y, v.z, v.w);
+      R.b_raw[it] = make_uint4(v.x, v.y, v.z, v.w);
     }
   };
 
-  auto stage = [&](int buf) {
+  auto stage = [&](int buf, StepRegs& R) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       f16x8 hi, lo;
-      if (a_ok[it]) {
+      if (R.a_ok[it]) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = a_raw[it][j];
+        for (int j = 0; j < 8; ++j) v[j] = R.a_raw[it][j];
         if (!PLAIN) {
           if (uni_n) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = v[j] * u_sc[j] + u_sh[j];
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * R.u_sc[j] + R.u_sh[j];
           } else if (p.pro_scale) {
-            const float* sc = p.pro_scale + (long)a_n[it] * p.Cin + a_c;
-            const float* sh = p.pro_shift + (long)a_n[it] * p.Cin + a_c;
+            const float* sc = p.pro_scale + (long)a_n[it] * p.Cin + R.a_c;
+            const float* sh = p.pro_shift + (long)a_n[it] * p.Cin + R.a_c;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
           }
@@ -906,11 +911,12 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
           }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float vs = v[j] * a_s[it];
-          const _Float16 h = (_Float16)vs;
-          hi[j] = h;
-          lo[j] = (_Float16)(vs - (float)h);
+        for (int j = 0; j < 8; j += 2) {      // two values per instruction: v_pk_mul, v_cvt_pk_f16_f32, v_pk_add (VALU is paid in full: coissue_probe)
+          const f32x2 vs = f32x2{v[j], v[j + 1]} * a_s[it];
+          const f16x2 h = __builtin_convertvector(vs, f16x2);
+          const f16x2 l = __builtin_convertvector(vs - __builtin_convertvector(h, f32x2), f16x2);
+          hi[j] = h.x; hi[j + 1] = h.y;
+          lo[j] = l.x; lo[j + 1] = l.y;
         }
       } else {
 #pragma unroll
@@ -922,7 +928,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it)
-      *reinterpret_cast<uint4*>(&Bs[buf][(b_row0 + it * 32) * XP + b_col]) = b_raw[it];
+      *reinterpret_cast<uint4*>(&Bs[buf][(b_row0 + it * 32) * XP + b_col]) = R.b_raw[it];
   };
 
   f32x16 acc[TM][TN];
@@ -964,15 +970,17 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
   };
 
   if (s_begin < s_end) {
-    fetch(s_begin);
-    stage(0);
+    // (A two-deep register pipeline -- loads issued two MFMA phases ahead, 248 VGPRs -- measured no gain: 2119 vs 2045 us on
+    // 256 -> 1024 at 0.62 M rows, 760 vs 734 us on 1024 -> 128: the K loop is not waiting for its loads.)
+    fetch(s_begin, R0);
+    stage(0, R0);
     __syncthreads();
     int buf = 0;
     for (int s = s_begin; s < s_end; ++s) {
       const bool more = (s + 1 < s_end);
-      if (more) fetch(s + 1);
+      if (more) fetch(s + 1, R0);
       mma_step(buf);
-      if (more) stage(buf ^ 1);
+      if (more) stage(buf ^ 1, R0);
       __syncthreads();
       buf ^= 1;
     }

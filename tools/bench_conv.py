@@ -56,6 +56,8 @@ def run(name, mma, in_bf16, iters=20):
         kw['residual'] = torch.randn(N, Ho, Wo, Cout, device='cuda')
     if os.environ.get('ACT') == 'gelu':
         kw['act'] = L.ACT_GELU
+    if os.environ.get('DOWN'):       # VQGAN Downsample geometry: 3x3 stride 2, pad right / bottom only
+        kw.update(down=True, pad=0)
     if os.environ.get('SPLITK'):
         kw['split_k'] = int(os.environ['SPLITK'])
     if pro is not None:

@@ -1041,12 +1041,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvP p, int tile
     // unroll depth measured: 8 without a residual (109 us vs 113 at 4 and 119 at 16 on 128 ch @256^2), 16 with one (all
     // residual rows in flight: 142 us vs 146 / 152)
     constexpr int UNR = HAS_RES ? 16 : 8;
+    auto m_of = [&](int q16) {
+      const int px = q16 * 4 + prow;
+      const int oy = it.oy0 + (2 * wave + (px >> 5)) * RPT + (px & 31) / TW;
+      return ((long)it.n * p.Ho + oy) * p.Wo + it.ox0 + (px & 31) % TW;
+    };
+    // all residual rows loaded before the first store: inside the loop each load sits behind the previous store (`res` may alias
+    // `out`) and its vmcnt wait exposes a memory round trip per row -- unrolling alone does not put them in flight
+    float4 rpre[HAS_RES ? 16 : 1];
+    if (HAS_RES && cok && p.split_k == 1) {
+#pragma unroll
+      for (int q16 = 0; q16 < 16; ++q16) rpre[q16] = *reinterpret_cast<const float4*>(p.res + m_of(q16) * p.res_ld + co);
+    }
 #pragma unroll UNR
     for (int q16 = 0; q16 < 16; ++q16) {
       if (!cok) break;
       const int px = q16 * 4 + prow;
-      const int oy = it.oy0 + (2 * wave + (px >> 5)) * RPT + (px & 31) / TW;
-      const long m = ((long)it.n * p.Ho + oy) * p.Wo + it.ox0 + (px & 31) % TW;
+      const long m = m_of(q16);
       const float4 v = *reinterpret_cast<const float4*>(et + px * EP + c4);
       if (!SIMPLE_EPI && p.split_k > 1) {
         *reinterpret_cast<float4*>(p.ws + ((long)it.z * p.M + m) * p.Cout + co) = v;
@@ -1058,7 +1069,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvP p, int tile
         for (int q = 0; q < 4; ++q) e[q] = act_apply_fast(e[q], p.epi_act);
       }
       if (HAS_RES) {
-        const float4 r4 = *reinterpret_cast<const float4*>(p.res + m * p.res_ld + co);
+        const float4 r4 = rpre[HAS_RES ? q16 : 0];
         const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
         if (!SIMPLE_EPI && p.aux) {
           const float4 a4 = *reinterpret_cast<const float4*>(p.aux + m * (long)p.Cout + co);

@@ -1082,6 +1082,32 @@ def test_conv_x3_halo_work_queue_matches_static_order(monkeypatch):
     assert torch.equal(ops.conv(small, ws, bs, mma=L.MMA_X3, wx3=wsx, x3_acc_scale=ascs), r2)
 
 
+def test_residual_in_place_matches_out_of_place():
+    """`residual` may be the output buffer itself (y += conv(x)): the epilogues load their residual rows before the first store, and a
+    thread reads exactly the addresses it later writes -- the in-place result equals the out-of-place one bit for bit on the x3 halo,
+    x3 GEMM, exact-f32 halo and exact-f32 gather kernels."""
+    N, H, C = 2, 64, 64
+    x, w, b = rnd('ip_x', (N, C, H, H), 2.0), rnd('ip_w', (C, C, 3, 3), 0.05), rnd('ip_b', (C,))
+    xd, wp, bd = dev(nhwc(x)), pack(w), dev(b)
+    wx3, asc = x3w(wp)
+    r = dev(nhwc(rnd('ip_r', (N, C, H, H))))
+    for kw in (dict(mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc), dict()):
+        ref = ops.conv(xd, wp, bd, residual=r, **kw)
+        buf = r.clone()
+        got = ops.conv(xd, wp, bd, residual=buf, out=buf, **kw)
+        assert got.data_ptr() == buf.data_ptr() and torch.equal(got, ref), f'in-place residual, 3x3 ({"x3" if kw else "f32"})'
+    tok = dev(rnd('ip_t', (4096, 256), 2.0))
+    wl, bl = dev(rnd('ip_wl', (256, 256), 0.05)), dev(rnd('ip_bl', (256,)))
+    wl3, ascl = x3w(wl.view(256, 1, 1, 256))
+    rt = dev(rnd('ip_rt', (4096, 256)))
+    for kw in (dict(mma=L.MMA_X3, wx3=wl3, x3_acc_scale=ascl), dict()):
+        x4 = tok.view(1, 4096, 1, 256)
+        ref = ops.conv(x4, wl.view(256, 1, 1, 256), bl, ksize=1, pad=0, residual=rt.view(1, 4096, 1, 256), **kw)
+        buf = rt.clone().view(1, 4096, 1, 256)
+        got = ops.conv(x4, wl.view(256, 1, 1, 256), bl, ksize=1, pad=0, residual=buf, out=buf, **kw)
+        assert torch.equal(got, ref), f'in-place residual, GEMM ({"x3" if kw else "f32"})'
+
+
 def test_conv_x3_rgb_first_conv_kernel():
     """KEEP_MMA_X3, Cin = 3 (VQ conv_in at 512^2): the im2col-in-LDS x3 kernel -- weights split on the fly, range-probed and
     bounded inputs, fused statistics and max|out| -- against the exact-f32 kernels."""

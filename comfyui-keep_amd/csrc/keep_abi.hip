@@ -17,7 +17,8 @@ void keep_set_error(const char* fmt, ...) {
 // slow CU simply takes fewer items; with static striding the slowest block set the kernel time, ~10 % above the mean).  A slot
 // is 16 u32 -- 8 tickets + a count of finished blocks -- and is ZERO between launches: the last block to finish clears it.
 // Kernels of one stream never overlap, so a slot belongs to a (device, stream) pair; the pool is allocated and zeroed once per
-// device (keep_device_ok at load time, or the first launch outside a stream capture) and never freed.
+// device (keep_device_ok at load time, or the first launch outside a stream capture) and never freed.  Launches recorded into a
+// stream capture keep the strided order.
 #include <mutex>
 #include <vector>
 #define KEEP_SCHED_SLOTS 256
@@ -45,13 +46,13 @@ static bool sched_pool_init(int dev) {
 unsigned* keep_sched_slot(hipStream_t st) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  // Not inside a stream capture: a captured kernel node keeps the slot of the CAPTURE stream, and two graphs captured on one stream
+  // but replayed concurrently on two others would share its counters (and the pool must not be allocated inside a capture either).
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
   std::lock_guard<std::mutex> lock(g_sched_mu);
   SchedPool& sp = g_sched[dev];
-  if (!sp.base) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;   // no allocation inside a capture
-    if (!sched_pool_init(dev)) return nullptr;
-  }
+  if (!sp.base && !sched_pool_init(dev)) return nullptr;
   for (size_t i = 0; i < sp.owners.size(); ++i)
     if (sp.owners[i] == st) return sp.base + i * 16;
   if (sp.owners.size() >= KEEP_SCHED_SLOTS) return nullptr;

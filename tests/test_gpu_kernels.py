@@ -1067,12 +1067,13 @@ def test_conv_x3_halo_work_queue_matches_static_order(monkeypatch):
     assert all(torch.equal(g, r) for g, r in zip(got, ref)), 'work queue on a second stream'
     y_static = torch.empty_like(ref[0])
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph):                      # (captured launches keep the strided order: a node would pin the capture stream's slot)
         y_g, _ = ops.conv(xd, wp, bd, out=y_static, **kw)
     for _ in range(2):
         graph.replay()
         torch.cuda.synchronize()
-        assert torch.equal(y_g, ref[0]), 'work queue inside a replayed graph'
+        assert torch.equal(y_g, ref[0]), 'captured launch, replayed twice'
+    assert all(torch.equal(g, r) for g, r in zip(run(), ref)), 'work queue after graph replays'
     small = dev(nhwc(rnd('wq_s', (4, 512, 16, 16), 2.0)))             # 16-wide tiles, split-K items
     ws, bs = pack(rnd('wq_ws', (512, 512, 3, 3), 0.03)), dev(rnd('wq_bs', (512,)))
     wsx, ascs = x3w(ws)

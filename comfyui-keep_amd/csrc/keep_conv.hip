@@ -1779,7 +1779,6 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   p.cin1 = a->in2_cin1;
   p.out_amax = nullptr;
   p.reflect = a->pad_mode == KEEP_PAD_REFLECT ? 1 : 0;
-  p.sched = nullptr;
   p.tile_cols = 0;
   p.bias = a->bias;
   p.out = (float*)a->out;

@@ -42,11 +42,9 @@ struct ConvP {
   int cin1;
   unsigned* out_amax;         // KEEP_MMA_X3: per-image max |output| as raw float bits (atomicMax), or NULL
   int reflect;                // padding pixels mirror the image (nn.ReflectionPad2d, ParseNet) instead of reading zeros
-  unsigned* sched;            // persistent kernels: ticket slot of the launch stream (keep_abi.hip), NULL = static striding
   int tile_cols;              // x3 gather kernel on a 1-D grid: column blocks per row block (0: blockIdx.x / .y are the row / column block)
 };
 
-unsigned* keep_sched_slot(hipStream_t st);
 
 // nn.ReflectionPad2d index map on the (virtual, post-upsample) input extent: -1 -> 1, n -> n - 2 (pad < n)
 #define KEEP_REFLECT(IY, IX, HV, WV)                                   \

@@ -86,11 +86,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   constexpr int RPT = 32 / TW;
   constexpr int MAIN_B = (HALO_MAXPIX + 9 * 64) * XPITCH * 2;
   constexpr int EPI_B = 4 * 64 * 68 * 4;
-  constexpr int LDS_B = MAIN_B > EPI_B ? MAIN_B : EPI_B;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_B + 16];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[MAIN_B > EPI_B ? MAIN_B : EPI_B];
   _Float16* Hs = reinterpret_cast<_Float16*>(lds_raw);
   _Float16* Ws = Hs + HALO_MAXPIX * XPITCH;
-  volatile unsigned* const ticket_lds = reinterpret_cast<volatile unsigned*>(lds_raw + LDS_B);   // next ticket of this block (p.sched)
   unsigned char* const wdma_base = lds_raw + HALO_MAXPIX * XPITCH * 2;      // == Ws as bytes
   int fetched_ch = 0;
 
@@ -346,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     constexpr bool HAS_RES = decltype(res_c)::value;
     constexpr int EP = 68;
     float* et = reinterpret_cast<float*>(lds_raw) + wave * 64 * EP;
-    if (EXP == 11 && acc[0][0][0] + acc[1][1][3] + acc[0][1][7] + acc[1][0][9] != 1.2345e-30f) return;
+    if (EXP == 11 && acc[0][0][0] + acc[1][1][3] + acc[0][1][7] + acc[1][0][9] != 1.2345e-30f) return 0.f;
     const float asc = p.acc_scale * item_inv;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -446,7 +444,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
         amx = fmaxf(amx, fabsf(e[q]));
       }
     }
-    if (p.out_amax) wave_amax_commit(p.out_amax + it.n, amx);
     if (p.stats) {          // one partial per 256-pixel tile (stats_P = tiles): the four waves' sums meet in LDS, added in wave order
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -476,10 +473,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
         }
       }
     }
+    return amx;
   };
 
+  int amax_n = -1;                       // image of the running max|out| of this thread
+  float amax_run = 0.f;
   int item = blockIdx.x;
-  if (item >= n_items) return;      // never taken: the grid is min(n_items, blocks the chip holds) (a block that left here would not be counted in p.sched[8])
+  if (item >= n_items) return;
   if (EXP == 6 && blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(54);     // start stagger of the second block per CU
   // EXP == 9: phase timeline (s_memtime) of wave 0, summed over blocks into p.ws as u64[8]:
   // 0 stage, 1 wait at the barrier after staging, 2 fetch issue, 3 mma, 4 wait at the barrier after mma, 5 item set-up, 6 epilogue
@@ -489,21 +489,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   setup(cur);
   if (cur.ch_begin < cur.ch_end) fetch(cur.ch_begin);
   if (EXP == 9) t0 = __builtin_amdgcn_s_memtime();
-  // Work queue (p.sched, keep_abi.hip): the first item of a block is blockIdx.x; every further one is a ticket of the block's
-  // XCD (blocks are dealt round-robin to the XCDs, and xcd_remap gives the items with item % 8 == x one contiguous range of
-  // tiles: the L2 locality of the static order is kept).  Thread 0 draws the ticket for the NEXT item at the top of the
-  // current one and publishes it through LDS at the barrier after the first chunk's MFMA phase: the atomic's latency is hidden.
-  const int xcd = blockIdx.x & 7, first_dyn = gridDim.x >> 3;
   while (true) {
     const bool valid = cur.ch_begin < cur.ch_end;
-    unsigned tk = 0;
-    if (p.sched && tid == 0) tk = atomicAdd(p.sched + xcd, 1u);
     if (EXP == 9) {
       __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): operand loads landed
       KEEP_T(7)
     }
     if (valid) stage();
-    if (p.sched && tid == 0 && !valid) *ticket_lds = tk;      // (an item without chunks: published at this barrier)
     KEEP_T(0)
     __syncthreads();
     KEEP_T(1)
@@ -519,7 +511,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
       KEEP_T(2)
       mma();
       KEEP_T(3)
-      if (p.sched && tid == 0 && ch == cur.ch_begin) *ticket_lds = tk;      // a whole MFMA phase after the atomic was issued
       __syncthreads();
       KEEP_T(4)
       if (more) {
@@ -533,8 +524,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
         KEEP_T(1)
       }
     }
-    // (readfirstlane: the compiler must see a wave-uniform item, or every buffer access of the next item gets a waterfall loop)
-    const int next_item = p.sched ? (first_dyn + __builtin_amdgcn_readfirstlane((int)*ticket_lds)) * 8 + xcd : item + gridDim.x;
+    const int next_item = item + gridDim.x;
     const bool has_next = next_item < n_items;
     const float cur_inv = in_inv;                               // setup(nxt) below moves in_s / in_inv on to the next item
     HaloItem nxt = cur;
@@ -544,24 +534,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
       if (nxt.ch_begin < nxt.ch_end) fetch(nxt.ch_begin);     // in flight during the epilogue below
     }
     KEEP_T(5)
-    if (p.res)
-      epilogue_t(cur, cur_inv, std::true_type{});
-    else
-      epilogue_t(cur, cur_inv, std::false_type{});
+    const float amx = p.res ? epilogue_t(cur, cur_inv, std::true_type{}) : epilogue_t(cur, cur_inv, std::false_type{});
+    if (p.out_amax) {       // max|out| of the image: a wave only goes to memory when it holds a value above everything it has committed
+      if (cur.n != amax_n) { // (or seen) for this image -- the per-item "read the running maximum, skip if not larger" test was a dependent
+        amax_n = cur.n;      // global read in every epilogue
+        amax_run = 0.f;
+      }
+      if (__builtin_amdgcn_ballot_w64(amx > amax_run) != 0ull) {
+        unsigned b = __float_as_uint(amx);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
+        unsigned* dst = p.out_amax + cur.n;
+        unsigned seen = b;
+        if (lane == 0) {
+          seen = *reinterpret_cast<volatile unsigned*>(dst);
+          if (b > seen) atomicMax(dst, b);
+        }
+        seen = max(b, (unsigned)__builtin_amdgcn_readfirstlane((int)seen));
+        amax_run = fmaxf(amax_run, __uint_as_float(seen));
+      }
+    }
     KEEP_T(6)
     if (!has_next) break;
     __syncthreads();
     KEEP_T(4)
     item = next_item;
     cur = nxt;
-  }
-  if (p.sched && tid == 0) {        // every ticket of this block is drawn: the last block to get here zeroes the slot for the next launch
-    __threadfence();
-    if (atomicAdd(p.sched + 8, 1u) == gridDim.x - 1) {
-#pragma unroll
-      for (int x = 0; x < 9; ++x) p.sched[x] = 0u;
-      __threadfence();
-    }
   }
   if (EXP != 0 && tid == 0) {
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.ws);
@@ -1250,12 +1248,6 @@ int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
   const int per_cu = getenv("KEEP_X3_BLOCKS_PER_CU") ? atoi(getenv("KEEP_X3_BLOCKS_PER_CU")) : 2;      // dev: occupancy scaling probe
   dim3 grid(n_items < per_cu * n_cu ? n_items : per_cu * n_cu), block(256);
   const bool simple = p.split_k == 1 && !a->aux && a->epi_act == KEEP_ACT_NONE;
-  // many items per block: dynamic order through the stream's ticket slot (measured, 16 images: +1.2 % from 16 items per block up --
-  // a block on a slow CU takes fewer items; with a handful of items per block the greedy tail costs 2-4 %, so those launches keep
-  // the strided order).  KEEP_X3_STATIC_ORDER=1: strided order everywhere, KEEP_X3_QUEUE_MIN_ITEMS: the threshold (A/B runs).
-  const bool static_order = getenv("KEEP_X3_STATIC_ORDER") != nullptr;
-  const int queue_min = getenv("KEEP_X3_QUEUE_MIN_ITEMS") ? atoi(getenv("KEEP_X3_QUEUE_MIN_ITEMS")) : 16;
-  p.sched = (!static_order && grid.x % 8 == 0 && n_items >= queue_min * (int)grid.x) ? keep_sched_slot(st) : nullptr;
   // pipelined single-block-per-CU kernel: wide tiles, no split-K, at least two work items per CU
 #ifdef KEEP_X3_ABLATE
   if (getenv("KEEP_X3_EXP") && wide && simple && (a->pro_act == KEEP_PRO_SWISH || a->pro_act == KEEP_PRO_NONE)) {

@@ -1034,55 +1034,6 @@ def test_conv_x3_halo_general_epilogue_two_blocks_per_cu():
         check(y3, y32, 1e-5, f'x3 halo cft off={off}')
 
 
-def test_conv_x3_halo_work_queue_matches_static_order(monkeypatch):
-    """More items than resident blocks: the blocks draw their items from the stream's per-XCD ticket counters (keep_abi.hip).
-    Output, fused statistics and max|out| are bit-identical to the strided order (KEEP_X3_STATIC_ORDER=1), the slot is clean again
-    after every launch (repeated launches, another stream, a captured graph replayed twice)."""
-    N, H, C = 6, 128, 128                                 # 6 x 64 tiles x 2 cout blocks = 768 items > 512 blocks; 4 x 16 x 16 x 8 for the 16-wide tile
-    x, w, b = rnd('wq_x', (N, C, H, H), 2.0), rnd('wq_w', (C, C, 3, 3), 0.05), rnd('wq_b', (C,))
-    gamma, beta = rnd('wq_g', (C,)) * 0.2 + 1, rnd('wq_bt', (C,)) * 0.2
-    xd, wp, bd = dev(nhwc(x)), pack(w), dev(b)
-    wx3, asc = x3w(wp)
-    res = dev(nhwc(rnd('wq_r', (N, C, H, H))))
-    kw = dict(mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, stats=True, residual=res,
-              pro=ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6), pro_act=L.PRO_SWISH)
-
-    def run():
-        y, st = ops.conv(xd, wp, bd, **kw)
-        return y.clone(), st.part.clone(), st.amax.clone()
-
-    monkeypatch.setenv('KEEP_X3_STATIC_ORDER', '1')
-    ref = run()
-    monkeypatch.delenv('KEEP_X3_STATIC_ORDER')
-    monkeypatch.setenv('KEEP_X3_QUEUE_MIN_ITEMS', '1')     # (the default threshold keeps launches this small on the strided order)
-    for rep in range(3):
-        got = run()
-        for g, r, what in zip(got, ref, ('output', 'statistics', 'max|out|')):
-            assert torch.equal(g, r), f'work queue vs static order: {what} differs (launch {rep})'
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        got = run()
-    side.synchronize()
-    assert all(torch.equal(g, r) for g, r in zip(got, ref)), 'work queue on a second stream'
-    y_static = torch.empty_like(ref[0])
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):                      # (captured launches keep the strided order: a node would pin the capture stream's slot)
-        y_g, _ = ops.conv(xd, wp, bd, out=y_static, **kw)
-    for _ in range(2):
-        graph.replay()
-        torch.cuda.synchronize()
-        assert torch.equal(y_g, ref[0]), 'captured launch, replayed twice'
-    assert all(torch.equal(g, r) for g, r in zip(run(), ref)), 'work queue after graph replays'
-    small = dev(nhwc(rnd('wq_s', (4, 512, 16, 16), 2.0)))             # 16-wide tiles, split-K items
-    ws, bs = pack(rnd('wq_ws', (512, 512, 3, 3), 0.03)), dev(rnd('wq_bs', (512,)))
-    wsx, ascs = x3w(ws)
-    monkeypatch.setenv('KEEP_X3_STATIC_ORDER', '1')
-    r2 = ops.conv(small, ws, bs, mma=L.MMA_X3, wx3=wsx, x3_acc_scale=ascs).clone()
-    monkeypatch.delenv('KEEP_X3_STATIC_ORDER')
-    assert torch.equal(ops.conv(small, ws, bs, mma=L.MMA_X3, wx3=wsx, x3_acc_scale=ascs), r2)
-
-
 def test_residual_in_place_matches_out_of_place():
     """`residual` may be the output buffer itself (y += conv(x)): the epilogues load their residual rows before the first store, and a
     thread reads exactly the addresses it later writes -- the in-place result equals the out-of-place one bit for bit on the x3 halo,

@@ -1,5 +1,5 @@
-"""A/B of the work-queue order against the strided order of the x3 halo kernel (KEEP_X3_STATIC_ORDER), alternating in one process.
-   python tools/dev/order_ab.py [N ...]"""
+"""A/B of one environment switch of the library on the x3 halo layers (AB_ENV, default KEEP_X3_NO_WDMA), alternating in one
+   process.  python tools/dev/order_ab.py [N ...]   (written for the work queue of DESIGN 5.3c, which was removed again)"""
 import os
 import sys
 
@@ -13,6 +13,7 @@ load_package()
 from comfyui_keep_amd.engine import hiplib as L  # noqa: E402
 from comfyui_keep_amd.engine import ops  # noqa: E402
 
+AB_ENV = os.environ.get('AB_ENV', 'KEEP_X3_NO_WDMA')
 SHAPES = [(512, 64, 64), (256, 128, 128), (128, 256, 256), (64, 256, 256), (32, 512, 512)]
 
 
@@ -41,10 +42,10 @@ for N in [int(a) for a in sys.argv[1:]] or [4, 16]:
         for rep in range(4):
             for so in (0, 1):
                 if so:
-                    os.environ['KEEP_X3_STATIC_ORDER'] = '1'
+                    os.environ[AB_ENV] = '1'
                 else:
-                    os.environ.pop('KEEP_X3_STATIC_ORDER', None)
+                    os.environ.pop(AB_ENV, None)
                 t[so].append(time_one(x, w, b, kw, iters))
-        os.environ.pop('KEEP_X3_STATIC_ORDER', None)
+        os.environ.pop(AB_ENV, None)
         q, s = min(t[0]), min(t[1])
-        print(f'N={N:2d} {cin:3d}->{cout:3d} @{hw:3d}^2  queue {q:8.1f} us  strided {s:8.1f} us  ratio {s / q:.3f}   (all: {[round(v) for v in t[0]]} vs {[round(v) for v in t[1]]})', flush=True)
+        print(f'N={N:2d} {cin:3d}->{cout:3d} @{hw:3d}^2  default {q:8.1f} us  {AB_ENV}=1 {s:8.1f} us  ratio {s / q:.3f}   (all: {[round(v) for v in t[0]]} vs {[round(v) for v in t[1]]})', flush=True)

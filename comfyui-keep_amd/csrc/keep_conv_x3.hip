@@ -114,8 +114,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.wx3, 0, p.Cout * 9 * p.Cin * 4, 0x00020000);
+  float4 bias_nx = make_float4(0.f, 0.f, 0.f, 0.f);
+  float amax_raw = 0.f;
   auto setup = [&](const HaloItem& it) {
-    if (p.in_amax) x3_range_scale(p.in_amax[it.n], in_s, in_inv);
+    if (p.in_amax) amax_raw = p.in_amax[it.n];      // turned into (in_s, in_inv) at the top of the item: the load has an epilogue to land
 #pragma unroll
     for (int k = 0; k < HALO_IT; ++k) {
       const int hp = (tid >> 2) + k * 64;
@@ -134,6 +136,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
     in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)bhi << 32) | blo), 0, p.H * p.W * p.in_ld * 4, 0x00020000);
     sc_off = (long)it.n * p.Cin + g * 4;
+    bias_nx = make_float4(0.f, 0.f, 0.f, 0.f);       // bias of the item's cout block for this lane's four epilogue channels: in flight
+    if (p.bias && p.split_k == 1 && it.n0 + (lane & 15) * 4 < p.Cout)      // over a whole item (loaded in the epilogue it was waited for at once)
+      bias_nx = *reinterpret_cast<const float4*>(p.bias + it.n0 + (lane & 15) * 4);
     w_voff = (it.n0 + (tid >> 2)) < p.Cout ? ((it.n0 + (tid >> 2)) * 9 * p.Cin * 2 + g * 8) * 2 : -16;
     if (WDMA) {
       // DMA instruction q of this chunk (36 per chunk, 9 per wave: q = wave * 9 + t) fills LDS rows q*16 .. q*16+15 = tap q/4, couts
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
   };
-  auto epilogue_t = [&](const HaloItem& it, float item_inv, auto res_c) {
+  auto epilogue_t = [&](const HaloItem& it, float item_inv, const float4 bias4, auto res_c) {
     constexpr bool HAS_RES = decltype(res_c)::value;
     constexpr int EP = 68;
     float* et = reinterpret_cast<float*>(lds_raw) + wave * 64 * EP;
@@ -374,8 +379,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     }
     float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
     float amx = 0.f;
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
     // Residual rows of the simple form: all 16 loads are issued before the first store.  Inside the loop every load sat behind
     // the previous iteration's store (the compiler must assume `res` and `out` alias -- in place they do) and its
     // `s_waitcnt vmcnt(0)` -- loads and stores share the counter on gfx9 -- exposed a full memory round trip 16 times per item.
@@ -491,6 +494,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   if (EXP == 9) t0 = __builtin_amdgcn_s_memtime();
   while (true) {
     const bool valid = cur.ch_begin < cur.ch_end;
+    if (p.in_amax) x3_range_scale(amax_raw, in_s, in_inv);
     if (EXP == 9) {
       __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): operand loads landed
       KEEP_T(7)
@@ -526,7 +530,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     }
     const int next_item = item + gridDim.x;
     const bool has_next = next_item < n_items;
-    const float cur_inv = in_inv;                               // setup(nxt) below moves in_s / in_inv on to the next item
+    const float cur_inv = in_inv;                               // setup(nxt) below moves in_s / in_inv / the bias on to the next item
+    const float4 cur_bias = bias_nx;
     HaloItem nxt = cur;
     if (has_next) {
       nxt = halo_decode<TW, 4>(p, next_item, items_per_z, tiles_x, tiles_y, ncb);
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
       if (nxt.ch_begin < nxt.ch_end) fetch(nxt.ch_begin);     // in flight during the epilogue below
     }
     KEEP_T(5)
-    const float amx = p.res ? epilogue_t(cur, cur_inv, std::true_type{}) : epilogue_t(cur, cur_inv, std::false_type{});
+    const float amx = p.res ? epilogue_t(cur, cur_inv, cur_bias, std::true_type{}) : epilogue_t(cur, cur_inv, cur_bias, std::false_type{});
     if (p.out_amax) {       // max|out| of the image: a wave only goes to memory when it holds a value above everything it has committed
       if (cur.n != amax_n) { // (or seen) for this image -- the per-item "read the running maximum, skip if not larger" test was a dependent
         amax_n = cur.n;      // global read in every epilogue

@@ -1034,6 +1034,25 @@ def test_conv_x3_halo_general_epilogue_two_blocks_per_cu():
         check(y3, y32, 1e-5, f'x3 halo cft off={off}')
 
 
+def test_conv_x3_halo_fused_probe_over_several_items_per_block():
+    """The fused max|out| of the x3 halo kernel when a block walks several items of different images (768 items on 512 blocks): a wave
+    goes to memory only above what it has already committed or seen for the image, and re-arms when the image changes -- the result
+    equals a direct reduction of the output, per image, bit for bit."""
+    N, H, C = 6, 128, 128
+    x, w, b = rnd('fp_x', (N, C, H, H), 2.0), rnd('fp_w', (C, C, 3, 3), 0.05), rnd('fp_b', (C,))
+    x = x * torch.tensor([1.0, 30.0, 0.01, 5.0, 0.3, 100.0]).view(N, 1, 1, 1)          # very different ranges per image
+    gamma, beta = rnd('fp_g', (C,)) * 0.2 + 1, rnd('fp_bt', (C,)) * 0.2
+    xd, wp, bd = dev(nhwc(x)), pack(w), dev(b)
+    wx3, asc = x3w(wp)
+    res = dev(nhwc(rnd('fp_r', (N, C, H, H)))) * dev(torch.tensor([1.0, 50.0, 0.0, 2.0, 0.1, 1000.0])).view(N, 1, 1, 1)
+    for pro in (True, False):
+        kw = dict(mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, stats=True, residual=res)
+        if pro:
+            kw.update(pro=ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6), pro_act=L.PRO_SWISH)
+        y, st = ops.conv(xd, wp, bd, **kw)
+        assert torch.equal(st.amax.cpu(), y.abs().flatten(1).max(1).values.cpu()), f'fused max|out| (prologue={pro})'
+
+
 def test_residual_in_place_matches_out_of_place():
     """`residual` may be the output buffer itself (y += conv(x)): the epilogues load their residual rows before the first store, and a
     thread reads exactly the addresses it later writes -- the in-place result equals the out-of-place one bit for bit on the x3 halo,

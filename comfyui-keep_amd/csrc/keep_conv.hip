@@ -1671,6 +1671,7 @@ __global__ void conv_splitk_reduce_kernel(ConvP p) {
 // statistics: plan_conv().  keep_conv2d_plan() exposes that decision to the host, which sizes the workspace / statistics
 // buffers from it and never re-derives kernel internals (a retune here cannot silently corrupt a caller).
 int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
+bool keep_conv_x3_up2_ok(const keep_conv2d_args* a);
 int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int big_tile, hipStream_t st);
 bool keep_conv_x3_gather_is_gemm(const keep_conv2d_args* a);
 int keep_conv2d_x3_c3(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
@@ -1748,6 +1749,8 @@ static int validate_conv(const keep_conv2d_args* a) {
                  "keep_conv2d: output extent %dx%d inconsistent with input %dx%d", a->Ho, a->Wo, Hv, Wv);
   }
   KEEP_REQUIRE(a->mma == KEEP_MMA_F32 || a->mma == KEEP_MMA_BF16 || a->mma == KEEP_MMA_X3, "keep_conv2d: bad mma %d", a->mma);
+  KEEP_REQUIRE(a->upsample == 0 || a->upsample == 1 || (a->upsample == KEEP_UPSAMPLE_X2_PHASES && a->mma == KEEP_MMA_X3),
+               "keep_conv2d: upsample must be 0, 1 or KEEP_UPSAMPLE_X2_PHASES (KEEP_MMA_X3 only), got %d", a->upsample);
   KEEP_REQUIRE(a->pad_mode == KEEP_PAD_ZERO || a->pad_mode == KEEP_PAD_REFLECT, "keep_conv2d: bad pad_mode %d", a->pad_mode);
   if (a->pad_mode == KEEP_PAD_REFLECT) {
     const int Hv = a->upsample ? 2 * a->H : a->H, Wv = a->upsample ? 2 * a->W : a->W;
@@ -1854,6 +1857,19 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
       pl.stats_rows = 64;
       pl.amax_ok = true;
       snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_c3_x3_kernel");
+      return KEEP_OK;
+    }
+    if (a->upsample == KEEP_UPSAMPLE_X2_PHASES) {      // weight_x3 holds the four phase kernels: only the phase form of the halo kernel can run it
+      if (!(have_w && is33s1 && keep_conv_x3_up2_ok(a))) {
+        keep_set_error("keep_conv2d: upsample = KEEP_UPSAMPLE_X2_PHASES needs KEEP_MMA_X3 phase weights, a 3x3 stride-1 pad-1 convolution without "
+                       "prologue / activation / aux / split-K, H %% 8 == 0, W %% 32 == 0, Cin %% 16 == 0 and Cout %% 64 == 0");
+        return KEEP_EUNSUP;
+      }
+      pl.path = PATH_HALO_X3;
+      pl.split_k = 1;
+      pl.stats_rows = 256;
+      pl.amax_ok = true;
+      snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3_kernel<32, x2 phases>");
       return KEEP_OK;
     }
     if (have_w && is33s1 && keep_conv_x3_halo_ok(a) && !getenv("KEEP_NO_HALO_X3")) {

@@ -80,8 +80,16 @@ __device__ __forceinline__ float xor32_sum(float x) {
 // (row >> 2) & 3 through the SOURCE address of each lane (an LDS-DMA destination is lane-linear), which keeps the B-fragment
 // ds_read_b128 conflict-free without padding.  Issued after the barrier that ends a chunk's MFMA phase, landed (vmcnt(0)) under the
 // VALU staging of the halo.
-template <int TW, int PRO, bool SIMPLE_EPI, int EXP = 0, bool FASTACT = true, bool WDMA = false>
+// UP2 (p.up2): nearest-x2 upsample + 3x3 convolution as FOUR 2x2-tap convolutions on the SOURCE grid, one per output parity (py, px):
+//   out[2y+py, 2x+px] = sum over the 2x2 source neighbourhood of the pre-added weights (row y-1: w[0], row y: w[1]+w[2] for py = 0;
+//   row y: w[0]+w[1], row y+1: w[2] for py = 1; columns alike) -- 4 of 9 taps per output instead of 9: the x2-replicated pixels of the
+//   upsampled tensor multiply the same source value.  The weight tensor holds the four phase kernels as 4*Cout virtual cout rows
+//   ([phase][Cout][9 taps][Cin/16][hi16|lo16], unused taps zero and never fetched); an item is (source tile, phase, cout block), its
+//   MFMA loop is compiled per phase (static tap list), its epilogue scatters to the stride-2 output pixels.  Tiles, halo and
+//   addressing are those of a plain 3x3 convolution on the source (p.upsample = 0, p.Ho / p.Wo = the OUTPUT extent).
+template <int TW, int PRO, bool SIMPLE_EPI, int EXP = 0, bool FASTACT = true, bool WDMA = false, bool UP2 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int tiles_x, int tiles_y, int ncb, int n_items) {
+  static_assert(!UP2 || (TW == 32 && WDMA && SIMPLE_EPI && PRO == KEEP_PRO_NONE), "UP2: wide tiles, DMA weights, simple epilogue, no prologue");
   constexpr int HALO_TH = 256 / TW, HALO_W = TW + 2, HALO_PIX = (HALO_TH + 2) * HALO_W;
   constexpr int RPT = 32 / TW;
   constexpr int MAIN_B = (HALO_MAXPIX + 9 * 64) * XPITCH * 2;
@@ -113,7 +121,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   float in_s = 1.f, in_inv = 1.f;        // range scale of the item being FETCHED / staged (image it.n)
   __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.wx3, 0, p.Cout * 9 * p.Cin * 4, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.wx3, 0, (UP2 ? 4 : 1) * p.Cout * 9 * p.Cin * 4, 0x00020000);
+  const int cout_rows = (UP2 ? 4 : 1) * p.Cout;      // weight rows (UP2: four phase kernels)
+  const int ncb_real = p.Cout >> 6;                  // UP2: cout blocks per phase (Cout % 64 == 0)
   float4 bias_nx = make_float4(0.f, 0.f, 0.f, 0.f);
   float amax_raw = 0.f;
   auto setup = [&](const HaloItem& it) {
@@ -137,9 +147,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)bhi << 32) | blo), 0, p.H * p.W * p.in_ld * 4, 0x00020000);
     sc_off = (long)it.n * p.Cin + g * 4;
     bias_nx = make_float4(0.f, 0.f, 0.f, 0.f);       // bias of the item's cout block for this lane's four epilogue channels: in flight
-    if (p.bias && p.split_k == 1 && it.n0 + (lane & 15) * 4 < p.Cout)      // over a whole item (loaded in the epilogue it was waited for at once)
-      bias_nx = *reinterpret_cast<const float4*>(p.bias + it.n0 + (lane & 15) * 4);
-    w_voff = (it.n0 + (tid >> 2)) < p.Cout ? ((it.n0 + (tid >> 2)) * 9 * p.Cin * 2 + g * 8) * 2 : -16;
+    const int n0r = UP2 ? ((it.n0 >> 6) % ncb_real) << 6 : it.n0;          // real cout of the block's first channel
+    if (p.bias && p.split_k == 1 && n0r + (lane & 15) * 4 < p.Cout)      // over a whole item (loaded in the epilogue it was waited for at once)
+      bias_nx = *reinterpret_cast<const float4*>(p.bias + n0r + (lane & 15) * 4);
+    w_voff = (it.n0 + (tid >> 2)) < cout_rows ? ((it.n0 + (tid >> 2)) * 9 * p.Cin * 2 + g * 8) * 2 : -16;
     if (WDMA) {
       // DMA instruction q of this chunk (36 per chunk, 9 per wave: q = wave * 9 + t) fills LDS rows q*16 .. q*16+15 = tap q/4, couts
       // (q%4)*16 + lane/4; lane's physical 16-byte slot lane&3 holds logical piece (lane&3) ^ ((lane>>4)&3) of its row
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int co = it.n0 + ((wave + j) & 3) * 16 + (lane >> 2);
-        dma_voff[j] = co < p.Cout ? co * 9 * p.Cin * 4 + lp * 16 : -16;
+        dma_voff[j] = co < cout_rows ? co * 9 * p.Cin * 4 + lp * 16 : -16;
       }
     }
   };
@@ -186,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     }
     fetched_ch = ch;
   };
+  int up_par = 0, up_mask = 0x1ff;       // UP2: phase (py * 2 + px) and tap set of the CURRENT item
   auto stage = [&]() {
     constexpr bool FAST = FASTACT && EXP != 7;
     if (EXP == 3) return;
@@ -194,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int q = __builtin_amdgcn_readfirstlane(wave) * 9 + t;            // wave-uniform (M0 / soffset operands)
+        if (UP2 && !((up_mask >> (q >> 2)) & 1)) continue;                      // a tap this phase does not use: never fetched
         if (EXP == 15)      // every piece from the same 1 KB of the weight tensor: L1 hits, no L2 traffic
           __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(wdma_base + q * 1024), 16,
                                                    lane * 16, 0, 0, 0);
@@ -276,7 +289,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   const int a_base = (((2 * wave) * RPT + l31 / TW) * HALO_W + (l31 % TW)) * XPITCH + lhi * 8;
   // WDMA: 64-byte rows, physical slot = logical piece ^ ((row >> 2) & 3); tap / cout-block offsets are multiples of 16 rows
   const int b_base = WDMA ? l31 * 32 + ((lhi ^ ((l31 >> 2) & 3)) * 8) : l31 * XPITCH + lhi * 8;
-  auto mma = [&]() {
+  auto mma_m = [&](auto mask_c) {
+    constexpr int MASK = decltype(mask_c)::value;      // taps of this instantiation (bit kh * 3 + kw)
     f16x8 ah[2], al[2], bh[2], bl[2];
     if (EXP == 1) {
 #pragma unroll
@@ -292,6 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
+        if (!((MASK >> (kh * 3 + kw)) & 1)) continue;
         if (EXP != 1) {
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
@@ -335,6 +350,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     }
     if (EXP == 8) __builtin_amdgcn_s_setprio(0);
   };
+  auto mma = [&]() {
+    if (!UP2) {
+      mma_m(std::integral_constant<int, 0x1ff>{});
+      return;
+    }
+    switch (up_par) {      // (py, px): taps kh in {py, py + 1}, kw in {px, px + 1}
+      case 0: mma_m(std::integral_constant<int, 0x01b>{}); break;
+      case 1: mma_m(std::integral_constant<int, 0x036>{}); break;
+      case 2: mma_m(std::integral_constant<int, 0x0d8>{}); break;
+      default: mma_m(std::integral_constant<int, 0x1b0>{}); break;
+    }
+  };
   // Epilogue: the wave parks its 64 x 64 tile in LDS and reads it back channel-contiguous (16 B per lane, 4 pixels x 256 B per
   // store instruction).  Addressing is image-relative and 32-bit: per-lane byte offset once per item, the (row, column)
   // displacement of each of the 16 pixel groups in the scalar offset of a buffer store -- no 64-bit multiplies per row.
@@ -361,10 +388,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     __builtin_amdgcn_s_waitcnt(0xc07f);
     KEEP_T(11)
     const int c4 = (lane & 15) * 4, prow = lane >> 4;
-    const int co = it.n0 + c4;
+    const int e_par = UP2 ? (it.n0 >> 6) / ncb_real : 0;
+    const int e_n0 = UP2 ? it.n0 - e_par * p.Cout : it.n0;                    // real first cout of the block
+    const int co = e_n0 + c4;
     const bool cok = co < p.Cout;
     const int hw_o = p.Ho * p.Wo;
-    const int pix_b = (it.oy0 + 2 * wave * RPT) * p.Wo + it.ox0 + prow;       // pixel of group 0 inside the image
+    // pixel of group 0 inside the image (UP2: source pixel (y, x) of phase (py, px) -> output pixel (2y + py, 2x + px))
+    const int pix_b = UP2 ? (2 * (it.oy0 + 2 * wave) + (e_par >> 1)) * p.Wo + 2 * (it.ox0 + prow) + (e_par & 1)
+                          : (it.oy0 + 2 * wave * RPT) * p.Wo + it.ox0 + prow;
     const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc(p.out + (long)it.n * hw_o * p.out_ld, hw_o * p.out_ld * 4);
     const int v_out = cok ? (pix_b * p.out_ld + co) * 4 : -16;
     __amdgpu_buffer_rsrc_t res_rsrc = out_rsrc, aux_rsrc = out_rsrc;
@@ -386,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
     auto dpix_of = [&](int q16) {
       const int drow = (q16 >> 3) * RPT + (TW == 32 ? 0 : ((q16 & 7) >> 2));
       const int dcol = TW == 32 ? (q16 & 7) * 4 : (q16 & 3) * 4;
-      return drow * p.Wo + dcol;                                              // wave-uniform
+      return (UP2 ? 2 : 1) * (drow * p.Wo + dcol);                            // wave-uniform
     };
     u32x4 rpre[SIMPLE_EPI && HAS_RES ? 16 : 1];
     if (SIMPLE_EPI && HAS_RES) {
@@ -469,8 +500,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
           a += e0[w * 64 * EP + lane * 2 + 0];
           b2 += e0[w * 64 * EP + lane * 2 + 1];
         }
-        if (it.n0 + lane < p.Cout) {
-          float* dst = p.stats + (((long)it.n * p.stats_P + (it.ty * tiles_x + it.tx)) * p.Cout + it.n0 + lane) * 2;
+        if (e_n0 + lane < p.Cout) {      // (UP2: four partials per source tile, one per phase -- each covers 256 output pixels)
+          const int part = UP2 ? (it.ty * tiles_x + it.tx) * 4 + e_par : it.ty * tiles_x + it.tx;
+          float* dst = p.stats + (((long)it.n * p.stats_P + part) * p.Cout + e_n0 + lane) * 2;
           dst[0] = a;
           dst[1] = b2;
         }
@@ -495,6 +527,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
   while (true) {
     const bool valid = cur.ch_begin < cur.ch_end;
     if (p.in_amax) x3_range_scale(amax_raw, in_s, in_inv);
+    if (UP2) {
+      up_par = __builtin_amdgcn_readfirstlane((cur.n0 >> 6) / ncb_real);
+      up_mask = up_par == 0 ? 0x01b : up_par == 1 ? 0x036 : up_par == 2 ? 0x0d8 : 0x1b0;
+    }
     if (EXP == 9) {
       __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): operand loads landed
       KEEP_T(7)
@@ -1230,6 +1266,13 @@ bool keep_conv_x3_halo_ok(const keep_conv2d_args* a) {
          (!a->workspace || (uintptr_t)a->workspace % 16 == 0);
 }
 
+// KEEP_UPSAMPLE_X2_PHASES: the halo geometry on the SOURCE map (8 x 32 tiles), whole 64-cout blocks, no prologue / activation / aux / split-K
+bool keep_conv_x3_up2_ok(const keep_conv2d_args* a) {
+  return keep_conv_x3_halo_ok(a) && a->H % 8 == 0 && a->W % 32 == 0 && a->Cout % 64 == 0 && !a->pro_scale && a->pro_act == KEEP_PRO_NONE &&
+         a->epi_act == KEEP_ACT_NONE && !a->aux && a->split_k <= 1 && a->pad_mode == KEEP_PAD_ZERO &&
+         (long)4 * a->Cout * 9 * a->Cin * 4 < (1L << 31);
+}
+
 bool keep_conv_x3_gather_ok(const keep_conv2d_args* a, const ConvP& p) {
   return a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && !a->upsample && (a->Cin % 16 == 0) && (a->in_ld % 4 == 0) &&
          ((uintptr_t)a->in % 16 == 0) && p.vec_epi && (long)a->Cout * a->KH * a->KW * a->Cin * 4 < (1L << 31);   // weight buffer offsets
@@ -1243,6 +1286,17 @@ bool keep_conv_x3_gather_is_gemm(const keep_conv2d_args* a) {
 
 // the pipelined kernel wants wide tiles, no split-K and at least two work items per CU (one block per CU walks them)
 int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
+  if (a->upsample == KEEP_UPSAMPLE_X2_PHASES) {      // four 2x2-tap phase convolutions on the source grid (kernel comment: UP2)
+    const int tx = a->W / 32, ty = a->H / 8, ncbv = 4 * (a->Cout / 64);
+    const int n_items = a->N * tx * ty * ncbv;
+    const int n_cu = x3_num_cu();
+    p.upsample = 0;                                    // the kernel addresses the source like a plain 3x3 convolution
+    p.split_k = 1;
+    dim3 grid(n_items < 2 * n_cu ? n_items : 2 * n_cu), block(256);
+    hipLaunchKernelGGL((conv3x3_halo_x3_kernel<32, KEEP_PRO_NONE, true, 0, true, true, true>), grid, block, 0, st, p, tx, ty, ncbv, n_items);
+    KEEP_LAUNCH_CHECK("keep_conv2d(halo x3, x2 phases)");
+    return KEEP_OK;
+  }
   const int nchunks = a->Cin / 16;
   if (p.split_k > nchunks) p.split_k = nchunks;
   const bool wide = (a->Ho % 8 == 0 && a->Wo % 32 == 0);

@@ -12,13 +12,14 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 F32, BF16 = 0, 1
 MMA_F32, MMA_BF16, MMA_X3 = 0, 1, 2
 PRO_NONE, PRO_SWISH, PRO_RELU = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REFLECT = 0, 1
+UPSAMPLE_X2_PHASES = 2
 
 _vp, _i32, _i64, _f32, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
 STATUS_NONFINITE_LOGITS, STATUS_NONFINITE_TENSOR = 1, 2

@@ -154,6 +154,10 @@ class KeepNet:
             if self._dev_blobx3 is None:
                 self._make_x3()
             self.o.set_precision(L.MMA_X3, self._dev_blob, None, self._dev_blobx3, 1.0 / self._x3_scale)
+            if ops.UP2_PHASES:      # phase kernels of the generator's Upsample convolutions: built here, never inside a stream capture
+                for i, (kind, _, _) in enumerate(generator_blocks(self.cfg)):
+                    if kind == 'up':
+                        self.o.up2_twin(self.w[f'generator.blocks.{i}.conv.weight'])
         else:
             self.o.set_precision(L.MMA_F32, self._dev_blob, None)
 

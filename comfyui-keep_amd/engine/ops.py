@@ -17,6 +17,7 @@ import torch
 from . import hiplib as L
 
 TOKEN_LINEAR = os.environ.get('KEEP_NO_TOKEN_LINEAR') is None   # dev switch: streaming GEMM for the GMFlow projections
+UP2_PHASES = os.environ.get('KEEP_X3_UP2', '1') != '0'      # x3 policy: nearest x2 + 3x3 as four 2x2-tap phase convolutions (A/B: 0)
 USE_BK256 = bool(int(os.environ.get('KEEP_BK256', '0')))   # measured slower than BK=64 + split-K at B<=4 (kept for A/B)
 # bf16 policy: inputs of fewer pixels (N*H*W) than this skip the normalise+activate -> bf16 pass in front of the halo
 # conv and use the kernel variant that applies the prologue while staging (A/B switch, default: always the two-pass form)
@@ -80,6 +81,7 @@ class Ops:
         self.blob16 = None      # bf16 twin
         self.blobx3 = None      # split-fp16 twin: int16 tensor, 2 elements per weight, per-tensor [.., Cin/16, hi16|lo16]
         self.x3_acc_scale = 1.0
+        self._up2 = {}
         # bench.py's roofline leg: when a list, every keep_conv2d launch is bracketed by HIP events on the launch stream
         # and appended as (kernel family, algorithmic_flops, split_k, start_event, end_event, algorithmic_bytes)
         self.profile = None
@@ -109,6 +111,8 @@ class Ops:
 
     def set_precision(self, mma, blob32=None, blob16=None, blobx3=None, x3_acc_scale=1.0):
         self.mma = self.attn_mma = mma
+        if blob32 is None or self.blob32 is None or blob32.data_ptr() != self.blob32.data_ptr():
+            self._up2 = {}      # phase kernels of the Upsample convolutions (up2_twin): tied to the blob's addresses
         self.blob32, self.blob16, self.blobx3, self.x3_acc_scale = blob32, blob16, blobx3, float(x3_acc_scale)
 
     # ------------------------------------------------------------------ weight twins
@@ -126,6 +130,18 @@ class Ops:
             raise RuntimeError("bf16 policy needs the bf16 blob registered (Ops.set_precision)")
         off = self._blob_off(w)
         return self.blob16[off:off + w.numel()]
+
+    def up2_twin(self, w):
+        """(weight_x3, acc_scale) of the four 2x2-tap phase kernels of ``w`` (packed [Cout,3,3,Cin]) for
+        ``upsample = UPSAMPLE_X2_PHASES`` -- built once per weight tensor (the first, eager, call) and kept for the lifetime of the
+        blob it points into."""
+        key = (w.data_ptr(), tuple(w.shape))
+        tw = self._up2.get(key)
+        if tw is None:
+            w4 = up2_phase_weights(w)
+            sc = x3_scale_for(float(w4.abs().max()))
+            tw = self._up2[key] = (split_x3(w4.reshape(-1, w.shape[-1]), sc).view(-1), 1.0 / sc)
+        return tw
 
     def x3_twin(self, w):
         """split-fp16 copy of an fp32 weight view (row slices of a [Cout, .., Cin] tensor keep their layout), or None
@@ -168,6 +184,14 @@ class Ops:
         in_dtype = L.BF16 if x.dtype == torch.bfloat16 else L.F32
         if mma == L.MMA_BF16 and wb is None and self.blob16 is not None:
             wb = self.bf16_twin(w)      # (without a twin the library still accepts the exact-fp32 Cout <= 4 kernel)
+        up_mode = L.UPSAMPLE_X2_PHASES if upsample == L.UPSAMPLE_X2_PHASES and upsample is not True else int(bool(upsample))   # (explicit 2: the caller brings phase weights)
+        if (upsample and mma == L.MMA_X3 and wx3 is None and UP2_PHASES and KH == 3 and stride == 1 and pad == 1 and not down
+                and pro is None and pro_act == L.PRO_NONE and act == L.ACT_NONE and aux is None and x2 is None and not reflect
+                and split_k in (None, 1) and H % 8 == 0 and W % 32 == 0 and Cin % 16 == 0 and Cout % 64 == 0 and in_dtype == L.F32
+                and not out_bf16 and self.x3_twin(w) is not None):
+            # nearest x2 + 3x3 as four 2x2-tap phase convolutions on the source grid: 4 of 9 taps are multiplied
+            wx3, x3_acc_scale = self.up2_twin(w)
+            up_mode = L.UPSAMPLE_X2_PHASES
         if mma == L.MMA_X3 and wx3 is None:
             wx3 = self.x3_twin(w)
         if x3_acc_scale is None:
@@ -185,14 +209,14 @@ class Ops:
                 pro_shift=None if pro_t is None else pro_t[1], residual=residual, aux=aux, workspace=None,
                 N=N, H=H, W=W, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=stride, pad_t=pad_t, pad_l=pad_l, Ho=Ho, Wo=Wo,
                 in_ld=ld, out_ld=out_ld, res_ld=0 if residual is None else residual.shape[-1],
-                upsample=int(upsample), pro_act=pro_a, epi_act=act, aux_w=float(aux_w), split_k=sk, dtype=dtype,
+                upsample=up_mode, pro_act=pro_a, epi_act=act, aux_w=float(aux_w), split_k=sk, dtype=dtype,
                 mma=mma, weight_bf16=wb if mma == L.MMA_BF16 else None, stats_out=None, stats_P=0,
                 bk256=int(USE_BK256), out_dtype=odt, weight_x3=wx3 if mma == L.MMA_X3 else None,
                 x3_acc_scale=float(x3_acc_scale), x3_in_amax=in_amax, x3_out_amax=None,
                 in2=x2, in2_cin1=0 if x2 is None else ld, pad_mode=L.PAD_REFLECT if reflect else L.PAD_ZERO)
 
         def key_of(dtype, pro_t, pro_a, odt, sk):
-            return (N, H, W, ld, Cin, Cout, KH, stride, pad_t, pad_l, Ho, Wo, out_ld, int(upsample), pro_a, act, dtype, mma,
+            return (N, H, W, ld, Cin, Cout, KH, stride, pad_t, pad_l, Ho, Wo, out_ld, up_mode, pro_a, act, dtype, mma,
                     odt, sk, pro_t is not None, residual is not None, 0 if residual is None else residual.shape[-1],
                     aux is not None, bias is not None, in_off % 8, wx3 is not None, USE_BK256, x2 is not None, bool(reflect))
 
@@ -432,6 +456,18 @@ def split_x3(w2d, scale):
     lo = (ws - hi.float()).to(torch.float16)
     out = torch.stack((hi.view(rows, cin // 16, 16), lo.view(rows, cin // 16, 16)), dim=2)
     return out.contiguous().view(torch.int16)
+
+
+def up2_phase_weights(w):
+    """Packed [Cout,3,3,Cin] fp32 -> [4,Cout,3,3,Cin]: the 3x3 kernel of `nearest x2 -> conv3x3(pad 1)` (VQ:146-156) as four phase
+    kernels on the SOURCE grid.  Output pixel (2y+py, 2x+px) reads upsampled rows 2y+py-1 .. 2y+py+1 = source rows (y-1, y, y) for
+    py = 0 and (y, y, y+1) for py = 1: taps that meet the same source pixel are added (fp32), the freed taps are zero -- phase
+    (py, px) keeps taps kh in {py, py+1}, kw in {px, px+1} of a 3x3 window centred on source pixel (y, x)."""
+    r = torch.zeros(2, 3, 3, dtype=w.dtype, device=w.device)          # r[p][new][old]
+    r[0, 0, 0] = 1; r[0, 1, 1] = 1; r[0, 1, 2] = 1                     # phase 0: new0 = old0, new1 = old1 + old2
+    r[1, 1, 0] = 1; r[1, 1, 1] = 1; r[1, 2, 2] = 1                     # phase 1: new1 = old0 + old1, new2 = old2
+    w4 = torch.einsum('pak,qbl,oklc->pqoabc', r, r, w.float())
+    return w4.reshape(4, w.shape[0], 3, 3, w.shape[3]).contiguous()
 
 
 def x3_scale_for(max_abs):

@@ -28,8 +28,9 @@ extern "C" {
 /* Bumped on EVERY layout or signature change.  v12: keep_conv2d_args / keep_attention_args start with `struct_size`
  * (callers set it to sizeof of the struct THEY were compiled against; the library rejects sizes it does not know and reads
  * the fields a shorter known layout lacks as zero), keep_sizeof_*_args(), keep_argmax_gather takes the non-finite status word,
- * keep_nonfinite_flag. */
-#define KEEP_ABI_VERSION 12
+ * keep_nonfinite_flag.  v13: keep_conv2d_args.upsample accepts KEEP_UPSAMPLE_X2_PHASES (same layout; a v12 library refuses the
+ * value, so the binding asks for 13). */
+#define KEEP_ABI_VERSION 13
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -66,6 +67,7 @@ extern "C" {
 #define KEEP_ACT_SIGMOID 4 /* KA:771 */
 
 /* padding mode of keep_conv2d */
+#define KEEP_UPSAMPLE_X2_PHASES 2
 #define KEEP_PAD_ZERO 0
 #define KEEP_PAD_REFLECT 1
 
@@ -104,7 +106,12 @@ typedef struct {
   float* workspace;       /* split-K partials or NULL                        */
   int32_t N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo;
   int32_t in_ld, out_ld, res_ld;
-  int32_t upsample; /* 1: `in` is [N,H,W,*] and is read as its nearest x2 upsampling [N,2H,2W,*] */
+  int32_t upsample; /* 1: `in` is [N,H,W,*] and is read as its nearest x2 upsampling [N,2H,2W,*];
+                       KEEP_UPSAMPLE_X2_PHASES (KEEP_MMA_X3 only, v13): the same operation with the x2 folded into the WEIGHTS --
+                       `weight_x3` holds four 2x2-tap phase kernels [4][Cout][3*3][Cin/16][hi16|lo16] (engine/ops.py:up2_phase_weights:
+                       out[2y+py, 2x+px] only sees source rows {y-1, y} (py = 0) or {y, y+1} (py = 1), whose replicated taps are added
+                       beforehand), `x3_acc_scale` is theirs; 4 of 9 taps are multiplied.  Needs H % 8 == 0, W % 32 == 0, Cout % 64 == 0,
+                       no prologue / activation / aux / split-K (keep_conv2d_plan refuses otherwise).  VQ:146-156 (Upsample) */
   int32_t pro_act, epi_act;
   float aux_w;
   int32_t split_k; /* 0: the library chooses (keep_conv2d_plan reports the choice and the workspace it needs) */

@@ -1053,6 +1053,39 @@ def test_conv_x3_halo_fused_probe_over_several_items_per_block():
         assert torch.equal(st.amax.cpu(), y.abs().flatten(1).max(1).values.cpu()), f'fused max|out| (prologue={pro})'
 
 
+@pytest.mark.parametrize("n,cin,cout,h,wd,res", [(2, 64, 64, 32, 32, True), (3, 128, 128, 16, 64, False), (1, 32, 192, 8, 32, True),
+                                                 (8, 32, 128, 64, 64, True)])      # the last: 1024 items on 512 blocks
+def test_conv_x3_upsample_as_four_phase_convolutions(n, cin, cout, h, wd, res):
+    """`upsample = KEEP_UPSAMPLE_X2_PHASES`: nearest x2 + 3x3 (VQ:146-156) as four 2x2-tap phase convolutions on the source grid
+    (engine/ops.py:up2_phase_weights).  Against an fp64 reference of interpolate + conv2d the error is of the size of the 9-tap x3
+    form's; the fused statistics and max|out| describe the scattered output; borders (phases looking outside the image) included."""
+    x, w, b = rnd('u2x', (n, cin, h, wd), 2.0) + 0.3, rnd('u2w', (cout, cin, 3, 3), 0.05), rnd('u2b', (cout,))
+    r = rnd('u2r', (n, cout, 2 * h, 2 * wd)) if res else None
+    xd, wp, bd = dev(nhwc(x)), pack(w), dev(b)
+    wx3, asc = x3w(wp)
+    w4 = ops.up2_phase_weights(wp)
+    sc4 = ops.x3_scale_for(float(w4.abs().max()))
+    w4x3 = ops.split_x3(w4.reshape(-1, cin), sc4).view(-1)
+    kw = dict(stats=True, residual=None if r is None else dev(nhwc(r)), mma=L.MMA_X3)
+    ops.DEFAULT.profile = []
+    y2, st2 = ops.conv(xd, wp, bd, upsample=L.UPSAMPLE_X2_PHASES, wx3=w4x3, x3_acc_scale=1.0 / sc4, **kw)
+    kname = ops.DEFAULT.profile[-1][0]
+    ops.DEFAULT.profile = None
+    assert 'phases' in kname, kname
+    y1, _ = ops.conv(xd, wp, bd, upsample=True, wx3=wx3, x3_acc_scale=asc, **kw)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2.0, mode='nearest'), w.double(), b.double(), padding=1)
+    if r is not None:
+        ref = ref + r.double()
+    ref = ref.permute(0, 2, 3, 1)
+    e2, e1 = err64(y2, ref), err64(y1, ref)
+    scale = max(1.0, ref.abs().max().item())
+    assert e2 <= max(3.0 * e1, 2e-6 * scale), f'phase form err {e2:.3e} vs 9-tap x3 err {e1:.3e} (scale {scale:.3g})'
+    assert torch.equal(st2.amax.cpu(), y2.abs().flatten(1).max(1).values.cpu())
+    sc, sh = ops.norm_affine(y2, None, None, cout, 1e-5, stats=st2)
+    sc_d, sh_d = ops.norm_affine(y2, None, None, cout, 1e-5)
+    check(sc, sc_d, 1e-5, 'phase form fused stats scale'); check(sh, sh_d, 1e-5, 'phase form fused stats shift')
+
+
 def test_residual_in_place_matches_out_of_place():
     """`residual` may be the output buffer itself (y += conv(x)): the epilogues load their residual rows before the first store, and a
     thread reads exactly the addresses it later writes -- the in-place result equals the out-of-place one bit for bit on the x3 halo,

@@ -56,6 +56,10 @@ def run(name, mma, in_bf16, iters=20):
         kw['residual'] = torch.randn(N, Ho, Wo, Cout, device='cuda')
     if os.environ.get('ACT') == 'gelu':
         kw['act'] = L.ACT_GELU
+    if os.environ.get('UP2') and up and mma == L.MMA_X3:      # nearest x2 + 3x3 as four 2x2-tap phase convolutions
+        w4 = ops.up2_phase_weights(w)
+        sc4 = ops.x3_scale_for(float(w4.abs().max()))
+        kw.update(upsample=L.UPSAMPLE_X2_PHASES, wx3=ops.split_x3(w4.reshape(-1, Cin), sc4).view(-1), x3_acc_scale=1.0 / sc4)
     if os.environ.get('DOWN'):       # VQGAN Downsample geometry: 3x3 stride 2, pad right / bottom only
         kw.update(down=True, pad=0)
     if os.environ.get('SPLITK'):

@@ -81,7 +81,7 @@ class Ops:
         self.blob16 = None      # bf16 twin
         self.blobx3 = None      # split-fp16 twin: int16 tensor, 2 elements per weight, per-tensor [.., Cin/16, hi16|lo16]
         self.x3_acc_scale = 1.0
-        self._up2 = {}
+        self._up2, self._up2_src = {}, (None, None)
         # bench.py's roofline leg: when a list, every keep_conv2d launch is bracketed by HIP events on the launch stream
         # and appended as (kernel family, algorithmic_flops, split_k, start_event, end_event, algorithmic_bytes)
         self.profile = None
@@ -111,8 +111,11 @@ class Ops:
 
     def set_precision(self, mma, blob32=None, blob16=None, blobx3=None, x3_acc_scale=1.0):
         self.mma = self.attn_mma = mma
-        if blob32 is None or self.blob32 is None or blob32.data_ptr() != self.blob32.data_ptr():
-            self._up2 = {}      # phase kernels of the Upsample convolutions (up2_twin): tied to the blob's addresses
+        if blobx3 is not None and (blob32 is not self._up2_src[0] or blobx3 is not self._up2_src[1]):
+            # phase kernels of the Upsample convolutions (up2_twin): derived from THESE blob objects -- a new upload, even one that lands
+            # on the same addresses, starts from an empty cache; a policy switch on the same blobs keeps it (captured x3 graphs hold
+            # the addresses of its tensors)
+            self._up2, self._up2_src = {}, (blob32, blobx3)
         self.blob32, self.blob16, self.blobx3, self.x3_acc_scale = blob32, blob16, blobx3, float(x3_acc_scale)
 
     # ------------------------------------------------------------------ weight twins

@@ -1109,29 +1109,60 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_x3_kernel(ConvP p, int tile
   f32x16 acc[2][2];
   const bool has_act = p.epi_act != KEEP_ACT_NONE;
   const int py = tid >> 5, px = tid & 31;
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+  // The halo values (<= 4 per thread) and the input range of the NEXT item are loaded while the current one multiplies and stores:
+  // loaded at the top of their own item they were waited for at once (two resident blocks per CU hide little of a memory round trip).
+  struct Item { int cb, tx, ty, n; };
+  auto decode = [&](int item) {
+    Item it;
     const int lid = xcd_remap(item, n_items);
-    const int cb = lid % ncb;
+    it.cb = lid % ncb;
     int t = lid / ncb;
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y;
-    const int n = t / tiles_y;
+    it.tx = t % tiles_x; t /= tiles_x;
+    it.ty = t % tiles_y;
+    it.n = t / tiles_y;
+    return it;
+  };
+  constexpr int HV = (HROWS * HW_ * 3 + 255) / 256;                          // halo floats per thread (Cin <= 3)
+  float hv[HV], amax_raw = 0.f;
+  auto load_halo = [&](const Item& it) {
+    const float* img = p.in + (long)it.n * p.H * p.W * p.in_ld;
+    const int oy0 = it.ty * 8, ox0 = it.tx * 32;
+#pragma unroll
+    for (int u = 0; u < HV; ++u) {
+      const int i = tid + u * 256;
+      hv[u] = 0.f;
+      if (i < HROWS * rowf) {
+        const int hy = i / rowf, r = i - hy * rowf;
+        const int hx = r / Cin, c = r - hx * Cin;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) hv[u] = img[((long)iy * p.W + ix) * p.in_ld + c];
+      }
+    }
+    if (p.in_amax) amax_raw = p.in_amax[it.n];
+  };
+  int amax_n = -1;                                                           // image of the max|out| this wave has committed or seen
+  float amax_seen = 0.f;
+  int item = blockIdx.x;
+  if (item >= n_items) return;
+  Item nxt = decode(item);
+  load_halo(nxt);
+  for (; item < n_items; item += gridDim.x) {
+    const Item cur = nxt;
+    const int cb = cur.cb, tx = cur.tx, ty = cur.ty, n = cur.n;
     const int oy0 = ty * 8, ox0 = tx * 32, n0 = cb * 64;
     float in_s = 1.f, in_inv = 1.f;
-    if (p.in_amax) x3_range_scale(p.in_amax[n], in_s, in_inv);
+    if (p.in_amax) x3_range_scale(amax_raw, in_s, in_inv);
     __syncthreads();                                                         // previous item's staging tile fully stored
     if (cb != cur_cb) {
       load_weights(cb);
       cur_cb = cb;
     }
-    const float* img = p.in + (long)n * p.H * p.W * p.in_ld;
-    for (int i = tid; i < HROWS * rowf; i += 256) {
-      const int hy = i / rowf, r = i - hy * rowf;
-      const int hx = r / Cin, c = r - hx * Cin;
-      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-      float v = 0.f;
-      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = img[((long)iy * p.W + ix) * p.in_ld + c];
-      Hs[i] = v * in_s;
+#pragma unroll
+    for (int u = 0; u < HV; ++u)
+      if (tid + u * 256 < HROWS * rowf) Hs[tid + u * 256] = hv[u] * in_s;
+    if (item + (int)gridDim.x < n_items) {
+      nxt = decode(item + gridDim.x);
+      load_halo(nxt);
     }
     __syncthreads();
     {
@@ -1223,7 +1254,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_x3_kernel(ConvP p, int tile
         amx = fmaxf(amx, fabsf(e[q]));
       }
     }
-    if (p.out_amax) wave_amax_commit(p.out_amax + n, amx);
+    if (p.out_amax) {       // to memory only above what this wave has committed or seen for the image (see the halo kernel)
+      if (n != amax_n) {
+        amax_n = n;
+        amax_seen = 0.f;
+      }
+      if (__builtin_amdgcn_ballot_w64(amx > amax_seen) != 0ull) {
+        unsigned b = __float_as_uint(amx);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
+        unsigned* dst = p.out_amax + n;
+        unsigned seen = b;
+        if (lane == 0) {
+          seen = *reinterpret_cast<volatile unsigned*>(dst);
+          if (b > seen) atomicMax(dst, b);
+        }
+        seen = max(b, (unsigned)__builtin_amdgcn_readfirstlane((int)seen));
+        amax_seen = fmaxf(amax_seen, __uint_as_float(seen));
+      }
+    }
     if (p.stats) {          // per wave: stats_P = Ho*Wo/64, partial index = tile*4 + wave
 #pragma unroll
       for (int q = 0; q < 4; ++q) {

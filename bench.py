@@ -263,8 +263,22 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='only the headline measurement + roofline')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher -- one rank per GPU under torch.distributed.run on the
+        # loopback address (what the driver's own command line does).  KEEP_DIST_DEVICE=<d> puts every rank on device d
+        # (a 1-GPU box: gloo wire, engine/dist.py), otherwise rank r drives GPU r over RCCL.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        sys.exit(subprocess.call(cmd, env=env))
+
     rank, world, local = kdist.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     net, bcast_ms = build_net(rank, world)
     net.set_precision(args.precision)

@@ -1333,7 +1333,9 @@ bool keep_conv_x3_gather_is_gemm(const keep_conv2d_args* a) {
          (long)a->in_ld * 4 * 128 < (1L << 30);
 }
 
-// the pipelined kernel wants wide tiles, no split-K and at least two work items per CU (one block per CU walks them)
+bool keep_conv_x3_stream_ok(const keep_conv2d_args* a, const ConvP& p);
+int keep_conv2d_x3_stream(const keep_conv2d_args* a, ConvP& p, int n_cu, hipStream_t st);
+
 int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
   if (a->upsample == KEEP_UPSAMPLE_X2_PHASES) {      // four 2x2-tap phase convolutions on the source grid (kernel comment: UP2)
     const int tx = a->W / 32, ty = a->H / 8, ncbv = 4 * (a->Cout / 64);
@@ -1348,6 +1350,7 @@ int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
   }
   const int nchunks = a->Cin / 16;
   if (p.split_k > nchunks) p.split_k = nchunks;
+  if (keep_conv_x3_stream_ok(a, p)) return keep_conv2d_x3_stream(a, p, x3_num_cu(), st);      // keep_conv_x3s.hip
   const bool wide = (a->Ho % 8 == 0 && a->Wo % 32 == 0);
   const int tw = wide ? 32 : 16, th = 256 / tw;
   const int tiles_x = a->Wo / tw, tiles_y = a->Ho / th, ncb = (a->Cout + 63) / 64;

@@ -23,7 +23,9 @@ def init_from_env(backend=None):
         local = int(os.environ['KEEP_DIST_DEVICE'])
     if not dist.is_initialized():
         if backend is None:
-            backend = os.environ.get('KEEP_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+            # several ranks on ONE device (KEEP_DIST_DEVICE): RCCL refuses that ("Duplicate GPU detected"), the wire is gloo
+            shared = os.environ.get('KEEP_DIST_DEVICE') is not None
+            backend = os.environ.get('KEEP_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() and not shared else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

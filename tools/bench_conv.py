@@ -13,6 +13,8 @@ from __graft_entry__ import load_package  # noqa: E402
 
 load_package()
 from comfyui_keep_amd.engine import hiplib as L  # noqa: E402
+if os.environ.get('ABL_LIB'):      # dev library (-DKEEP_X3_ABLATE: tools/dev/README.md)
+    L.LIB_PATH = os.environ['ABL_LIB']
 from comfyui_keep_amd.engine import ops  # noqa: E402
 
 LAYERS = {  # name: (N, H, W, Cin, Cout, ksize, upsample)

@@ -56,12 +56,14 @@ def digest(frames):
     return grid.numpy(), stats.numpy()
 
 
-def full_forward(KEEP, cfg_over, T, fname):
+def full_forward(KEEP, cfg_over, T, fname, wide=False):
+    """wide: round 3's regime (i.i.d. flownet weights + the plane-wave clip: flows of hundreds of pixels), kept as the
+    out-of-range edge case of the warp path; default: the physical regime of engine/synth.py."""
     cfg = dict(arch.DEFAULT_ARCH, **cfg_over)
-    W = synth.synth_state_dict(cfg, seed=0)
+    W = synth.synth_state_dict(cfg, seed=0, flow_regime='wide' if wide else 'physical')
     net = KEEP(**cfg).eval()
     net.load_state_dict(W, strict=True)
-    x = synth.synth_clip(T=T, B=1, seed=1234)
+    x = synth.synth_clip(T=T, B=1, seed=1234, pattern='waves' if wide else 'texture')
     cap = {'logits': [], 'gains': None, 'flows': None}
     net.idx_pred_layer.register_forward_hook(lambda m, i, o: cap['logits'].append(o.detach().permute(1, 0, 2).clone()))
     orig_gain = net.kalman_filter.calc_gain
@@ -94,7 +96,10 @@ def full_forward(KEEP, cfg_over, T, fname):
         gains=cap['gains'][0, :, 0].reshape(T, -1).numpy().astype(np.float32),
         out_grid=grid.astype(np.float32), out_stats=stats.astype(np.float32),
         flow_grid=fgrid.astype(np.float32), flow_stats=fstats.astype(np.float32))
-    print(fname, 'out range', float(out.min()), float(out.max()), 'min margin', float((top2.values[..., 0] - top2.values[..., 1]).min()))
+    mag = cap['flows'][0].pow(2).sum(1).sqrt().flatten()
+    q = [float(mag.kthvalue(max(1, int(mag.numel() * f))).values) for f in (0.5, 0.9, 0.99)]
+    print(fname, 'out range', float(out.min()), float(out.max()), 'min margin', float((top2.values[..., 0] - top2.values[..., 1]).min()),
+          '| |flow| median %.2f p90 %.2f p99 %.2f max %.2f px, above 8 px: %.2f %%' % (*q, float(mag.max()), 100 * float((mag > 8).float().mean())))
     return W
 
 
@@ -181,6 +186,7 @@ def main():
     full_forward(KEEP, ASIAN, 2, 'keep_forward_asian_T2.npz')
     # the metric's own clip length: 19 recurrent steps of prev_out -> warp -> hq_encoder -> indices (KA:1062-1127)
     full_forward(KEEP, {}, 20, 'keep_forward_T20.npz')
+    full_forward(KEEP, {}, 3, 'keep_forward_T3_wide.npz', wide=True)
 
 
 if __name__ == '__main__':

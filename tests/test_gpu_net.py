@@ -18,14 +18,17 @@ from comfyui_keep_amd.engine import arch, ops, synth
 from comfyui_keep_amd.engine.arch import DEFAULT_ARCH, encoder_blocks, generator_blocks
 
 pytestmark = pytest.mark.gpu
-# Largest |top-1 logit - reference's| tolerated on frames up to (and at) the first index flip of a free-running clip.  Frame 0
-# sees no optical flow and is held to 1e-3.  Later frames see GMFlow's flows -- 4096-way soft-arg-maxes over a 512-px grid
-# whose fp32 re-association moves the flow by 1-2e-2 px (asserted <= 2e-4 of the flow scale below) -- and the synthetic net's
-# pixel-level texture turns a 1e-2 px shift of the warped previous frame into logit shifts of 8e-3 ... 1.7e-2, for the
-# exact-f32 policy and the x3 policy alike (measured, 1 x MI355X, round 3: T=3 8.3e-3 / 8.3e-3, T=20 8.4e-3 / 1.3e-2,
-# Asian T=2 1.7e-2; `per_frame_top1_logit_err` is printed by every run).  A token can only flip if its margin is below twice
-# the logit error, so flips are allowed up to 2 x this bound and nowhere else.
-LOGIT_ERR_BOUND = 2.5e-2
+# Largest |top-1 logit - reference's| tolerated on the frames of a free-running clip up to (and at) its first index flip.  Frame 0
+# sees no optical flow and is held to 1e-3.  Later frames see GMFlow's flows -- 4096-way soft-arg-maxes whose fp32 re-association
+# moves a flow by ~1e-3 px -- through the warped previous output, and the synthetic net's pixel-level texture turns that into a
+# logit shift of a few 1e-3, for the exact-f32 policy and the x3 policy alike.
+#   physical regime (round 4: engine/synth.py, flows of median 1 px / p99 6-13 px): measured 1.4e-3 (T=3), 3.3e-3 / 3.0e-3 (T=20,
+#     x3 / fp32), 6.2e-3 (Asian T=2, frames of +-3.8)                                      -> bound 8e-3
+#   wide regime (round 3's weights + clip, flows of hundreds of pixels: the out-of-range edge case): 8.3e-3 ... 1.7e-2  -> 2.5e-2
+# The flip rule is NOT this constant: a token may differ from the reference only if its margin is below twice the top-1 logit
+# error MEASURED in the same run (`per_frame_top1_logit_err` is printed by every run).
+LOGIT_ERR_BOUND = 8e-3
+LOGIT_ERR_BOUND_WIDE = 2.5e-2
 OPS = np.load(os.path.join(GOLDEN, 'ops.npz'))
 
 
@@ -110,30 +113,32 @@ def _digest(frames):
     return frames[:, :, 7::H // 32, 5::Wd // 32][:, :, :32, :32]
 
 
-def _full_forward_check(net, gold_name, T):
-    """Golden vectors come from the imported reference.  Frame 0 does not depend on the optical flow and is asserted
-    strictly.  Later frames see the flow only through the code indices (z_hat -> transformer -> argmax); with the
-    synthetic weights GMFlow produces flows of hundreds of pixels, so fp32 re-association in its 4096-way softmaxes
-    (~5e-5 relative, ~1e-2 px) moves a few logits by more than the smallest margins.  Short clips (T <= 3): agreement on
-    confidently-decided tokens and >= 99 % overall.  Long clips: the recurrence is chaotic once ONE token flips (the next
-    frame restores a different prev_out), so indices are compared frame by frame up to the first frame with a flip, and
-    the flipped tokens of that frame must be low-margin ones: at most twice the measured top-1 logit error, which is itself
-    asserted against LOGIT_ERR_BOUND (the size of the logit shift a 0.02 px flow difference causes); beyond it only frame-independent quantities (gains, flows) are comparable.  The arithmetic is
-    pinned separately with the reference's indices injected.  The strict all-frames free-running check runs against the
-    oracle with its flows injected (tests below)."""
+def _full_forward_check(net, gold_name, T, wide=False):
+    """Free running (own GMFlow, own indices: NO injection) against the golden vectors of the imported reference.
+    Frame 0 does not depend on the optical flow and is asserted strictly.  Later frames see the flow through the warped
+    previous output; the recurrence is chaotic once ONE token flips (the next frame restores a different prev_out), so indices
+    are compared frame by frame up to and including the first frame with a flip:
+      * the top-1 logit of every token is within LOGIT_ERR_BOUND of the reference's (asserted, printed per frame);
+      * every token whose reference margin exceeds max(1e-3, 2 x the MEASURED logit error of this run) agrees;
+      * a flipped token has a margin below twice the measured logit error -- nowhere else;
+      * the restored frames BEFORE the first flip are within 1e-3 max-abs of the reference, absolute.
+    The arithmetic over all T frames is pinned separately with the reference's indices injected (<= 1e-3 absolute and
+    <= 3e-4 of the output scale), and all-frames / all-pixels free running against the oracle with its flows injected (tests
+    below).  (The reference goldens hold a 32 x 32 strided digest + per-channel statistics per frame, not every pixel.)
+    wide: round 3's regime (flows of hundreds of pixels) -- the out-of-range edge case, with its own logit bound."""
+    bound = LOGIT_ERR_BOUND_WIDE if wide else LOGIT_ERR_BOUND
     g = np.load(os.path.join(GOLDEN, gold_name))
-    x = synth.synth_clip(T=T, B=1, seed=1234).cuda()
+    x = synth.synth_clip(T=T, B=1, seed=1234, pattern='waves' if wide else 'texture').cuda()
     out, aux = net(x, need_upscale=False, return_aux=True)
     idx = aux['indices'][0].cpu().numpy().astype(np.int16)
     agree = (idx == g['indices'])
     first_div = next((t for t in range(T) if not agree[t].all()), T)
-    # top-1 logit of every token against the reference's (golden `logit_top1`), frame by frame up to and including the first
-    # frame with a flip: THE quantity that decides whether an index can flip.  A token can only flip if its margin is below
-    # twice the logit error, so the flip rule is derived from the measured error instead of being a free constant.
     top1 = aux['logit_top1'][0].cpu().numpy()
     upto = min(first_div + 1, T)
     dlogit = np.abs(top1[:upto] - g['logit_top1'][:upto])
     dlogit_agree = float(dlogit[agree[:upto]].max())
+    free = np.abs(_digest(out[0].cpu()).numpy() - g['out_grid']).reshape(T, -1).max(1)
+    scale = float(np.abs(g['out_grid']).max())
     report = {'index_agreement': float(agree.mean()), 'frame0_agreement': float(agree[0].mean()),
               'first_frame_with_a_flip': first_div,
               'max_top1_logit_err_up_to_first_flip': dlogit_agree,
@@ -141,36 +146,39 @@ def _full_forward_check(net, gold_name, T):
               'gain_err': float(np.abs(aux['gains'][0].cpu().numpy() - g['gains']).max()),
               'flow_err_px': float(np.abs(_digest(aux['flows'][0].permute(0, 3, 1, 2).cpu()).numpy() - g['flow_grid']).max()),
               'flow_scale_px': float(np.abs(g['flow_grid']).max()),
-              'margins_of_first_flips': (g['margins'][first_div][~agree[first_div]].tolist() if first_div < T else [])}
+              'flow_median_px': float(np.median(np.sqrt((g['flow_grid'] ** 2).sum(1)))),
+              'margins_of_first_flips': (g['margins'][first_div][~agree[first_div]].tolist() if first_div < T else []),
+              'free_running_pixel_err_before_first_flip': [round(float(v), 7) for v in free[:first_div]]}
     print(gold_name, f'[{net.precision}]', report)
     assert report['flow_err_px'] <= 2e-4 * max(1.0, report['flow_scale_px']), report
     assert report['gain_err'] <= 2e-4, report
     assert agree[0][g['margins'][0] > 1e-3].all(), report
     assert float(dlogit[0].max()) <= 1e-3, report                 # frame 0 sees no flow: fp32 re-association only
-    assert dlogit_agree <= LOGIT_ERR_BOUND, report
+    assert dlogit_agree <= bound, report
+    flip_margin = 2.0 * dlogit_agree                              # derived from THIS run's measured logit error
+    for t in range(upto):
+        assert agree[t][g['margins'][t] > max(1e-3, flip_margin)].all(), (t, report)
+    assert first_div >= 1 and all(m <= flip_margin for m in report['margins_of_first_flips']), report
     if T <= 3:
-        assert agree[g['margins'] > 0.1].all() and agree.mean() >= 0.99, report
-    else:
-        assert first_div >= 1 and all(m <= 2 * LOGIT_ERR_BOUND for m in report['margins_of_first_flips']), report
+        assert agree.mean() >= 0.99, report
+    # free running, no injection: the frames before the first flip, absolute 1e-3 (north_star) and relative to the frames' scale
+    if first_div > 0:
+        assert float(free[:first_div].max()) <= min(1e-3, 3e-4 * scale), report
+    assert float(free[0]) <= 5e-5 * scale, report                 # frame 0: fp32 re-association only
     # arithmetic drift with the reference's indices injected (separates index flips from drift)
     forced = torch.from_numpy(g['indices'].astype(np.int32)).view(1, T, -1)
     out_f = net(x, need_upscale=False, force_indices=forced)
     per_frame = np.abs(_digest(out_f[0].cpu()).numpy() - g['out_grid']).reshape(T, -1).max(1)
     err_f = float(per_frame.max())
-    scale = float(np.abs(g['out_grid']).max())
     print(gold_name, f'[{net.precision}] max-abs pixel diff (reference indices injected): {err_f:.3e}; per frame:',
           [round(float(v), 6) for v in per_frame], f'; output scale {scale:.3g}')
-    # <= 1e-3 max-abs (north_star), ABSOLUTE, at every clip length incl. the metric's own T = 20: the synthetic net's frames
-    # live in the range the tolerance is stated for (engine/synth.py HEAD_GAIN; goldens: [-1.26, 0.97] over 20 frames)
-    tol = 1e-3
-    assert err_f <= tol, (err_f, tol)
+    # <= 1e-3 max-abs (north_star), ABSOLUTE, at every clip length incl. the metric's own T = 20 (the synthetic net's frames live
+    # in the range the tolerance is stated for: engine/synth.py HEAD_GAIN) AND relative to the frames' scale (a change of the
+    # synthetic output gain must not loosen the gate)
+    assert err_f <= 1e-3 and err_f <= 3e-4 * scale, (err_f, scale)
     st = out_f[0].cpu().reshape(T, 3, -1)
     stats = torch.stack([st.mean(-1), st.std(-1), st.min(-1).values, st.max(-1).values], -1).numpy()
     assert np.abs(stats - g['out_stats']).max() <= 2e-3
-    if agree.all():
-        err = np.abs(_digest(out[0].cpu()).numpy() - g['out_grid']).max()
-        print(gold_name, f'[{net.precision}] max-abs pixel diff (free running):', err)
-        assert err <= tol, err
     return out
 
 
@@ -208,6 +216,16 @@ def test_full_forward_T3_vs_oracle_flows_injected(gpu_net, synth_weights):
 
 def test_full_forward_T3_vs_reference_golden(gpu_net):
     _full_forward_check(gpu_net, 'keep_forward_T3.npz', 3)
+
+
+def test_full_forward_T3_wide_flow_regime_vs_reference_golden(gpu_net):
+    """Round 3's regime as the out-of-range edge case of the warp path: i.i.d. flownet weights + the plane-wave clip give flows
+    of hundreds of pixels (median 97 px, 99.7 % above 8 px: most warp samples fall outside the frame)."""
+    from comfyui_keep_amd.engine.net import KeepNet
+    net = KeepNet(**DEFAULT_ARCH)
+    net.load_state_dict(synth.synth_state_dict(DEFAULT_ARCH, seed=0, flow_regime='wide'), strict=True)
+    net.to('cuda').eval().set_precision(gpu_net.precision)
+    _full_forward_check(net, 'keep_forward_T3_wide.npz', 3, wide=True)
 
 
 def test_full_forward_T20_vs_reference_golden(gpu_net):

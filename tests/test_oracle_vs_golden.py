@@ -121,6 +121,22 @@ def test_full_forward_T3_vs_golden(synth_weights):
 
 
 @pytest.mark.slow
+def test_full_forward_T3_wide_flow_regime_vs_golden():
+    """Round 3's regime (i.i.d. flownet weights + the plane-wave clip: flows of hundreds of pixels, most warp samples outside the
+    frame) kept as the out-of-range edge case: tests/golden/keep_forward_T3_wide.npz."""
+    from comfyui_keep_amd.engine.arch import DEFAULT_ARCH
+    g = np.load(os.path.join(GOLDEN, 'keep_forward_T3_wide.npz'))
+    assert np.median(np.sqrt((g['flow_grid'] ** 2).sum(1))) > 50.0
+    W = synth.synth_state_dict(DEFAULT_ARCH, seed=0, flow_regime='wide')
+    x = synth.synth_clip(T=3, B=1, seed=1234, pattern='waves')
+    out, aux = O.keep_forward(x, W, return_aux=True)
+    safe = g['margins'] > 1e-2
+    assert np.array_equal(aux['indices'][0].numpy().astype(np.int16)[safe], g['indices'][safe])
+    assert np.abs(aux['gains'][0, :, 0].reshape(3, -1).numpy() - g['gains']).max() <= 1e-4
+    assert np.abs(_digest(out[0])[0] - g['out_grid'][0]).max() <= 3e-4
+
+
+@pytest.mark.slow
 def test_full_forward_T20_vs_golden(synth_weights):
     """The metric's own clip length on the CPU oracle against the imported reference (tests/golden/keep_forward_T20.npz):
     code indices wherever the reference's margin exceeds 1e-3, frame by frame up to the first frame with any differing

@@ -727,9 +727,10 @@ class KeepNet:
     def run_clips(self, clips, need_upscale=False, max_b=None):
         """list of [1,T_i,3,H,W] -> list of restored clips.  Clips share no state (KA:1050,1064,1113), so equal-length
         clips are stacked on the batch axis (as many as free HBM allows, ``clips_per_call``).  A clip's result does not
-        depend on its batch-mates beyond fp32 re-association: kernel choice and split-K factors follow the launch size
-        (<= 5e-4 on the output of a short clip, tests/test_gpu_net.py::test_batched_clips_equal_sequential; on long clips the
-        recurrence can amplify that into a low-margin code flip)."""
+        depend on its batch-mates AT ALL under the parity policies: kernel tiles, split-K factors and statistics partitions
+        follow the per-image geometry and a fixed reference batch (``keep_conv2d_plan``, DESIGN.md section 6 "batch
+        invariance"), so batched == sequential bit for bit (tests/test_gpu_net.py::test_batched_clips_equal_sequential,
+        ``torch.equal``)."""
         order = {}
         for n, c in enumerate(clips):
             order.setdefault((c.shape[1], c.shape[3], c.shape[4]), []).append(n)
@@ -808,8 +809,12 @@ class KeepNet:
             comp = torch.cuda.current_stream()
             io = self._io_stream = getattr(self, '_io_stream', None) or torch.cuda.Stream(device=self.device)
 
+            slot_ev = {}                                        # staging slot -> event of the H2D copy that last read it
+
             def upload(gi):
                 T, H, Wd, grp = groups[gi]
+                if (gi & 1) in slot_ev:                         # group gi - 2 was copied from this pinned buffer: the CPU must not
+                    slot_ev[gi & 1].synchronize()               # overwrite it before that copy has finished (satisfied in steady state)
                 host = self._pinned_staging((len(grp), T, H, Wd, 3), gi & 1)
                 for k, n in enumerate(grp):
                     if isinstance(mine[n], _FrameList):         # T separate [H,W,3] crops: one copy each, straight into pinned
@@ -821,6 +826,7 @@ class KeepNet:
                     dev = host.to(self.device, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(io)
+                slot_ev[gi & 1] = ev
                 return host, dev, ev
 
             def finish(job):

@@ -276,7 +276,7 @@ class RetinaFaceEngine:
 
     # ------------------------------------------------------------------ detection (retinaface.py:208-256, per frame of a batch)
     def detect_batch(self, frames_bgr_u8, conf_threshold=0.8, nms_threshold=0.4):
-        """frames: uint8 [N,H,W,3] BGR (numpy or tensor, one size) -> list of float32 [n_i, 15] arrays (x1,y1,x2,y2,score,
+        """frames: uint8 (or float: converted to float32 like the reference does) [N,H,W,3] BGR (numpy or tensor, one size) -> list of float32 [n_i, 15] arrays (x1,y1,x2,y2,score,
         5 landmarks x,y): what ``detect_faces`` returns for each frame with ``use_origin_size=True``."""
         frames = torch.as_tensor(np.ascontiguousarray(frames_bgr_u8) if isinstance(frames_bgr_u8, np.ndarray) else frames_bgr_u8)
         N, H, W, _ = frames.shape
@@ -290,9 +290,12 @@ class RetinaFaceEngine:
         for s in range(0, N, self.max_frames):
             chunk = frames[s:s + self.max_frames].to(self.device, non_blocking=True).contiguous()
             n = chunk.shape[0]
-            x = torch.empty((n, H, W, 3), dtype=torch.float32, device=self.device)
             with torch.cuda.device(self.device):
-                L.call('keep_u8_to_f32', chunk, x, chunk.numel())
+                if chunk.dtype == torch.uint8:
+                    x = torch.empty((n, H, W, 3), dtype=torch.float32, device=self.device)
+                    L.call('keep_u8_to_f32', chunk, x, chunk.numel())
+                else:                                                             # 16-bit sources: read_image made them float64
+                    x = chunk.to(torch.float32)                                   # (np.float32(image), retinaface.py:213)
                 x = ops.add_bcast(x, self._mean, alpha=-1.0)                      # image - mean_tensor (retinaface.py:224)
             loc, cls, lm = (t.float().cpu().numpy() for t in self.raw_outputs(x))
             for i in range(n):
@@ -328,7 +331,7 @@ class EngineRetinaFace:
         if not use_origin_size:
             raise NotImplementedError("EngineRetinaFace: the helper always passes use_origin_size=True (it resizes itself)")
         img = np.asarray(image)
-        return self.engine.detect_batch(img[None].astype(np.uint8) if img.dtype != np.uint8 else img[None], conf_threshold, nms_threshold)[0]
+        return self.engine.detect_batch(img[None], conf_threshold, nms_threshold)[0]
 
     def detect_batch(self, frames, conf_threshold=0.8, nms_threshold=0.4):
         return self.engine.detect_batch(frames, conf_threshold, nms_threshold)

@@ -14,10 +14,11 @@ Detection / tracking / alignment / paste-back stay with the reference's ``FaceRe
 
 What this build adds: independent clips are handed to the engine in one call
 (``keep_net.run_clips_u8``) so it can batch equal-length clips per GPU (bounded by free HBM) and,
-when a torch.distributed group is up, shard them across GPUs.  Clips share no state, so the result
-equals the sequential loop up to fp32 re-association (kernel tiles / split-K follow the batch): within
-one uint8 level until the recurrence's first low-margin code flip (batch dependence).
-The paste-back compositing can run on the GPU (``KEEP_AMD_GPU_PASTE=1``, ``_paste`` below).
+when a torch.distributed group or the worker pool (``KEEP_AMD_GPUS``, engine/pool.py) is up, shard them across
+GPUs.  Clips share no state and the kernel plans are batch-invariant (tiles / split-K follow the per-image geometry,
+DESIGN.md section 6), so the result equals the sequential one-clip-at-a-time loop BIT FOR BIT
+(tests/test_gpu_net.py::test_config3_config4_clip_mixes_equal_sequential).
+The paste-back compositing can run on the GPU (``KEEP_AMD_GPU_PASTE``, ``_paste`` below).
 """
 import os
 
@@ -128,6 +129,7 @@ class KEEPFaceProcessor:
         # holds on this installation (cv2 is a hard dependency of the reference helper, so it exists wherever this code pastes).
         env = os.environ.get('KEEP_AMD_GPU_PASTE')
         self.gpu_paste = {'1': True, '0': False}.get(env, None)
+        self._gpu_paste_forced = env == '1'        # the erosion-mask branch (use_parse=False) is not part of the cv2 self-check
         self._paster = None
 
     # ------------------------------------------------------------------ net invocation
@@ -259,7 +261,8 @@ class KEEPFaceProcessor:
         """``helper.align_warp_face()`` (face_restoration_helper.py:256-320).  With the GPU cv path and the default configuration
         (no pad_blur, constant border) only the similarity fit stays on the host (``cv2.estimateAffinePartial2D``, :305); the
         ``cv2.warpAffine`` that produces the 512 x 512 crops (:316-318) runs on the device (``keep_warp_affine_u8``)."""
-        if not self._gpu_cv_path() or getattr(helper, 'pad_blur', False) or not hasattr(helper, 'face_template'):
+        if (not self._gpu_cv_path() or getattr(helper, 'pad_blur', False) or not hasattr(helper, 'face_template')
+                or getattr(helper.input_img, 'dtype', None) != np.uint8):       # (16-bit sources are float64 after read_image)
             return helper.align_warp_face()
         from ..engine.paste import crop_faces
         cv2 = _cv2()
@@ -273,6 +276,11 @@ class KEEPFaceProcessor:
         if draw_box or self.face_upscale_model is not None:
             return False
         use_parse = getattr(helper, 'use_parse', False)
+        if not use_parse and not getattr(self, '_gpu_paste_forced', False):
+            # face_restoration_helper.py:386-415 (erode + GaussianBlur(k, 0) at data-dependent sizes): bit-equal to
+            # oracle/paste_oracle.py, but ``opencv_agrees_with_gpu_paste`` compares only the parse-mask composite and the crop warp
+            # with cv2 itself -- this branch stays opt-in (KEEP_AMD_GPU_PASTE=1) until it has been compared on an installation
+            return False
         if getattr(helper, 'is_gray', False) or (use_parse and getattr(helper, 'face_parse', None) is None) or not faces or mats is None:
             return False
         if len(faces) != len(mats) or not isinstance(bg, np.ndarray) or bg.dtype != np.uint8 or bg.ndim != 3 or bg.shape[2] != 3:
@@ -316,47 +324,62 @@ class KEEPFaceProcessor:
     def _detect_all(self, frames_bgr, only_center_face):
         """Landmarks of every frame (keep_processor.py:207-213: one ``get_face_landmarks_5`` call -- one detector forward and
         one host round trip -- per frame).  With the engine's detector (engine/retinaface.py, ``detect_batch``) the network
-        runs ONCE over all frames of the video in chunks of the batch axis; the helper's own per-frame host logic (resize
-        rule, eye-distance filter, centre-face selection: face_restoration_helper.py:206-252) then runs unchanged on the
-        stored detections, so the landmarks are what the per-frame loop produces."""
+        runs over the video in chunks of the detector's batch axis (``KEEP_AMD_DETECT_BATCH`` frames: the host never holds more
+        than one chunk of detector inputs -- a 3000-frame 1080p video would otherwise stack ~13 GB of resized frames); the
+        helper's own per-frame host logic (resize rule, eye-distance filter, centre-face selection:
+        face_restoration_helper.py:206-252) then runs unchanged on the stored detections of the chunk, on the SAME
+        ``read_image`` result the detector input was built from, so the landmarks are what the per-frame loop produces."""
         raw = []
         helper = self.face_helper
         det = getattr(helper, 'face_detector', None)
-        batched = None
-        if hasattr(det, 'detect_batch') and getattr(helper, 'det_model', 'retinaface') != 'dlib' and frames_bgr:
-            batched = self._detect_batched(det, frames_bgr, resize=640)
-        for i, frame in enumerate(tqdm(frames_bgr, desc="Detecting face landmarks")):
-            helper.clean_all()
-            helper.read_image(frame)
-            if batched is None:
-                helper.get_face_landmarks_5(only_center_face=only_center_face, resize=640, eye_dist_threshold=5)
-            else:
-                helper.face_detector = _ReplayDetector(batched[i])
-                try:
+        use_batch = hasattr(det, 'detect_batch') and getattr(helper, 'det_model', 'retinaface') != 'dlib' and len(frames_bgr) > 0
+        chunk = max(1, int(getattr(getattr(det, 'engine', None), 'max_frames', 32))) if use_batch else 1
+        bar = tqdm(total=len(frames_bgr), desc="Detecting face landmarks")
+        for s in range(0, len(frames_bgr), chunk):
+            part = frames_bgr[s:s + chunk]
+            states, batched = None, None
+            if use_batch:
+                states, batched = self._detect_batched(det, part, resize=640)
+            for j, frame in enumerate(part):
+                helper.clean_all()
+                if states is not None:
+                    helper.input_img, helper.is_gray = states[j]       # what read_image(frame) left behind (:172-184)
+                else:
+                    helper.read_image(frame)
+                if batched is None:
                     helper.get_face_landmarks_5(only_center_face=only_center_face, resize=640, eye_dist_threshold=5)
-                finally:
-                    helper.face_detector = det
-            raw.append(list(helper.all_landmarks_5))
+                else:
+                    helper.face_detector = _ReplayDetector(batched[j])
+                    try:
+                        helper.get_face_landmarks_5(only_center_face=only_center_face, resize=640, eye_dist_threshold=5)
+                    finally:
+                        helper.face_detector = det
+                raw.append(list(helper.all_landmarks_5))
+                bar.update(1)
+        bar.close()
         return raw
 
     def _detect_batched(self, det, frames_bgr, resize):
-        """The detector inputs ``get_face_landmarks_5`` would build, frame by frame (face_restoration_helper.py:206-216: frames
-        whose short side exceeds ``resize`` are scaled down with INTER_AREA), stacked and run through ``det.detect_batch`` with
-        the helper's 0.97 confidence threshold (:221).  None when the frames differ in size (the per-frame path handles it)."""
+        """One chunk of frames: the helper state ``read_image`` leaves behind per frame (input image, grey flag) and the detector
+        inputs ``get_face_landmarks_5`` would build from it (face_restoration_helper.py:206-216: frames whose short side exceeds
+        ``resize`` are scaled down with INTER_AREA), stacked and run through ``det.detect_batch`` with the helper's 0.97
+        confidence threshold (:221).  Detections are None when the frames differ in size or are not uint8 (16-bit sources
+        become float64 in ``read_image``: the per-frame path converts them the way the reference does)."""
         helper = self.face_helper
-        imgs = []
+        states, imgs = [], []
         for frame in frames_bgr:
             helper.clean_all()
             helper.read_image(frame)
             img = helper.input_img
+            states.append((img, getattr(helper, 'is_gray', False)))
             h, w = img.shape[:2]
             if resize is not None and min(h, w) > resize:
                 scale = resize / min(h, w)
                 img = _resize(img, int(w * scale), int(h * scale), 'INTER_AREA' if scale < 1 else 'INTER_LINEAR')
             imgs.append(np.ascontiguousarray(img))
         if any(im.shape != imgs[0].shape or im.dtype != np.uint8 for im in imgs):
-            return None
-        return det.detect_batch(np.stack(imgs), 0.97)
+            return states, None
+        return states, det.detect_batch(np.stack(imgs), 0.97)
 
     @torch.no_grad()
     def process_image_sequence(self, image_sequence_tensor: torch.Tensor, final_upscale_factor: float,

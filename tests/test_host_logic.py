@@ -411,7 +411,11 @@ def test_paste_hook_defers_to_the_helper():
     assert not proc._gpu_paste_applies(h, bg.astype(np.float32), False)              # not uint8
     assert not proc._gpu_paste_applies(h, np.zeros((32, 32, 3), np.uint8), False)    # background still to be resized
     h.use_parse = False
-    assert proc._gpu_paste_applies(h, bg, False)                                    # the erosion-mask path is on the device too
+    # the erosion-mask path (face_restoration_helper.py:386-415) is on the device too, but it is not part of the cv2 self-check:
+    # only an explicit KEEP_AMD_GPU_PASTE=1 turns it on
+    assert not proc._gpu_paste_applies(h, bg, False)
+    proc._gpu_paste_forced = True
+    assert proc._gpu_paste_applies(h, bg, False)
     h.use_parse, proc.face_upscale_model = True, object()
     assert not proc._gpu_paste_applies(h, bg, False)
 

@@ -167,6 +167,14 @@ def per_op(KEEP, W):
     out['encoder64'] = run(enc, 'encoder', op_input('encoder64', (1, 3, 64, 64)))
     gen = VQ.Generator(64, 256, [1, 2, 2, 4, 4, 8], 2, 512, [16])
     out['generator_2x2'] = run(gen, 'generator', op_input('generator_2x2', (1, 256, 2, 2), 0.7))
+    # P4 converters: the reference's own img2tensor / tensor2img (img_util.py:9-94) as keep_processor.py:258-259,272 calls them
+    IU = import_reference_module('wm_basicsr.utils.img_util')
+    crops = [synth.ramp_image(64, 64), np.ascontiguousarray(synth.ramp_image(64, 64)[::-1])]
+    ts = [IU.img2tensor(c / 255., bgr2rgb=True, float32=True) for c in crops]
+    out['conv_in_crops'] = torch.stack([(t - 0.5) / 0.5 for t in ts])      # torchvision normalize(t, (0.5,)*3, (0.5,)*3)
+    xo = op_input('t2i', (2, 3, 64, 64), 1.3)
+    xo[0, :, 0, :8] = torch.tensor([-1.2, -1.0, -0.5 / 255, 0.0, 1.0 / 255, 1.0, 1.3, 0.00392156862])
+    out['conv_out_u8'] = torch.from_numpy(np.stack([IU.tensor2img(xo[n].clone(), rgb2bgr=True, min_max=(-1, 1)) for n in range(2)]))
     np.savez_compressed(os.path.join(GOLD, 'ops.npz'), **{k: v.numpy() for k, v in out.items()})
     print('ops.npz:', {k: tuple(v.shape) for k, v in out.items()})
 
@@ -181,6 +189,9 @@ def main():
         spec[name] = {k: list(v.shape) for k, v in net.state_dict().items()}
     with open(os.path.join(GOLD, 'arch_spec.json'), 'w') as f:
         json.dump(spec, f)
+    if '--ops-only' in sys.argv:             # per-op goldens only (seconds)
+        per_op(KEEP, synth.synth_state_dict(dict(arch.DEFAULT_ARCH), seed=0))
+        return
     W = full_forward(KEEP, {}, 3, 'keep_forward_T3.npz')
     per_op(KEEP, W)
     full_forward(KEEP, ASIAN, 2, 'keep_forward_asian_T2.npz')

@@ -67,6 +67,23 @@ def _install_stubs():
         tv.__version__ = "0.0.0"
         tv.ops = _ns("torchvision.ops")
 
+    # cv2 / torchvision.utils: touched by wm_basicsr/utils/img_util.py (the P4 converters).  The only cv2 call on that path is
+    # cvtColor(img, COLOR_BGR2RGB | COLOR_RGB2BGR) on a 3-channel array: the channel flip OpenCV documents for those codes.
+    if "cv2" not in sys.modules:
+        import numpy as _np
+        cv = _ns("cv2")
+        cv._keep_oracle_stub = True
+        cv.COLOR_BGR2RGB, cv.COLOR_RGB2BGR = 4, 4
+
+        def _cvt(img, code):
+            assert code == 4 and img.ndim == 3 and img.shape[2] == 3
+            return _np.ascontiguousarray(img[..., ::-1])
+
+        cv.cvtColor = _cvt
+    tvu = _ns("torchvision.utils")
+    tvu.make_grid = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("make_grid: 4-D tensor2img is not on the path"))
+    sys.modules["torchvision"].utils = tvu
+
     # diffusers.models.attention: FeedForward (GEGLU) + AdaLayerNorm placeholder
     class GEGLU(nn.Module):
         def __init__(self, dim_in, dim_out):

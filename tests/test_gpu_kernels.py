@@ -606,18 +606,35 @@ def test_convex_upsample_and_layouts():
 
 
 def test_tensor2img_img2tensor_bit_exact():
-    from comfyui_keep_amd.modules import utils as U
+    """P4 on the device (keep_img2tensor / keep_tensor2img) against the ORACLE (oracle/converters_oracle.py) and the golden
+    outputs of the reference's own img2tensor / tensor2img (tests/golden/ops.npz: conv_in_crops, conv_out_u8), bit for bit."""
+    import converters_oracle as CO
+    g = np.load(os.path.join(GOLDEN, 'ops.npz'))
     x = rnd('t2i', (2, 3, 64, 64), 1.3)
     x[0, :, 0, :8] = torch.tensor([-1.2, -1.0, -0.5 / 255, 0.0, 1.0 / 255, 1.0, 1.3, 0.00392156862])
     out = torch.empty(2, 64, 64, 3, dtype=torch.uint8, device='cuda')
     L.call('keep_tensor2img', dev(nhwc(x)), out, 2 * 64 * 64)
     for n in range(2):
-        assert np.array_equal(out[n].cpu().numpy(), U.net_output_to_bgr_u8(x[n]))
+        assert np.array_equal(out[n].cpu().numpy(), CO.net_output_to_bgr_u8(x[n].numpy()))
+        assert np.array_equal(out[n].cpu().numpy(), g['conv_out_u8'][n])
+    # a dense sweep around every rounding boundary of the uint8 map: k / 255 steps +- a few float32 ulps, half-way points
+    k = torch.arange(0, 256, dtype=torch.float64)
+    pts = torch.cat([(k / 255.0 * 2 - 1), ((k + 0.5) / 255.0 * 2 - 1)]).float()
+    sweep = torch.cat([pts, torch.nextafter(pts, torch.tensor(2.0)), torch.nextafter(pts, torch.tensor(-2.0))])
+    sweep = sweep[: (sweep.numel() // 3) * 3].view(1, 3, 1, -1).contiguous()
+    o2 = torch.empty(1, 1, sweep.shape[-1], 3, dtype=torch.uint8, device='cuda')
+    L.call('keep_tensor2img', dev(nhwc(sweep)), o2, sweep.shape[-1])
+    assert np.array_equal(o2[0].cpu().numpy(), CO.net_output_to_bgr_u8(sweep[0].numpy()))
     crops = [synth.ramp_image(64, 64), synth.ramp_image(64, 64)[::-1].copy()]
     u8 = torch.from_numpy(np.stack(crops)).cuda()
     f = torch.empty(2, 64, 64, 3, device='cuda')
     L.call('keep_img2tensor', u8, f, 2 * 64 * 64)
-    assert torch.equal(nchw(f).cpu(), U.crops_to_net_input(crops))
+    assert np.array_equal(nchw(f).cpu().numpy(), CO.crops_to_net_input(crops))
+    assert np.array_equal(nchw(f).cpu().numpy(), g['conv_in_crops'])
+    allv = np.arange(256, dtype=np.uint8).repeat(3).reshape(1, 16, 16, 3)          # every uint8 value
+    fa = torch.empty(1, 16, 16, 3, device='cuda')
+    L.call('keep_img2tensor', torch.from_numpy(allv).cuda(), fa, 256)
+    assert np.array_equal(nchw(fa).cpu().numpy(), CO.crops_to_net_input(list(allv)))
 
 
 def test_bad_arguments_fail_loudly():
@@ -1051,6 +1068,70 @@ def test_conv_x3_halo_fused_probe_over_several_items_per_block():
             kw.update(pro=ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6), pro_act=L.PRO_SWISH)
         y, st = ops.conv(xd, wp, bd, **kw)
         assert torch.equal(st.amax.cpu(), y.abs().flatten(1).max(1).values.cpu()), f'fused max|out| (prologue={pro})'
+
+
+@pytest.mark.parametrize("name,n,cin,cout,h,wd,up,res,gn", [('64->64 @512^2, GroupNorm-swish, residual', 16, 64, 64, 512, 512, False, True, True),
+                                                            ('128->128 @256^2, GroupNorm-swish', 16, 128, 128, 256, 256, False, False, True),
+                                                            ('128->64 @512^2, GroupNorm-swish', 16, 128, 64, 512, 512, False, False, True),
+                                                            ('Upsample 128 @256^2 -> 512^2 (phase form)', 16, 128, 128, 256, 256, True, False, False)])
+def test_conv_x3_at_the_shapes_of_the_step(name, n, cin, cout, h, wd, up, res, gn):
+    """The launches that ARE the bench step (16 images: persistent blocks walk 4 ... 16 work items each, the streaming kernel's
+    item seams and weight ring at full occupancy), against fp64 on sampled strips -- top and bottom border rows of the first and
+    the last image and a strip in the middle of the batch -- with the exact-f32 kernel's error on the same strips as the yardstick."""
+    g = torch.Generator().manual_seed(1234)
+    x = (torch.randn((n, h, wd, cin), generator=g) * 2.0 + 0.3)
+    w, b = rnd('rsw', (cout, cin, 3, 3), 0.05), rnd('rsb', (cout,))
+    gamma, beta = rnd('rsg', (cin,)) * 0.2 + 1, rnd('rsbt', (cin,)) * 0.2
+    Ho, Wo = (2 * h, 2 * wd) if up else (h, wd)
+    r = torch.randn((n, Ho, Wo, cout), generator=g) if res else None
+    xd, wp, bd = dev(x), pack(w), dev(b)
+    wx3, asc = x3w(wp)
+    kw = dict(upsample=up, stats=True, residual=None if r is None else dev(r))
+    pro = None
+    if gn:
+        pro = ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6)
+        kw.update(pro=pro, pro_act=L.PRO_SWISH)
+    ops.DEFAULT.profile = []
+    if up:         # the net's form of the Upsample convolutions: four 2x2-tap phase kernels (engine/ops.py:up2_phase_weights)
+        w4 = ops.up2_phase_weights(wp)
+        sc4 = ops.x3_scale_for(float(w4.abs().max()))
+        y, st = ops.conv(xd, wp, bd, mma=L.MMA_X3, wx3=ops.split_x3(w4.reshape(-1, cin), sc4).view(-1), x3_acc_scale=1.0 / sc4,
+                         **dict(kw, upsample=L.UPSAMPLE_X2_PHASES))
+    else:
+        y, st = ops.conv(xd, wp, bd, mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, **kw)
+    kname = ops.DEFAULT.profile[-1][0]
+    ops.DEFAULT.profile = None
+    assert kname.startswith('conv3x3_halo_x3_kernel') and (('phases' in kname) == up), kname
+    y32, _ = ops.conv(xd, wp, bd, **kw)
+    assert torch.isfinite(y).all()
+    worst3 = worst32 = 0.0
+    scale = 1.0
+    for (img, r0, r1) in ((0, 0, 12), (n // 2, Ho // 2 - 6, Ho // 2 + 6), (n - 1, Ho - 12, Ho)):
+        # input rows the output rows r0 .. r1-1 need (on the upsampled grid: -1 .. +1), fp64 on the CPU
+        lo, hi = max(r0 - 1, 0), min(r1 + 1, Ho)
+        slo, shi = (lo // 2, (hi + 1) // 2) if up else (lo, hi)
+        xs = x[img, slo:shi].double().permute(2, 0, 1)[None]                       # [1, C, rows, W]
+        if gn:
+            sc, sh = pro[0][img].double().cpu().view(1, cin, 1, 1), pro[1][img].double().cpu().view(1, cin, 1, 1)
+            xs = xs * sc + sh
+            xs = xs * torch.sigmoid(xs)
+        if up:
+            xs = F.interpolate(xs, scale_factor=2.0, mode='nearest')[:, :, lo - 2 * slo: lo - 2 * slo + (hi - lo)]
+        top, bot = (1 if r0 == 0 else 0), (1 if r1 == Ho else 0)                  # zero padding only at the image border
+        ref = F.conv2d(F.pad(xs, (1, 1, top, bot)), w.double(), b.double())
+        assert ref.shape[2] == r1 - r0, (ref.shape, r0, r1)
+        ref = ref[0].permute(1, 2, 0)
+        if r is not None:
+            ref = ref + r[img, r0:r1].double()
+        worst3 = max(worst3, (y[img, r0:r1].double().cpu() - ref).abs().max().item())
+        worst32 = max(worst32, (y32[img, r0:r1].double().cpu() - ref).abs().max().item())
+        scale = max(scale, ref.abs().max().item())
+    print(f'{name}: {kname}: x3 err {worst3:.3e}, exact-f32 kernel err {worst32:.3e} (scale {scale:.3g})')
+    assert worst3 <= max(3.0 * worst32, 2e-6 * scale), f'x3 err {worst3:.3e} vs f32-kernel err {worst32:.3e} (scale {scale:.3g})'
+    assert torch.equal(st.amax.cpu(), y.abs().flatten(1).max(1).values.cpu())
+    sc1, sh1 = ops.norm_affine(y, None, None, 32, 1e-6, stats=st)
+    sc2, sh2 = ops.norm_affine(y, None, None, 32, 1e-6)
+    check(sc1, sc2, 1e-5, 'fused statistics: scale'); check(sh1, sh2, 1e-5, 'fused statistics: shift')
 
 
 @pytest.mark.parametrize("n,cin,cout,h,wd,res", [(2, 64, 64, 32, 32, True), (3, 128, 128, 16, 64, False), (1, 32, 192, 8, 32, True),

@@ -157,6 +157,25 @@ def test_full_forward_T20_vs_golden(synth_weights):
     assert err <= 1e-3, err
 
 
+def test_converters_oracle_and_host_converters_vs_reference_golden():
+    """P4: oracle/converters_oracle.py against the reference's own img2tensor / tensor2img (img_util.py:9-94, called as
+    keep_processor.py:258-259,272 do; golden ``conv_in_crops`` / ``conv_out_u8``), bit for bit; the product's host converters
+    (modules/utils.py) against the oracle."""
+    import converters_oracle as CO
+    from comfyui_keep_amd.modules import utils as U
+    g = np.load(os.path.join(GOLDEN, 'ops.npz'))
+    crops = [synth.ramp_image(64, 64), np.ascontiguousarray(synth.ramp_image(64, 64)[::-1])]
+    x_in = CO.crops_to_net_input(crops)
+    assert x_in.dtype == np.float32 and np.array_equal(x_in, g['conv_in_crops'])
+    assert torch.equal(U.crops_to_net_input(crops), torch.from_numpy(x_in))
+    xo = op_input('t2i', (2, 3, 64, 64), 1.3)
+    xo[0, :, 0, :8] = torch.tensor([-1.2, -1.0, -0.5 / 255, 0.0, 1.0 / 255, 1.0, 1.3, 0.00392156862])
+    for n in range(2):
+        got = CO.net_output_to_bgr_u8(xo[n].numpy())
+        assert got.dtype == np.uint8 and np.array_equal(got, g['conv_out_u8'][n])
+        assert np.array_equal(U.net_output_to_bgr_u8(xo[n]), got)
+
+
 def test_parsenet_oracle_vs_reference_golden():
     """oracle/facelib_oracle.py:parsenet_forward against the imported reference ParseNet (tests/golden/facelib.npz)."""
     import facelib_oracle as FO

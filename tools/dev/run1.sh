@@ -1,1 +1,1 @@
-python -m pytest tests/test_gpu_net.py -x -q -m gpu -s 2>&1 | grep -v "^$" | cut -c1-1300 | tail -45
+python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -s -k "shapes_of_the_step or tensor2img" 2>&1 | grep -v "^$" | cut -c1-400 | tail -25

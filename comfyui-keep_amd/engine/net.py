@@ -39,6 +39,27 @@ PRECISIONS = ('fp32', 'x3', 'bf16')
 DEFAULT_PRECISION = 'x3'
 
 
+ROCTX = os.environ.get('KEEP_AMD_ROCTX', '0') == '1'      # per-stage roctx ranges (rocprofv3 --marker-trace / --kernel-trace timelines)
+
+
+class _Range:
+    """``with _Range('K2 lq_encoder'):`` -- a roctx range around one stage of the forward (torch.cuda.nvtx is roctx on ROCm);
+    off by default: a range is a host-side marker, but ~90 of them per clip are not free at B = 1."""
+    __slots__ = ('name',)
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if ROCTX:
+            torch.cuda.nvtx.range_push(self.name)
+
+    def __exit__(self, *exc):
+        if ROCTX:
+            torch.cuda.nvtx.range_pop()
+        return False
+
+
 class _FrameList:
     """A clip handed to run_clips_u8 as T separate uint8 [H,W,3] crops (what the processor holds): behaves like a [T,H,W,3]
     tensor for shape checks and is copied crop by crop into the pinned upload buffer -- no intermediate np.stack."""
@@ -74,7 +95,7 @@ class KeepNet:
         self.last_aux = None
         self._dev_blob16 = None    # bf16 twin of the packed blob (same offsets) for the bf16-MFMA policy
         self._dev_blobx3 = None    # split-fp16 twin (2 x int16 per weight) for the x3 policy
-        self._x3_scale = 1.0       # power of two the x3 weights were multiplied by
+        self._x3_scales = None     # per-tensor accumulator scales of the x3 twin (ops.make_x3_blob)
         self.o = ops.Ops()         # this net's precision policy + weight twins (never shared between nets)
         self.x3_fallbacks = 0      # batches the x3 policy handed back to the f32 kernels (non-finite output)
         # hipGraph replay of the whole forward for small batches (launch-bound: ~9 k kernels per clip): 'auto' = at most
@@ -85,6 +106,7 @@ class KeepNet:
         # With an initialised process group, ONE clip list handed to run_clips_u8 on every rank is sharded over the ranks
         # (True, default).  False: every rank restores the list IT is given (one video per GPU, BASELINE configs[4]).
         self.shard_across_ranks = os.environ.get('KEEP_AMD_SHARD', '1') == '1'
+        self.pool = None           # engine/pool.py:GpuPool when this process drives several GPUs (KEEP_AMD_GPUS=N)
         self._aux_top1 = []
         self._pinned_in = {}       # pinned upload staging buffers of run_clips_u8, by (shape, slot)
         self._pinned = None        # pinned host copy of the packed blob (made at the first upload)
@@ -136,14 +158,9 @@ class KeepNet:
         # elementwise / gather kernels (a large-magnitude table must not shrink the scale of every convolution weight)
         names = [n for n, (_, shape) in self._index.items() if len(shape) >= 2 and shape[-1] % 16 == 0
                  and n not in ('position_emb', 'quantize.embedding.weight')]
-        amax = max(float(self.w[n].abs().max()) for n in names)
-        self._x3_scale = ops.x3_scale_for(amax)
-        bx = torch.zeros(2 * self._dev_blob.numel(), dtype=torch.int16, device=self._dev_blob.device)
-        for n in names:
-            off, shape = self._index[n]
-            t = self.w[n]
-            bx[2 * off:2 * (off + t.numel())] = ops.split_x3(t.reshape(-1, shape[-1]), self._x3_scale).view(-1)
-        self._dev_blobx3 = bx
+        # one power-of-two scale PER TENSOR (the ABI carries x3_acc_scale per launch): a tensor with one 100x weight does not
+        # cost every other layer its `lo` bits (tests/test_gpu_net.py::test_x3_scale_is_per_tensor)
+        self._dev_blobx3, self._x3_scales = ops.make_x3_blob(self._dev_blob, self._index, self.w, names)
 
     def _activate_precision(self):
         if self.precision == 'bf16':
@@ -153,7 +170,7 @@ class KeepNet:
         elif self.precision == 'x3':
             if self._dev_blobx3 is None:
                 self._make_x3()
-            self.o.set_precision(L.MMA_X3, self._dev_blob, None, self._dev_blobx3, 1.0 / self._x3_scale)
+            self.o.set_precision(L.MMA_X3, self._dev_blob, None, self._dev_blobx3, 1.0, x3_scales=self._x3_scales)
             if ops.UP2_PHASES:      # phase kernels of the generator's Upsample convolutions: built here, never inside a stream capture
                 for i, (kind, _, _) in enumerate(generator_blocks(self.cfg)):
                     if kind == 'up':
@@ -182,6 +199,10 @@ class KeepNet:
             if self._blob is not None and changed:
                 with torch.cuda.device(device):
                     self._upload()
+            if self.pool is None and self._dev_blob is not None:
+                from . import pool as kpool
+                if kpool.wanted_gpus() > 1 and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+                    self.start_pool(kpool.wanted_gpus())         # KEEP_AMD_GPUS=N: N - 1 worker processes, one weight broadcast
         elif RESIDENT and self._dev_blob is not None:
             # residency policy: KEEPModelPack.offload() after every node call would drop 633 MB of packed
             # weights (plus the policy's twin) and the next call would upload and re-derive them; with KEEP_AMD_RESIDENT=1
@@ -194,6 +215,15 @@ class KeepNet:
             self._const = {}
             self._graphs = {}
         return self
+
+    def start_pool(self, n_gpus):
+        """Drive ``n_gpus`` GPUs of this node from THIS process (engine/pool.py): spawns n_gpus - 1 workers, broadcasts the packed
+        weights to them once (RCCL over xGMI), and makes ``run_clips_u8`` shard its clips over all of them."""
+        from .pool import GpuPool
+        if self.pool is not None:
+            self.pool.close()
+        self.pool = GpuPool(self, n_gpus)
+        return self.pool
 
     def packed_blob(self):
         """Device blob (for the RCCL weight broadcast, engine/dist.py)."""
@@ -647,17 +677,20 @@ class KeepNet:
         if force_flows is not None:      # parity tests: inject the oracle's flows [B,T-1,2,H,W] (isolates GMFlow drift)
             flows = force_flows.to(device=self.device, dtype=torch.float32).permute(0, 1, 3, 4, 2).contiguous()
         elif T > 1:
-            flows = self._gmflow_clip(x)
+            with _Range('K1 gmflow'):
+                flows = self._gmflow_clip(x)
             flows = flows.view(B, T - 1, H, Wd, 2)
         # K2: LQ encoder over all B*T frames, stash CFT taps
         xn = ops.nchw_to_nhwc(x.view(B * T, 3, H, Wd))
         taps = [FUSE_ENCODER_BLOCK[s] for s in cfg['cft_list']]
-        z, feats = self._vq_stack(xn, 'encoder', encoder_blocks(cfg), taps)
+        with _Range('K2 lq_encoder'):
+            z, feats = self._vq_stack(xn, 'encoder', encoder_blocks(cfg), taps)
         enc_feat = {k: v.view(B, T, *v.shape[1:]) for k, v in feats.items()}
         zc = z.view(B, T, *z.shape[1:])
         # K3: Kalman gains over the whole clip.  They only enter frames i >= 1 (KA:1067-1070), so a T = 1 "clip" (the
         # single-image fast path: frame 0 depends on neither the flows nor the gains nor the other frames) skips them.
-        gains = self._kalman_gain(z, B, T).view(B, T, -1) if T > 1 else None
+        with _Range('K3 kalman_gain'):
+            gains = self._kalman_gain(z, B, T).view(B, T, -1) if T > 1 else None
         cft_at = {FUSE_GENERATOR_BLOCK[s]: s for s in cfg['cft_list']}
         cfa_at = {FUSE_GENERATOR_BLOCK[s]: s for s in cfg['cfa_list']}
         gblocks = generator_blocks(cfg)
@@ -673,14 +706,16 @@ class KeepNet:
             if i == 0:
                 z_hat = z_i
             else:                                                        # K4 (KA:1067-1070)
-                warped = torch.empty_like(prev_out)
-                L.call('keep_flow_warp', prev_out, self._frame(flows, i - 1), warped, B, H, Wd, 3)
-                z_prime, _ = self._vq_stack(warped, 'hq_encoder', encoder_blocks(cfg))
-                z_hat = torch.empty_like(z_i)
-                L.call('keep_kalman_update', z_i, z_prime, self._frame(gains, i), z_hat, B,
-                       z_i.shape[1] * z_i.shape[2], z_i.shape[3])
-            quant, idx, margin = self._predict_codes(                    # K5, K6
-                z_hat, None if fi is None else self._frame(fi, i).view(-1), return_aux)
+                with _Range('K4 warp + hq_encoder + kalman_update'):
+                    warped = torch.empty_like(prev_out)
+                    L.call('keep_flow_warp', prev_out, self._frame(flows, i - 1), warped, B, H, Wd, 3)
+                    z_prime, _ = self._vq_stack(warped, 'hq_encoder', encoder_blocks(cfg))
+                    z_hat = torch.empty_like(z_i)
+                    L.call('keep_kalman_update', z_i, z_prime, self._frame(gains, i), z_hat, B,
+                           z_i.shape[1] * z_i.shape[2], z_i.shape[3])
+            with _Range('K5-K6 code transformer + argmax'):
+                quant, idx, margin = self._predict_codes(                # K5, K6
+                    z_hat, None if fi is None else self._frame(fi, i).view(-1), return_aux)
             idx_all.append(idx)
             margin_all.append(margin)
 
@@ -695,7 +730,8 @@ class KeepNet:
                     cross_prev[s] = y
                 return y, yst
 
-            y, _ = self._vq_stack(quant, 'generator', gblocks, hook=hook)
+            with _Range('K7 generator + CFT + CFA'):
+                y, _ = self._vq_stack(quant, 'generator', gblocks, hook=hook)
             prev_out = y
             out_nhwc[:, i].copy_(y)
         out = ops.nhwc_to_nchw(out_nhwc.view(B * T, H, Wd, 3)).view(B, T, 3, H, Wd)
@@ -767,6 +803,9 @@ class KeepNet:
         for c in clips_u8:
             if len(c.shape) != 4 or c.shape[-1] != 3 or c.dtype != torch.uint8:
                 raise ValueError(f"expected uint8 [T,H,W,3], got {c.dtype} {tuple(c.shape)}")
+        if self.pool is not None and self.shard_across_ranks and len(clips_u8) > 1:
+            # single-process product (a ComfyUI node): this process is the root of a worker pool, one worker per additional GPU
+            return self.pool.run(clips_u8, max_b)
         if not self.shard_across_ranks:      # per-rank workloads (BASELINE configs[4]: one video per GPU): nothing to exchange
             local = self._run_clips_u8_local(dict(enumerate(clips_u8)), max_b)
             return [torch.from_numpy(local[i]) for i in range(len(clips_u8))]

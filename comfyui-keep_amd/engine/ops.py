@@ -109,7 +109,12 @@ class Ops:
             self.status = self._block[:1].view(torch.int32)
             self.arena_generation += 1
 
-    def set_precision(self, mma, blob32=None, blob16=None, blobx3=None, x3_acc_scale=1.0):
+    def set_precision(self, mma, blob32=None, blob16=None, blobx3=None, x3_acc_scale=1.0, x3_scales=None):
+        """x3_scales: per-tensor accumulator scales of the split-fp16 twin, [(first element, one past the last, 2^-e), ...] sorted
+        by offset (``make_x3_blob``); without it every tensor of the blob carries ``x3_acc_scale``."""
+        self._x3_table = None
+        if x3_scales:
+            self._x3_table = ([a for a, _, _ in x3_scales], list(x3_scales))
         self.mma = self.attn_mma = mma
         if blobx3 is not None and (blob32 is not self._up2_src[0] or blobx3 is not self._up2_src[1]):
             # phase kernels of the Upsample convolutions (up2_twin): derived from THESE blob objects -- a new upload, even one that lands
@@ -154,6 +159,18 @@ class Ops:
         off = self._blob_off(w)
         return self.blobx3[2 * off:2 * (off + w.numel())]
 
+    def x3_scale_of(self, w):
+        """Accumulator scale (2^-e) of the twin of weight view ``w``: its own tensor's (a row slice shares its tensor's scale)."""
+        if getattr(self, '_x3_table', None) is None:
+            return self.x3_acc_scale
+        import bisect
+        off = self._blob_off(w)
+        starts, rows = self._x3_table
+        i = bisect.bisect_right(starts, off) - 1
+        if i < 0 or not (rows[i][0] <= off and off + w.numel() <= rows[i][1]):
+            raise RuntimeError("weight view does not lie inside one tensor of the x3 blob")
+        return rows[i][2]
+
     # ------------------------------------------------------------------ keep_conv2d
     def conv(self, x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=False, pro=None, pro_act=L.PRO_NONE,
              act=L.ACT_NONE, residual=None, aux=None, aux_w=1.0, cin=None, in_off=0, out=None, split_k=None, wb=None,
@@ -197,6 +214,8 @@ class Ops:
             up_mode = L.UPSAMPLE_X2_PHASES
         if mma == L.MMA_X3 and wx3 is None:
             wx3 = self.x3_twin(w)
+            if wx3 is not None and x3_acc_scale is None:
+                x3_acc_scale = self.x3_scale_of(w)
         if x3_acc_scale is None:
             x3_acc_scale = self.x3_acc_scale
         want_bf16_out = bool(out_bf16) and mma == L.MMA_BF16 and residual is None
@@ -471,6 +490,25 @@ def up2_phase_weights(w):
     r[1, 1, 0] = 1; r[1, 1, 1] = 1; r[1, 2, 2] = 1                     # phase 1: new1 = old0 + old1, new2 = old2
     w4 = torch.einsum('pak,qbl,oklc->pqoabc', r, r, w.float())
     return w4.reshape(4, w.shape[0], 3, 3, w.shape[3]).contiguous()
+
+
+def make_x3_blob(dev_blob, index, weights, names):
+    """Split-fp16 twin of the tensors ``names`` of a packed fp32 blob (``index``: name -> (element offset, shape); ``weights``:
+    name -> device view) with ONE POWER-OF-TWO SCALE PER TENSOR: each tensor's largest |w| lands just below 2^15, so a tensor of
+    small weights keeps normal `lo` halves whatever the largest weight elsewhere in the net is (one shared scale -- rounds 2 / 3 --
+    let a single large tensor push every other layer's `lo` halves towards the fp16 subnormals).  Returns (int16 blob with two
+    elements per weight, [(first element, one past the last, accumulator scale 2^-e), ...] sorted by offset) for
+    ``Ops.set_precision(..., x3_scales=)``."""
+    bx = torch.zeros(2 * dev_blob.numel(), dtype=torch.int16, device=dev_blob.device)
+    table = []
+    for n in names:
+        off, shape = index[n]
+        t = weights[n]
+        sc = x3_scale_for(float(t.abs().max()))
+        bx[2 * off:2 * (off + t.numel())] = split_x3(t.reshape(-1, shape[-1]), sc).view(-1)
+        table.append((int(off), int(off + t.numel()), 1.0 / sc))
+    table.sort()
+    return bx, table
 
 
 def x3_scale_for(max_abs):

@@ -145,12 +145,8 @@ class ParseNetEngine:
         self.w = views(self._dev, self._index)
         if self.precision == 'x3':
             names = [n for n, (_, sh) in self._index.items() if len(sh) == 4 and sh[-1] % 16 == 0]
-            scale = ops.x3_scale_for(max(float(self.w[n].abs().max()) for n in names))
-            bx = torch.zeros(2 * self._dev.numel(), dtype=torch.int16, device=device)
-            for n in names:
-                off, sh = self._index[n]
-                bx[2 * off:2 * (off + self.w[n].numel())] = ops.split_x3(self.w[n].reshape(-1, sh[-1]), scale).view(-1)
-            self.o.set_precision(L.MMA_X3, self._dev, None, bx, 1.0 / scale)
+            bx, table = ops.make_x3_blob(self._dev, self._index, self.w, names)       # one power-of-two scale per tensor
+            self.o.set_precision(L.MMA_X3, self._dev, None, bx, 1.0, x3_scales=table)
         else:
             self.o.set_precision(L.MMA_F32, self._dev, None)
         return self

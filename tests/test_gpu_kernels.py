@@ -1070,6 +1070,36 @@ def test_conv_x3_halo_fused_probe_over_several_items_per_block():
         assert torch.equal(st.amax.cpu(), y.abs().flatten(1).max(1).values.cpu()), f'fused max|out| (prologue={pro})'
 
 
+def test_x3_scale_is_per_tensor():
+    """engine/ops.py:make_x3_blob gives every tensor of a packed blob its own power-of-two scale (the ABI carries x3_acc_scale per
+    launch): a huge weight in ONE tensor (here 1e6, seven decades above the others) must not cost another layer its `lo` halves.
+    With one shared scale (rounds 2 / 3) the small tensor's `lo` falls into the fp16 subnormals and its convolution loses
+    ~8 bits; per tensor, its error vs fp64 stays the exact-f32 kernel's."""
+    cin, cout = 64, 64
+    wa, wb_ = rnd('pt_a', (cout, 3, 3, cin), 0.05), rnd('pt_b', (cout, 3, 3, cin), 0.05)
+    wb_[3, 1, 1, 5] = 1.0e6
+    blob = dev(torch.cat([wa.reshape(-1), wb_.reshape(-1)]))
+    index = {'a': (0, tuple(wa.shape)), 'b': (wa.numel(), tuple(wb_.shape))}
+    views = {'a': blob[:wa.numel()].view(wa.shape), 'b': blob[wa.numel():].view(wb_.shape)}
+    bx, table = ops.make_x3_blob(blob, index, views, ['a', 'b'])
+    assert table[0][2] != table[1][2] and table[1][2] / table[0][2] >= 2.0 ** 20        # 2^-e: seven decades apart
+    o = ops.Ops()
+    o.set_precision(L.MMA_X3, blob, None, bx, 1.0, x3_scales=table)
+    assert o.x3_scale_of(views['a']) == table[0][2] and o.x3_scale_of(views['b'][8:24]) == table[1][2]     # a row slice: its tensor's
+    x = rnd('pt_x', (2, cin, 32, 32), 1.5)
+    xd = dev(nhwc(x))
+    y = o.conv(xd, views['a'], None, split_k=1)
+    ref = F.conv2d(x.double(), wa.permute(0, 3, 1, 2).double(), None, padding=1).permute(0, 2, 3, 1)
+    y32 = ops.conv(xd, views['a'], None, split_k=1)
+    e3, e32 = err64(y, ref), err64(y32, ref)
+    shared = ops.x3_scale_for(1.0e6)                                                      # what one scale for the whole blob would be
+    y_sh = ops.conv(xd, views['a'], None, split_k=1, mma=L.MMA_X3, wx3=ops.split_x3(views['a'].reshape(-1, cin), shared).view(-1),
+                    x3_acc_scale=1.0 / shared)
+    e_sh = err64(y_sh, ref)
+    print(f'per-tensor scale: x3 err {e3:.3e} (exact-f32 kernel {e32:.3e}); one shared scale: {e_sh:.3e}')
+    assert e3 <= max(3.0 * e32, 2e-6) and e_sh > 10.0 * e3
+
+
 @pytest.mark.parametrize("name,n,cin,cout,h,wd,up,res,gn", [('64->64 @512^2, GroupNorm-swish, residual', 16, 64, 64, 512, 512, False, True, True),
                                                             ('128->128 @256^2, GroupNorm-swish', 16, 128, 128, 256, 256, False, False, True),
                                                             ('128->64 @512^2, GroupNorm-swish', 16, 128, 64, 512, 512, False, False, True),

@@ -449,6 +449,35 @@ def test_two_ranks_share_the_gpu_product_path(tmp_path, synth_weights):
         assert np.array_equal(got[f'arr_{c}'], solo[c].numpy()), c
 
 
+def test_single_process_pool_drives_two_workers(synth_weights, monkeypatch):
+    """What a ComfyUI node can reach (engine/pool.py): ONE process owns the weights, ``start_pool(3)`` spawns two worker processes
+    (here on the same device: KEEP_DIST_DEVICE, gloo wire for the one weight broadcast), and ``run_clips_u8`` -- the call
+    KEEPFaceProcessor makes -- shards 7 ragged clips over root + workers.  Bit-equal to the same net without the pool, through the
+    tensor entry point and through the processor's list-of-crops entry point; the process group does not outlive the broadcast."""
+    from comfyui_keep_amd.engine.net import KeepNet
+    monkeypatch.setenv('KEEP_DIST_DEVICE', '0')
+    net = KeepNet(**DEFAULT_ARCH)
+    net.load_state_dict(synth_weights, strict=True)
+    net.to('cuda').eval()
+    g = torch.Generator().manual_seed(11)
+    clips = [torch.randint(0, 256, (3 if c % 3 == 0 else (2 if c % 3 == 1 else 1), 512, 512, 3), generator=g, dtype=torch.uint8)
+             for c in range(7)]
+    solo = net.run_clips_u8(clips, max_b=2)
+    pool = net.start_pool(3)
+    try:
+        assert not torch.distributed.is_initialized() and len(pool._procs) == 2
+        print(f'pool of 3 on one device: weight broadcast {pool.broadcast_ms:.0f} ms')
+        got = net.run_clips_u8(clips, max_b=2)
+        assert len(got) == 7 and all(torch.equal(a, b) for a, b in zip(got, solo))
+        as_lists = net.run_clips_u8([[f.numpy() for f in c] for c in clips], max_b=2)       # what _restore_crops_u8 hands over
+        assert all(torch.equal(a, b) for a, b in zip(as_lists, solo))
+        assert torch.equal(net.run_clips_u8(clips[:1])[0], solo[0])                        # a single clip stays on the root
+    finally:
+        pool.close()
+        net.pool = None
+    assert all(p.poll() is not None for p in pool._procs) or not pool._procs
+
+
 def _rccl_world1_worker(rank, port, out_dir):
     os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY='0')

@@ -223,6 +223,82 @@ def facelib_leg():
     return out
 
 
+def pipeline_leg(net, n_frames, H, W, faces, batch=20):
+    """BASELINE configs[2] / [3] END TO END on the engine, video frames in host memory -> restored video frames in host memory:
+    RetinaFace(resnet50) on the frames resized to the helper's 640-px short side (engine/retinaface.py, device-side decode),
+    the crop warp of every face (``keep_warp_affine_u8``), the clip loop (``run_clips_u8``: chunks of 20 crops per face track),
+    ParseNet on the restored faces (engine/parsenet.py), the parse-mask paste-back (engine/paste.py), D2H of the frames.
+    Synthetic frames, weights and face geometry (fixed crop <-> frame similarities per track: the detector's boxes on random
+    weights are not faces; cv2's estimateAffinePartial2D / the landmark smoothing stay on the host in the product and are not
+    on this leg); the frame resize in front of the detector is an area interpolation on the device (the helper's INTER_AREA)."""
+    from comfyui_keep_amd.engine import parsenet as PN
+    from comfyui_keep_amd.engine import retinaface as RF
+    from comfyui_keep_amd.engine import hiplib as L
+    from comfyui_keep_amd.engine.paste import GpuPaster, crop_faces, invert_affine
+    dev = net.device
+    det = RF.RetinaFaceEngine(RF.synth_retinaface_state_dict(seed=0)).to(dev)
+    par = PN.ParseNetEngine(PN.synth_parsenet_state_dict(seed=0)).to(dev)
+    paster = GpuPaster(dev)
+    g = torch.Generator().manual_seed(faces)
+    frames = torch.randint(0, 256, (n_frames, H, W, 3), generator=g, dtype=torch.uint8)
+    sc = 640.0 / min(H, W)
+    dh, dw = int(H * sc), int(W * sc)
+    # crop -> frame similarities of the face tracks (face i: centre drifts slowly), scale so that a face spans ~0.35 of the height
+    s0 = 0.35 * H / 512.0
+    inv = [[np.array([[s0, 0.0, (0.25 + 0.25 * i) * W - 256 * s0 + 0.5 * t], [0.0, s0, 0.5 * H - 256 * s0 + 0.2 * t]], np.float64)
+            for i in range(faces)] for t in range(n_frames)]
+
+    def run():
+        timings = {}
+        t0 = time.perf_counter()
+        n_det = 0
+        for s in range(0, n_frames, 32):                      # 1. detection on the resized frames
+            chunk = frames[s:s + 32].to(dev, non_blocking=True)
+            small = torch.nn.functional.interpolate(chunk.permute(0, 3, 1, 2).float(), size=(dh, dw), mode='area')
+            small = small.round_().clamp_(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+            n_det += sum(len(d) for d in det.detect_batch(small, 0.97))
+        torch.cuda.synchronize()
+        timings['detect_s'] = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        crops = [[] for _ in range(faces)]                    # 2. crop warps, per face track
+        for t in range(n_frames):
+            c = crop_faces(frames[t], [invert_affine(m) for m in inv[t]], (512, 512), dev)
+            for i in range(faces):
+                crops[i].append(c[i])
+        torch.cuda.synchronize()
+        timings['crop_s'] = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        clips = [torch.stack(tr[s:s + 20]) for tr in crops for s in range(0, n_frames, 20)]      # 3. the clip loop
+        restored = net.run_clips_u8(clips)
+        per_track = n_frames // 20 + (1 if n_frames % 20 else 0)
+        tracks = [torch.cat(restored[i * per_track:(i + 1) * per_track]) for i in range(faces)]
+        timings['restore_s'] = time.perf_counter() - t2
+        t3 = time.perf_counter()
+        out = torch.empty((n_frames, H, W, 3), dtype=torch.uint8, pin_memory=True)
+        for s in range(0, n_frames, batch):                   # 4. ParseNet + paste-back, D2H of the finished frames
+            e = min(s + batch, n_frames)
+            fb = torch.stack([tracks[i][t] for t in range(s, e) for i in range(faces)]).to(dev, non_blocking=True)
+            x = torch.empty(fb.shape, dtype=torch.float32, device=dev)
+            L.call('keep_img2tensor', fb, x, fb.numel() // 3)
+            cls = par.classes(x)
+            for k, t in enumerate(range(s, e)):
+                o = paster.paste(frames[t], fb[k * faces:(k + 1) * faces], inv[t], cls[k * faces:(k + 1) * faces])
+                out[t].copy_(o, non_blocking=True)
+        torch.cuda.synchronize()
+        timings['parse_paste_s'] = time.perf_counter() - t3
+        timings['total_s'] = time.perf_counter() - t0
+        return timings, n_det, out
+
+    run()                                                     # warm: allocator, plan caches, pinned buffers
+    tm, n_det, out = run()
+    assert out.shape == (n_frames, H, W, 3)
+    return {"value": round(n_frames / tm['total_s'], 2), "unit": "video frames/s", "frames": n_frames, "frame_size": [H, W],
+            "faces_per_frame": faces, "restored_faces_per_s": round(n_frames * faces / tm['total_s'], 2),
+            "seconds": {k: round(v, 3) for k, v in tm.items()},
+            "what": "uint8 frames in host memory -> detect (RetinaFace on the engine) -> crop warp -> KEEP clip loop -> ParseNet -> "
+                    "paste-back -> uint8 frames in host memory, every stage on the MI355X; synthetic face geometry"}
+
+
 def processor_leg(net, n_crops, faces):
     """BASELINE configs[2] / [3] as the hot path sees them: `n_crops` crops stacked frame-major (`faces` crops per frame,
     interleaved: keep_processor.py:252-253) and cut into max_clip_length = 20 chunks by the processor's own code."""
@@ -434,6 +510,9 @@ def main():
                                "config4_900_crops_3_faces": processor_leg(net, 900, 3)}
             line["paste_back_gpu"] = paste_leg()
             line["facelib"] = facelib_leg()
+            # ---- BASELINE configs[2] / [3] end to end: frames -> frames, every stage on the engine
+            line["end_to_end"] = {"config3_300_frames_720p_1_face": pipeline_leg(net, 300, 720, 1280, 1),
+                                  "config4_300_frames_1080p_3_faces": pipeline_leg(net, 300, 1080, 1920, 3)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_frames)
         print(json.dumps(line))

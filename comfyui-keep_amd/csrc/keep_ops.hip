@@ -626,6 +626,66 @@ extern "C" int32_t keep_maxpool3s2(const float* x, float* out, int32_t N, int32_
   return KEEP_OK;
 }
 
+// RetinaFace post-processing on the device (retinaface.py:208-256 per frame; retinaface_utils.py:254-294): per anchor the face
+// score softmax(cls)[1], and -- only for anchors above the confidence threshold -- the decoded box and five landmarks in pixels,
+// appended to the frame's compact list (one atomic slot per survivor).  heads: [N, P, 32] rows of the fused head convolution, per
+// pixel [cls a0 a1 (2 each) | box a0 a1 (4 each) | landmarks a0 a1 (10 each)]; anchor index = 2 * pixel + a; priors [2P, 4]
+// (cx, cy, w, h).  dets: [N, cap, 16] = x1 y1 x2 y2 score lm x 10 anchor-index (as float: < 2^24).  Only survivors cross PCIe:
+// a 640 x 1138 frame has 60 160 anchors (3.9 MB of head outputs), a handful above 0.97.  The arithmetic is the host decoder's
+// (engine/retinaface.py:decode_boxes / decode_landmarks), float32, in the same order.
+__global__ __launch_bounds__(256) void retina_decode_kernel(const float* __restrict__ heads, const float* __restrict__ priors,
+                                                            float* __restrict__ dets, int* __restrict__ counts, int N, int P, int cap,
+                                                            float var0, float var1, float sx, float sy, float thr) {
+  const long total = (long)N * P * 2;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int a = (int)(i & 1);
+    const long pix = i >> 1;
+    const int n = (int)(pix / P);
+    const int p = (int)(pix - (long)n * P);
+    const float* row = heads + pix * 32;
+    const float c0 = row[2 * a], c1 = row[2 * a + 1];
+    const float m = fmaxf(c0, c1);
+    const float e0 = expf(c0 - m), e1 = expf(c1 - m);
+    const float score = e1 / (e0 + e1);
+    if (!(score > thr)) continue;
+    const int slot = atomicAdd(counts + n, 1);
+    if (slot >= cap) continue;                 // (the count still says how many there were: the host falls back when it exceeds cap)
+    const int ai = 2 * p + a;
+    const float4 pr = *reinterpret_cast<const float4*>(priors + 4L * ai);
+    const float* lb = row + 4 + 4 * a;
+    float bx = pr.x + lb[0] * var0 * pr.z, by = pr.y + lb[1] * var0 * pr.w;
+    float bw = pr.z * expf(lb[2] * var1), bh = pr.w * expf(lb[3] * var1);
+    bx -= bw / 2;
+    by -= bh / 2;
+    bw += bx;
+    bh += by;
+    float* d = dets + ((long)n * cap + slot) * 16;
+    d[0] = bx * sx; d[1] = by * sy; d[2] = bw * sx; d[3] = bh * sy;
+    d[4] = score;
+    const float* lm = row + 12 + 10 * a;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      d[5 + 2 * k] = (pr.x + lm[2 * k] * var0 * pr.z) * sx;
+      d[6 + 2 * k] = (pr.y + lm[2 * k + 1] * var0 * pr.w) * sy;
+    }
+    d[15] = (float)ai;
+  }
+}
+
+extern "C" int32_t keep_retina_decode(const float* heads, const float* priors, float* dets, int32_t* counts, int32_t N, int32_t P,
+                                      int32_t cap, float var0, float var1, float scale_x, float scale_y, float conf_threshold,
+                                      void* stream) {
+  KEEP_REQUIRE(heads && priors && dets && counts && N > 0 && P > 0 && cap > 0 && 2L * P < (1L << 24) && (uintptr_t)priors % 16 == 0,
+               "keep_retina_decode: bad args (2 P < 2^24 anchors, 16-byte aligned priors)");
+  const long total = (long)N * P * 2;
+  int blocks = cdiv(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(retina_decode_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, heads, priors, dets, counts, N, P, cap, var0,
+                     var1, scale_x, scale_y, conf_threshold);
+  KEEP_LAUNCH_CHECK("keep_retina_decode");
+  return KEEP_OK;
+}
+
 // out[n, y, x, :] = a[n, y, x, :] + b[n, floor(y * hb / H), floor(x * wb / W), :]: the FPN top-down step
 // `a + F.interpolate(b, size=a.shape[2:], mode='nearest')` (retinaface_net.py:86-92); C % 4 == 0.  (torch's nearest index is
 // floor(dst * scale) with scale = in / out as a float; the integer form below equals it for every size with in <= out.)

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 F32, BF16 = 0, 1
 MMA_F32, MMA_BF16, MMA_X3 = 0, 1, 2
@@ -83,6 +83,7 @@ _SIGNATURES = {
     'keep_maxpool3s2': [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     'keep_upsample_add': [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     'keep_act_inplace': [_vp, _i64, _i32, _vp],
+    'keep_retina_decode': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _vp],
     'keep_sep_filter': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
     'keep_u8_to_f32': [_vp, _vp, _i64, _vp],
     'keep_f32_round_u8': [_vp, _vp, _i64, _vp],

@@ -30,7 +30,7 @@ extern "C" {
  * the fields a shorter known layout lacks as zero), keep_sizeof_*_args(), keep_argmax_gather takes the non-finite status word,
  * keep_nonfinite_flag.  v13: keep_conv2d_args.upsample accepts KEEP_UPSAMPLE_X2_PHASES (same layout; a v12 library refuses the
  * value, so the binding asks for 13). */
-#define KEEP_ABI_VERSION 13
+#define KEEP_ABI_VERSION 14
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -333,6 +333,13 @@ int32_t keep_upsample_add(const float* a, const float* b, float* out, int32_t N,
                           int32_t C, void* stream);
 /* x = act(x) in place, act = KEEP_ACT_*: the ReLU after a Bottleneck's residual sum (torchvision resnet.py Bottleneck.forward) */
 int32_t keep_act_inplace(float* x, int64_t n, int32_t act, void* stream);
+/* RetinaFace.detect_faces post-processing (retinaface.py:231-246; decode / decode_landm: retinaface_utils.py:254-294) on the
+ * device: heads [N,P,32] = per pixel [cls a0 a1 | box a0 a1 | landmarks a0 a1] of the fused head convolutions, priors [2P,4]
+ * (cx,cy,w,h).  For every anchor with softmax(cls)[1] > conf_threshold one row of dets [N,cap,16] = x1 y1 x2 y2 score lm0..lm9
+ * anchor-index (scaled to pixels by scale_x / scale_y), appended in arrival order; counts[n] (zeroed by the caller) = survivors of
+ * frame n (may exceed cap: rows beyond cap are dropped, the caller re-runs its host decoder).  ABI v14. */
+int32_t keep_retina_decode(const float* heads, const float* priors, float* dets, int32_t* counts, int32_t N, int32_t P, int32_t cap,
+                           float var0, float var1, float scale_x, float scale_y, float conf_threshold, void* stream);
 
 /* ---- paste-back compositing (face_restoration_helper.py:346-475, use_parse=True branch) ----------------
  * Separable filter with BORDER_REFLECT_101 (cv2.GaussianBlur, :433-434): n images [H,W]; the input is `src` (float) or a

@@ -127,3 +127,35 @@ def test_retinaface_engine_vs_reference_golden(precision):
             j = np.argmin(np.abs(boxes - d[:4]).sum(1))
             assert np.abs(boxes[j] - d[:4]).max() <= 1e-2 and abs(sc[j] - d[4]) <= 1e-4, (i, d[:5], boxes[j], sc[j])
         assert len(dets[i]) <= len(keep_ref) + int((~sure).sum())
+
+
+def test_retina_decode_on_the_device_equals_the_host_decoder():
+    """keep_retina_decode (scores, threshold, decode / decode_landm on the device; only survivors cross PCIe) against the numpy
+    decoder of rounds 2-3 on the SAME head rows: the same anchors survive (up to scores within 1e-6 of the threshold), boxes /
+    landmarks agree to 1e-4 px on a 640-px frame, the final detections (after NMS) are the same set in the same order; a frame with
+    more survivors than the compact list holds takes the host decoder; float frames (16-bit sources) take the float path."""
+    from comfyui_keep_amd.engine import retinaface as RF
+    eng = RF.RetinaFaceEngine(RF.synth_retinaface_state_dict(seed=0)).to('cuda')
+    g = torch.Generator().manual_seed(9)
+    frames = torch.randint(0, 256, (3, 320, 448, 3), generator=g, dtype=torch.uint8)
+    H, W = 320, 448
+    pri = RF.prior_boxes(H, W)
+    scale, scale1 = np.array([W, H, W, H], np.float32), np.array([W, H] * 5, np.float32)
+    x = frames.cuda().float() - torch.tensor(RF.MEAN_BGR, device='cuda')
+    heads = eng.raw_heads(x).float().cpu().numpy()
+    for thr in (0.9, 0.6):
+        got = eng.detect_batch(frames, thr)
+        for i in range(3):
+            ref = eng._host_decode(heads[i], pri, scale, scale1, thr, 0.4)
+            assert len(ref) > 3 and got[i].shape == ref.shape, (thr, i, got[i].shape, ref.shape)
+            assert np.abs(got[i] - ref).max() <= 1e-4 * max(H, W), (thr, i, np.abs(got[i] - ref).max())
+            assert np.abs(got[i][:, 4] - ref[:, 4]).max() <= 1e-6
+    eng.max_survivors = 8                                   # overflow of the compact list: the frame is decoded on the host
+    few = eng.detect_batch(frames, 0.6)
+    eng.max_survivors = 4096
+    full = eng.detect_batch(frames, 0.6)
+    for a, b in zip(few, full):
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-4 * max(H, W)
+    as_float = eng.detect_batch(frames.double().numpy(), 0.9)                     # read_image's float64 frames
+    for a, b in zip(as_float, eng.detect_batch(frames, 0.9)):
+        assert np.array_equal(a, b)

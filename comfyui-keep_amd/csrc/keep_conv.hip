@@ -1676,6 +1676,7 @@ int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int big_tile, hip
 bool keep_conv_x3_gather_is_gemm(const keep_conv2d_args* a);
 int keep_conv2d_x3_c3(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 bool keep_conv_x3_halo_ok(const keep_conv2d_args* a);
+bool keep_conv_x3_stream_ok(const keep_conv2d_args* a, const ConvP& p, int split_k);
 bool keep_conv_x3_gather_ok(const keep_conv2d_args* a, const ConvP& p);
 
 enum ConvPath {
@@ -1880,7 +1881,10 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
       if (pl.split_k > a->Cin / 16) pl.split_k = a->Cin / 16;
       pl.stats_rows = 256;      // one statistics partial per 256-pixel tile (the block adds its four waves' sums in LDS)
       pl.amax_ok = pl.split_k == 1;
-      snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3_kernel<%d>", pl.wide ? 32 : 16);
+      if (keep_conv_x3_stream_ok(a, p, pl.split_k))      // the streaming form (keep_conv_x3s.hip): what rocprofv3 prints
+        snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3s_kernel");
+      else
+        snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3_kernel<%d>", pl.wide ? 32 : 16);
       return KEEP_OK;
     }
     if (a->in2) {      // K-concatenated input: GEMM form of the x3 gather kernel only

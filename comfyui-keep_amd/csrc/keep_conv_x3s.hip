@@ -548,9 +548,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3s_kernel(ConvP p, int t
 // Geometry of the streaming kernel inside what keep_conv_x3_halo_ok() already admits: 8x32 tiles, whole-item K ranges of at least two
 // chunks, the simple epilogue (bias / residual / statistics / max|out|), the fast activation forms.  Everything else stays on
 // conv3x3_halo_x3_kernel.  KEEP_X3_NO_STREAM=1: round 3's kernel everywhere (A/B runs).
-bool keep_conv_x3_stream_ok(const keep_conv2d_args* a, const ConvP& p) {
+bool keep_conv_x3_stream_ok(const keep_conv2d_args* a, const ConvP& p, int split_k) {
   static const bool off = getenv("KEEP_X3_NO_STREAM") != nullptr;
-  const bool simple = p.split_k == 1 && !a->aux && a->epi_act == KEEP_ACT_NONE;
+  const bool simple = split_k == 1 && !a->aux && a->epi_act == KEEP_ACT_NONE;
   const bool aff = a->pro_scale != nullptr;
   return !off && simple && a->Ho % 8 == 0 && a->Wo % 32 == 0 && a->Cin >= 32 && a->upsample != KEEP_UPSAMPLE_X2_PHASES &&
          (a->pro_act == KEEP_PRO_NONE || (aff && (a->pro_act == KEEP_PRO_RELU || (a->pro_act == KEEP_PRO_SWISH && p.fast)))) &&

@@ -114,7 +114,7 @@ def test_conv_x3_halo_is_fp32_grade(n, cin, cout, h, wd, up, res, gn):
     y, st = ops.conv(xd, wp, dev(b), mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, **kw)
     kname = ops.DEFAULT.profile[-1][0]
     ops.DEFAULT.profile = None
-    assert kname.startswith('conv3x3_halo_x3_kernel'), kname
+    assert kname.startswith(('conv3x3_halo_x3_kernel', 'conv3x3_halo_x3s_kernel')), kname
     y32, _ = ops.conv(xd, wp, dev(b), **kw)
     hn = x.double()
     if gn:
@@ -1131,7 +1131,7 @@ def test_conv_x3_at_the_shapes_of_the_step(name, n, cin, cout, h, wd, up, res, g
         y, st = ops.conv(xd, wp, bd, mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, **kw)
     kname = ops.DEFAULT.profile[-1][0]
     ops.DEFAULT.profile = None
-    assert kname.startswith('conv3x3_halo_x3_kernel') and (('phases' in kname) == up), kname
+    assert kname == ('conv3x3_halo_x3_kernel<32, x2 phases>' if up else 'conv3x3_halo_x3s_kernel'), kname      # the streaming kernel IS what the step runs
     y32, _ = ops.conv(xd, wp, bd, **kw)
     assert torch.isfinite(y).all()
     worst3 = worst32 = 0.0

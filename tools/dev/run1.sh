@@ -1,8 +1,12 @@
-prune() { find gpurun_out/$1 -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} + ; find gpurun_out/$1 -name "*.log" -size +1M -delete; }
-bash tools/profile_step.sh x3 16 r4p_x3_b16 > gpurun_out/r4p_x3_b16.out 2>&1; prune r4p_x3_b16
-KEEP_AMD_GRAPH=0 bash tools/profile_step.sh x3 1 r4p_x3_b1 > gpurun_out/r4p_x3_b1.out 2>&1; prune r4p_x3_b1
-bash tools/profile_step.sh fp32 16 r4p_fp32_b16 > gpurun_out/r4p_fp32_b16.out 2>&1; prune r4p_fp32_b16
-bash tools/dev/pmc_conv.sh r4p_pmc_sq c64_512 c128_256 > gpurun_out/r4p_pmc_sq.txt 2>&1; rm -rf gpurun_out/r4p_pmc_sq
-KEEP_X3_NO_STREAM=1 bash tools/dev/pmc_conv.sh r4p_pmc_sq_r3kernel c64_512 c128_256 > gpurun_out/r4p_pmc_sq_r3kernel.txt 2>&1; rm -rf gpurun_out/r4p_pmc_sq_r3kernel
-du -sh gpurun_out; ls gpurun_out/r4p_x3_b16
-head -12 gpurun_out/r4p_x3_b16/x3_b16_kernel_stats.txt | cut -c1-150
+python bench.py > gpurun_out/r4p_bench.json 2> gpurun_out/r4p_bench.err; echo rc $?
+KEEP_DIST_DEVICE=0 python bench.py --gpus 2 --clips 4 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r4p_bench_2ranks_1gpu.json 2> gpurun_out/r4p_bench2.err; echo rc $?
+python - <<'PY'
+import json
+d=json.loads([l for l in open('gpurun_out/r4p_bench.json') if l.startswith('{')][-1])
+print({k:d[k] for k in ('value','ms_per_step')}, 'frac', d['roofline'].get('frac'), 'conv_path', d['roofline'].get('conv_path_frac'), 'b1', d.get('b1',{}).get('value'), 'pcie', d.get('pcie_inclusive',{}).get('value'))
+print({k:v['value'] for k,v in d['configs'].items()}, {k:v['value'] for k,v in d['end_to_end'].items()})
+print(d['cpu_baseline'])
+print(d['roofline'])
+d2=json.loads([l for l in open('gpurun_out/r4p_bench_2ranks_1gpu.json') if l.startswith('{')][-1])
+print('2 ranks on 1 gpu:', d2['value'], d2.get('broadcast_ms'), d2.get('config5_one_video_per_gpu',{}).get('value'))
+PY

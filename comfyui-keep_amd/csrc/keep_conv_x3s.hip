@@ -358,6 +358,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3s_kernel(ConvP p, int t
         const float4 v = *reinterpret_cast<const float4*>(et + (u * 4 + prow) * XS_EP + c4);
         float e[4] = {__builtin_fmaf(v.x, asc, bias4.x), __builtin_fmaf(v.y, asc, bias4.y), __builtin_fmaf(v.z, asc, bias4.z),
                       __builtin_fmaf(v.w, asc, bias4.w)};
+        if (p.epi_act != KEEP_ACT_NONE) {       // (uniform; the activation comes before the residual: keep_conv_common.h epilogue_one)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) e[q] = p.fast ? act_apply_fast(e[q], p.epi_act) : act_apply(e[q], p.epi_act);
+        }
         if (HAS_RES) {
           const u32x4 r4 = rpre[HAS_RES ? rd * 4 + u : 0];
           e[0] += __uint_as_float(r4.x); e[1] += __uint_as_float(r4.y);
@@ -540,17 +544,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3s_kernel(ConvP p, int t
     atomicAdd(dst + 12, 1ull);
     atomicAdd(dst + 13, __builtin_amdgcn_s_memtime() - cyc0);
     atomicAdd(dst + 14, __builtin_amdgcn_s_memrealtime() - rtc0);
+    if (blockIdx.x < 1024) {                   // per-block start / end (100 MHz ticks) behind the 16 sums
+      dst[16 + blockIdx.x * 2] = rtc0;
+      dst[17 + blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
+    }
   }
 #undef XS_T
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
 // Geometry of the streaming kernel inside what keep_conv_x3_halo_ok() already admits: 8x32 tiles, whole-item K ranges of at least two
-// chunks, the simple epilogue (bias / residual / statistics / max|out|), the fast activation forms.  Everything else stays on
+// chunks, no split-K / aux tensor (bias / activation / residual / statistics / max|out| epilogue), the fast activation forms.
+// (Round 4 also tried drawing the items from a global ticket counter instead of the static stride -- block lifetimes of one launch
+// spread by +-20 %, bimodal -- with the ticket prefetched one item ahead: bit-identical results, 1.5 % (64 ch @512^2) to 5 % (128 ch
+// @256^2) SLOWER: the launch is bound by chip-wide throughput, early finishers hand their share to the rest; removed.)  Everything else stays on
 // conv3x3_halo_x3_kernel.  KEEP_X3_NO_STREAM=1: round 3's kernel everywhere (A/B runs).
 bool keep_conv_x3_stream_ok(const keep_conv2d_args* a, const ConvP& p, int split_k) {
   static const bool off = getenv("KEEP_X3_NO_STREAM") != nullptr;
-  const bool simple = split_k == 1 && !a->aux && a->epi_act == KEEP_ACT_NONE;
+  const bool simple = split_k == 1 && !a->aux;      // (an epilogue activation is one uniform branch per row here: ParseNet's LeakyReLU)
   const bool aff = a->pro_scale != nullptr;
   return !off && simple && a->Ho % 8 == 0 && a->Wo % 32 == 0 && a->Cin >= 32 && a->upsample != KEEP_UPSAMPLE_X2_PHASES &&
          (a->pro_act == KEEP_PRO_NONE || (aff && (a->pro_act == KEEP_PRO_RELU || (a->pro_act == KEEP_PRO_SWISH && p.fast)))) &&
@@ -570,7 +581,7 @@ int keep_conv2d_x3_stream(const keep_conv2d_args* a, ConvP& p, int n_cu, hipStre
 #ifdef KEEP_X3_ABLATE
   if (getenv("KEEP_X3_EXP") && atoi(getenv("KEEP_X3_EXP")) == 21 && a->pro_act == KEEP_PRO_SWISH) {      // timeline of wave 0
     static unsigned long long* dbg = nullptr;
-    if (!dbg) (void)hipMalloc(&dbg, 128);
+    if (!dbg) (void)hipMalloc(&dbg, 128 + 1024 * 16);
     (void)hipMemsetAsync(dbg, 0, 128, st);
     ConvP q = p;
     q.ws = reinterpret_cast<float*>(dbg);
@@ -583,6 +594,29 @@ int keep_conv2d_x3_stream(const keep_conv2d_args* a, ConvP& p, int n_cu, hipStre
     fprintf(stderr, "[x3s timeline] abl %d clock %.0f MHz | blocks %.0f cycles/block %.0f (whole %.0f) | mma+conv %.1f%%  sync %.1f%% | dma issue %.1f%%  epilogue %.1f%%  advance %.1f%%  dma wait %.1f%%  sync %.1f%%\n",
             XS_ABL, (double)h[13] / ((double)h[14] / 100.0), (double)h[12], tot / h[12], (double)h[13] / h[12], 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot,
             100.0 * h[5] / tot, 100.0 * h[6] / tot);
+    {      // block lifetimes of the launch (100 MHz ticks): spread and histogram
+      static unsigned long long se[2048];
+      const int nblk = (int)grid.x < 1024 ? (int)grid.x : 1024;
+      (void)hipMemcpy(se, dbg + 16, nblk * 16, hipMemcpyDeviceToHost);
+      unsigned long long t_min = ~0ull, t_max = 0;
+      for (int b = 0; b < nblk; ++b) {
+        if (se[2 * b] < t_min) t_min = se[2 * b];
+        if (se[2 * b + 1] > t_max) t_max = se[2 * b + 1];
+      }
+      double lsum = 0, lmin = 1e30, lmax = 0;
+      for (int b = 0; b < nblk; ++b) {
+        const double l = (se[2 * b + 1] - se[2 * b]) / 100.0;
+        lsum += l;
+        if (l < lmin) lmin = l;
+        if (l > lmax) lmax = l;
+      }
+      int hist[10] = {0};
+      for (int b = 0; b < nblk; ++b) hist[(int)(9.999 * ((se[2 * b + 1] - se[2 * b]) / 100.0 - lmin) / (lmax - lmin + 1e-9))]++;
+      fprintf(stderr, "[x3s blocks] span %.1f us | block life min %.1f mean %.1f max %.1f us | histogram (min..max, 10 bins):", (t_max - t_min) / 100.0, lmin,
+              lsum / nblk, lmax);
+      for (int i = 0; i < 10; ++i) fprintf(stderr, " %d", hist[i]);
+      fprintf(stderr, "\n");
+    }
     return KEEP_OK;
   }
 #endif

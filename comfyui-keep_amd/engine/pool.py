@@ -75,9 +75,19 @@ class GpuPool:
         atexit.register(self.close)
         # control connections (workers connect as soon as they are up), then the process group, then the one collective
         self._conns = {}
-        self._listener._listener._socket.settimeout(timeout)
-        for _ in range(1, self.world):
-            c = self._listener.accept()
+        sock = getattr(getattr(self._listener, '_listener', None), '_socket', None)      # (accept() itself has no timeout)
+        if sock is not None:
+            sock.settimeout(5.0)
+        deadline = time.monotonic() + timeout
+        while len(self._conns) < self.world - 1:
+            dead = [p.args[p.args.index('--rank') + 1] for p in self._procs if p.poll() is not None]
+            if dead or time.monotonic() > deadline:
+                self.close()
+                raise RuntimeError(f"GPU pool: worker(s) {dead or '?'} did not come up (see their stderr above)")
+            try:
+                c = self._listener.accept()
+            except (socket.timeout, TimeoutError, OSError):
+                continue
             self._conns[int(c.recv())] = c
         t0 = time.perf_counter()
         torch.distributed.init_process_group(backend=backend, init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=self.world)

@@ -13,7 +13,7 @@ import os
 import sys
 import traceback
 import types
-from multiprocessing import shared_memory
+from multiprocessing import resource_tracker, shared_memory
 from multiprocessing.connection import Client
 
 
@@ -68,6 +68,11 @@ def main():
         _, name_in, name_out, ids, shapes, max_b = msg
         try:
             shm_in, shm_out = shared_memory.SharedMemory(name=name_in), shared_memory.SharedMemory(name=name_out)
+            for m in (shm_in, shm_out):            # the ROOT owns (and unlinks) the blocks: python 3.10 registers attachments with this
+                try:                               # process's resource tracker as well, which would unlink them a second time at exit
+                    resource_tracker.unregister(m._name, 'shared_memory')
+                except Exception:
+                    pass
             try:
                 mine, off = {}, 0
                 for i, s in zip(ids, shapes):

@@ -478,6 +478,39 @@ def test_single_process_pool_drives_two_workers(synth_weights, monkeypatch):
     assert all(p.poll() is not None for p in pool._procs) or not pool._procs
 
 
+def test_node_level_pool_from_the_environment(synth_weights, monkeypatch):
+    """KEEP_AMD_GPUS=2 in the environment of the ONE ComfyUI process: ``KEEPModelPack.load_device()`` (keep_model_loader.py:28-43)
+    starts the pool, ``KEEPFaceProcessor._restore_crops_u8`` -- the clip loop of keep_processor.py:263-270 -- shards its clips over
+    root + worker; the restored crops equal the same processor without a pool, bit for bit."""
+    import test_host_logic as H   # installs the ComfyUI stubs
+    from comfyui_keep_amd.engine.net import KeepNet
+    from comfyui_keep_amd.modules.keep_model_loader import KEEPModelPack
+    from comfyui_keep_amd.modules.keep_processor import KEEPFaceProcessor
+    g = np.random.default_rng(3)
+    crops = [g.integers(0, 256, (512, 512, 3), dtype=np.uint8) for _ in range(7)]          # max_clip_length 2 -> clips of 2, 2, 2, 1
+
+    def restored(with_pool):
+        net = KeepNet(**DEFAULT_ARCH)
+        net.load_state_dict(synth_weights, strict=True)
+        pack = KEEPModelPack(net.eval(), H._Helper(), None, None, 'KEEP')
+        pack.device = torch.device('cuda')
+        pack.load_device()
+        assert (net.pool is not None) == with_pool
+        try:
+            return KEEPFaceProcessor(pack)._restore_crops_u8(crops, 2)
+        finally:
+            if net.pool is not None:
+                net.pool.close()
+                net.pool = None
+
+    solo = restored(False)
+    monkeypatch.setenv('KEEP_AMD_GPUS', '2')
+    monkeypatch.setenv('KEEP_DIST_DEVICE', '0')
+    pooled = restored(True)
+    assert len(pooled) == 7 and all(np.array_equal(a, b) for a, b in zip(pooled, solo))
+    assert not torch.distributed.is_initialized()
+
+
 def _rccl_world1_worker(rank, port, out_dir):
     os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY='0')

@@ -37,6 +37,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
     case KEEP_ACT_RELU: return relu_keep_nan(v);   // (NaN < 0 is false: a NaN stays a NaN)
     case KEEP_ACT_LRELU02: return v < 0.f ? 0.2f * v : v;
+    case KEEP_ACT_LRELU01: return v < 0.f ? 0.1f * v : v;
     case KEEP_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     case KEEP_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
     default: return v;
@@ -57,6 +58,7 @@ __device__ __forceinline__ float act_apply_fast(float v, int act) {
   switch (act) {
     case KEEP_ACT_RELU: return relu_keep_nan(v);   // (NaN < 0 is false: a NaN stays a NaN)
     case KEEP_ACT_LRELU02: return v < 0.f ? 0.2f * v : v;
+    case KEEP_ACT_LRELU01: return v < 0.f ? 0.1f * v : v;
     case KEEP_ACT_GELU: return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f));
     case KEEP_ACT_SIGMOID: return __frcp_rn(1.0f + __expf(-v));
     default: return v;

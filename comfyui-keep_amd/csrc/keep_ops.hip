@@ -626,6 +626,56 @@ extern "C" int32_t keep_maxpool3s2(const float* x, float* out, int32_t N, int32_
   return KEEP_OK;
 }
 
+// Depthwise 3x3 convolution (padding 1, stride 1 | 2) + bias + activation on NHWC maps: the first half of every conv_dw block of
+// the retinaface_mobile0.25 trunk (retinaface_net.py:25-34), BatchNorm folded into w / bias by the host.  Pure streaming work
+// (9 MACs per loaded float): one thread owns 4 channels of one output pixel, the 9 taps are float4 loads that neighbouring
+// threads (consecutive channel groups, then consecutive pixels) coalesce; the input row is re-read from L2 by the 3 output rows
+// that touch it.  Taps accumulate ky-major, kx-minor (the order oracle/facelib_oracle.py restates).
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float4* __restrict__ x, const float4* __restrict__ w,
+                                                        const float4* __restrict__ bias, float4* __restrict__ out, int N, int H, int W,
+                                                        int Ho, int Wo, int C4, int stride, int act) {
+  const long total = (long)N * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float4 a = bias ? bias[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * stride - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * stride - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        const float4 v = x[(((long)n * H + iy) * W + ix) * C4 + c];
+        const float4 k = w[(ky * 3 + kx) * C4 + c];
+        a.x = fmaf(v.x, k.x, a.x); a.y = fmaf(v.y, k.y, a.y); a.z = fmaf(v.z, k.z, a.z); a.w = fmaf(v.w, k.w, a.w);
+      }
+    }
+    out[i] = make_float4(act_apply(a.x, act), act_apply(a.y, act), act_apply(a.z, act), act_apply(a.w, act));
+  }
+}
+
+extern "C" int32_t keep_dwconv3x3(const float* x, const float* w, const float* bias, float* out, int32_t N, int32_t H, int32_t W,
+                                  int32_t C, int32_t stride, int32_t act, void* stream) {
+  KEEP_REQUIRE(x && w && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2) &&
+                   act >= KEEP_ACT_NONE && act <= KEEP_ACT_LRELU01 && (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 &&
+                   (uintptr_t)out % 16 == 0 && (uintptr_t)bias % 16 == 0,
+               "keep_dwconv3x3: bad args (C %% 4 == 0, stride 1 | 2, 16-byte aligned tensors)");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const long total = (long)N * Ho * Wo * (C / 4);
+  int blocks = cdiv(total, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(dwconv3x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x),
+                     reinterpret_cast<const float4*>(w), reinterpret_cast<const float4*>(bias), reinterpret_cast<float4*>(out), N, H, W,
+                     Ho, Wo, C / 4, stride, act);
+  KEEP_LAUNCH_CHECK("keep_dwconv3x3");
+  return KEEP_OK;
+}
+
 // RetinaFace post-processing on the device (retinaface.py:208-256 per frame; retinaface_utils.py:254-294): per anchor the face
 // score softmax(cls)[1], and -- only for anchors above the confidence threshold -- the decoded box and five landmarks in pixels,
 // appended to the frame's compact list (one atomic slot per survivor).  heads: [N, P, 32] rows of the fused head convolution, per

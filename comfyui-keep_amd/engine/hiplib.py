@@ -12,12 +12,12 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 F32, BF16 = 0, 1
 MMA_F32, MMA_BF16, MMA_X3 = 0, 1, 2
 PRO_NONE, PRO_SWISH, PRO_RELU = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_GELU, ACT_SIGMOID, ACT_LRELU01 = 0, 1, 2, 3, 4, 5
 PAD_ZERO, PAD_REFLECT = 0, 1
 UPSAMPLE_X2_PHASES = 2
 
@@ -81,6 +81,7 @@ _SIGNATURES = {
     'keep_img2tensor': [_vp, _vp, _i64, _vp],
     'keep_channel_argmax': [_vp, _vp, _i64, _i32, _i32, _vp],
     'keep_maxpool3s2': [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    'keep_dwconv3x3': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     'keep_upsample_add': [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     'keep_act_inplace': [_vp, _i64, _i32, _vp],
     'keep_retina_decode': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _vp],

@@ -1,4 +1,4 @@
-"""RetinaFace (resnet50 configuration) on the MI355X kernels, batched over frames -- SURVEY.md 8f-4.
+"""RetinaFace (resnet50 and mobile0.25 configurations) on the MI355X kernels, batched over frames -- SURVEY.md 8f-4.
 
 Reference: ``wm_facelib/detection/retinaface/retinaface.py:83-146`` (RetinaFace.__init__ / forward), ``retinaface_net.py:37-196``
 (SSH, FPN, ClassHead / BboxHead / LandmarkHead), ``retinaface_utils.py:8-36,254-295`` (PriorBox, decode, decode_landm) and the
@@ -17,6 +17,10 @@ How it maps onto the engine
     ``relu(cat(..))`` is the epilogue of each branch's last convolution;
   * the nine 1x1 heads of a level (2 anchors x (2 class + 4 box + 10 landmark) = 32 channels) are ONE 256 -> 32 GEMM whose
     NHWC output is already the ``permute(0, 2, 3, 1)`` layout the reference reshapes to [N, anchors, k];
+  * ``retinaface_mobile0.25`` (detection/__init__.py:38-41; MobileNetV1 is part of the reference tree, retinaface_net.py:101-134,
+    so this configuration is pinned END TO END against the reference's own modules): conv_dw = ``keep_dwconv3x3`` (depthwise 3x3
+    + folded BatchNorm + LeakyReLU(0.1)) followed by a 1x1 ``keep_conv2d`` with the LeakyReLU(0.1) in its epilogue; FPN / SSH take
+    ``leaky = 0.1`` because out_channel = 64 (retinaface_net.py:41-43,74-76); 64 -> 32 fused heads;
   * frames ride the batch axis; logits come back in one D2H copy per chunk of frames and the (tiny) softmax / prior decoding /
     NMS run in numpy on the host, restating retinaface_utils.py (``torchvision.ops.nms`` = greedy IoU suppression).
 """
@@ -34,36 +38,68 @@ from .weights import pack_blob, views
 BN_EPS = 1e-5
 CFG_RE50 = {'min_sizes': [[16, 32], [64, 128], [256, 512]], 'steps': [8, 16, 32], 'variance': [0.1, 0.2], 'clip': False,
             'in_channel': 256, 'out_channel': 256}          # retinaface.py:49-71
+CFG_MNET = {'min_sizes': [[16, 32], [64, 128], [256, 512]], 'steps': [8, 16, 32], 'variance': [0.1, 0.2], 'clip': False,
+            'in_channel': 32, 'out_channel': 64}            # retinaface.py:22-44
 MEAN_BGR = (104.0, 117.0, 123.0)                             # retinaface.py:96-97
 LAYERS = (('layer1', 64, 3, 1), ('layer2', 128, 4, 2), ('layer3', 256, 6, 2), ('layer4', 512, 3, 2))   # ResNet-50
+# MobileNetV1 x0.25 (retinaface_net.py:101-124): (cin, cout, stride); the first entry of stage1 is a plain conv_bn, the rest conv_dw
+MNET_STAGES = (('stage1', ((3, 8, 2), (8, 16, 1), (16, 32, 2), (32, 32, 1), (32, 64, 2), (64, 64, 1))),
+               ('stage2', ((64, 128, 2),) + ((128, 128, 1),) * 5),
+               ('stage3', ((128, 256, 2), (256, 256, 1))))
+BACKBONES = {'resnet50': CFG_RE50, 'mobile0.25': CFG_MNET}
 
 
-def retinaface_state_dict_spec():
-    """name -> shape of RetinaFace('resnet50').state_dict() (BatchNorm num_batches_tracked included)."""
+def backbone_of(state_dict):
+    """Which of the two configurations a state dict belongs to (by the names of its trunk)."""
+    keys = {k.replace('module.', '') for k in state_dict}
+    if 'body.stage1.0.0.weight' in keys:
+        return 'mobile0.25'
+    if 'body.conv1.weight' in keys:
+        return 'resnet50'
+    raise RuntimeError("RetinaFaceEngine: neither a RetinaFace(resnet50) nor a RetinaFace(mobile0.25) state dict")
+
+
+def retinaface_state_dict_spec(backbone='resnet50'):
+    """name -> shape of RetinaFace(backbone).state_dict() (BatchNorm num_batches_tracked included; the classifier of MobileNetV1
+    is dropped by IntermediateLayerGetter, retinaface.py:97-98)."""
     spec = {}
 
     def bn(p, c):
         for leaf in ('weight', 'bias', 'running_mean', 'running_var'):
             spec[f'{p}.{leaf}'] = (c,)
         spec[f'{p}.num_batches_tracked'] = ()
-    spec['body.conv1.weight'] = (64, 3, 7, 7)
-    bn('body.bn1', 64)
-    cin = 64
-    for name, width, n, _ in LAYERS:
-        for i in range(n):
-            p = f'body.{name}.{i}'
-            spec[f'{p}.conv1.weight'] = (width, cin, 1, 1)
-            bn(f'{p}.bn1', width)
-            spec[f'{p}.conv2.weight'] = (width, width, 3, 3)
-            bn(f'{p}.bn2', width)
-            spec[f'{p}.conv3.weight'] = (4 * width, width, 1, 1)
-            bn(f'{p}.bn3', 4 * width)
-            if i == 0:
-                spec[f'{p}.downsample.0.weight'] = (4 * width, cin, 1, 1)
-                bn(f'{p}.downsample.1', 4 * width)
-            cin = 4 * width
-    oc = CFG_RE50['out_channel']
-    for k, c in enumerate((512, 1024, 2048)):
+    cfg = BACKBONES[backbone]
+    if backbone == 'mobile0.25':
+        for stage, blocks in MNET_STAGES:
+            for i, (ci, co, _) in enumerate(blocks):
+                p = f'body.{stage}.{i}'
+                if ci == 3:                                   # conv_bn (retinaface_net.py:6-9)
+                    spec[f'{p}.0.weight'] = (co, ci, 3, 3)
+                    bn(f'{p}.1', co)
+                else:                                         # conv_dw (retinaface_net.py:25-34)
+                    spec[f'{p}.0.weight'] = (ci, 1, 3, 3)
+                    bn(f'{p}.1', ci)
+                    spec[f'{p}.3.weight'] = (co, ci, 1, 1)
+                    bn(f'{p}.4', co)
+    else:
+        spec['body.conv1.weight'] = (64, 3, 7, 7)
+        bn('body.bn1', 64)
+        cin = 64
+        for name, width, n, _ in LAYERS:
+            for i in range(n):
+                p = f'body.{name}.{i}'
+                spec[f'{p}.conv1.weight'] = (width, cin, 1, 1)
+                bn(f'{p}.bn1', width)
+                spec[f'{p}.conv2.weight'] = (width, width, 3, 3)
+                bn(f'{p}.bn2', width)
+                spec[f'{p}.conv3.weight'] = (4 * width, width, 1, 1)
+                bn(f'{p}.bn3', 4 * width)
+                if i == 0:
+                    spec[f'{p}.downsample.0.weight'] = (4 * width, cin, 1, 1)
+                    bn(f'{p}.downsample.1', 4 * width)
+                cin = 4 * width
+    oc = cfg['out_channel']
+    for k, c in enumerate((cfg['in_channel'] * 2, cfg['in_channel'] * 4, cfg['in_channel'] * 8)):
         spec[f'fpn.output{k + 1}.0.weight'] = (oc, c, 1, 1)
         bn(f'fpn.output{k + 1}.1', oc)
     for m in ('merge1', 'merge2'):
@@ -89,7 +125,7 @@ def _fold(sd, conv, bn):
     return (w * s.view(-1, 1, 1, 1)).float(), (b - m * s).float()
 
 
-def prior_boxes(h, w, cfg=CFG_RE50):
+def prior_boxes(h, w, cfg=CFG_RE50):      # (both configurations share min_sizes / steps / clip)
     """PriorBox(cfg, image_size=(h, w)).forward() (retinaface_utils.py:8-36) as a float32 [P,4] array (cx, cy, w, h)."""
     anchors = []
     for k, step in enumerate(cfg['steps']):
@@ -151,13 +187,17 @@ def nms(dets, thresh):
 
 
 class RetinaFaceEngine:
-    def __init__(self, state_dict, precision='x3'):
-        spec = retinaface_state_dict_spec()
+    def __init__(self, state_dict, precision='x3', backbone=None):
+        self.backbone = backbone or backbone_of(state_dict)
+        self.cfg = BACKBONES[self.backbone]
+        # LeakyReLU(0.1) in the FPN / SSH when out_channel <= 64 (retinaface_net.py:41-43,74-76), ReLU (= LeakyReLU(0)) otherwise
+        self._act = L.ACT_LRELU01 if self.cfg['out_channel'] <= 64 else L.ACT_RELU
+        spec = retinaface_state_dict_spec(self.backbone)
         sd = {k.replace('module.', ''): v for k, v in state_dict.items()}
         missing = [k for k in spec if k not in sd]
         bad = [k for k in spec if k in sd and tuple(sd[k].shape) != tuple(spec[k])]
         if missing or bad:
-            raise RuntimeError(f"RetinaFaceEngine: not a RetinaFace(resnet50) state dict: missing {missing[:4]}, shapes {bad[:4]}")
+            raise RuntimeError(f"RetinaFaceEngine: not a RetinaFace({self.backbone}) state dict: missing {missing[:4]}, shapes {bad[:4]}")
         sd = {k: v.detach().float().cpu() for k, v in sd.items()}
         t = {}
 
@@ -166,14 +206,25 @@ class RetinaFaceEngine:
             if w.shape[1] == 1 and w.shape[2] == 1:
                 w = w.reshape(w.shape[0], w.shape[3])
             t[f'{name}.weight'], t[f'{name}.bias'] = w, b.contiguous()
-        put('stem', *_fold(sd, 'body.conv1', 'body.bn1'))
-        for name, width, n, _ in LAYERS:
-            for i in range(n):
-                p = f'body.{name}.{i}'
-                for c in (1, 2, 3):
-                    put(f'{name}.{i}.conv{c}', *_fold(sd, f'{p}.conv{c}', f'{p}.bn{c}'))
-                if i == 0:
-                    put(f'{name}.{i}.down', *_fold(sd, f'{p}.downsample.0', f'{p}.downsample.1'))
+        if self.backbone == 'mobile0.25':
+            for stage, blocks in MNET_STAGES:
+                for i, (ci, _, _) in enumerate(blocks):
+                    p = f'body.{stage}.{i}'
+                    if ci == 3:
+                        put(f'{stage}.{i}', *_fold(sd, f'{p}.0', f'{p}.1'))
+                    else:
+                        w, b = _fold(sd, f'{p}.0', f'{p}.1')                      # depthwise [C,1,3,3] -> tap-major [3,3,C]
+                        t[f'{stage}.{i}.dw.weight'], t[f'{stage}.{i}.dw.bias'] = w[:, 0].permute(1, 2, 0).contiguous(), b.contiguous()
+                        put(f'{stage}.{i}.pw', *_fold(sd, f'{p}.3', f'{p}.4'))
+        else:
+            put('stem', *_fold(sd, 'body.conv1', 'body.bn1'))
+            for name, width, n, _ in LAYERS:
+                for i in range(n):
+                    p = f'body.{name}.{i}'
+                    for c in (1, 2, 3):
+                        put(f'{name}.{i}.conv{c}', *_fold(sd, f'{p}.conv{c}', f'{p}.bn{c}'))
+                    if i == 0:
+                        put(f'{name}.{i}.down', *_fold(sd, f'{p}.downsample.0', f'{p}.downsample.1'))
         for k in (1, 2, 3):
             put(f'fpn.output{k}', *_fold(sd, f'fpn.output{k}.0', f'fpn.output{k}.1'))
         for m in ('merge1', 'merge2'):
@@ -212,7 +263,7 @@ class RetinaFaceEngine:
         self.w = views(self._dev, self._index)
         self._mean = torch.tensor(MEAN_BGR, dtype=torch.float32, device=device)
         if self.precision == 'x3':
-            names = [n for n, (_, sh) in self._index.items() if len(sh) >= 2 and sh[-1] % 16 == 0]
+            names = [n for n, (_, sh) in self._index.items() if len(sh) >= 2 and sh[-1] % 16 == 0 and not n.endswith('.dw.weight')]
             bx, table = ops.make_x3_blob(self._dev, self._index, self.w, names)       # one power-of-two scale per tensor
             self.o.set_precision(L.MMA_X3, self._dev, None, bx, 1.0, x3_scales=table)
         else:
@@ -241,30 +292,17 @@ class RetinaFaceEngine:
             raise RuntimeError("RetinaFaceEngine: call .to('cuda') first")
         with torch.cuda.device(self.device):
             self.o.begin_forward(self.device)
-            y = self._c(x.contiguous(), 'stem', stride=2, pad=3, act=L.ACT_RELU)
-            N, H, W, C = y.shape
-            p = ops.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), y)
-            L.call('keep_maxpool3s2', y, p, N, H, W, C)
-            x = p
-            feats = []
-            for name, width, n, stride in LAYERS:
-                for i in range(n):
-                    s = stride if i == 0 else 1
-                    idt = self._c(x, f'{name}.{i}.down', stride=s) if i == 0 else x
-                    h = self._c(x, f'{name}.{i}.conv1', act=L.ACT_RELU)
-                    h = self._c(h, f'{name}.{i}.conv2', stride=s, pad=1, act=L.ACT_RELU)
-                    x = self._relu_(self._c(h, f'{name}.{i}.conv3', residual=idt))
-                if name != 'layer1':
-                    feats.append(x)
+            act = self._act
+            feats = self._mobilenet(x.contiguous()) if self.backbone == 'mobile0.25' else self._resnet50(x.contiguous())
             # FPN (retinaface_net.py:79-98)
-            o1, o2, o3 = (self._c(f, f'fpn.output{k + 1}', act=L.ACT_RELU) for k, f in enumerate(feats))
+            o1, o2, o3 = (self._c(f, f'fpn.output{k + 1}', act=act) for k, f in enumerate(feats))
 
             def up_add(a, b):
                 out = torch.empty_like(a)
                 L.call('keep_upsample_add', a, b, out, a.shape[0], a.shape[1], a.shape[2], b.shape[1], b.shape[2], a.shape[3])
                 return out
-            o2 = self._c(up_add(o2, o3), 'fpn.merge2', pad=1, act=L.ACT_RELU)
-            o1 = self._c(up_add(o1, o2), 'fpn.merge1', pad=1, act=L.ACT_RELU)
+            o2 = self._c(up_add(o2, o3), 'fpn.merge2', pad=1, act=act)
+            o1 = self._c(up_add(o1, o2), 'fpn.merge1', pad=1, act=act)
             outs = []
             for k, f in enumerate((o1, o2, o3)):
                 s = f'ssh{k + 1}'
@@ -273,12 +311,48 @@ class RetinaFaceEngine:
                 flat = cat.view(-1)
                 # relu(cat[conv3X3 | conv5X5 | conv7X7]) == cat of the three ReLUs: each branch's last conv writes its slice
                 self._c(f, f'{s}.conv3X3', pad=1, act=L.ACT_RELU, out=flat, out_ld=C)
-                c5 = self._c(f, f'{s}.conv5X5_1', pad=1, act=L.ACT_RELU)
+                c5 = self._c(f, f'{s}.conv5X5_1', pad=1, act=act)
                 self._c(c5, f'{s}.conv5X5_2', pad=1, act=L.ACT_RELU, out=flat[C // 2:], out_ld=C)
-                c7 = self._c(c5, f'{s}.conv7X7_2', pad=1, act=L.ACT_RELU)
+                c7 = self._c(c5, f'{s}.conv7X7_2', pad=1, act=act)
                 self._c(c7, f'{s}.conv7x7_3', pad=1, act=L.ACT_RELU, out=flat[C // 2 + C // 4:], out_ld=C)
                 outs.append(self._c(cat, f'heads.{k}'))
             return outs
+
+    def _resnet50(self, x):
+        """torchvision ResNet-50 v1.5 up to layer4 -> the layer2 / layer3 / layer4 maps (retinaface.py:100-102)."""
+        y = self._c(x, 'stem', stride=2, pad=3, act=L.ACT_RELU)
+        N, H, W, C = y.shape
+        p = ops.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), y)
+        L.call('keep_maxpool3s2', y, p, N, H, W, C)
+        x = p
+        feats = []
+        for name, width, n, stride in LAYERS:
+            for i in range(n):
+                s = stride if i == 0 else 1
+                idt = self._c(x, f'{name}.{i}.down', stride=s) if i == 0 else x
+                h = self._c(x, f'{name}.{i}.conv1', act=L.ACT_RELU)
+                h = self._c(h, f'{name}.{i}.conv2', stride=s, pad=1, act=L.ACT_RELU)
+                x = self._relu_(self._c(h, f'{name}.{i}.conv3', residual=idt))
+            if name != 'layer1':
+                feats.append(x)
+        return feats
+
+    def _mobilenet(self, x):
+        """MobileNetV1 x0.25 (retinaface_net.py:101-124) -> the stage1 / stage2 / stage3 maps (64, 128, 256 channels at strides
+        8, 16, 32; return_layers of cfg_mnet, retinaface.py:37-41)."""
+        feats = []
+        for stage, blocks in MNET_STAGES:
+            for i, (ci, co, stride) in enumerate(blocks):
+                if ci == 3:
+                    x = self._c(x, f'{stage}.{i}', stride=stride, pad=1, act=L.ACT_LRELU01)
+                    continue
+                N, H, W, C = x.shape
+                d = ops.empty((N, (H - 1) // stride + 1, (W - 1) // stride + 1, C), x)
+                L.call('keep_dwconv3x3', x, self.w[f'{stage}.{i}.dw.weight'], self.w[f'{stage}.{i}.dw.bias'], d, N, H, W, C, stride,
+                       L.ACT_LRELU01)
+                x = self._c(d, f'{stage}.{i}.pw', act=L.ACT_LRELU01)
+            feats.append(x)
+        return feats
 
     def raw_heads(self, x_nhwc):
         """-> [N, P, 32]: the fused head convolutions of the three FPN levels, rows = pixels in the reference's prior order
@@ -304,7 +378,7 @@ class RetinaFaceEngine:
         N, H, W, _ = frames.shape
         key = (H, W)
         if key not in self._priors:
-            self._priors[key] = prior_boxes(H, W)
+            self._priors[key] = prior_boxes(H, W, self.cfg)
         priors = self._priors[key]
         scale = np.array([W, H, W, H], np.float32)
         scale1 = np.array([W, H] * 5, np.float32)
@@ -331,7 +405,7 @@ class RetinaFaceEngine:
                 dets = torch.empty((n, cap, 16), dtype=torch.float32, device=self.device)
                 counts = torch.zeros(n, dtype=torch.int32, device=self.device)
                 L.call('keep_retina_decode', heads, self._priors_dev[key], dets, counts, n, P, cap,
-                       float(CFG_RE50['variance'][0]), float(CFG_RE50['variance'][1]), float(W), float(H), float(conf_threshold))
+                       float(self.cfg['variance'][0]), float(self.cfg['variance'][1]), float(W), float(H), float(conf_threshold))
                 cnt = counts.cpu().numpy()
                 kmax = int(min(cnt.max(initial=0), cap))
                 rows = dets[:, :kmax].cpu().numpy() if kmax else np.zeros((n, 0, 16), np.float32)
@@ -359,8 +433,8 @@ class RetinaFaceEngine:
         lm = flat[:, 12:32].reshape(-1, 10)
         e = np.exp(cls - cls.max(1, keepdims=True))
         scores = (e[:, 1] / e.sum(1)).astype(np.float32)                          # F.softmax(classifications, -1)[:, 1]
-        boxes = decode_boxes(loc, priors, CFG_RE50['variance']) * scale
-        lms = decode_landmarks(lm, priors, CFG_RE50['variance']) * scale1
+        boxes = decode_boxes(loc, priors, self.cfg['variance']) * scale
+        lms = decode_landmarks(lm, priors, self.cfg['variance']) * scale1
         inds = np.where(scores > conf_threshold)[0]
         boxes, lms, sc = boxes[inds], lms[inds], scores[inds]
         order = sc.argsort()[::-1]
@@ -382,13 +456,13 @@ class RetinaFaceEngine:
 
 
 class EngineRetinaFace:
-    """Drop-in for the helper's ``face_detector`` (an ``init_detection_model('retinaface_resnet50')`` RetinaFace): the calls
+    """Drop-in for the helper's ``face_detector`` (an ``init_detection_model('retinaface_resnet50' | 'retinaface_mobile0.25')``
+    RetinaFace, detection/__init__.py:34-41): the calls
     FaceRestoreHelper makes -- ``detect_faces(image, conf_threshold)`` -- plus ``detect_batch`` for the processor's batched
     pre-pass over a whole video (one engine call per chunk of frames instead of one detector call per frame)."""
-    backbone = 'Resnet50'
-
     def __init__(self, engine):
         self.engine = engine
+        self.backbone = {'resnet50': 'Resnet50', 'mobile0.25': 'mobilenet0.25'}[engine.backbone]      # cfg['name'], retinaface.py:24,47
 
     @classmethod
     def from_module(cls, module, device=None, precision='x3'):
@@ -412,24 +486,25 @@ class EngineRetinaFace:
         return self
 
 
-def synth_retinaface_state_dict(seed=0):
-    """Deterministic synthetic RetinaFace(resnet50) weights: He-like conv weights, BatchNorm gamma 1 +- 0.1 (0.5 on the last BN of
+def synth_retinaface_state_dict(seed=0, backbone='resnet50'):
+    """Deterministic synthetic RetinaFace(resnet50 | mobile0.25) weights: He-like conv weights, BatchNorm gamma 1 +- 0.1 (0.5 on the last BN of
     a Bottleneck so the residual stream stays O(1) over 16 blocks), beta / mean +- 0.1, var in [0.7, 1.3]."""
     from .synth import uniform_pm1
     out = {}
-    for name, shape in retinaface_state_dict_spec().items():
+    tag = 'retinaface.' if backbone == 'resnet50' else f'retinaface[{backbone}].'
+    for name, shape in retinaface_state_dict_spec(backbone).items():
         leaf = name.rsplit('.', 1)[-1]
         if leaf == 'num_batches_tracked':
             out[name] = torch.tensor(100, dtype=torch.int64)
             continue
         n = int(np.prod(shape))
-        u = uniform_pm1('retinaface.' + name, n, seed)
+        u = uniform_pm1(tag + name, n, seed)
         if len(shape) == 4:
             v = u * (math.sqrt(3.0) * math.sqrt(2.0 / (shape[1] * shape[2] * shape[3])))
-            if name == 'body.conv1.weight':
+            if name in ('body.conv1.weight', 'body.stage1.0.0.weight'):
                 v = v * 0.01            # inputs are BGR - mean, O(100): bring the stem's output to O(1) like a trained BatchNorm does
             elif 'Head' in name:
-                v = v * 0.2             # logits / regressions of a few units: an informative softmax, exp() in range
+                v = v * (0.2 if backbone == 'resnet50' else 2.0)   # logits / regressions of a few units: an informative softmax, exp() in range
         elif leaf == 'running_var':
             v = 1.0 + 0.3 * u
         elif leaf == 'weight':

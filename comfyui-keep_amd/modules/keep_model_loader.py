@@ -72,10 +72,10 @@ def engine_facelib(helper):
         helper.face_parse = EngineFaceParse.from_module(fp)
         logger.debug("face_parse (ParseNet) runs on the HIP engine")
     det = getattr(helper, 'face_detector', None)
-    if det is not None and hasattr(det, 'state_dict') and getattr(det, 'backbone', None) == 'Resnet50':
+    if det is not None and hasattr(det, 'state_dict') and getattr(det, 'backbone', None) in ('Resnet50', 'mobilenet0.25'):
         from ..engine.retinaface import EngineRetinaFace
-        helper.face_detector = EngineRetinaFace.from_module(det)
-        logger.debug("face_detector (RetinaFace resnet50) runs on the HIP engine")
+        helper.face_detector = EngineRetinaFace.from_module(det)            # (the configuration is read off the state dict)
+        logger.debug("face_detector (RetinaFace %s) runs on the HIP engine", det.backbone)
     return helper
 
 

@@ -30,7 +30,7 @@ extern "C" {
  * the fields a shorter known layout lacks as zero), keep_sizeof_*_args(), keep_argmax_gather takes the non-finite status word,
  * keep_nonfinite_flag.  v13: keep_conv2d_args.upsample accepts KEEP_UPSAMPLE_X2_PHASES (same layout; a v12 library refuses the
  * value, so the binding asks for 13). */
-#define KEEP_ABI_VERSION 14
+#define KEEP_ABI_VERSION 15
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -65,6 +65,7 @@ extern "C" {
 #define KEEP_ACT_LRELU02 2 /* LeakyReLU(0.2)        KA:449,454 */
 #define KEEP_ACT_GELU 3    /* exact erf GELU        KA:437, GM/transformer.py:141 */
 #define KEEP_ACT_SIGMOID 4 /* KA:771 */
+#define KEEP_ACT_LRELU01 5 /* LeakyReLU(0.1): MobileNetV1 / FPN / SSH of retinaface_mobile0.25, retinaface_net.py:6-34,41-43,74-76 */
 
 /* padding mode of keep_conv2d */
 #define KEEP_UPSAMPLE_X2_PHASES 2
@@ -328,6 +329,12 @@ int32_t keep_channel_argmax(const float* x, uint8_t* out, int64_t M, int32_t C, 
 /* ---- face detection (wm_facelib/detection/retinaface on keep_conv2d, engine/retinaface.py) ----
  * nn.MaxPool2d(3, stride 2, padding 1) of the ResNet-50 stem on an NHWC map: [N,H,W,C] -> [N,(H-1)/2+1,(W-1)/2+1,C] */
 int32_t keep_maxpool3s2(const float* x, float* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+/* depthwise 3x3 convolution, padding 1, stride 1 or 2, + bias + activation (v15): the first half of a conv_dw block of the
+ * retinaface_mobile0.25 trunk with its BatchNorm folded (retinaface_net.py:25-34: Conv2d(inp, inp, 3, stride, 1, groups=inp) +
+ * BatchNorm2d + LeakyReLU(0.1)).  x [N,H,W,C] NHWC, w [3][3][C] (tap-major: w[ky][kx][c] = weight[c, 0, ky, kx]), bias [C] or
+ * NULL, out [N,(H-1)/stride+1,(W-1)/stride+1,C]; C % 4 == 0.  Taps are accumulated ky-major, kx-minor in float32. */
+int32_t keep_dwconv3x3(const float* x, const float* w, const float* bias, float* out, int32_t N, int32_t H, int32_t W, int32_t C,
+                       int32_t stride, int32_t act, void* stream);
 /* FPN top-down step (retinaface_net.py:86-92): out = a + nearest-resize(b [N,hb,wb,C] -> [N,H,W,C]) */
 int32_t keep_upsample_add(const float* a, const float* b, float* out, int32_t N, int32_t H, int32_t W, int32_t hb, int32_t wb,
                           int32_t C, void* stream);

@@ -4,15 +4,17 @@ cpu_baseline leg are the only callers of anything under oracle/).
 CPU restatements (plain PyTorch fp32) of the two face-analysis networks either side of the KEEP hot path:
 
   * ``parsenet_forward``    wm_facelib/parsing/parsenet.py:72-194 (ConvLayer / ResidualBlock / ParseNet.forward)
-  * ``retinaface_forward``  wm_facelib/detection/retinaface/retinaface.py:83-146 (RetinaFace.forward, resnet50 configuration),
-                            retinaface_net.py:37-196 (SSH, FPN, heads) and retinaface_utils.py (PriorBox, decode, NMS)
+  * ``retinaface_forward``  wm_facelib/detection/retinaface/retinaface.py:83-146 (RetinaFace.forward, resnet50 and mobile0.25
+                            configurations), retinaface_net.py:25-34,101-124 (conv_dw, MobileNetV1), 37-196 (SSH, FPN, heads) and
+                            retinaface_utils.py (PriorBox, decode, NMS)
 
 Pinned against the imported reference modules by ``oracle/make_golden_facelib.py`` -> ``tests/golden/facelib.npz``
 (``tests/test_oracle_vs_golden.py``).  PARITY UNPINNED for the ResNet-50 trunk of RetinaFace: the reference takes it from
 ``torchvision.models.resnet50`` (retinaface.py:103-105), torchvision is not vendored under /root/reference and not installed
 in the build image; the trunk below restates torchvision's published ResNet-50 v1.5 (Bottleneck with the stride on the 3x3
 convolution, state-dict names ``body.conv1 / bn1 / layer{1..4}.{i}.conv{1,2,3} / bn{1,2,3} / downsample.{0,1}``) and the golden
-generator feeds the SAME restated trunk to the reference's FPN / SSH / heads.
+generator feeds the SAME restated trunk to the reference's FPN / SSH / heads.  The mobile0.25 configuration has no such gap:
+MobileNetV1 is the reference's own class, and its golden is the output of the reference's modules from image to heads.
 """
 import math
 
@@ -64,11 +66,36 @@ def parsenet_forward(x, W, blocks):
     raise AssertionError('no out_mask_conv in the block list')
 
 
-# ------------------------------------------------------------------------------------------------------- RetinaFace (resnet50)
-def _cbr(x, W, conv, bn, stride=1, pad=0, relu=True):
-    x = F.conv2d(x, W[f'{conv}.weight'], None, stride=stride, padding=pad)
+# ------------------------------------------------------------------------------------------------------- RetinaFace (resnet50, mobile0.25)
+def _cbr(x, W, conv, bn, stride=1, pad=0, relu=True, leaky=0.0, groups=1):
+    x = F.conv2d(x, W[f'{conv}.weight'], None, stride=stride, padding=pad, groups=groups)
     x = F.batch_norm(x, W[f'{bn}.running_mean'], W[f'{bn}.running_var'], W[f'{bn}.weight'], W[f'{bn}.bias'], False, 0.0, BN_EPS)
-    return F.relu(x) if relu else x
+    if not relu:
+        return x
+    return F.leaky_relu(x, leaky) if leaky else F.relu(x)
+
+
+MNET_STAGES = (('stage1', ((3, 8, 2), (8, 16, 1), (16, 32, 2), (32, 32, 1), (32, 64, 2), (64, 64, 1))),
+               ('stage2', ((64, 128, 2),) + ((128, 128, 1),) * 5),
+               ('stage3', ((128, 256, 2), (256, 256, 1))))
+
+
+def mobilenet_trunk(x, W):
+    """MobileNetV1 x0.25 as RetinaFace('mobile0.25') uses it (retinaface_net.py:101-124 through IntermediateLayerGetter with
+    return_layers stage1 / stage2 / stage3, retinaface.py:37-41,96-98): conv_bn(3, 8, stride 2, leaky 0.1), then conv_dw blocks =
+    depthwise 3x3 (groups = channels) + BN + LeakyReLU(0.1), 1x1 + BN + LeakyReLU(0.1) (retinaface_net.py:25-34).
+    Pinned: tests/golden/facelib.npz holds the reference modules' own outputs (oracle/make_golden_facelib.py)."""
+    feats = []
+    for stage, blocks in MNET_STAGES:
+        for i, (ci, co, stride) in enumerate(blocks):
+            p = f'body.{stage}.{i}'
+            if ci == 3:
+                x = _cbr(x, W, f'{p}.0', f'{p}.1', stride=stride, pad=1, leaky=0.1)
+            else:
+                x = _cbr(x, W, f'{p}.0', f'{p}.1', stride=stride, pad=1, leaky=0.1, groups=ci)
+                x = _cbr(x, W, f'{p}.3', f'{p}.4', leaky=0.1)
+        feats.append(x)
+    return feats
 
 
 def resnet50_trunk(x, W):
@@ -92,22 +119,23 @@ def resnet50_trunk(x, W):
     return feats
 
 
-def retinaface_forward(x, W):
+def retinaface_forward(x, W, backbone='resnet50'):
     """RetinaFace.forward, phase 'test' (retinaface.py:124-146) -> (bbox_regressions [N,P,4], softmax conf [N,P,2], landmarks [N,P,10])."""
-    f = resnet50_trunk(x, W)
-    # FPN, retinaface_net.py:79-98 (out_channels 256 -> leaky 0 = ReLU)
-    o1 = _cbr(f[0], W, 'fpn.output1.0', 'fpn.output1.1')
-    o2 = _cbr(f[1], W, 'fpn.output2.0', 'fpn.output2.1')
-    o3 = _cbr(f[2], W, 'fpn.output3.0', 'fpn.output3.1')
-    o2 = _cbr(o2 + F.interpolate(o3, size=o2.shape[2:], mode='nearest'), W, 'fpn.merge2.0', 'fpn.merge2.1', pad=1)
-    o1 = _cbr(o1 + F.interpolate(o2, size=o1.shape[2:], mode='nearest'), W, 'fpn.merge1.0', 'fpn.merge1.1', pad=1)
+    f = mobilenet_trunk(x, W) if backbone == 'mobile0.25' else resnet50_trunk(x, W)
+    # FPN, retinaface_net.py:66-98 (out_channels 256 -> leaky 0 = ReLU; 64 -> LeakyReLU(0.1), lines 74-76; SSH likewise, 41-43)
+    lk = 0.1 if W['fpn.output1.0.weight'].shape[0] <= 64 else 0.0
+    o1 = _cbr(f[0], W, 'fpn.output1.0', 'fpn.output1.1', leaky=lk)
+    o2 = _cbr(f[1], W, 'fpn.output2.0', 'fpn.output2.1', leaky=lk)
+    o3 = _cbr(f[2], W, 'fpn.output3.0', 'fpn.output3.1', leaky=lk)
+    o2 = _cbr(o2 + F.interpolate(o3, size=o2.shape[2:], mode='nearest'), W, 'fpn.merge2.0', 'fpn.merge2.1', pad=1, leaky=lk)
+    o1 = _cbr(o1 + F.interpolate(o2, size=o1.shape[2:], mode='nearest'), W, 'fpn.merge1.0', 'fpn.merge1.1', pad=1, leaky=lk)
     feats = []
     for k, o in enumerate((o1, o2, o3)):          # SSH, retinaface_net.py:37-63
         s = f'ssh{k + 1}'
         c3 = _cbr(o, W, f'{s}.conv3X3.0', f'{s}.conv3X3.1', pad=1, relu=False)
-        c51 = _cbr(o, W, f'{s}.conv5X5_1.0', f'{s}.conv5X5_1.1', pad=1)
+        c51 = _cbr(o, W, f'{s}.conv5X5_1.0', f'{s}.conv5X5_1.1', pad=1, leaky=lk)
         c5 = _cbr(c51, W, f'{s}.conv5X5_2.0', f'{s}.conv5X5_2.1', pad=1, relu=False)
-        c72 = _cbr(c51, W, f'{s}.conv7X7_2.0', f'{s}.conv7X7_2.1', pad=1)
+        c72 = _cbr(c51, W, f'{s}.conv7X7_2.0', f'{s}.conv7X7_2.1', pad=1, leaky=lk)
         c7 = _cbr(c72, W, f'{s}.conv7x7_3.0', f'{s}.conv7x7_3.1', pad=1, relu=False)
         feats.append(F.relu(torch.cat([c3, c5, c7], 1)))
 

@@ -73,9 +73,53 @@ def retinaface_golden():
     boxes = utils.decode(heads['BboxHead'][0], priors, cfg['variance'])
     lms = utils.decode_landm(heads['LandmarkHead'][0], priors, cfg['variance'])
     print('RetinaFace golden: conf range', float(conf[..., 1].min()), float(conf[..., 1].max()), 'priors', tuple(priors.shape))
-    return {'retinaface_loc': heads['BboxHead'].numpy().astype(np.float32), 'retinaface_conf': conf.numpy().astype(np.float32),
+    extra = retinaface_mnet_golden(net, utils)
+    return {**extra, 'retinaface_loc': heads['BboxHead'].numpy().astype(np.float32), 'retinaface_conf': conf.numpy().astype(np.float32),
             'retinaface_landm': heads['LandmarkHead'].numpy().astype(np.float32), 'retinaface_priors': priors.numpy().astype(np.float32),
             'retinaface_boxes0': boxes.numpy().astype(np.float32), 'retinaface_lms0': lms.numpy().astype(np.float32)}
+
+
+def retinaface_mnet_golden(net, utils):
+    """RetinaFace('mobile0.25') END TO END on the reference's own modules: MobileNetV1 (stage1 / stage2 / stage3, what
+    IntermediateLayerGetter returns for cfg_mnet's return_layers, retinaface.py:37-41,96-98), FPN([64, 128, 256], 64), three
+    SSH(64, 64) and the heads (retinaface.py:100-122), composed in the order of RetinaFace.forward (retinaface.py:129-146).
+    (RetinaFace itself is not instantiated: its module imports torchvision and cv2.)"""
+    from comfyui_keep_amd.engine import retinaface as RF
+    W = RF.synth_retinaface_state_dict(seed=0, backbone='mobile0.25')
+    x = op_input('retinaface_mnet_img', (2, 3, 160, 224), 100.0)
+    with torch.no_grad():
+        body = net.MobileNetV1().eval()
+        missing = body.load_state_dict({k[5:]: v for k, v in W.items() if k.startswith('body.')}, strict=False)
+        assert not missing.unexpected_keys and set(missing.missing_keys) == {'fc.weight', 'fc.bias'}, missing     # (the classifier is not part of the detector)
+        feats = []
+        h = x
+        for stage in (body.stage1, body.stage2, body.stage3):
+            h = stage(h)
+            feats.append(h)
+        fpn = net.FPN([64, 128, 256], 64).eval()
+        fpn.load_state_dict({k[4:]: v for k, v in W.items() if k.startswith('fpn.')}, strict=True)
+        pyr = fpn(feats)
+        sshs = []
+        for k in (1, 2, 3):
+            m = net.SSH(64, 64).eval()
+            m.load_state_dict({kk[5:]: v for kk, v in W.items() if kk.startswith(f'ssh{k}.')}, strict=True)
+            sshs.append(m(pyr[k - 1]))
+        heads = {}
+        for name, maker in (('ClassHead', net.make_class_head), ('BboxHead', net.make_bbox_head), ('LandmarkHead', net.make_landmark_head)):
+            hs = maker(fpn_num=3, inchannels=64).eval()
+            hs.load_state_dict({kk[len(name) + 1:]: v for kk, v in W.items() if kk.startswith(name + '.')}, strict=True)
+            heads[name] = torch.cat([hs[i](f) for i, f in enumerate(sshs)], dim=1)
+    conf = torch.softmax(heads['ClassHead'], dim=-1)
+    cfg = dict(RF.CFG_MNET)
+    priors = utils.PriorBox(cfg, image_size=(160, 224)).forward()
+    boxes = utils.decode(heads['BboxHead'][0], priors, cfg['variance'])
+    lms = utils.decode_landm(heads['LandmarkHead'][0], priors, cfg['variance'])
+    print('RetinaFace(mobile0.25) golden: conf range', float(conf[..., 1].min()), float(conf[..., 1].max()),
+          'feature rms', [float(f.pow(2).mean().sqrt()) for f in feats])
+    return {'mnet_stage_grid': torch.cat([f[:, ::8, ::3, ::5].reshape(-1) for f in feats]).numpy().astype(np.float32),
+            'mnet_loc': heads['BboxHead'].numpy().astype(np.float32), 'mnet_conf': conf.numpy().astype(np.float32),
+            'mnet_landm': heads['LandmarkHead'].numpy().astype(np.float32),
+            'mnet_boxes0': boxes.numpy().astype(np.float32), 'mnet_lms0': lms.numpy().astype(np.float32)}
 
 
 def main():

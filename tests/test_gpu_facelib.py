@@ -129,6 +129,66 @@ def test_retinaface_engine_vs_reference_golden(precision):
         assert len(dets[i]) <= len(keep_ref) + int((~sure).sum())
 
 
+@pytest.mark.parametrize("precision", ['x3', 'fp32'])
+def test_retinaface_mobile025_engine_vs_reference_golden(precision):
+    """RetinaFace('mobile0.25') on the engine against the golden of the reference's OWN modules from image to heads (MobileNetV1,
+    FPN, SSH, heads: nothing restated in between), then detect_batch against the oracle network + host post-processing."""
+    from comfyui_keep_amd.engine import retinaface as RF
+    W = RF.synth_retinaface_state_dict(seed=0, backbone='mobile0.25')
+    eng = RF.RetinaFaceEngine(W, precision=precision).to('cuda')
+    assert eng.backbone == 'mobile0.25'
+    x = op_input('retinaface_mnet_img', (2, 3, 160, 224), 100.0)
+    loc, cls, lm = (t.cpu() for t in eng.raw_outputs(nhwc(x)))
+    conf = torch.softmax(cls, -1)
+    for got, key, tol in ((loc, 'mnet_loc', 3e-4), (conf, 'mnet_conf', 3e-4), (lm, 'mnet_landm', 3e-4)):
+        err = np.abs(got.numpy() - G[key]).max()
+        print(f'RetinaFace mobile0.25 [{precision}] {key}: max-abs diff {err:.3e} (scale {np.abs(G[key]).max():.1f})')
+        assert err <= tol * max(1.0, np.abs(G[key]).max()), (key, err)
+    g = torch.Generator().manual_seed(5)
+    frames = torch.randint(0, 256, (3, 150, 210, 3), generator=g, dtype=torch.uint8)
+    dets = eng.detect_batch(frames, conf_threshold=0.7)
+    single = RF.EngineRetinaFace(eng).detect_faces(frames[2].numpy(), 0.7)
+    assert np.array_equal(single, dets[2])
+    xf = frames.float().permute(0, 3, 1, 2) - torch.tensor(RF.MEAN_BGR).view(1, 3, 1, 1)
+    with torch.no_grad():
+        rloc, rconf, rlm = FO.retinaface_forward(xf, W, backbone='mobile0.25')
+    pri = RF.prior_boxes(150, 210, RF.CFG_MNET)
+    total = 0
+    for i in range(3):
+        sc = rconf[i, :, 1].numpy()
+        sure = (np.abs(sc - 0.7) > 1e-3)
+        boxes = RF.decode_boxes(rloc[i].numpy(), pri, RF.CFG_MNET['variance']) * np.array([210, 150, 210, 150], np.float32)
+        lms = RF.decode_landmarks(rlm[i].numpy(), pri, RF.CFG_MNET['variance']) * np.array([210, 150] * 5, np.float32)
+        keep_ref = np.where((sc > 0.7) & sure)[0]
+        total += len(dets[i])
+        for d in dets[i]:
+            j = np.argmin(np.abs(boxes - d[:4]).sum(1))
+            assert np.abs(boxes[j] - d[:4]).max() <= 1e-2 and abs(sc[j] - d[4]) <= 1e-4 and np.abs(lms[j] - d[5:]).max() <= 1e-2
+        assert len(dets[i]) <= len(keep_ref) + int((~sure).sum())
+    assert total > 0
+
+
+def test_dwconv3x3_vs_torch_grouped_convolution():
+    """keep_dwconv3x3 (depthwise 3x3, padding 1, stride 1 | 2, bias + activation) against F.conv2d(groups = C) on odd and even map
+    sizes, every activation the trunk uses; float32 FMA chains of 9 taps: 1e-6 relative."""
+    import torch.nn.functional as F
+    for (N, H, W, C, stride, act) in ((2, 17, 23, 8, 1, L.ACT_LRELU01), (1, 40, 56, 64, 2, L.ACT_LRELU01), (3, 9, 9, 256, 2, L.ACT_NONE),
+                                      (1, 16, 16, 32, 1, L.ACT_RELU)):
+        x = op_input(f'dw_x{C}', (N, C, H, W))
+        w = op_input(f'dw_w{C}', (C, 1, 3, 3), 0.5)
+        b = op_input(f'dw_b{C}', (C,), 0.2)
+        ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=1, groups=C)
+        ref = {L.ACT_LRELU01: lambda t: F.leaky_relu(t, 0.1), L.ACT_RELU: F.relu, L.ACT_NONE: lambda t: t}[act](ref)
+        xd, wd, bd = nhwc(x), w[:, 0].permute(1, 2, 0).contiguous().cuda(), b.cuda()
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        out = torch.empty((N, Ho, Wo, C), device='cuda')
+        L.call('keep_dwconv3x3', xd, wd, bd, out, N, H, W, C, stride, act)
+        got = out.cpu().permute(0, 3, 1, 2).double()
+        assert got.shape == ref.shape and (got - ref).abs().max() <= 2e-6 * ref.abs().max(), (C, stride, (got - ref).abs().max())
+    with pytest.raises(L.KeepHipError):
+        L.call('keep_dwconv3x3', xd, wd, bd, out, N, H, W, 6, 1, L.ACT_NONE)          # C % 4 != 0: loud
+
+
 def test_retina_decode_on_the_device_equals_the_host_decoder():
     """keep_retina_decode (scores, threshold, decode / decode_landm on the device; only survivors cross PCIe) against the numpy
     decoder of rounds 2-3 on the SAME head rows: the same anchors survive (up to scores within 1e-6 of the threshold), boxes /

@@ -514,7 +514,7 @@ def test_device_crop_warp_hook_keeps_the_helper_contract(monkeypatch):
 
 
 def test_loader_swaps_the_helpers_networks_for_engine_objects(monkeypatch):
-    """SURVEY 8f-4 host logic: ``engine_facelib`` replaces a ParseNet-shaped ``face_parse`` and a RetinaFace(resnet50)-shaped
+    """SURVEY 8f-4 host logic: ``engine_facelib`` replaces a ParseNet-shaped ``face_parse`` and a RetinaFace(resnet50 | mobile0.25)-shaped
     ``face_detector`` by engine-backed objects with the same call surface (weights packed on the host, nothing uploaded until
     ``.to('cuda')``), leaves other detectors alone, and KEEP_AMD_ENGINE_FACELIB=0 switches the swap off."""
     from comfyui_keep_amd.modules.keep_model_loader import engine_facelib
@@ -541,10 +541,17 @@ def test_loader_swaps_the_helpers_networks_for_engine_objects(monkeypatch):
         h.face_parse.engine.logits_nhwc(torch.zeros(1, 128, 128, 3))                                   # loud: not on a device
     h2 = Hp()
     h2.face_parse = object()                                    # not a ParseNet: untouched
-    h2.face_detector = FakeModule({}, backbone='mobilenet0.25')
+    h2.face_detector = FakeModule({}, backbone='YOLOv5')       # no engine counterpart: untouched
     det2 = h2.face_detector
     engine_facelib(h2)
     assert h2.face_detector is det2 and not isinstance(h2.face_parse, PN.EngineFaceParse)
+    hm = Hp()                                                   # retinaface_mobile0.25 (detection/__init__.py:38-41)
+    hm.face_detector = FakeModule(RF.synth_retinaface_state_dict(seed=0, backbone='mobile0.25'), backbone='mobilenet0.25')
+    engine_facelib(hm)
+    assert isinstance(hm.face_detector, RF.EngineRetinaFace) and hm.face_detector.engine.backbone == 'mobile0.25'
+    assert hm.face_detector.backbone == 'mobilenet0.25' and hm.face_detector.engine.w is None
+    with pytest.raises(RuntimeError):                           # a resnet50 trunk under the mobile name: loud
+        RF.RetinaFaceEngine(RF.synth_retinaface_state_dict(seed=0), backbone='mobile0.25')
     monkeypatch.setenv('KEEP_AMD_ENGINE_FACELIB', '0')
     h3 = Hp()
     h3.face_parse = FakeModule(PN.synth_parsenet_state_dict(seed=0, in_size=128, out_size=128))

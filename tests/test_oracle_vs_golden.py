@@ -209,6 +209,19 @@ def test_retinaface_oracle_and_host_decode_vs_reference_golden():
     assert pri.shape == g['retinaface_priors'].shape and np.abs(pri - g['retinaface_priors']).max() <= 1e-7
     assert np.abs(RF.decode_boxes(g['retinaface_loc'][0], pri, RF.CFG_RE50['variance']) - g['retinaface_boxes0']).max() <= 1e-5
     assert np.abs(RF.decode_landmarks(g['retinaface_landm'][0], pri, RF.CFG_RE50['variance']) - g['retinaface_lms0']).max() <= 1e-5
+    # mobile0.25: the reference's OWN MobileNetV1 + FPN + SSH + heads from image to heads (no unpinned part)
+    Wm = RF.synth_retinaface_state_dict(seed=0, backbone='mobile0.25')
+    assert set(Wm) == set(RF.retinaface_state_dict_spec('mobile0.25')) and RF.backbone_of(Wm) == 'mobile0.25' and RF.backbone_of(W) == 'resnet50'
+    xm = op_input('retinaface_mnet_img', (2, 3, 160, 224), 100.0)
+    with torch.no_grad():
+        feats = FO.mobilenet_trunk(xm, Wm)
+        loc, conf, lm = FO.retinaface_forward(xm, Wm, backbone='mobile0.25')
+    grid = torch.cat([f[:, ::8, ::3, ::5].reshape(-1) for f in feats]).numpy()
+    assert [f.shape[1] for f in feats] == [64, 128, 256] and np.abs(grid - g['mnet_stage_grid']).max() <= 1e-5
+    for got, key in ((loc, 'mnet_loc'), (conf, 'mnet_conf'), (lm, 'mnet_landm')):
+        assert np.abs(got.numpy() - g[key]).max() <= 1e-4 * max(1.0, np.abs(g[key]).max()), key
+    assert np.abs(RF.decode_boxes(g['mnet_loc'][0], pri, RF.CFG_MNET['variance']) - g['mnet_boxes0']).max() <= 1e-5
+    assert np.abs(RF.decode_landmarks(g['mnet_landm'][0], pri, RF.CFG_MNET['variance']) - g['mnet_lms0']).max() <= 1e-5
     # greedy NMS: a cluster of overlapping boxes keeps its best, disjoint boxes all survive, order = descending score
     d = np.array([[0, 0, 10, 10, 0.9], [1, 1, 11, 11, 0.95], [20, 20, 30, 30, 0.5], [0, 0, 10, 10.5, 0.7]], np.float32)
     assert RF.nms(d, 0.4) == [1, 2]

@@ -1,4 +1,4 @@
-"""RetinaFace(resnet50) on the engine at 640 x 1138, batch 16: network-only vs host-inclusive time (dev)."""
+"""RetinaFace on the engine at 640 x 1138, batch 16: network-only vs host-inclusive time (dev).  det_prof.py [x3|fp32] [resnet50|mobile0.25]"""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,7 +7,8 @@ from __graft_entry__ import load_package
 load_package()
 from comfyui_keep_amd.engine import retinaface as RF
 prec = sys.argv[1] if len(sys.argv) > 1 else 'x3'
-det = RF.RetinaFaceEngine(RF.synth_retinaface_state_dict(seed=0), precision=prec).to('cuda')
+bb = sys.argv[2] if len(sys.argv) > 2 else 'resnet50'
+det = RF.RetinaFaceEngine(RF.synth_retinaface_state_dict(seed=0, backbone=bb), precision=prec).to('cuda')
 frames = torch.randint(0, 256, (16, 640, 1138, 3), dtype=torch.uint8)
 x = torch.rand((16, 640, 1138, 3), device='cuda') * 255 - 110
 for _ in range(2):
@@ -25,7 +26,7 @@ for _ in range(3):
     r = det.detect_batch(frames, 0.97)
 torch.cuda.synchronize()
 dd = (time.perf_counter() - t0) / 3
-print(f'[{prec}] network only: {dn * 1e3:.1f} ms per 16 frames = {16 / dn:.1f} frames/s | detect_batch (host in/out): {dd * 1e3:.1f} ms = {16 / dd:.1f} frames/s | detections per frame {[len(a) for a in r][:4]}')
+print(f'[{prec} {bb}] network only: {dn * 1e3:.1f} ms per 16 frames = {16 / dn:.1f} frames/s | detect_batch (host in/out): {dd * 1e3:.1f} ms = {16 / dd:.1f} frames/s | detections per frame {[len(a) for a in r][:4]}')
 # section timing of one detect_batch call (synchronising between sections)
 import numpy as np
 def sect():

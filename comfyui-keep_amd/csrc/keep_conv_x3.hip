@@ -764,6 +764,9 @@ __device__ __forceinline__ void x3_gather_epilogue(const ConvP& p, f32x16 (&acc)
 
 #define XBK 32
 #define XP (2 * XBK + 8)
+#ifndef XG_ABL
+#define XG_ABL 0      // dev (tools/dev/README.md): 1 no operand split, 2 no output stores, 3 no MFMAs, 4 no A loads, 5 no B loads
+#endif
 
 // ONE: 1x1 stride-1 unpadded convolution == a row-major GEMM: the A rows are fetched with block-relative buffer loads (rows
 // beyond M read zeros through the descriptor's range check), no im2col index arithmetic.
@@ -892,6 +895,11 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
 #pragma unroll
       for (int it = 0; it < A_IT; ++it) {
         R.a_ok[it] = ca < p.Cin;             // rows beyond M: zeros from the range check
+        if (XG_ABL == 4) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) R.a_raw[it][j] = (float)(j + s);
+          continue;
+        }
         const bool second = p.in2 && c0 >= p.cin1;                      // wave-uniform
         const u32x4 v0 = second ? __builtin_amdgcn_raw_buffer_load_b128(a2_rsrc, a2_voff[it], (c0 - p.cin1) * 4, 0)
                                 : __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[it], c0 * 4, 0);
@@ -921,6 +929,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
     const bool cb_ok = c0 + (b_pc >> 2) * 16 < p.Cin;
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
+      if (XG_ABL == 5) { R.b_raw[it] = make_uint4(s, it, s, it); continue; }
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, cb_ok ? b_voff[it] : (int)0x80000000, (tap * p.Cin + c0) * 4, 0);
       R.b_raw[it] = make_uint4(v.x, v.y, v.z, v.w);
     }
@@ -949,6 +958,10 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
             for (int j = 0; j < 8; ++j) v[j] = p.fast ? pro_apply_x3(v[j], p.pro_act) : pro_apply(v[j], p.pro_act);
           }
         }
+        if (XG_ABL == 1 && PLAIN && ONE) {
+          *reinterpret_cast<float4*>(&hi) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(&lo) = make_float4(v[4], v[5], v[6], v[7]);
+        } else
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {      // two values per instruction: v_pk_mul, v_cvt_pk_f16_f32, v_pk_add (VALU is paid in full: coissue_probe)
           const f32x2 vs = f32x2{v[j], v[j + 1]} * a_s[it];
@@ -984,6 +997,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
   const int b_f0 = (wn * TN * 32 + l31) * XP + lhi * 8;
 
   auto mma_step = [&](int buf) {
+    if (XG_ABL == 3) return;
     const _Float16* Ab = As[buf];
     const _Float16* Bb = Bs[buf];
 #pragma unroll
@@ -1024,6 +1038,8 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
       buf ^= 1;
     }
   }
+  if (XG_ABL == 2 && acc[0][0][0] != 1234.5f) return;
+  if (XG_ABL == 3) acc[0][0][0] = (float)R0.b_raw[0].x + R0.a_raw[0][0] + (float)As[0][threadIdx.x];
   const float asc = p.acc_scale;
   if (p.in_amax) {          // undo the per-image range scale: accumulator register r of tile i holds output row ...
 #pragma unroll
@@ -1464,11 +1480,16 @@ static unsigned long long* dbg = nullptr;
   return KEEP_OK;
 }
 
+// the streaming form of the plain GEMM launches (keep_conv_x3g.hip)
+bool keep_conv_x3_gemm_stream_ok(const keep_conv2d_args* a, const ConvP& p, int split_k);
+int keep_conv2d_x3_gemm_stream(const keep_conv2d_args* a, ConvP& p, int n_cu, hipStream_t st);
+
 // big_tile: plan_conv's choice (128x128 block tiles instead of 64x64) -- the launch never re-derives it
 int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int big_tile, hipStream_t st) {
   const long M = p.M;
   const int steps = a->KH * a->KW * ((a->Cin + XBK - 1) / XBK);
   if (p.split_k > steps) p.split_k = steps;
+  if (keep_conv_x3_gemm_stream_ok(a, p, p.split_k)) return keep_conv2d_x3_gemm_stream(a, p, x3_num_cu(), st);
   const bool plain = !a->pro_scale && a->pro_act == KEEP_PRO_NONE;
   dim3 block(256);
   // 1x1 stride-1 unpadded convolutions (token GEMMs): block-relative buffer-load fetch, no im2col index arithmetic

@@ -1260,6 +1260,51 @@ def test_absmax_paths():
     assert torch.equal(ops.absmax(dev(big), 1, 300000, 128, 128, 300000 * 128).cpu(), big.abs().flatten(1).max(1).values)
 
 
+@pytest.mark.parametrize("name,M,K,N,act,bias,two,img", [
+    ('ffn1', 40000 + 77, 256, 1024, True, True, True, 0),        # GMFlow mlp.0 on cat(source, message): GELU, K-concatenated input, ragged M
+    ('qkv', 300000 + 5, 128, 384, False, False, False, 0),       # K = 128: 4 K steps per tile
+    ('ffn2', 270000, 1024, 128, False, True, False, 0),          # K = 1024: the epilogue rides the first of four rounds
+    ('short', 4 * 65536, 128, 64, False, True, False, 4),        # VQGAN 1x1 shortcut 128 -> 64 with per-image range scales (narrow tile)
+    ('k64', 4 * 65536 + 128, 64, 128, False, True, False, 0),    # K = 64: two K steps per tile
+    ('tail', 2048 * 128 + 1, 96 + 32, 100, False, True, False, 0)])   # Cout % 128 != 0: column tail, one row in the last tile
+def test_gemm_x3_streaming_kernel_equals_the_tile_kernel_bit_for_bit(name, M, K, N, act, bias, two, img, monkeypatch):
+    """gemm_x3s_kernel (keep_conv_x3g.hip: persistent blocks, the previous tile's epilogue inside the next tile's MFMA stream, DPP
+    transposes + 16-byte stores) against conv_x3_kernel<.., ONE> (KEEP_X3_NO_GEMM_STREAM=1) on the shapes the step launches: same
+    operands, same order of the three terms and of the K steps per accumulator -> torch.equal; and fp32-grade against float64."""
+    x = rnd(f'gs_x_{name}', (M, K), 3.0 if img else 1.0)
+    w = rnd(f'gs_w_{name}', (N, K), 0.05)
+    b = rnd(f'gs_b_{name}', (N,), 0.3) if bias else None
+    if img:
+        x = x * torch.tensor([1.0, 40.0, 0.01, 7.0]).repeat_interleave(M // img).view(-1, 1)      # a different range per image
+    wx3, asc = x3w(dev(w))
+    kw = dict(mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, pad=0, ksize=1, act=L.ACT_GELU if act else L.ACT_NONE, bounded=not img)
+    xd, wd, bd = dev(x), dev(w), None if b is None else dev(b)
+
+    def run():
+        ops._PLAN_CACHE.clear()
+        ops.DEFAULT.profile = []
+        if two:
+            y = ops.conv(xd[:, :K // 2].contiguous().view(1, M, 1, K // 2), wd, bd, x2=xd[:, K // 2:].contiguous().view(1, M, 1, K // 2), **kw)
+        else:
+            y = ops.conv(xd.view(max(img, 1), M // max(img, 1), 1, K), wd, bd, **kw)
+        torch.cuda.synchronize()
+        rec, ops.DEFAULT.profile = ops.DEFAULT.profile, None
+        return y.reshape(M, N), rec[0][0]
+    monkeypatch.delenv('KEEP_X3_NO_GEMM_STREAM', raising=False)
+    y_s, k_s = run()
+    monkeypatch.setenv('KEEP_X3_NO_GEMM_STREAM', '1')
+    y_t, k_t = run()
+    monkeypatch.delenv('KEEP_X3_NO_GEMM_STREAM')
+    ops._PLAN_CACHE.clear()
+    assert k_s.startswith('gemm_x3s_kernel') and k_t.startswith('conv_x3_kernel'), (k_s, k_t)
+    assert torch.equal(y_s, y_t), (name, (y_s - y_t).abs().max().item())
+    ref = x.double() @ w.double().t() + (0 if b is None else b.double())
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    scale = (x.double().abs() @ w.double().abs().t()).max().item()
+    assert err64(y_s, ref) <= 2e-6 * scale, (name, err64(y_s, ref), scale)
+
+
 def test_linear_x3_k_concatenated_inputs():
     """keep_conv2d in2 (x3 GEMM form): cat([a, b], -1) @ W^T without materialising the concatenation (GM/transformer.py:182);
     equals the concat path bit for bit (same K order, same kernel), ragged M; rejected loudly outside the x3 policy."""

@@ -232,6 +232,21 @@ def facelib_leg():
                                                    "D2H of the survivors, host NMS: ~110 survivors per frame with the synthetic "
                                                    "weights -- a real video has a handful); network_only: device tensor in, head "
                                                    "rows on the device out"}
+    del det
+    # retinaface_mobile0.25 (detection/__init__.py:38-41): the same pipeline on the MobileNetV1 x0.25 trunk.  The synthetic head
+    # weights leave thousands of candidates per frame above any threshold, so the host-inclusive number is a host-NMS number here:
+    # only the network is reported.
+    det = RF.RetinaFaceEngine(RF.synth_retinaface_state_dict(seed=0, backbone='mobile0.25')).to('cuda')
+    det.raw_heads(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        det.raw_heads(x)
+    torch.cuda.synchronize()
+    dm = (time.perf_counter() - t0) / 5
+    out["retinaface_mobile0.25_640x1138"] = {"network_only_frames_per_s": round(16 / dm, 1), "ms_per_call": round(dm * 1e3, 2), "batch": 16,
+                                             "what": "device tensor in, head rows on the device out (depthwise 3x3 kernel + 1x1 GEMMs + "
+                                                     "LeakyReLU(0.1) epilogues)"}
     return out
 
 

@@ -1678,7 +1678,6 @@ int keep_conv2d_x3_c3(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 bool keep_conv_x3_halo_ok(const keep_conv2d_args* a);
 bool keep_conv_x3_stream_ok(const keep_conv2d_args* a, const ConvP& p, int split_k);
 bool keep_conv_x3_gather_ok(const keep_conv2d_args* a, const ConvP& p);
-bool keep_conv_x3_gemm_stream_ok(const keep_conv2d_args* a, const ConvP& p, int split_k);
 
 enum ConvPath {
   PATH_COUT4 = 0, PATH_C3, PATH_HALO_F32, PATH_HALO_BF16, PATH_HALO_BF16_V1, PATH_GATHER_BF16, PATH_GATHER_F32, PATH_HALO_X3,
@@ -1910,9 +1909,6 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
       pl.stats_rows = pl.tile == 1 ? 64 : 128;
       // a wave's rows must lie in one image: Ho*Wo a multiple of the wave tile (32 or 64 rows)
       pl.amax_ok = pl.split_k == 1 && ((long)a->Ho * a->Wo) % (pl.tile == 1 ? 32 : 64) == 0;
-      if (keep_conv_x3_gemm_stream_ok(a, p, pl.split_k))      // (a launch that asks for statistics / range outputs takes conv_x3_kernel)
-        snprintf(pl.kernel, sizeof(pl.kernel), "gemm_x3s_kernel<%s>", a->Cout <= 64 ? "4, 1, 1, 2" : "2, 2, 2, 2");
-      else
       snprintf(pl.kernel, sizeof(pl.kernel), "conv_x3_kernel<%s, %s, %s>", pl.tile == 1 ? "2, 2, 1, 1" : "2, 2, 2, 2",
                pl.plain ? "true" : "false", keep_conv_x3_gather_is_gemm(a) ? "true" : "false");
       return KEEP_OK;

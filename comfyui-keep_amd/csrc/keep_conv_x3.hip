@@ -1480,16 +1480,11 @@ static unsigned long long* dbg = nullptr;
   return KEEP_OK;
 }
 
-// the streaming form of the plain GEMM launches (keep_conv_x3g.hip)
-bool keep_conv_x3_gemm_stream_ok(const keep_conv2d_args* a, const ConvP& p, int split_k);
-int keep_conv2d_x3_gemm_stream(const keep_conv2d_args* a, ConvP& p, int n_cu, hipStream_t st);
-
 // big_tile: plan_conv's choice (128x128 block tiles instead of 64x64) -- the launch never re-derives it
 int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int big_tile, hipStream_t st) {
   const long M = p.M;
   const int steps = a->KH * a->KW * ((a->Cin + XBK - 1) / XBK);
   if (p.split_k > steps) p.split_k = steps;
-  if (keep_conv_x3_gemm_stream_ok(a, p, p.split_k)) return keep_conv2d_x3_gemm_stream(a, p, x3_num_cu(), st);
   const bool plain = !a->pro_scale && a->pro_act == KEEP_PRO_NONE;
   dim3 block(256);
   // 1x1 stride-1 unpadded convolutions (token GEMMs): block-relative buffer-load fetch, no im2col index arithmetic

@@ -40,6 +40,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     case KEEP_ACT_LRELU01: return v < 0.f ? 0.1f * v : v;
     case KEEP_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     case KEEP_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case KEEP_ACT_SILU: return v / (1.0f + expf(-v));
     default: return v;
   }
 }
@@ -61,6 +62,7 @@ __device__ __forceinline__ float act_apply_fast(float v, int act) {
     case KEEP_ACT_LRELU01: return v < 0.f ? 0.1f * v : v;
     case KEEP_ACT_GELU: return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f));
     case KEEP_ACT_SIGMOID: return __frcp_rn(1.0f + __expf(-v));
+    case KEEP_ACT_SILU: return v * __frcp_rn(1.0f + __expf(-v));
     default: return v;
   }
 }

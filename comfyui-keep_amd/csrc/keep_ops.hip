@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float4* __restrict
 extern "C" int32_t keep_dwconv3x3(const float* x, const float* w, const float* bias, float* out, int32_t N, int32_t H, int32_t W,
                                   int32_t C, int32_t stride, int32_t act, void* stream) {
   KEEP_REQUIRE(x && w && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2) &&
-                   act >= KEEP_ACT_NONE && act <= KEEP_ACT_LRELU01 && (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 &&
+                   act >= KEEP_ACT_NONE && act <= KEEP_ACT_SILU && (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 &&
                    (uintptr_t)out % 16 == 0 && (uintptr_t)bias % 16 == 0,
                "keep_dwconv3x3: bad args (C %% 4 == 0, stride 1 | 2, 16-byte aligned tensors)");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
@@ -673,6 +673,155 @@ extern "C" int32_t keep_dwconv3x3(const float* x, const float* w, const float* b
                      reinterpret_cast<const float4*>(w), reinterpret_cast<const float4*>(bias), reinterpret_cast<float4*>(out), N, H, W,
                      Ho, Wo, C / 4, stride, act);
   KEEP_LAUNCH_CHECK("keep_dwconv3x3");
+  return KEEP_OK;
+}
+
+// ---- YOLOv5-face helpers (wm_facelib/detection/yolov5face/models/common.py, yolo.py): all HBM-bound float4 passes
+// nn.MaxPool2d(k, stride, pad, ceil_mode) on a channel slice (padding = -inf; a ceil-mode window may hang over the right / bottom edge)
+__global__ __launch_bounds__(256) void maxpool2d_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int H, int W, int C4,
+                                                        int in_ld, int out_ld, int k, int stride, int pad, int Ho, int Wo) {
+  const long total = (long)N * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int ky = 0; ky < k; ++ky) {
+      const int iy = oy * stride - pad + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int ix = ox * stride - pad + kx;
+        if (ix < 0 || ix >= W) continue;
+        const float4 v = *reinterpret_cast<const float4*>(x + (((long)n * H + iy) * W + ix) * in_ld + c * 4);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    *reinterpret_cast<float4*>(out + (((long)n * Ho + oy) * Wo + ox) * out_ld + c * 4) = m;
+  }
+}
+
+extern "C" int32_t keep_maxpool2d(const float* x, float* out, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_ld, int32_t out_ld,
+                                  int32_t k, int32_t stride, int32_t pad, int32_t Ho, int32_t Wo, void* stream) {
+  KEEP_REQUIRE(x && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && in_ld >= C && out_ld >= C && in_ld % 4 == 0 && out_ld % 4 == 0 &&
+                   k >= 1 && k <= 15 && stride >= 1 && pad >= 0 && 2 * pad <= k && Ho > 0 && Wo > 0 &&
+                   (long)(Ho - 1) * stride - pad < H && (long)(Wo - 1) * stride - pad < W && (uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0,
+               "keep_maxpool2d: bad args (C, in_ld, out_ld %% 4 == 0, k <= 15, every window meets the map, 16-byte aligned slices)");
+  const long total = (long)N * Ho * Wo * (C / 4);
+  int blocks = cdiv(total, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(maxpool2d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, N, H, W, C / 4, in_ld, out_ld, k, stride, pad,
+                     Ho, Wo);
+  KEEP_LAUNCH_CHECK("keep_maxpool2d");
+  return KEEP_OK;
+}
+
+__global__ __launch_bounds__(256) void slice_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int H, int W, int C4,
+                                                         int src_ld, int dst_ld, int up) {
+  const long total = (long)N * H * W * C4;
+  const int Hs = H >> up, Ws = W >> up;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    *reinterpret_cast<float4*>(dst + (((long)n * H + y) * W + x) * dst_ld + c * 4) =
+        *reinterpret_cast<const float4*>(src + (((long)n * Hs + (y >> up)) * Ws + (x >> up)) * src_ld + c * 4);
+  }
+}
+
+extern "C" int32_t keep_slice_copy(const float* src, float* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t src_ld, int32_t dst_ld,
+                                   int32_t up, void* stream) {
+  KEEP_REQUIRE(src && dst && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && src_ld >= C && dst_ld >= C && src_ld % 4 == 0 &&
+                   dst_ld % 4 == 0 && (up == 0 || (up == 1 && H % 2 == 0 && W % 2 == 0)) && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0,
+               "keep_slice_copy: bad args (C, lds %% 4 == 0, up in {0, 1} with an even destination, 16-byte aligned slices)");
+  const long total = (long)N * H * W * (C / 4);
+  int blocks = cdiv(total, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(slice_copy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, N, H, W, C / 4, src_ld, dst_ld, up);
+  KEEP_LAUNCH_CHECK("keep_slice_copy");
+  return KEEP_OK;
+}
+
+// channel_shuffle(cat(a, b), 2): a thread interleaves 4 channels of a with 4 of b -> 8 consecutive output channels
+__global__ __launch_bounds__(256) void channel_shuffle2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                               long rows, int h4, int a_ld, int b_ld) {
+  const long total = rows * h4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % h4);
+    const long r = i / h4;
+    const float4 va = *reinterpret_cast<const float4*>(a + r * a_ld + c * 4);
+    const float4 vb = *reinterpret_cast<const float4*>(b + r * b_ld + c * 4);
+    float4* o = reinterpret_cast<float4*>(out + (r * h4 + c) * 8);
+    o[0] = make_float4(va.x, vb.x, va.y, vb.y);
+    o[1] = make_float4(va.z, vb.z, va.w, vb.w);
+  }
+}
+
+extern "C" int32_t keep_channel_shuffle2(const float* a, const float* b, float* out, int64_t rows, int32_t half, int32_t a_ld, int32_t b_ld,
+                                         void* stream) {
+  KEEP_REQUIRE(a && b && out && rows > 0 && half > 0 && half % 4 == 0 && a_ld >= half && b_ld >= half && a_ld % 4 == 0 && b_ld % 4 == 0 &&
+                   (uintptr_t)a % 16 == 0 && (uintptr_t)b % 16 == 0 && (uintptr_t)out % 16 == 0,
+               "keep_channel_shuffle2: bad args (half, lds %% 4 == 0, 16-byte aligned)");
+  const long total = (long)rows * (half / 4);
+  int blocks = cdiv(total, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(channel_shuffle2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)rows, half / 4, a_ld, b_ld);
+  KEEP_LAUNCH_CHECK("keep_channel_shuffle2");
+  return KEEP_OK;
+}
+
+// Detect.forward (inference), one level: a thread decodes one (image, anchor, pixel) row of 16 values
+__global__ __launch_bounds__(256) void yolo_decode_kernel(const float* __restrict__ raw, float* __restrict__ pred, int N, int ny, int nx,
+                                                          float stride, const float* __restrict__ anchors_wh, int row0, int rows_total) {
+  const long total = (long)N * 3 * ny * nx;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    long t = i;
+    const int x = (int)(t % nx); t /= nx;
+    const int y = (int)(t % ny); t /= ny;
+    const int a = (int)(t % 3);
+    const int n = (int)(t / 3);
+    const float4* src = reinterpret_cast<const float4*>(raw + ((((long)n * ny + y) * nx + x) * 3 + a) * 16);
+    const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+    const float aw = anchors_wh[2 * a], ah = anchors_wh[2 * a + 1];
+    const float gx = (float)x, gy = (float)y;
+    auto sg = [](float v) { return 1.0f / (1.0f + expf(-v)); };
+    const float sw = sg(r0.z) * 2.0f, sh = sg(r0.w) * 2.0f;
+    float4 o0, o1, o2, o3;
+    o0.x = (sg(r0.x) * 2.0f - 0.5f + gx) * stride;       // (y * 2 - 0.5 + grid) * stride, yolo.py:58
+    o0.y = (sg(r0.y) * 2.0f - 0.5f + gy) * stride;
+    o0.z = sw * sw * aw;                                  // (y * 2) ** 2 * anchor_grid, yolo.py:59
+    o0.w = sh * sh * ah;
+    o1.x = sg(r1.x);                                      // objectness
+    o1.y = r1.y * aw + gx * stride;                       // landmarks: raw * anchor_grid + grid * stride, yolo.py:60-74
+    o1.z = r1.z * ah + gy * stride;
+    o1.w = r1.w * aw + gx * stride;
+    o2.x = r2.x * ah + gy * stride;
+    o2.y = r2.y * aw + gx * stride;
+    o2.z = r2.z * ah + gy * stride;
+    o2.w = r2.w * aw + gx * stride;
+    o3.x = r3.x * ah + gy * stride;
+    o3.y = r3.y * aw + gx * stride;
+    o3.z = r3.z * ah + gy * stride;
+    o3.w = sg(r3.w);                                      // class score
+    float4* dst = reinterpret_cast<float4*>(pred + ((long)n * rows_total + row0 + ((long)a * ny + y) * nx + x) * 16);
+    dst[0] = o0; dst[1] = o1; dst[2] = o2; dst[3] = o3;
+  }
+}
+
+extern "C" int32_t keep_yolo_decode(const float* raw, float* pred, int32_t N, int32_t ny, int32_t nx, float stride, const float* anchors_wh,
+                                    int32_t row0, int32_t rows_total, void* stream) {
+  KEEP_REQUIRE(raw && pred && anchors_wh && N > 0 && ny > 0 && nx > 0 && row0 >= 0 && (long)row0 + 3L * ny * nx <= rows_total &&
+                   (uintptr_t)raw % 16 == 0 && (uintptr_t)pred % 16 == 0,
+               "keep_yolo_decode: bad args (the level's rows lie inside pred, 16-byte aligned)");
+  const long total = (long)N * 3 * ny * nx;
+  int blocks = cdiv(total, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(yolo_decode_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, raw, pred, N, ny, nx, stride, anchors_wh, row0,
+                     rows_total);
+  KEEP_LAUNCH_CHECK("keep_yolo_decode");
   return KEEP_OK;
 }
 

@@ -17,7 +17,7 @@ ABI_VERSION = 15
 F32, BF16 = 0, 1
 MMA_F32, MMA_BF16, MMA_X3 = 0, 1, 2
 PRO_NONE, PRO_SWISH, PRO_RELU = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_GELU, ACT_SIGMOID, ACT_LRELU01 = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_GELU, ACT_SIGMOID, ACT_LRELU01, ACT_SILU = 0, 1, 2, 3, 4, 5, 6
 PAD_ZERO, PAD_REFLECT = 0, 1
 UPSAMPLE_X2_PHASES = 2
 
@@ -82,6 +82,10 @@ _SIGNATURES = {
     'keep_channel_argmax': [_vp, _vp, _i64, _i32, _i32, _vp],
     'keep_maxpool3s2': [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     'keep_dwconv3x3': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    'keep_maxpool2d': [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    'keep_slice_copy': [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    'keep_channel_shuffle2': [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    'keep_yolo_decode': [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _i32, _i32, _vp],
     'keep_upsample_add': [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     'keep_act_inplace': [_vp, _i64, _i32, _vp],
     'keep_retina_decode': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _vp],

@@ -76,6 +76,11 @@ def engine_facelib(helper):
         from ..engine.retinaface import EngineRetinaFace
         helper.face_detector = EngineRetinaFace.from_module(det)            # (the configuration is read off the state dict)
         logger.debug("face_detector (RetinaFace %s) runs on the HIP engine", det.backbone)
+    yolo = getattr(det, 'detector', None)                  # YoloDetector (YOLOv5l / YOLOv5n, detection/__init__.py:42-49): its network
+    if yolo is not None and hasattr(yolo, 'state_dict') and 'model.0.stem_1.conv.weight' in yolo.state_dict():
+        from ..engine.yoloface import EngineYoloModel
+        det.detector = EngineYoloModel.from_module(yolo)    # pre / post-processing stay YoloDetector's own (face_detector.py)
+        logger.debug("face_detector (%s) runs its network on the HIP engine", det.detector.engine.name)
     return helper
 
 

@@ -65,6 +65,7 @@ extern "C" {
 #define KEEP_ACT_LRELU02 2 /* LeakyReLU(0.2)        KA:449,454 */
 #define KEEP_ACT_GELU 3    /* exact erf GELU        KA:437, GM/transformer.py:141 */
 #define KEEP_ACT_SIGMOID 4 /* KA:771 */
+#define KEEP_ACT_SILU 6    /* x * sigmoid(x): Conv / ShuffleV2Block of the YOLOv5-face detectors, yolov5face/models/common.py:39-45,123-146 */
 #define KEEP_ACT_LRELU01 5 /* LeakyReLU(0.1): MobileNetV1 / FPN / SSH of retinaface_mobile0.25, retinaface_net.py:6-34,41-43,74-76 */
 
 /* padding mode of keep_conv2d */
@@ -335,6 +336,25 @@ int32_t keep_maxpool3s2(const float* x, float* out, int32_t N, int32_t H, int32_
  * NULL, out [N,(H-1)/stride+1,(W-1)/stride+1,C]; C % 4 == 0.  Taps are accumulated ky-major, kx-minor in float32. */
 int32_t keep_dwconv3x3(const float* x, const float* w, const float* bias, float* out, int32_t N, int32_t H, int32_t W, int32_t C,
                        int32_t stride, int32_t act, void* stream);
+/* ---- YOLOv5-face detectors on keep_conv2d (v15; wm_facelib/detection/yolov5face/models/common.py, yolo.py; engine/yoloface.py) ----
+ * nn.MaxPool2d(k, stride, padding = pad, ceil_mode) on a channel slice of an NHWC map (padding = -inf): StemBlock's 2x2 stride-2
+ * ceil-mode pool (common.py:53) and SPP's k x k stride-1 pools (common.py:160-163).  x rows of in_ld floats, out rows of out_ld
+ * floats (the pointers already point at the slices' first channels), C % 4 == 0; Ho / Wo: the output size the caller computed. */
+int32_t keep_maxpool2d(const float* x, float* out, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_ld, int32_t out_ld,
+                       int32_t k, int32_t stride, int32_t pad, int32_t Ho, int32_t Wo, void* stream);
+/* channel-slice copy with optional nearest x2 upsampling: dst[n, y, x, 0..C) = src[n, y >> up, x >> up, 0..C) -- torch.cat along
+ * channels (common.py Concat) one source at a time, nn.Upsample(None, 2, 'nearest') folded in.  H, W: the DESTINATION size. */
+int32_t keep_slice_copy(const float* src, float* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t src_ld, int32_t dst_ld,
+                        int32_t up, void* stream);
+/* ShuffleV2Block tail (common.py:148-155): channel_shuffle(cat(a, b), 2) -- out[r, 2 i] = a[r, i], out[r, 2 i + 1] = b[r, i];
+ * a / b rows of a_ld / b_ld floats (a is usually the untouched first half of the block's input), out dense [rows, 2 half]. */
+int32_t keep_channel_shuffle2(const float* a, const float* b, float* out, int64_t rows, int32_t half, int32_t a_ld, int32_t b_ld,
+                              void* stream);
+/* Detect.forward, inference branch (yolo.py:44-78) for one level: raw [N, ny, nx, 3 * 16] (the level's 1x1 convolution, NHWC =
+ * the reference's permute(0, 1, 3, 4, 2) up to the anchor axis) -> pred[n, row0 + (a * ny + y) * nx + x, 0..16): sigmoid on box /
+ * objectness / class, grid + anchor decode of the box and of the five landmarks, in pixels of the network input. */
+int32_t keep_yolo_decode(const float* raw, float* pred, int32_t N, int32_t ny, int32_t nx, float stride, const float* anchors_wh,
+                         int32_t row0, int32_t rows_total, void* stream);
 /* FPN top-down step (retinaface_net.py:86-92): out = a + nearest-resize(b [N,hb,wb,C] -> [N,H,W,C]) */
 int32_t keep_upsample_add(const float* a, const float* b, float* out, int32_t N, int32_t H, int32_t W, int32_t hb, int32_t wb,
                           int32_t C, void* stream);

@@ -146,3 +146,88 @@ def retinaface_forward(x, W, backbone='resnet50'):
             outs.append(o.permute(0, 2, 3, 1).contiguous().view(o.shape[0], -1, k))
         return torch.cat(outs, 1)
     return head('BboxHead', 4), F.softmax(head('ClassHead', 2), dim=-1), head('LandmarkHead', 10)
+
+
+# ------------------------------------------------------------------------------------------------------- YOLOv5-face (n, l)
+def _yconv(x, W, p, k=1, s=1, act=True, eps=BN_EPS):
+    """Conv.forward (yolov5face/models/common.py:32-45): Conv2d(k, s, k // 2, bias=False) -> BatchNorm2d -> SiLU."""
+    x = F.conv2d(x, W[f'{p}.conv.weight'], None, stride=s, padding=k // 2)
+    x = F.batch_norm(x, W[f'{p}.bn.running_mean'], W[f'{p}.bn.running_var'], W[f'{p}.bn.weight'], W[f'{p}.bn.bias'], False, 0.0, eps)
+    return F.silu(x) if act else x
+
+
+def _ybn(x, W, p, eps=BN_EPS):
+    return F.batch_norm(x, W[f'{p}.running_mean'], W[f'{p}.running_var'], W[f'{p}.weight'], W[f'{p}.bias'], False, 0.0, eps)
+
+
+def _yshuffle(x, W, p, stride):
+    """ShuffleV2Block.forward + channel_shuffle (common.py:17-22,103-155)."""
+    def branch2(t):
+        t = F.silu(_ybn(F.conv2d(t, W[f'{p}.branch2.0.weight']), W, f'{p}.branch2.1'))
+        t = _ybn(F.conv2d(t, W[f'{p}.branch2.3.weight'], None, stride, 1, groups=t.shape[1]), W, f'{p}.branch2.4')
+        return F.silu(_ybn(F.conv2d(t, W[f'{p}.branch2.5.weight']), W, f'{p}.branch2.6'))
+    if stride == 1:
+        x1, x2 = x.chunk(2, dim=1)
+        out = torch.cat((x1, branch2(x2)), 1)
+    else:
+        b1 = _ybn(F.conv2d(x, W[f'{p}.branch1.0.weight'], None, stride, 1, groups=x.shape[1]), W, f'{p}.branch1.1')
+        b1 = F.silu(_ybn(F.conv2d(b1, W[f'{p}.branch1.2.weight']), W, f'{p}.branch1.3'))
+        out = torch.cat((b1, branch2(x)), 1)
+    n, c, h, w = out.shape
+    return out.view(n, 2, c // 2, h, w).transpose(1, 2).contiguous().view(n, c, h, w)
+
+
+def _yc3(x, W, p, n, shortcut):
+    """C3.forward with n Bottleneck(c_, c_, shortcut, e=1.0) (common.py:56-66,86-100)."""
+    y = _yconv(x, W, f'{p}.cv1')
+    for k in range(n):
+        h = _yconv(_yconv(y, W, f'{p}.m.{k}.cv1'), W, f'{p}.m.{k}.cv2', k=3)
+        y = y + h if shortcut else h
+    return _yconv(torch.cat((y, _yconv(x, W, f'{p}.cv2')), 1), W, f'{p}.cv3')
+
+
+def yolo_forward(x, W, layers, anchors, strides):
+    """Model.forward_once + Detect.forward, inference (yolov5face/models/yolo.py:44-84,133-142) on a restated layer list
+    ``layers`` = engine/yoloface.py:yolo_layers(name) (parse_model of the yaml) -> pred [N, anchors, 16].
+    Pinned: tests/golden/facelib.npz holds the outputs of the reference's own Model(yaml) (oracle/make_golden_facelib.py)."""
+    ys = []
+    y = x
+    for i, f, kind, n, c1, c2, args in layers:
+        p = f'model.{i}'
+        if kind == 'StemBlock':                      # common.py:47-61
+            s1 = _yconv(y, W, f'{p}.stem_1', k=3, s=2)
+            b = _yconv(_yconv(s1, W, f'{p}.stem_2a'), W, f'{p}.stem_2b', k=3, s=2)
+            y = _yconv(torch.cat((b, F.max_pool2d(s1, 2, 2, ceil_mode=True)), 1), W, f'{p}.stem_3')
+        elif kind == 'Conv':
+            y = _yconv(y, W, p, k=args[1], s=args[2])
+        elif kind == 'C3':
+            y = _yc3(y, W, p, n, args[1])
+        elif kind == 'SPP':                          # common.py:157-166
+            t = _yconv(y, W, f'{p}.cv1')
+            y = _yconv(torch.cat([t] + [F.max_pool2d(t, k, 1, k // 2) for k in args[1]], 1), W, f'{p}.cv2')
+        elif kind == 'Shuffle':
+            for k in range(n):
+                y = _yshuffle(y, W, f'{p}.{k}' if n > 1 else p, args[1])
+        elif kind == 'Up':
+            y = F.interpolate(y, scale_factor=2, mode='nearest')
+        elif kind == 'Concat':
+            y = torch.cat([y if j == -1 else ys[j] for j in f], 1)
+        elif kind == 'Detect':
+            z = []
+            for k, j in enumerate(f):
+                r = F.conv2d(ys[j], W[f'{p}.m.{k}.weight'], W[f'{p}.m.{k}.bias'])
+                bs, _, ny, nx = r.shape
+                r = r.view(bs, 3, 16, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
+                yv, xv = torch.meshgrid(torch.arange(ny), torch.arange(nx), indexing='ij')
+                grid = torch.stack((xv, yv), 2).view(1, 1, ny, nx, 2).float()
+                ag = torch.tensor(anchors[k], dtype=torch.float32).view(1, 3, 1, 1, 2)
+                o = torch.zeros_like(r)
+                o[..., [0, 1, 2, 3, 4, 15]] = r[..., [0, 1, 2, 3, 4, 15]].sigmoid()
+                o[..., 0:2] = (o[..., 0:2] * 2.0 - 0.5 + grid) * strides[k]
+                o[..., 2:4] = (o[..., 2:4] * 2) ** 2 * ag
+                for q in range(5):
+                    o[..., 5 + 2 * q:7 + 2 * q] = r[..., 5 + 2 * q:7 + 2 * q] * ag + grid * strides[k]
+                z.append(o.view(bs, -1, 16))
+            return torch.cat(z, 1)
+        ys.append(y)
+    raise AssertionError('no Detect layer')

@@ -122,6 +122,44 @@ def retinaface_mnet_golden(net, utils):
             'mnet_boxes0': boxes.numpy().astype(np.float32), 'mnet_lms0': lms.numpy().astype(np.float32)}
 
 
+def yolo_golden():
+    """YOLOv5n / YOLOv5l face detectors: the reference's OWN ``Model(cfg=yolov5{n,l}.yaml)`` (yolov5face/models/yolo.py: parse_model
+    of its yaml, every block of common.py, Detect) on synthetic weights, image -> ``model(x)[0]``.  The package ``__init__`` files
+    are not run (namespace packages with the real paths); cv2 and torchvision are imported by utils/datasets.py / general.py at
+    module level only (letterbox / NMS: not on this path) and are stubbed empty."""
+    import types
+    from comfyui_keep_amd.engine import yoloface as YF
+    deps = os.path.join(REF, 'modules', 'deps')
+    for name, sub in (('wm_facelib', ''), ('wm_facelib.detection', 'detection'), ('wm_facelib.detection.yolov5face', 'detection/yolov5face'),
+                      ('wm_facelib.detection.yolov5face.models', 'detection/yolov5face/models'),
+                      ('wm_facelib.detection.yolov5face.utils', 'detection/yolov5face/utils')):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(deps, 'wm_facelib', sub)]
+            sys.modules[name] = m
+    for stub in ('cv2', 'torchvision'):
+        sys.modules.setdefault(stub, types.ModuleType(stub))
+    import importlib
+    yolo = importlib.import_module('wm_facelib.detection.yolov5face.models.yolo')
+    out = {}
+    for name, fn in (('YOLOv5n', 'yolov5n.yaml'), ('YOLOv5l', 'yolov5l.yaml')):
+        model = yolo.Model(cfg=os.path.join(deps, 'wm_facelib', 'detection', 'yolov5face', 'models', fn)).eval()
+        W = YF.synth_yolo_state_dict(name, seed=0)
+        ref_spec = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        assert ref_spec == {k: tuple(v) for k, v in YF.yolo_state_dict_spec(name).items()}, (name, 'spec drift',
+                                                                                             set(ref_spec) ^ set(YF.yolo_state_dict_spec(name)))
+        assert [float(s) for s in model.stride] == list(YF.STRIDES)
+        model.load_state_dict(W, strict=True)
+        x = op_input(f'yolo_img_{name}', (2, 3, 96, 128)).mul(0.5).add(0.5).clamp(0, 1)      # [0, 1] like _preprocess's uint8 / 255
+        with torch.no_grad():
+            pred = model(x)[0]
+        key = name.lower()
+        out[f'{key}_pred'] = pred.numpy().astype(np.float32)
+        print(f'{name} golden: pred', tuple(pred.shape), 'obj range', float(pred[..., 4].min()), float(pred[..., 4].max()),
+              'xy range', float(pred[..., :2].min()), float(pred[..., :2].max()), '|raw landmarks| max', float(pred[..., 5:15].abs().max()))
+    return out
+
+
 def main():
     ref = _load(os.path.join(REF, 'modules', 'deps', 'wm_facelib', 'parsing', 'parsenet.py'), 'ref_parsenet')
     out = {}
@@ -146,6 +184,7 @@ def main():
             out['parsenet512_margin'] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
         print(f'ParseNet({size}): logits range', float(mask.min()), float(mask.max()))
     out.update(retinaface_golden())
+    out.update(yolo_golden())
     np.savez_compressed(os.path.join(GOLD, 'facelib.npz'), **out)
     print('facelib.npz:', {k: v.shape for k, v in out.items()})
 

@@ -189,6 +189,75 @@ def test_dwconv3x3_vs_torch_grouped_convolution():
         L.call('keep_dwconv3x3', xd, wd, bd, out, N, H, W, 6, 1, L.ACT_NONE)          # C % 4 != 0: loud
 
 
+@pytest.mark.parametrize("name", ['YOLOv5n', 'YOLOv5l'])
+@pytest.mark.parametrize("precision", ['x3', 'fp32'])
+def test_yolov5_face_engine_vs_reference_golden(name, precision):
+    """YOLOv5n / YOLOv5l on the engine (StemBlock, ShuffleV2 / C3 / SPP blocks, Detect decode on the device) against the output of
+    the reference's own Model(yaml) on the same synthetic weights; batched == one by one; through the drop-in for
+    ``YoloDetector.detector`` (NCHW in, ``(pred, None)`` out)."""
+    from comfyui_keep_amd.engine import yoloface as YF
+    W = YF.synth_yolo_state_dict(name, seed=0)
+    eng = YF.YoloFaceEngine(W, precision=precision).to('cuda')
+    x = op_input(f'yolo_img_{name}', (2, 3, 96, 128)).mul(0.5).add(0.5).clamp(0, 1)
+    pred = eng.forward_nhwc(nhwc(x)).cpu().numpy()
+    ref = G[f'{name.lower()}_pred']
+    assert pred.shape == ref.shape
+    err_px = np.abs(pred[..., :4] - ref[..., :4]).max()
+    err_lm = np.abs(pred[..., 5:15] - ref[..., 5:15]).max()
+    err_sc = np.abs(pred[..., [4, 15]] - ref[..., [4, 15]]).max()
+    print(f'{name} [{precision}]: box {err_px:.2e} px (max {np.abs(ref[..., :4]).max():.0f}), landmarks {err_lm:.2e} (max {np.abs(ref[..., 5:15]).max():.0f}), scores {err_sc:.2e}')
+    assert err_px <= 2e-3 and err_sc <= 1e-5 and err_lm <= 3e-5 * np.abs(ref[..., 5:15]).max()
+    model = YF.EngineYoloModel(eng)
+    out = model(x.cuda())
+    assert out[1] is None and np.array_equal(out[0].cpu().numpy(), pred)
+    one = eng.forward_nhwc(nhwc(x[1:2])).cpu().numpy()
+    assert np.abs(one[0] - pred[1]).max() <= 1e-4 * max(1.0, np.abs(pred).max())
+    with pytest.raises(ValueError):
+        eng.forward_nhwc(torch.zeros(1, 100, 128, 3, device='cuda'))
+
+
+def test_yolo_helper_kernels_vs_torch():
+    """keep_maxpool2d (ceil-mode 2x2 stride 2, k x k stride 1 on channel slices), keep_slice_copy (concat, nearest x2 + concat),
+    keep_channel_shuffle2 and keep_yolo_decode against their torch statements: all bit-exact except the decode's sigmoid."""
+    x = op_input('yk_x', (2, 24, 17, 21))
+    xd = nhwc(x)
+    for (k, s, p, ceil) in ((2, 2, 0, True), (3, 1, 1, False), (5, 1, 2, False), (7, 1, 3, False)):
+        ref = F.max_pool2d(x, k, s, p, ceil_mode=ceil)
+        Ho, Wo = ref.shape[2:]
+        wide = torch.full((2, Ho, Wo, 40), -7.0, device='cuda')
+        L.call('keep_maxpool2d', xd.view(-1)[8:], wide.view(-1)[12:], 2, 17, 21, 16, 24, 40, k, s, p, Ho, Wo)      # channels 8..24 -> 12..28
+        assert torch.equal(wide[..., 12:28].cpu(), ref[:, 8:24].permute(0, 2, 3, 1)) and float(wide[..., :12].max()) == -7.0 == float(wide[..., 28:].min())
+    a, b = op_input('yk_a', (2, 8, 6, 10)), op_input('yk_b', (2, 12, 12, 20))
+    cat = torch.zeros((2, 12, 20, 20), device='cuda')
+    L.call('keep_slice_copy', nhwc(a), cat.view(-1), 2, 12, 20, 8, 8, 20, 1)
+    L.call('keep_slice_copy', nhwc(b), cat.view(-1)[8:], 2, 12, 20, 12, 12, 20, 0)
+    ref = torch.cat((F.interpolate(a, scale_factor=2, mode='nearest'), b), 1)
+    assert torch.equal(cat.cpu().permute(0, 3, 1, 2), ref)
+    src = op_input('yk_s', (1, 32, 5, 7))
+    y = op_input('yk_y', (1, 16, 5, 7))
+    out = torch.empty((1, 5, 7, 32), device='cuda')
+    L.call('keep_channel_shuffle2', nhwc(src), nhwc(y), out, 35, 16, 32, 16)
+    t = torch.cat((src[:, :16], y), 1)
+    ref = t.view(1, 2, 16, 5, 7).transpose(1, 2).contiguous().view(1, 32, 5, 7)
+    assert torch.equal(out.cpu().permute(0, 3, 1, 2), ref)
+    raw = op_input('yk_raw', (2, 48, 4, 6), 2.0)
+    pred = torch.zeros((2, 100 + 72, 16), device='cuda')
+    anchors = torch.tensor([23., 29., 43., 55., 73., 105.], device='cuda')
+    L.call('keep_yolo_decode', nhwc(raw), pred, 2, 4, 6, 16.0, anchors, 100, 172)
+    r = raw.view(2, 3, 16, 4, 6).permute(0, 1, 3, 4, 2)
+    yv, xv = torch.meshgrid(torch.arange(4), torch.arange(6), indexing='ij')
+    grid = torch.stack((xv, yv), 2).view(1, 1, 4, 6, 2).float()
+    ag = anchors.cpu().view(1, 3, 1, 1, 2)
+    o = torch.zeros_like(r)
+    o[..., [0, 1, 2, 3, 4, 15]] = r[..., [0, 1, 2, 3, 4, 15]].sigmoid()
+    o[..., 0:2] = (o[..., 0:2] * 2.0 - 0.5 + grid) * 16.0
+    o[..., 2:4] = (o[..., 2:4] * 2) ** 2 * ag
+    for q in range(5):
+        o[..., 5 + 2 * q:7 + 2 * q] = r[..., 5 + 2 * q:7 + 2 * q] * ag + grid * 16.0
+    got = pred.cpu()
+    assert float(got[:, :100].abs().max()) == 0.0 and (got[:, 100:] - o.reshape(2, 72, 16)).abs().max() <= 2e-5 * o.abs().max()
+
+
 def test_retina_decode_on_the_device_equals_the_host_decoder():
     """keep_retina_decode (scores, threshold, decode / decode_landm on the device; only survivors cross PCIe) against the numpy
     decoder of rounds 2-3 on the SAME head rows: the same anchors survive (up to scores within 1e-6 of the threshold), boxes /

@@ -550,6 +550,17 @@ def test_loader_swaps_the_helpers_networks_for_engine_objects(monkeypatch):
     engine_facelib(hm)
     assert isinstance(hm.face_detector, RF.EngineRetinaFace) and hm.face_detector.engine.backbone == 'mobile0.25'
     assert hm.face_detector.backbone == 'mobilenet0.25' and hm.face_detector.engine.w is None
+    hy = Hp()                                                   # YOLOv5n / YOLOv5l: the YoloDetector keeps its host code, its network is swapped
+    from comfyui_keep_amd.engine import yoloface as YF
+
+    class FakeYolo:
+        def __init__(self, sd):
+            self.detector = FakeModule(sd)
+    hy.face_detector = FakeYolo(YF.synth_yolo_state_dict('YOLOv5n', seed=0))
+    engine_facelib(hy)
+    assert isinstance(hy.face_detector, FakeYolo) and isinstance(hy.face_detector.detector, YF.EngineYoloModel)
+    assert hy.face_detector.detector.engine.name == 'YOLOv5n' and float(hy.face_detector.detector.stride.max()) == 32.0
+    assert set(YF.synth_yolo_state_dict('YOLOv5l', seed=0)) == set(YF.yolo_state_dict_spec('YOLOv5l')) and YF.config_of(YF.yolo_state_dict_spec('YOLOv5l')) == 'YOLOv5l'
     with pytest.raises(RuntimeError):                           # a resnet50 trunk under the mobile name: loud
         RF.RetinaFaceEngine(RF.synth_retinaface_state_dict(seed=0), backbone='mobile0.25')
     monkeypatch.setenv('KEEP_AMD_ENGINE_FACELIB', '0')

@@ -222,6 +222,15 @@ def test_retinaface_oracle_and_host_decode_vs_reference_golden():
         assert np.abs(got.numpy() - g[key]).max() <= 1e-4 * max(1.0, np.abs(g[key]).max()), key
     assert np.abs(RF.decode_boxes(g['mnet_loc'][0], pri, RF.CFG_MNET['variance']) - g['mnet_boxes0']).max() <= 1e-5
     assert np.abs(RF.decode_landmarks(g['mnet_landm'][0], pri, RF.CFG_MNET['variance']) - g['mnet_lms0']).max() <= 1e-5
+    # YOLOv5n / YOLOv5l: the reference's own Model(yaml) from image to the decoded [N, anchors, 16] predictions
+    from comfyui_keep_amd.engine import yoloface as YF
+    for name in ('YOLOv5n', 'YOLOv5l'):
+        Wy = YF.synth_yolo_state_dict(name, seed=0)
+        xy = op_input(f'yolo_img_{name}', (2, 3, 96, 128)).mul(0.5).add(0.5).clamp(0, 1)
+        with torch.no_grad():
+            pred = FO.yolo_forward(xy, Wy, YF.yolo_layers(name), YF.ANCHORS, YF.STRIDES)
+        ref = g[f'{name.lower()}_pred']
+        assert pred.shape == ref.shape and np.abs(pred.numpy() - ref).max() <= 1e-5 * np.abs(ref).max(), name
     # greedy NMS: a cluster of overlapping boxes keeps its best, disjoint boxes all survive, order = descending score
     d = np.array([[0, 0, 10, 10, 0.9], [1, 1, 11, 11, 0.95], [20, 20, 30, 30, 0.5], [0, 0, 10, 10.5, 0.7]], np.float32)
     assert RF.nms(d, 0.4) == [1, 2]

@@ -247,6 +247,23 @@ def facelib_leg():
     out["retinaface_mobile0.25_640x1138"] = {"network_only_frames_per_s": round(16 / dm, 1), "ms_per_call": round(dm * 1e3, 2), "batch": 16,
                                              "what": "device tensor in, head rows on the device out (depthwise 3x3 kernel + 1x1 GEMMs + "
                                                      "LeakyReLU(0.1) epilogues)"}
+    del det, x
+    # YOLOv5n / YOLOv5l face detectors (detection/__init__.py:42-49): the network behind YoloDetector.detect_faces (its letterbox and
+    # NMS are the reference's host / torch code), frames letterboxed to 640 x 1152 like a 720p frame (face_detector.py:50-62)
+    from comfyui_keep_amd.engine import yoloface as YF
+    xy = torch.rand((16, 640, 1152, 3), device='cuda')
+    for name in ('YOLOv5n', 'YOLOv5l'):
+        yolo = YF.YoloFaceEngine(YF.synth_yolo_state_dict(name, seed=0)).to('cuda')
+        yolo.forward_nhwc(xy)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            yolo.forward_nhwc(xy)
+        torch.cuda.synchronize()
+        dy = (time.perf_counter() - t0) / 3
+        out[f"{name.lower()}_face_640x1152"] = {"network_only_frames_per_s": round(16 / dy, 1), "ms_per_call": round(dy * 1e3, 2), "batch": 16,
+                                                "what": "device tensor in, decoded [N, anchors, 16] predictions on the device out"}
+        del yolo
     return out
 
 

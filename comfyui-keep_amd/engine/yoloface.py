@@ -383,6 +383,29 @@ class EngineYoloModel:
         return self
 
 
+def yolo_detect_batch(det, frames_bgr, conf_thres=0.7, iou_thres=0.5):
+    """``YoloDetector.detect_faces`` (face_detector.py:113-141) for a stack of equally sized frames with ONE network call: the
+    detector's own ``_preprocess`` (letterbox) and ``_postprocess`` (NMS, rescaling, min_face filter) on the whole list, then what
+    ``detect_faces`` assembles from them, per frame: ``[x1, y1, x2, y2, x1, lm x 10]`` rows, or None for a frame without faces
+    (detect_faces called on that frame alone returns None).  ``KEEPFaceProcessor._detect_all`` finds it as ``det.detect_batch``."""
+    import copy
+    import cv2
+    images = [cv2.cvtColor(np.ascontiguousarray(img), cv2.COLOR_BGR2RGB) for img in frames_bgr]
+    origimgs = copy.deepcopy(images)
+    x = det._preprocess(images)
+    with torch.no_grad():
+        pred = det.detector(x)[0]
+    bboxes, points = det._postprocess(x, origimgs, pred, conf_thres, iou_thres)
+    out = []
+    for b, p in zip(bboxes, points):
+        if len(p) == 0:
+            out.append(None)
+            continue
+        b = np.array(b).reshape(-1, 4)
+        out.append(np.concatenate((b, b[:, 0].reshape(-1, 1), np.array(p).reshape(-1, 10)), axis=1))
+    return out
+
+
 def synth_yolo_state_dict(name='YOLOv5n', seed=0):
     """Deterministic synthetic weights: He-like convolutions, BatchNorm gamma 1 +- 0.1 (0.6 on a Bottleneck's second convolution so a
     stack of 9 residual blocks stays O(1)), beta / mean +- 0.1, var in [0.7, 1.3]; Detect: small weights, objectness / class biases

@@ -79,7 +79,11 @@ def engine_facelib(helper):
     yolo = getattr(det, 'detector', None)                  # YoloDetector (YOLOv5l / YOLOv5n, detection/__init__.py:42-49): its network
     if yolo is not None and hasattr(yolo, 'state_dict') and 'model.0.stem_1.conv.weight' in yolo.state_dict():
         from ..engine.yoloface import EngineYoloModel
+        from ..engine.yoloface import yolo_detect_batch
         det.detector = EngineYoloModel.from_module(yolo)    # pre / post-processing stay YoloDetector's own (face_detector.py)
+        if hasattr(det, '_preprocess') and hasattr(det, '_postprocess'):      # the processor's batched pre-pass (one network call per chunk)
+            import functools
+            det.detect_batch = functools.partial(yolo_detect_batch, det)
         logger.debug("face_detector (%s) runs its network on the HIP engine", det.detector.engine.name)
     return helper
 

@@ -560,6 +560,33 @@ def test_loader_swaps_the_helpers_networks_for_engine_objects(monkeypatch):
     engine_facelib(hy)
     assert isinstance(hy.face_detector, FakeYolo) and isinstance(hy.face_detector.detector, YF.EngineYoloModel)
     assert hy.face_detector.detector.engine.name == 'YOLOv5n' and float(hy.face_detector.detector.stride.max()) == 32.0
+    assert not hasattr(hy.face_detector, 'detect_batch')      # (this fake has no _preprocess / _postprocess: per-frame path)
+    # the batched pre-pass of a YoloDetector: its own _preprocess / _postprocess around ONE network call, detect_faces' rows per frame
+    import types
+    cv = types.ModuleType('cv2')
+    cv.COLOR_BGR2RGB = 4
+    cv.cvtColor = lambda img, code: img[..., ::-1]
+    monkeypatch.setitem(sys.modules, 'cv2', cv)
+    calls = []
+
+    class FakeYolo2(FakeYolo):
+        def _preprocess(self, images):
+            calls.append(('pre', len(images), images[0][0, 0].tolist()))
+            return torch.zeros(len(images), 3, 32, 32)
+
+        def _postprocess(self, x, origimgs, pred, conf, iou):
+            calls.append(('post', conf, iou, tuple(pred.shape)))
+            return [[[1, 2, 30, 40]], [], [[5, 6, 7, 80], [9, 9, 20, 30]]], [[[[1, 1]] * 5], [], [[[2, 3]] * 5, [[4, 5]] * 5]]
+    hy2 = Hp()
+    hy2.face_detector = FakeYolo2(YF.synth_yolo_state_dict('YOLOv5n', seed=0))
+    engine_facelib(hy2)
+    hy2.face_detector.detector = lambda x: (torch.ones(x.shape[0], 7, 16), None)      # (no GPU here: the network itself is test_gpu_facelib's)
+    frames = np.zeros((3, 8, 8, 3), np.uint8)
+    frames[..., 0] = 9
+    res = hy2.face_detector.detect_batch(frames, 0.97)
+    assert calls == [('pre', 3, [0, 0, 9]), ('post', 0.97, 0.5, (3, 7, 16))]
+    assert res[1] is None and res[0].shape == (1, 15) and res[2].shape == (2, 15)
+    assert res[2][1].tolist() == [9, 9, 20, 30, 9, 4, 5, 4, 5, 4, 5, 4, 5, 4, 5]
     assert set(YF.synth_yolo_state_dict('YOLOv5l', seed=0)) == set(YF.yolo_state_dict_spec('YOLOv5l')) and YF.config_of(YF.yolo_state_dict_spec('YOLOv5l')) == 'YOLOv5l'
     with pytest.raises(RuntimeError):                           # a resnet50 trunk under the mobile name: loud
         RF.RetinaFaceEngine(RF.synth_retinaface_state_dict(seed=0), backbone='mobile0.25')

@@ -1,4 +1,4 @@
 cd /root/repo
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | grep -v "^$" | cut -c1-300 | tail -12
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-python bench.py > gpurun_out/bench_r4c.json 2> gpurun_out/bench_r4c.err; tail -c 300 gpurun_out/bench_r4c.json; tail -3 gpurun_out/bench_r4c.err
+bash tools/profile_step.sh x3 16 r4p_x3_b16 > gpurun_out/prof_final.log 2>&1
+rm -rf gpurun_out/r4p_x3_b16/trace_x3_b16 gpurun_out/r4p_x3_b16/pmc_x3_b16
+du -sh gpurun_out/r4p_x3_b16; head -8 gpurun_out/r4p_x3_b16/x3_b16_kernel_stats.txt | cut -c1-160

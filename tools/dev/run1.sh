@@ -1,4 +1,5 @@
 cd /root/repo
-bash tools/profile_step.sh x3 16 r4p_x3_b16 > gpurun_out/prof_final.log 2>&1
-rm -rf gpurun_out/r4p_x3_b16/trace_x3_b16 gpurun_out/r4p_x3_b16/pmc_x3_b16
-du -sh gpurun_out/r4p_x3_b16; head -8 gpurun_out/r4p_x3_b16/x3_b16_kernel_stats.txt | cut -c1-160
+timeout 900 python -m pytest tests/test_gpu_net.py -x -q -m gpu -k "gmflow" 2>&1 | grep -v "^$" | cut -c1-300 | tail -6
+for v in 0 8 4 16; do echo "== KEEP_GM_FFN_IMAGES=$v"; KEEP_GM_FFN_IMAGES=$v python bench.py --no-extras --no-cpu-baseline --steps 3 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; done

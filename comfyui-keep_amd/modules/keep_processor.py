@@ -281,7 +281,7 @@ class KEEPFaceProcessor:
             # oracle/paste_oracle.py, but ``opencv_agrees_with_gpu_paste`` compares only the parse-mask composite and the crop warp
             # with cv2 itself -- this branch stays opt-in (KEEP_AMD_GPU_PASTE=1) until it has been compared on an installation
             return False
-        if getattr(helper, 'is_gray', False) or (use_parse and getattr(helper, 'face_parse', None) is None) or not faces or mats is None:
+        if (use_parse and getattr(helper, 'face_parse', None) is None) or not faces or mats is None:
             return False
         if len(faces) != len(mats) or not isinstance(bg, np.ndarray) or bg.dtype != np.uint8 or bg.ndim != 3 or bg.shape[2] != 3:
             return False
@@ -290,7 +290,10 @@ class KEEPFaceProcessor:
         if (int(h * up), int(w * up)) != bg.shape[:2]:          # :355-356 would resize the background first
             return False
         fw, fh = getattr(helper, 'face_size', (512, 512))
-        return (fh, fw) == (512, 512) and all(np.asarray(f).shape == (512, 512, 3) and np.asarray(f).dtype == np.uint8 for f in faces)
+        # grey sources (is_gray: add_restored_face stored bgr2gray + AdaIN faces, [512,512]): the reference replicates the channel
+        # BEFORE the warp and the parse input (cv2.cvtColor GRAY2BGR, :377-378,418-419), and so does _paste_gpu
+        return (fh, fw) == (512, 512) and all(np.asarray(f).shape in ((512, 512, 3), (512, 512)) and np.asarray(f).dtype == np.uint8
+                                              for f in faces)
 
     @torch.no_grad()
     def _paste_gpu(self, helper, bg):
@@ -298,7 +301,9 @@ class KEEPFaceProcessor:
         from ..engine.paste import GpuPaster
         if self._paster is None:
             self._paster = GpuPaster(self.device)
-        faces = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(f) for f in helper.restored_faces]))).to(self.device)
+        faces = torch.from_numpy(np.ascontiguousarray(np.stack(
+            [np.asarray(f) if np.asarray(f).ndim == 3 else np.repeat(np.asarray(f)[:, :, None], 3, axis=2)      # GRAY2BGR
+             for f in helper.restored_faces]))).to(self.device)
         if not getattr(helper, 'use_parse', False):       # :386-415 erosion mask instead of the parse mask
             out = self._paster.paste(bg, faces, list(helper.inverse_affine_matrices), None, getattr(helper, 'upscale_factor', 1))
             if out is None:                                # a face larger than the blur kernel takes: the helper's own path

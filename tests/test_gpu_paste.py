@@ -144,3 +144,11 @@ def test_processor_paste_hook_runs_on_the_device_when_opted_in():
     assert np.array_equal(out, P.paste_faces(frame, list(faces), list(mats), list(classes)))
     proc._paste(helper, frame, True)                                                    # draw_box: not the GPU configuration
     assert helper.own_calls == 2
+    # grey faces (is_gray sources: add_restored_face stores [512,512] arrays): pasted as their 3-channel replication (GRAY2BGR)
+    grey = [np.ascontiguousarray(f[..., 1]) for f in faces]
+    helper2 = _StubHelper(frame, grey, mats, classes)
+    helper2.is_gray = True
+    helper2.face_parse = _StubParse([np.repeat(g[:, :, None], 3, axis=2) for g in grey], classes)      # the parse input is the replication too
+    out_g = proc._paste(helper2, frame, False)
+    assert helper2.own_calls == 0
+    assert np.array_equal(out_g, P.paste_faces(frame, [np.repeat(g[:, :, None], 3, axis=2) for g in grey], list(mats), list(classes)))

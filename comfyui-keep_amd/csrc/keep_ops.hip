@@ -885,6 +885,115 @@ extern "C" int32_t keep_retina_decode(const float* heads, const float* priors, f
   return KEEP_OK;
 }
 
+// RetinaFace.detect_faces, the rest of the post-processing on the device (retinaface.py:240-246; py_cpu_nms =
+// torchvision.ops.nms, retinaface_utils.py:39-47): one block per frame orders the frame's survivors by descending score (equal
+// scores: descending anchor index -- what `scores.argsort()[::-1]` yields whenever numpy's sort is stable), suppresses greedily with
+// the float32 IoU arithmetic of engine/retinaface.py:nms (areas (x2 - x1) * (y2 - y1), inter / (a_i + a_j - inter) > threshold, no
+// contraction) and writes the kept rows, in order, to out[n, 0 .. out_counts[n]).  counts[n] > cap (the compact list overflowed):
+// out_counts[n] = -1, the caller decodes that frame on the host.  Bitonic sort of (key, row) pairs in LDS, cap <= 4096.
+#define NMS_MAX 4096
+__global__ __launch_bounds__(1024) void retina_nms_kernel(const float* __restrict__ dets, const int* __restrict__ counts,
+                                                          float* __restrict__ out, int* __restrict__ out_counts, int cap, float thr) {
+  __shared__ unsigned long long keys[NMS_MAX];
+  __shared__ unsigned short rows[NMS_MAX];
+  __shared__ float4 box[NMS_MAX];
+  __shared__ float area[NMS_MAX];
+  __shared__ unsigned char alive[NMS_MAX];
+  __shared__ int scan[1024];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int cnt = counts[f];
+  if (cnt > cap) {
+    if (tid == 0) out_counts[f] = -1;
+    return;
+  }
+  const int n = cnt;
+  const float* fd = dets + (long)f * cap * 16;
+  int npad = 1;
+  while (npad < n) npad <<= 1;
+  for (int i = tid; i < npad; i += 1024) {
+    unsigned long long k = ~0ULL;
+    if (i < n) {
+      const unsigned sb = __float_as_uint(fd[i * 16 + 4]);                // scores are positive: their bits order like the values
+      const unsigned an = (unsigned)fd[i * 16 + 15];
+      k = ((unsigned long long)(~sb) << 32) | (unsigned long long)(0xFFFFFFFFu - an);
+    }
+    keys[i] = k;
+    rows[i] = (unsigned short)i;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npad; i += 1024) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool up = (i & k) == 0;
+          const unsigned long long a = keys[i], b = keys[l];
+          if ((a > b) == up) {
+            keys[i] = b; keys[l] = a;
+            const unsigned short r = rows[i]; rows[i] = rows[l]; rows[l] = r;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < n; i += 1024) {
+    const float4 b = *reinterpret_cast<const float4*>(fd + (int)rows[i] * 16);
+    box[i] = b;
+    area[i] = __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y));
+    alive[i] = 1;
+  }
+  __syncthreads();
+  for (int i = 0; i < n; ++i) {
+    if (!alive[i]) continue;               // (uniform: alive[i] was last written before the previous barrier)
+    const float4 bi = box[i];
+    const float ai = area[i];
+    for (int j = i + 1 + tid; j < n; j += 1024) {
+      if (!alive[j]) continue;
+      const float4 bj = box[j];
+      const float w = fmaxf(__fsub_rn(fminf(bi.z, bj.z), fmaxf(bi.x, bj.x)), 0.f);
+      const float h = fmaxf(__fsub_rn(fminf(bi.w, bj.w), fmaxf(bi.y, bj.y)), 0.f);
+      const float inter = __fmul_rn(w, h);
+      if (__fdiv_rn(inter, __fsub_rn(__fadd_rn(ai, area[j]), inter)) > thr) alive[j] = 0;
+    }
+    __syncthreads();
+  }
+  // order-preserving compaction: thread t owns candidates 4 t .. 4 t + 3
+  int c = 0;
+  for (int q = 0; q < 4; ++q) {
+    const int i = tid * 4 + q;
+    c += (i < n && alive[i]) ? 1 : 0;
+  }
+  scan[tid] = c;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = tid >= o ? scan[tid - o] : 0;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  int pos = scan[tid] - c;
+  float* fo = out + (long)f * cap * 16;
+  for (int q = 0; q < 4; ++q) {
+    const int i = tid * 4 + q;
+    if (i < n && alive[i]) {
+      const float4* src = reinterpret_cast<const float4*>(fd + (int)rows[i] * 16);
+      float4* dst = reinterpret_cast<float4*>(fo + pos * 16);
+      dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+      ++pos;
+    }
+  }
+  if (tid == 1023) out_counts[f] = scan[1023];
+}
+
+extern "C" int32_t keep_retina_nms(const float* dets, const int32_t* counts, float* out, int32_t* out_counts, int32_t N, int32_t cap,
+                                   float iou_threshold, void* stream) {
+  KEEP_REQUIRE(dets && counts && out && out_counts && N > 0 && cap > 0 && cap <= NMS_MAX && (uintptr_t)dets % 16 == 0 && (uintptr_t)out % 16 == 0,
+               "keep_retina_nms: bad args (cap <= 4096 rows per frame, 16-byte aligned lists)");
+  hipLaunchKernelGGL(retina_nms_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, dets, counts, out, out_counts, cap, iou_threshold);
+  KEEP_LAUNCH_CHECK("keep_retina_nms");
+  return KEEP_OK;
+}
+
 // out[n, y, x, :] = a[n, y, x, :] + b[n, floor(y * hb / H), floor(x * wb / W), :]: the FPN top-down step
 // `a + F.interpolate(b, size=a.shape[2:], mode='nearest')` (retinaface_net.py:86-92); C % 4 == 0.  (torch's nearest index is
 // floor(dst * scale) with scale = in / out as a float; the integer form below equals it for every size with in <= out.)

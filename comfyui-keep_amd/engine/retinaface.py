@@ -246,6 +246,8 @@ class RetinaFaceEngine:
         self._pinned = {}
         self.max_survivors = int(os.environ.get('KEEP_AMD_DETECT_SURVIVORS', '4096'))      # rows of the device-side compact list per frame
         self.max_frames = int(os.environ.get('KEEP_AMD_DETECT_BATCH', '32'))
+        # score ordering + NMS of the survivors on the device (keep_retina_nms); 0: the numpy path of round 3 (the tests' reference)
+        self.device_nms = os.environ.get('KEEP_AMD_DEVICE_NMS', '1') != '0' and self.max_survivors <= 4096
 
     def to(self, device):
         device = torch.device(device)
@@ -406,6 +408,22 @@ class RetinaFaceEngine:
                 counts = torch.zeros(n, dtype=torch.int32, device=self.device)
                 L.call('keep_retina_decode', heads, self._priors_dev[key], dets, counts, n, P, cap,
                        float(self.cfg['variance'][0]), float(self.cfg['variance'][1]), float(W), float(H), float(conf_threshold))
+                if self.device_nms:      # ordering + greedy IoU suppression on the device too: only the kept rows cross PCIe
+                    kept = torch.empty_like(dets)
+                    kcnt = torch.empty(n, dtype=torch.int32, device=self.device)
+                    L.call('keep_retina_nms', dets, counts, kept, kcnt, n, cap, float(nms_threshold))
+                    kc = kcnt.cpu().numpy()
+                    kmax = int(kc.max(initial=0))
+                    rows = kept[:, :kmax, :15].cpu().numpy() if kmax > 0 else np.zeros((n, 0, 15), np.float32)
+                    over = [i for i in range(n) if kc[i] < 0]
+                    if over:
+                        flat_over = heads[over].float().cpu().numpy()
+                    for i in range(n):
+                        if kc[i] < 0:        # more survivors than the compact list holds: that frame's heads go to the host decoder
+                            results.append(self._host_decode(flat_over[over.index(i)], priors, scale, scale1, conf_threshold, nms_threshold))
+                        else:
+                            results.append(np.ascontiguousarray(rows[i, :kc[i]]))
+                    continue
                 cnt = counts.cpu().numpy()
                 kmax = int(min(cnt.max(initial=0), cap))
                 rows = dets[:, :kmax].cpu().numpy() if kmax else np.zeros((n, 0, 16), np.float32)

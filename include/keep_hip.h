@@ -336,6 +336,12 @@ int32_t keep_maxpool3s2(const float* x, float* out, int32_t N, int32_t H, int32_
  * NULL, out [N,(H-1)/stride+1,(W-1)/stride+1,C]; C % 4 == 0.  Taps are accumulated ky-major, kx-minor in float32. */
 int32_t keep_dwconv3x3(const float* x, const float* w, const float* bias, float* out, int32_t N, int32_t H, int32_t W, int32_t C,
                        int32_t stride, int32_t act, void* stream);
+/* RetinaFace.detect_faces, ordering + NMS of the survivors on the device (v15; retinaface.py:240-246, retinaface_utils.py:39-47 =
+ * torchvision.ops.nms): dets / counts as keep_retina_decode left them -> out [N, cap, 16]: the kept rows of each frame in descending
+ * score order (equal scores: descending anchor index), out_counts[n] their number, or -1 when counts[n] > cap (host path).
+ * cap <= 4096.  float32 IoU: inter / (area_i + area_j - inter) > iou_threshold, areas (x2 - x1) * (y2 - y1). */
+int32_t keep_retina_nms(const float* dets, const int32_t* counts, float* out, int32_t* out_counts, int32_t N, int32_t cap,
+                        float iou_threshold, void* stream);
 /* ---- YOLOv5-face detectors on keep_conv2d (v15; wm_facelib/detection/yolov5face/models/common.py, yolo.py; engine/yoloface.py) ----
  * nn.MaxPool2d(k, stride, padding = pad, ceil_mode) on a channel slice of an NHWC map (padding = -inf): StemBlock's 2x2 stride-2
  * ceil-mode pool (common.py:53) and SPP's k x k stride-1 pools (common.py:160-163).  x rows of in_ld floats, out rows of out_ld

@@ -258,6 +258,13 @@ def test_yolo_helper_kernels_vs_torch():
     assert float(got[:, :100].abs().max()) == 0.0 and (got[:, 100:] - o.reshape(2, 72, 16)).abs().max() <= 2e-5 * o.abs().max()
 
 
+def tie_canon(d):
+    """Rows of one frame's detections with runs of EQUAL scores put in a canonical order (by x1, y1): `scores.argsort()[::-1]`
+    (retinaface.py:240) leaves the order inside such a run to numpy's introsort; the device orders it by descending anchor index
+    (what numpy gives whenever its sort is stable: up to 16 candidates)."""
+    return d[np.lexsort((d[:, 1], d[:, 0], -d[:, 4]))]
+
+
 def test_retina_decode_on_the_device_equals_the_host_decoder():
     """keep_retina_decode (scores, threshold, decode / decode_landm on the device; only survivors cross PCIe) against the numpy
     decoder of rounds 2-3 on the SAME head rows: the same anchors survive (up to scores within 1e-6 of the threshold), boxes /
@@ -277,14 +284,27 @@ def test_retina_decode_on_the_device_equals_the_host_decoder():
         for i in range(3):
             ref = eng._host_decode(heads[i], pri, scale, scale1, thr, 0.4)
             assert len(ref) > 3 and got[i].shape == ref.shape, (thr, i, got[i].shape, ref.shape)
-            assert np.abs(got[i] - ref).max() <= 1e-4 * max(H, W), (thr, i, np.abs(got[i] - ref).max())
-            assert np.abs(got[i][:, 4] - ref[:, 4]).max() <= 1e-6
+            assert np.array_equal(got[i][:, 4], ref[:, 4]) or np.abs(got[i][:, 4] - ref[:, 4]).max() <= 1e-6      # the same descending score sequence
+            a, b = tie_canon(got[i]), tie_canon(ref)
+            assert np.abs(a - b).max() <= 1e-4 * max(H, W), (thr, i, np.abs(a - b).max())
+    # keep_retina_nms (ordering + greedy IoU suppression on the device) against the numpy ordering / NMS on the same survivors: the same
+    # rows in the same order, bit for bit (same float32 IoU arithmetic; no two survivors of these frames share a score)
+    assert eng.device_nms
+    on_device = eng.detect_batch(frames, 0.6)
+    eng.device_nms = False
+    on_host = eng.detect_batch(frames, 0.6)
+    eng.device_nms = True
+    ties = 0
+    for a, b in zip(on_device, on_host):
+        assert a.shape == b.shape and len(a) > 3 and np.array_equal(tie_canon(a), tie_canon(b))
+        ties += int(not np.array_equal(a, b))
+    print(f'keep_retina_nms: {ties} of 3 frames differ from the numpy order -- only inside runs of equal scores (anchors of one pixel)')
     eng.max_survivors = 8                                   # overflow of the compact list: the frame is decoded on the host
     few = eng.detect_batch(frames, 0.6)
     eng.max_survivors = 4096
     full = eng.detect_batch(frames, 0.6)
     for a, b in zip(few, full):
-        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-4 * max(H, W)
+        assert a.shape == b.shape and np.abs(tie_canon(a) - tie_canon(b)).max() <= 1e-4 * max(H, W)
     as_float = eng.detect_batch(frames.double().numpy(), 0.9)                     # read_image's float64 frames
     for a, b in zip(as_float, eng.detect_batch(frames, 0.9)):
         assert np.array_equal(a, b)

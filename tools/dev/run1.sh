@@ -1,2 +1,2 @@
 cd /root/repo
-python bench.py > gpurun_out/bench_r4e.json 2> gpurun_out/bench_r4e.err; tail -c 200 gpurun_out/bench_r4e.json
+python tools/dev/parse_prof.py census 2>&1 | grep -v amdgpu | cut -c1-200

@@ -194,6 +194,57 @@ extern "C" int32_t keep_warp_ones(float* dst, int32_t H, int32_t W, int32_t fh, 
   return KEEP_OK;
 }
 
+// ---- draw_box (face_restoration_helper.py:393-400,467-475): mask_border = ones(face_size) with the rectangle (bt, bt) .. (fw - bt - 1,
+// fh - bt - 1) zeroed (cv2.rectangle, filled, corners inclusive), warped like the coverage mask above; pixels where it exceeds 0.5 are
+// painted (0, 255, 0) in the rounded uint8 frame.  One thread per pixel of the face's bounding box.
+struct BoxP {
+  uint8_t* frame;
+  double m00, m01, m02, m10, m11, m12;
+  int H, W, fh, fw, bt, x0, y0, x1, y1;
+};
+__global__ void draw_box_kernel(BoxP p) {
+  const int x = p.x0 + blockIdx.x * 32 + (threadIdx.x & 31), y = p.y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= p.x1 || y >= p.y1) return;
+  const long adelta = llrint(dmul_rn(dmul_rn(p.m00, (double)x), 1024.0));
+  const long bdelta = llrint(dmul_rn(dmul_rn(p.m10, (double)x), 1024.0));
+  const long X0 = llrint(dmul_rn(dadd_rn(dmul_rn(p.m01, (double)y), p.m02), 1024.0)) + 16;
+  const long Y0 = llrint(dmul_rn(dadd_rn(dmul_rn(p.m11, (double)y), p.m12), 1024.0)) + 16;
+  const long X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+  long sxl = X >> 5, syl = Y >> 5;
+  sxl = sxl < -32768 ? -32768 : (sxl > 32767 ? 32767 : sxl);
+  syl = syl < -32768 ? -32768 : (syl > 32767 ? 32767 : syl);
+  const int sx = (int)sxl, sy = (int)syl, fx = (int)(X & 31), fy = (int)(Y & 31);
+  const float ax = div_rn((float)fx, 32.f), ay = div_rn((float)fy, 32.f);
+  const float w00 = mul_rn(sub_rn(1.f, ax), sub_rn(1.f, ay)), w01 = mul_rn(ax, sub_rn(1.f, ay));
+  const float w10 = mul_rn(sub_rn(1.f, ax), ay), w11 = mul_rn(ax, ay);
+  auto border = [&](int yy, int xx) -> float {
+    if (xx < 0 || xx >= p.fw || yy < 0 || yy >= p.fh) return 0.f;
+    return (xx >= p.bt && xx <= p.fw - p.bt - 1 && yy >= p.bt && yy <= p.fh - p.bt - 1) ? 0.f : 1.f;
+  };
+  float v = mul_rn(border(sy, sx), w00);
+  v = add_rn(v, mul_rn(border(sy, sx + 1), w01));
+  v = add_rn(v, mul_rn(border(sy + 1, sx), w10));
+  v = add_rn(v, mul_rn(border(sy + 1, sx + 1), w11));
+  if (v > 0.5f) {
+    uint8_t* d = p.frame + ((long)y * p.W + x) * 3;
+    d[0] = 0; d[1] = 255; d[2] = 0;
+  }
+}
+extern "C" int32_t keep_draw_box(uint8_t* frame, int32_t H, int32_t W, int32_t fh, int32_t fw, int32_t thickness, const double* dst_to_src,
+                                 int32_t x0, int32_t y0, int32_t x1, int32_t y1, void* stream) {
+  KEEP_REQUIRE(frame && dst_to_src && H > 0 && W > 0 && fh > 0 && fw > 0 && thickness >= 1 && x0 >= 0 && y0 >= 0 && x1 <= W && y1 <= H,
+               "keep_draw_box: bad arguments");
+  if (x1 <= x0 || y1 <= y0) return KEEP_OK;
+  BoxP p;
+  p.frame = frame;
+  p.m00 = dst_to_src[0]; p.m01 = dst_to_src[1]; p.m02 = dst_to_src[2];
+  p.m10 = dst_to_src[3]; p.m11 = dst_to_src[4]; p.m12 = dst_to_src[5];
+  p.H = H; p.W = W; p.fh = fh; p.fw = fw; p.bt = thickness; p.x0 = x0; p.y0 = y0; p.x1 = x1; p.y1 = y1;
+  hipLaunchKernelGGL(draw_box_kernel, dim3(cdiv(x1 - x0, 32), cdiv(y1 - y0, 8)), dim3(256), 0, (hipStream_t)stream, p);
+  KEEP_LAUNCH_CHECK("keep_draw_box");
+  return KEEP_OK;
+}
+
 // cv2.erode(img, np.ones((k, k))): minimum over the k x k window anchored at k/2 (offsets -k/2 .. k-1-k/2), pixels outside the image
 // never win (constant border +inf).  A minimum is separable: rows, then columns.
 __global__ void erode_pass_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int k, int along_x) {

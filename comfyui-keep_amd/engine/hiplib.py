@@ -95,6 +95,7 @@ _SIGNATURES = {
     'keep_f32_round_u8': [_vp, _vp, _i64, _vp],
     'keep_warp_affine_u8': [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
     'keep_warp_ones': [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
+    'keep_draw_box': [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
     'keep_erode_rect': [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
     'keep_paste_face': [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
 }

@@ -99,18 +99,22 @@ class GpuPaster:
         L.call('keep_sep_filter', a, None, None, tmp, b, F, h, w, self._kern, PARSE_BLUR_KSIZE)
         return b
 
-    def erosion_mask(self, d2s, H, W, fh, fw, upscale_factor):
-        """The ``use_parse=False`` soft mask of one face in FRAME space (face_restoration_helper.py:386-415): coverage of the warped
-        face square -> erode(2 * upscale) -> area -> erode(2 * (sqrt(area) // 20)) -> GaussianBlur of the same odd size.  The area
-        (one float64 sum) comes back to the host: it sets the two kernel sizes.  None when the blur would need more than 127 taps."""
+    def eroded_coverage(self, d2s, H, W, fh, fw, upscale_factor):
+        """face_restoration_helper.py:382-391: the warped face square eroded by 2 * upscale, and its area (one float64 sum on the host)
+        -> (scratch, inv_mask_erosion, scratch, total_face_area)."""
         a = torch.empty((H, W), dtype=torch.float32, device=self.device)
         b = torch.empty_like(a)
         tmp = torch.empty_like(a)
         L.call('keep_warp_ones', a, H, W, fh, fw, d2s)
         L.call('keep_erode_rect', a, tmp, b, H, W, max(1, int(2 * upscale_factor)))
         total = float(b.sum(dtype=torch.float64).item())
-        if total == 0:
-            total = 1
+        return a, b, tmp, (1 if total == 0 else total)
+
+    def erosion_mask(self, d2s, H, W, fh, fw, upscale_factor):
+        """The ``use_parse=False`` soft mask of one face in FRAME space (face_restoration_helper.py:386-415): coverage of the warped
+        face square -> erode(2 * upscale) -> area -> erode(2 * (sqrt(area) // 20)) -> GaussianBlur of the same odd size.  The area
+        (one float64 sum) comes back to the host: it sets the two kernel sizes.  None when the blur would need more than 127 taps."""
+        a, b, tmp, total = self.eroded_coverage(d2s, H, W, fh, fw, upscale_factor)
         w_edge = int(total ** 0.5) // 20
         radius = max(1, w_edge * 2)
         blur = max(1, w_edge * 2)
@@ -123,7 +127,7 @@ class GpuPaster:
         L.call('keep_sep_filter', a, None, None, tmp, b, 1, H, W, kern, blur)
         return b
 
-    def paste(self, frame_u8, faces_u8, inverse_affines, parse_classes=None, upscale_factor=1.0):
+    def paste(self, frame_u8, faces_u8, inverse_affines, parse_classes=None, upscale_factor=1.0, draw_box=False):
         """frame_u8: uint8 [H,W,3] (numpy or tensor; the background at the output size), faces_u8: uint8 [F,fh,fw,3],
         inverse_affines: F crop -> frame matrices (``get_inverse_affine``; None entries are skipped), parse_classes: uint8
         [F,fh,fw] (``use_parse=True``) or None (``use_parse=False``: the erosion mask above, ``upscale_factor`` as the helper's).
@@ -154,4 +158,14 @@ class GpuPaster:
                 L.call('keep_paste_face', acc, H, W, faces[i], masks[i], fh, fw, d2s, x0, y0, x1, y1, PARSE_BORDER)
             out = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
             L.call('keep_f32_round_u8', acc, out, acc.numel())
+            if draw_box:            # :393-400,467-475: green borders over the finished frame, one warped border mask per face
+                for i in range(F):
+                    M = inverse_affines[i]
+                    if M is None:
+                        continue
+                    d2s = (C.c_double * 6)(*invert_affine(M).reshape(-1).tolist())
+                    total = self.eroded_coverage(d2s, H, W, fh, fw, upscale_factor)[3]
+                    t = max(1, min(int(1400 / np.sqrt(total)), min(fh, fw) // 20))
+                    x0, y0, x1, y1 = face_box(M, fw, fh, W, H)
+                    L.call('keep_draw_box', out, H, W, fh, fw, t, d2s, x0, y0, x1, y1)
         return out

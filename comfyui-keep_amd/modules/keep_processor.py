@@ -244,7 +244,7 @@ class KEEPFaceProcessor:
         per-face masks, warps and the blend run on the MI355X (engine/paste.py); every other configuration -- and every
         helper that is not the reference's -- goes to the helper's own method."""
         if self._gpu_cv_path() and self._gpu_paste_applies(helper, bg, draw_box):
-            return self._paste_gpu(helper, bg)
+            return self._paste_gpu(helper, bg, draw_box)
         return helper.paste_faces_to_input_image(upsample_img=bg, draw_box=draw_box, face_upsampler=self.face_upscale_model)
 
     def _gpu_cv_path(self):
@@ -273,7 +273,7 @@ class KEEPFaceProcessor:
 
     def _gpu_paste_applies(self, helper, bg, draw_box):
         faces, mats = getattr(helper, 'restored_faces', None), getattr(helper, 'inverse_affine_matrices', None)
-        if draw_box or self.face_upscale_model is not None:
+        if self.face_upscale_model is not None:            # (draw_box is on the device since round 4: keep_draw_box)
             return False
         use_parse = getattr(helper, 'use_parse', False)
         if not use_parse and not getattr(self, '_gpu_paste_forced', False):
@@ -296,7 +296,7 @@ class KEEPFaceProcessor:
                                               for f in faces)
 
     @torch.no_grad()
-    def _paste_gpu(self, helper, bg):
+    def _paste_gpu(self, helper, bg, draw_box=False):
         from ..engine import hiplib as L
         from ..engine.paste import GpuPaster
         if self._paster is None:
@@ -305,9 +305,9 @@ class KEEPFaceProcessor:
             [np.asarray(f) if np.asarray(f).ndim == 3 else np.repeat(np.asarray(f)[:, :, None], 3, axis=2)      # GRAY2BGR
              for f in helper.restored_faces]))).to(self.device)
         if not getattr(helper, 'use_parse', False):       # :386-415 erosion mask instead of the parse mask
-            out = self._paster.paste(bg, faces, list(helper.inverse_affine_matrices), None, getattr(helper, 'upscale_factor', 1))
+            out = self._paster.paste(bg, faces, list(helper.inverse_affine_matrices), None, getattr(helper, 'upscale_factor', 1), draw_box)
             if out is None:                                # a face larger than the blur kernel takes: the helper's own path
-                return helper.paste_faces_to_input_image(upsample_img=bg, draw_box=False, face_upsampler=None)
+                return helper.paste_faces_to_input_image(upsample_img=bg, draw_box=draw_box, face_upsampler=None)
             return out.cpu().numpy()
         # :418-424  BGR uint8 -> RGB float (x/255 - 0.5)/0.5, one face per ParseNet call like the reference
         x = torch.empty(faces.shape, dtype=torch.float32, device=self.device)
@@ -322,7 +322,7 @@ class KEEPFaceProcessor:
                 logits = helper.face_parse(x[i:i + 1].permute(0, 3, 1, 2).contiguous())[0]
                 classes.append(logits.argmax(dim=1).squeeze(0).to(torch.uint8))
             classes = torch.stack(classes)
-        out = self._paster.paste(bg, faces, list(helper.inverse_affine_matrices), classes)
+        out = self._paster.paste(bg, faces, list(helper.inverse_affine_matrices), classes, getattr(helper, 'upscale_factor', 1), draw_box)
         return out.cpu().numpy()
 
     # ------------------------------------------------------------------ sequence

@@ -391,6 +391,11 @@ int32_t keep_warp_affine_u8(const uint8_t* src, int32_t H, int32_t W, uint8_t* d
 /* use_parse=False soft mask (FH:386-415): keep_warp_ones = cv2.warpAffine(np.ones((fh, fw), float32), M, (W, H)) for the whole
  * frame; keep_erode_rect = cv2.erode(img, np.ones((k, k))) (separable minimum, +inf outside the image), tmp / dst: [H,W] floats. */
 int32_t keep_warp_ones(float* dst, int32_t H, int32_t W, int32_t fh, int32_t fw, const double* dst_to_src, void* stream);
+/* draw_box (v15; FH:393-400,467-475): the warped border mask of one face -- ones(fh, fw) with cv2.rectangle((t, t), (fw - t - 1,
+ * fh - t - 1), 0, filled) -- thresholded at 0.5 and painted (0, 255, 0) into the rounded uint8 frame [H,W,3], inside the face's
+ * bounding box [x0, x1) x [y0, y1). */
+int32_t keep_draw_box(uint8_t* frame, int32_t H, int32_t W, int32_t fh, int32_t fw, int32_t thickness, const double* dst_to_src,
+                      int32_t x0, int32_t y0, int32_t x1, int32_t y1, void* stream);
 int32_t keep_erode_rect(const float* src, float* tmp, float* dst, int32_t H, int32_t W, int32_t k, void* stream);
 /* One face into the float frame [H,W,3], in place, over the box [x0,x1) x [y0,y1): cv2.warpAffine(face uint8 [fh,fw,3]) (:382)
  * and cv2.warpAffine(mask float [fh,fw]) (:441) with INTER_LINEAR / BORDER_CONSTANT 0 and OpenCV's fixed-point coordinates,

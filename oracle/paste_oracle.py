@@ -174,13 +174,31 @@ def parse_soft_mask(parse_classes):
     return (m / np.float32(255.0)).astype(np.float32)
 
 
-def erosion_soft_mask(inv_affine, width, height, upscale_factor, face_hw=(512, 512)):
-    """:386-415 (use_parse=False): returns (inv_soft_mask [height,width] float32, total_face_area)."""
+def eroded_coverage(inv_affine, width, height, upscale_factor, face_hw=(512, 512)):
+    """:382-391: (inv_mask_erosion, total_face_area)."""
     inv_mask = warp_affine_f32(np.ones(face_hw, np.float32), inv_affine, width, height)
     inv_mask_erosion = erode_rect(inv_mask, int(2 * upscale_factor))
     total = float(np.sum(inv_mask_erosion.astype(np.float64)))      # np.sum over float32: pairwise; magnitude only matters
-    if total == 0:
-        total = 1
+    return inv_mask_erosion, (1 if total == 0 else total)
+
+
+def box_thickness(total_face_area, face_hw=(512, 512)):
+    """:396-397."""
+    t = int(1400 / np.sqrt(total_face_area))
+    return max(1, min(t, min(face_hw) // 20))
+
+
+def border_mask(inv_affine, width, height, thickness, face_hw=(512, 512)):
+    """:393-400: the warped ``mask_border`` (its three channels are equal: one is computed) -> bool [height,width], > 0.5 (:470)."""
+    h, w = face_hw
+    m = np.ones((h, w), np.float32)
+    m[thickness:h - thickness, thickness:w - thickness] = 0            # cv2.rectangle((t, t), (w - t - 1, h - t - 1), 0, -1): corners inclusive
+    return warp_affine_f32(m, inv_affine, width, height) > np.float32(0.5)
+
+
+def erosion_soft_mask(inv_affine, width, height, upscale_factor, face_hw=(512, 512)):
+    """:386-415 (use_parse=False): returns (inv_soft_mask [height,width] float32, total_face_area)."""
+    inv_mask_erosion, total = eroded_coverage(inv_affine, width, height, upscale_factor, face_hw)
     w_edge = int(total ** 0.5) // 20
     erosion_radius = max(1, w_edge * 2)
     center = erode_rect(inv_mask_erosion, erosion_radius)
@@ -190,16 +208,20 @@ def erosion_soft_mask(inv_affine, width, height, upscale_factor, face_hw=(512, 5
     return gaussian_blur(center, blur, 0), total
 
 
-def paste_faces(upsample_img, restored_faces, inverse_affines, parse_classes=None, upscale_factor=1.0):
-    """paste_faces_to_input_image(upsample_img=..., draw_box=False, face_upsampler=None) for colour frames.
+def paste_faces(upsample_img, restored_faces, inverse_affines, parse_classes=None, upscale_factor=1.0, draw_box=False):
+    """paste_faces_to_input_image(upsample_img=..., draw_box=..., face_upsampler=None) for colour frames.
     upsample_img uint8 [H,W,3] (already at the output size), restored_faces: uint8 [512,512,3] each, inverse_affines: the
     matrices of get_inverse_affine, parse_classes: per face the ParseNet arg-max map [512,512] (use_parse=True) or None."""
     h_up, w_up = upsample_img.shape[:2]
     up = upsample_img
+    borders = []
     for idx, face in enumerate(restored_faces):
         M = inverse_affines[idx]
         if M is None:
             continue
+        if draw_box:
+            _, total = eroded_coverage(M, w_up, h_up, upscale_factor, face.shape[:2])
+            borders.append(border_mask(M, w_up, h_up, box_thickness(total, face.shape[:2]), face.shape[:2]))
         inv_restored = warp_affine_u8(face, M, w_up, h_up)
         if parse_classes is not None:
             soft = warp_affine_f32(parse_soft_mask(parse_classes[idx]), M, w_up, h_up)
@@ -210,4 +232,7 @@ def paste_faces(upsample_img, restored_faces, inverse_affines, parse_classes=Non
         up = soft * inv_restored.astype(np.float32) + (np.float32(1) - soft) * up.astype(np.float32)
     if np.issubdtype(up.dtype, np.floating):
         up = np.clip(up, 0, 255)
-    return np.round(up).astype(np.uint8)
+    out = np.round(up).astype(np.uint8)
+    for b in borders:                                    # :467-475
+        out[b] = np.array([0, 255, 0], np.uint8)
+    return out

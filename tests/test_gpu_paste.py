@@ -142,8 +142,16 @@ def test_processor_paste_hook_runs_on_the_device_when_opted_in():
     out = proc._paste(helper, frame, False)
     assert helper.own_calls == 1 and helper.face_parse.i == 3
     assert np.array_equal(out, P.paste_faces(frame, list(faces), list(mats), list(classes)))
-    proc._paste(helper, frame, True)                                                    # draw_box: not the GPU configuration
-    assert helper.own_calls == 2
+    helper.face_parse.i = 0
+    boxed = proc._paste(helper, frame, True)                                            # draw_box: green borders on the device
+    assert helper.own_calls == 1
+    ref_boxed = P.paste_faces(frame, list(faces), list(mats), list(classes), draw_box=True)
+    assert np.array_equal(boxed, ref_boxed) and int((ref_boxed != out).any(2).sum()) > 500          # (the borders are really there)
+    helper.use_parse = False                                                            # erosion-mask path + borders (opt-in path)
+    proc._gpu_paste_forced = True
+    boxed2 = proc._paste(helper, frame, True)
+    assert np.array_equal(boxed2, P.paste_faces(frame, list(faces), list(mats), None, draw_box=True))
+    helper.use_parse, proc._gpu_paste_forced = True, False
     # grey faces (is_gray sources: add_restored_face stores [512,512] arrays): pasted as their 3-channel replication (GRAY2BGR)
     grey = [np.ascontiguousarray(f[..., 1]) for f in faces]
     helper2 = _StubHelper(frame, grey, mats, classes)

@@ -407,7 +407,7 @@ def test_paste_hook_defers_to_the_helper():
     assert proc.gpu_paste is False
     proc.gpu_paste = True
     assert proc._gpu_paste_applies(h, bg, False)
-    assert not proc._gpu_paste_applies(h, bg, True)                                  # draw_box
+    assert proc._gpu_paste_applies(h, bg, True)                                      # draw_box: on the device too (keep_draw_box)
     assert not proc._gpu_paste_applies(h, bg.astype(np.float32), False)              # not uint8
     assert not proc._gpu_paste_applies(h, np.zeros((32, 32, 3), np.uint8), False)    # background still to be resized
     h.use_parse = False

@@ -66,6 +66,26 @@ def test_paste_regression_vectors():
     assert int((out != frame).any(-1).sum()) == int(g['changed_pixels'])
 
 
+def test_draw_box_paints_a_closed_frame_around_each_face():
+    """draw_box (face_restoration_helper.py:393-400,467-475): an identity-placed face gets a green frame of the rule's thickness
+    (int(1400 / sqrt(area)), at least 1, at most face / 20) along the face square and nothing else changes."""
+    bg = np.full((600, 640, 3), 90, np.uint8)
+    face = np.full((512, 512, 3), 200, np.uint8)
+    M = np.array([[1, 0, 40], [0, 1, 30]], np.float64)                       # crop -> frame: a pure shift
+    cls = np.full((512, 512), 1, np.uint8)
+    plain = P.paste_faces(bg, [face], [M], [cls])
+    boxed = P.paste_faces(bg, [face], [M], [cls], draw_box=True)
+    diff = (plain != boxed).any(2)
+    green = (boxed == np.array([0, 255, 0], np.uint8)).all(2)
+    assert diff.sum() > 0 and np.array_equal(diff, green & diff) and not green[:30].any() and not green[:, :40].any()
+    t = P.box_thickness(P.eroded_coverage(M, 640, 600, 1.0)[1])
+    assert t == max(1, min(int(1400 / np.sqrt(510.0 * 510.0)), 25))           # the 2 x 2 erosion takes a pixel off the 512 x 512 coverage
+    ys, xs = np.where(green)
+    assert (ys.min(), xs.min(), ys.max(), xs.max()) == (30, 40, 30 + 511, 40 + 511)
+    inner = green[30 + t + 1:30 + 511 - t, 40 + t + 1:40 + 511 - t]
+    assert not inner.any() and green[30:30 + t, 40:40 + 512].all() and green[30:30 + 512, 40 + 512 - t:40 + 512].all()
+
+
 def test_restatement_equals_opencv_where_opencv_exists():
     """THE PIN (runs wherever cv2 is installed; the build image has none -> skipped there): every OpenCV call the paste-back
     and the crop warp make -- warpAffine uint8 with and without a border colour, warpAffine float32, GaussianBlur((101,101), 11),

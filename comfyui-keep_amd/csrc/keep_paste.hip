@@ -19,7 +19,7 @@ __device__ __forceinline__ float div_rn(float a, float b) { return a / b; }
 __device__ __forceinline__ double dmul_rn(double a, double b) { return a * b; }
 __device__ __forceinline__ double dadd_rn(double a, double b) { return a + b; }
 
-#define PASTE_MAXTAPS 128
+#define PASTE_MAXTAPS 1024     // (a 4 KB tap table per block; a face of ~10 000 px would need 1001 taps)
 
 // ---- separable filter, BORDER_REFLECT_101, float32, taps accumulated in index order.  src: float [n,H,W], or class map
 // uint8 [n,H,W] looked up through lut (MASK_COLORMAP, :428-429) when lut != nullptr.

@@ -113,14 +113,14 @@ class GpuPaster:
     def erosion_mask(self, d2s, H, W, fh, fw, upscale_factor):
         """The ``use_parse=False`` soft mask of one face in FRAME space (face_restoration_helper.py:386-415): coverage of the warped
         face square -> erode(2 * upscale) -> area -> erode(2 * (sqrt(area) // 20)) -> GaussianBlur of the same odd size.  The area
-        (one float64 sum) comes back to the host: it sets the two kernel sizes.  None when the blur would need more than 127 taps."""
+        (one float64 sum) comes back to the host: it sets the two kernel sizes.  None when the blur would need more than 1023 taps (or more than the frame holds)."""
         a, b, tmp, total = self.eroded_coverage(d2s, H, W, fh, fw, upscale_factor)
         w_edge = int(total ** 0.5) // 20
         radius = max(1, w_edge * 2)
         blur = max(1, w_edge * 2)
         if blur % 2 == 0:
             blur += 1
-        if blur > 127 or blur // 2 >= min(H, W):
+        if blur > 1023 or blur // 2 >= min(H, W):
             return None
         L.call('keep_erode_rect', b, tmp, a, H, W, radius)
         kern = torch.from_numpy(gaussian_kernel(blur, 0)).to(self.device)

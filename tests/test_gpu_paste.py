@@ -61,6 +61,14 @@ def test_erosion_mask_paste_use_parse_false_is_bit_exact():
     got = gp.paste(frame, faces, list(mats), None, 1.0).cpu().numpy()
     assert np.array_equal(got, ref), int(np.abs(got.astype(np.int16) - ref.astype(np.int16)).max())
     assert (got != frame).any()
+    # a face of ~1330 px in a 1400 x 1440 frame: 2 * (sqrt(area) // 20) + 1 = 133 taps (rounds 2-3 stopped at 127 and fell back)
+    rs = np.random.RandomState(4)
+    big = rs.randint(0, 256, (1400, 1440, 3)).astype(np.uint8)
+    Mb = np.array([[2.6, 0.1, 60.3], [-0.1, 2.6, 70.8]], np.float64)
+    face = rs.randint(0, 256, (1, 512, 512, 3)).astype(np.uint8)
+    refb = P.paste_faces(big, [face[0]], [Mb], None, upscale_factor=1.0)
+    gotb = gp.paste(big, face, [Mb], None, 1.0)
+    assert gotb is not None and np.array_equal(gotb.cpu().numpy(), refb)
 
 
 def test_crop_warp_align_warp_face_is_bit_exact():

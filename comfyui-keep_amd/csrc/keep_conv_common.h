@@ -7,6 +7,20 @@
 
 #define BK 16
 
+// Cache policy (the `aux` immediate of buffer_store: 0 default, 2 = nt, streaming) of the output stores of the x3 kernels:
+// the streaming halo kernel, round 3's halo kernel, the gather / GEMM kernel.  Measured per family on the whole step (DESIGN 5.4,
+// tools/dev/lib_ab.py): nt on the GEMM family -0.3 %, on round 3's halo kernel another -0.3 %, on the streaming kernel 0.0 % in time but
+// -6.5 % of its fetched HBM bytes (PMC: the written lines no longer evict the halo rows the neighbouring tiles re-read).
+#ifndef KEEP_ST_AUX_XS
+#define KEEP_ST_AUX_XS 2
+#endif
+#ifndef KEEP_ST_AUX_HALO
+#define KEEP_ST_AUX_HALO 2
+#endif
+#ifndef KEEP_ST_AUX_GEMM
+#define KEEP_ST_AUX_GEMM 2
+#endif
+
 struct ConvP {
   const float* in;
   const float* w;

@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
       if (EXP != 4 || e[0] == 1.2345e-30f) {
         u32x4 o;
         o.x = __float_as_uint(e[0]); o.y = __float_as_uint(e[1]); o.z = __float_as_uint(e[2]); o.w = __float_as_uint(e[3]);
-        __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, v_out, dpix * p.out_ld * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, v_out, dpix * p.out_ld * 4, KEEP_ST_AUX_HALO);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -712,7 +712,7 @@ __device__ __forceinline__ void x3_gather_epilogue(const ConvP& p, f32x16 (&acc)
     {
       u32x4 o;
       o.x = __float_as_uint(e[0]); o.y = __float_as_uint(e[1]); o.z = __float_as_uint(e[2]); o.w = __float_as_uint(e[3]);
-      __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, v_out + it * RPI * p.out_ld * 4, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, v_out + it * RPI * p.out_ld * 4, 0, KEEP_ST_AUX_GEMM);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

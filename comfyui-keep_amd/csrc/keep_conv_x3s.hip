@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3s_kernel(ConvP p, int t
         }
         u32x4 o;
         o.x = __float_as_uint(e[0]); o.y = __float_as_uint(e[1]); o.z = __float_as_uint(e[2]); o.w = __float_as_uint(e[3]);
-        if (XS_ABL != 7 || e[0] == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, v_out, dpix_of(rd * 4 + u) * p.out_ld * 4, 0);
+        if (XS_ABL != 7 || e[0] == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, v_out, dpix_of(rd * 4 + u) * p.out_ld * 4, KEEP_ST_AUX_XS);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           s4[q] += e[q];

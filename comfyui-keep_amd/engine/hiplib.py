@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')
+LIB_PATH = os.environ.get('KEEP_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')   # (KEEP_HIP_LIB: dev A/B builds)
 ABI_VERSION = 15
 
 F32, BF16 = 0, 1

@@ -1672,7 +1672,7 @@ __global__ void conv_splitk_reduce_kernel(ConvP p) {
 // buffers from it and never re-derives kernel internals (a retune here cannot silently corrupt a caller).
 int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 bool keep_conv_x3_up2_ok(const keep_conv2d_args* a);
-int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int big_tile, hipStream_t st);
+int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int tile, hipStream_t st);
 bool keep_conv_x3_gather_is_gemm(const keep_conv2d_args* a);
 int keep_conv2d_x3_c3(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 bool keep_conv_x3_halo_ok(const keep_conv2d_args* a);
@@ -1762,6 +1762,10 @@ static int validate_conv(const keep_conv2d_args* a) {
     }
   }
   KEEP_REQUIRE((long)a->N * a->Ho * a->Wo < (1L << 31), "keep_conv2d: M too large");
+  if (a->ln_gamma && (a->mma != KEEP_MMA_X3 || a->KH != 1 || a->KW != 1 || a->stride != 1 || a->upsample)) {
+    keep_set_error("keep_conv2d: ln_gamma (LayerNorm epilogue) is a feature of the KEEP_MMA_X3 GEMM form (1x1, stride 1)");
+    return KEEP_EUNSUP;
+  }
   return KEEP_OK;
 }
 
@@ -1784,6 +1788,9 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   p.out_amax = nullptr;
   p.reflect = a->pad_mode == KEEP_PAD_REFLECT ? 1 : 0;
   p.tile_cols = 0;
+  p.ln_gamma = a->ln_gamma;
+  p.ln_beta = a->ln_beta;
+  p.ln_eps = a->ln_eps;
   p.bias = a->bias;
   p.out = (float*)a->out;
   p.pro_scale = a->pro_scale;
@@ -1909,9 +1916,28 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
       pl.stats_rows = pl.tile == 1 ? 64 : 128;
       // a wave's rows must lie in one image: Ho*Wo a multiple of the wave tile (32 or 64 rows)
       pl.amax_ok = pl.split_k == 1 && ((long)a->Ho * a->Wo) % (pl.tile == 1 ? 32 : 64) == 0;
+      if (a->ln_gamma) {      // LayerNorm in the epilogue: one wave holds whole 128-channel rows (tile <4,1,1,4>), full row tiles only
+        if (!(a->ln_beta && keep_conv_x3_gather_is_gemm(a) && no_pro && a->Cout == 128 && a->out_ld == 128 && M_real % 128 == 0 &&
+              a->split_k <= 1 && a->epi_act == KEEP_ACT_NONE && !a->aux && !a->stats_out && a->out_dtype == KEEP_F32 &&
+              (uintptr_t)a->ln_gamma % 16 == 0 && (uintptr_t)a->ln_beta % 16 == 0 && (!a->residual || a->res_ld % 4 == 0))) {
+          keep_set_error("keep_conv2d: ln_gamma (LayerNorm epilogue) needs the KEEP_MMA_X3 GEMM form (1x1, stride 1, no prologue / activation / "
+                         "aux / split-K / statistics), Cout == out_ld == 128, fp32 output and N*Ho*Wo %% 128 == 0");
+          return KEEP_EUNSUP;
+        }
+        pl.tile = 3;
+        pl.split_k = 1;
+        pl.stats_rows = 0;
+        pl.amax_ok = ((long)a->Ho * a->Wo) % 32 == 0;
+        snprintf(pl.kernel, sizeof(pl.kernel), "conv_x3_kernel<4, 1, 1, 4, true, true> + LayerNorm");
+        return KEEP_OK;
+      }
       snprintf(pl.kernel, sizeof(pl.kernel), "conv_x3_kernel<%s, %s, %s>", pl.tile == 1 ? "2, 2, 1, 1" : "2, 2, 2, 2",
                pl.plain ? "true" : "false", keep_conv_x3_gather_is_gemm(a) ? "true" : "false");
       return KEEP_OK;
+    }
+    if (a->ln_gamma) {
+      keep_set_error("keep_conv2d: ln_gamma (LayerNorm epilogue) is a feature of the KEEP_MMA_X3 GEMM form");
+      return KEEP_EUNSUP;
     }
     mma = KEEP_MMA_F32;
   }
@@ -2115,7 +2141,7 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a_in, void* stream) {
       if (rc != KEEP_OK) return rc;
       break;
     case PATH_GATHER_X3:
-      rc = keep_conv2d_x3_gather(a, p, pl.tile == 2, st);
+      rc = keep_conv2d_x3_gather(a, p, pl.tile, st);
       if (rc != KEEP_OK) return rc;
       break;
     case PATH_HALO_F32: {

@@ -672,6 +672,14 @@ __device__ __forceinline__ void x3_gather_epilogue(const ConvP& p, f32x16 (&acc)
   float amx = 0.f;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias && p.split_k == 1 && cok) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
+  // LayerNorm over the row's 128 channels (tile <4,1,1,4>: the 32 lanes of a half-wave hold one whole row, 4 channels each)
+  constexpr bool LN_OK = SIMPLE && WGN == 1 && TN == 4;
+  const bool ln = LN_OK && p.ln_gamma != nullptr;
+  float4 lng = make_float4(1.f, 1.f, 1.f, 1.f), lnb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ln) {
+    lng = *reinterpret_cast<const float4*>(p.ln_gamma + c4);
+    lnb = *reinterpret_cast<const float4*>(p.ln_beta + c4);
+  }
   // SIMPLE form: groups of up to 8 rows, the group's residual rows loaded before its first store (inside the loop each load sat behind
   // the previous store and its `s_waitcnt vmcnt(0)` exposed a memory round trip per row: see the halo kernel's epilogue)
   constexpr int NIT = WR / RPI, GRP = NIT < 8 ? NIT : 8;
@@ -695,6 +703,21 @@ __device__ __forceinline__ void x3_gather_epilogue(const ConvP& p, f32x16 (&acc)
     if (!SIMPLE) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) e[q] = p.fast ? act_apply_fast(e[q], p.epi_act) : act_apply(e[q], p.epi_act);
+    }
+    if (LN_OK && ln) {      // two passes like layernorm128_kernel: mean, then the centred squares (biased variance)
+      float sm = (e[0] + e[1]) + (e[2] + e[3]);
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) sm += __shfl_xor(sm, o);
+      const float mean = sm * (1.0f / 128.0f);
+      const float d[4] = {e[0] - mean, e[1] - mean, e[2] - mean, e[3] - mean};
+      float qq = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) qq += __shfl_xor(qq, o);
+      const float rstd = 1.0f / sqrtf(qq * (1.0f / 128.0f) + p.ln_eps);
+      e[0] = d[0] * rstd * lng.x + lnb.x;
+      e[1] = d[1] * rstd * lng.y + lnb.y;
+      e[2] = d[2] * rstd * lng.z + lnb.z;
+      e[3] = d[3] * rstd * lng.w + lnb.w;
     }
     if (p.res) {
       const u32x4 r4 = SIMPLE ? rpre[SIMPLE ? it % GRP : 0] : __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, v_res + it * RPI * p.res_ld * 4, 0, 0);
@@ -1480,8 +1503,10 @@ static unsigned long long* dbg = nullptr;
   return KEEP_OK;
 }
 
-// big_tile: plan_conv's choice (128x128 block tiles instead of 64x64) -- the launch never re-derives it
-int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int big_tile, hipStream_t st) {
+// tile: plan_conv's choice (1: 64x64 block tiles, 2: 128x128, 3: 128x128 as four 32-row waves with the LayerNorm epilogue) --
+// the launch never re-derives it
+int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int tile, hipStream_t st) {
+  const int big_tile = tile >= 2;
   const long M = p.M;
   const int steps = a->KH * a->KW * ((a->Cin + XBK - 1) / XBK);
   if (p.split_k > steps) p.split_k = steps;
@@ -1504,7 +1529,9 @@ int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int big_tile, hip
   const bool rowmajor = gy > 1 && gx >= 1024 && gx * gy < (1L << 30) && !getenv("KEEP_X3_GEMM_2D");
   p.tile_cols = rowmajor ? (int)gy : 0;
   dim3 grid(rowmajor ? (unsigned)(gx * gy) : (unsigned)gx, rowmajor ? 1u : (unsigned)gy, p.split_k);
-  if (!big_tile) {
+  if (tile == 3) {
+    hipLaunchKernelGGL((conv_x3_kernel<4, 1, 1, 4, true, true>), grid, block, 0, st, p);
+  } else if (!big_tile) {
     KEEP_LAUNCH_GX(2, 2, 1, 1)
   } else {
     KEEP_LAUNCH_GX(2, 2, 2, 2)

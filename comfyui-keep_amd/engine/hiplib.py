@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('KEEP_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')   # (KEEP_HIP_LIB: dev A/B builds)
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 F32, BF16 = 0, 1
 MMA_F32, MMA_BF16, MMA_X3 = 0, 1, 2
@@ -33,7 +33,8 @@ class ConvArgs(C.Structure):
                [(n, _i32) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad_t', 'pad_l', 'Ho', 'Wo',
                                     'in_ld', 'out_ld', 'res_ld', 'upsample', 'pro_act', 'epi_act')] + \
                [('aux_w', _f32), ('split_k', _i32), ('dtype', _i32), ('mma', _i32), ('weight_bf16', _vp), ('stats_out', _vp), ('stats_P', _i32), ('bk256', _i32), ('out_dtype', _i32),
-                ('weight_x3', _vp), ('x3_acc_scale', _f32), ('x3_in_amax', _vp), ('x3_out_amax', _vp), ('x3_out_amax_zeroed', _i32), ('in2', _vp), ('in2_cin1', _i32), ('pad_mode', _i32)]
+                ('weight_x3', _vp), ('x3_acc_scale', _f32), ('x3_in_amax', _vp), ('x3_out_amax', _vp), ('x3_out_amax_zeroed', _i32), ('in2', _vp), ('in2_cin1', _i32), ('pad_mode', _i32),
+                ('ln_gamma', _vp), ('ln_beta', _vp), ('ln_eps', _f32), ('reserved1', _i32)]
 
 
 class ConvPlanOut(C.Structure):

@@ -483,10 +483,17 @@ class KeepNet:
         self.o.attention(q, k, v, o, B=n_img * 4, H=1, Lq=Ltok // 4, Lk=Ltok // 4, D=C, Dv=C, scale=1.0 / (C ** 0.5),
                       q_str=sq, k_str=skv, v_str=skv, o_str=(Ltok * C, C, 0), mode=2, img_h=h8, img_w=w8, ksplit=2,
                       shift=shift, kv_rot=kv_rot, n_img=n_img)
-        m = self.o.linear(o, w[f'{p}.merge.weight'], bounded=True, n_img=n_img)
+        n1 = (w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], 1e-5)
+        fuse = self.o.ln_fusable(w[f'{p}.merge.weight'], Ltok)      # LayerNorm in the GEMM's epilogue (keep_conv2d ln_gamma, ABI v16)
         if not ffn:
-            return ops.layernorm(m, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], res=src)
-        m = ops.layernorm(m, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'])
+            if fuse:
+                return self.o.linear(o, w[f'{p}.merge.weight'], bounded=True, n_img=n_img, ln=n1, residual=src)
+            m = self.o.linear(o, w[f'{p}.merge.weight'], bounded=True, n_img=n_img)
+            return ops.layernorm(m, n1[0], n1[1], res=src)
+        if fuse:
+            m = self.o.linear(o, w[f'{p}.merge.weight'], bounded=True, n_img=n_img, ln=n1)
+        else:
+            m = ops.layernorm(self.o.linear(o, w[f'{p}.merge.weight'], bounded=True, n_img=n_img), n1[0], n1[1])
         if self.o.mma == L.MMA_BF16 and C == 128 and FUSED_GM_MLP:
             m2 = self.o.gm_mlp(src, m, w[f'{p}.mlp.0.weight'], w[f'{p}.mlp.2.weight'])      # [M,8C] never leaves the CU
         else:
@@ -494,6 +501,9 @@ class KeepNet:
                 hmid = self.o.linear(src, w[f'{p}.mlp.0.weight'], act=L.ACT_GELU, bounded=True, x2=m, n_img=n_img)
             else:
                 hmid = self.o.linear(ops.concat2(src, m), w[f'{p}.mlp.0.weight'], act=L.ACT_GELU, bounded=True, n_img=n_img)
+            if self.o.ln_fusable(w[f'{p}.mlp.2.weight'], Ltok):
+                return self.o.linear(hmid, w[f'{p}.mlp.2.weight'], bounded=True, n_img=n_img, residual=src,
+                                     ln=(w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], 1e-5))
             m2 = self.o.linear(hmid, w[f'{p}.mlp.2.weight'], bounded=True, n_img=n_img)
         return ops.layernorm(m2, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], res=src)
 

@@ -18,6 +18,7 @@ from . import hiplib as L
 
 TOKEN_LINEAR = os.environ.get('KEEP_NO_TOKEN_LINEAR') is None   # dev switch: streaming GEMM for the GMFlow projections
 UP2_PHASES = os.environ.get('KEEP_X3_UP2', '1') != '0'      # x3 policy: nearest x2 + 3x3 as four 2x2-tap phase convolutions (A/B: 0)
+FUSE_LN = os.environ.get('KEEP_X3_FUSE_LN', '1') != '0'      # x3 policy: GMFlow `merge -> norm1` / `mlp.2 -> norm2` LayerNorms in the GEMM epilogue (A/B: 0)
 USE_BK256 = bool(int(os.environ.get('KEEP_BK256', '0')))   # measured slower than BK=64 + split-K at B<=4 (kept for A/B)
 # bf16 policy: inputs of fewer pixels (N*H*W) than this skip the normalise+activate -> bf16 pass in front of the halo
 # conv and use the kernel variant that applies the prologue while staging (A/B switch, default: always the two-pass form)
@@ -175,14 +176,16 @@ class Ops:
     def conv(self, x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=False, pro=None, pro_act=L.PRO_NONE,
              act=L.ACT_NONE, residual=None, aux=None, aux_w=1.0, cin=None, in_off=0, out=None, split_k=None, wb=None,
              wx3=None, x3_acc_scale=None, mma=None, stats=False, out_bf16=False, bounded=False, x_amax=None, x2=None,
-             reflect=False, out_ld=None):
+             reflect=False, out_ld=None, ln=None):
         """x [N,H,W,ld] -> [N,Ho,Wo,Cout].  ``w`` packed [Cout,KH,KW,Cin].  ``cin``/``in_off`` select a channel
         slice of a wider input buffer.  ``down`` = VQGAN Downsample geometry (pad right/bottom only, stride 2).
         ``stats=True`` returns ``(out, st)``: ``st`` is a ``Stats`` (epilogue-reduced GroupNorm partials and, under the x3
         policy, the per-image max |out|), or None when this launch could emit neither (split-K).  ``x_amax``: the
         producer's ``Stats.amax`` of x (any upper bound of max |x| per image works), replacing the range probe.
         ``bounded=True``: the caller vouches that |x| stays far below the fp16 range (normalised / attention-averaged
-        inputs); otherwise an x3 launch without a normalising prologue first probes the input range (keep_absmax)."""
+        inputs); otherwise an x3 launch without a normalising prologue first probes the input range (keep_absmax).
+        ``ln=(gamma, beta, eps)``: LayerNorm over the output channels in the epilogue, BEFORE the residual is added (x3 GEMM form,
+        Cout == 128, rows % 128 == 0: ``ln_fusable``); the library refuses anything else."""
         N, H, W, ld = x.shape
         Cout = w.shape[0]
         Cin = ld if cin is None else cin
@@ -235,12 +238,15 @@ class Ops:
                 mma=mma, weight_bf16=wb if mma == L.MMA_BF16 else None, stats_out=None, stats_P=0,
                 bk256=int(USE_BK256), out_dtype=odt, weight_x3=wx3 if mma == L.MMA_X3 else None,
                 x3_acc_scale=float(x3_acc_scale), x3_in_amax=in_amax, x3_out_amax=None,
-                in2=x2, in2_cin1=0 if x2 is None else ld, pad_mode=L.PAD_REFLECT if reflect else L.PAD_ZERO)
+                in2=x2, in2_cin1=0 if x2 is None else ld, pad_mode=L.PAD_REFLECT if reflect else L.PAD_ZERO,
+                ln_gamma=None if ln is None else ln[0], ln_beta=None if ln is None else ln[1],
+                ln_eps=0.0 if ln is None else float(ln[2]))
 
         def key_of(dtype, pro_t, pro_a, odt, sk):
             return (N, H, W, ld, Cin, Cout, KH, stride, pad_t, pad_l, Ho, Wo, out_ld, up_mode, pro_a, act, dtype, mma,
                     odt, sk, pro_t is not None, residual is not None, 0 if residual is None else residual.shape[-1],
-                    aux is not None, bias is not None, in_off % 8, wx3 is not None, USE_BK256, x2 is not None, bool(reflect))
+                    aux is not None, bias is not None, in_off % 8, wx3 is not None, USE_BK256, x2 is not None, bool(reflect),
+                    ln is not None)
 
         sk_req = 0 if split_k is None else int(split_k)
         odt = L.BF16 if want_bf16_out else L.F32
@@ -306,7 +312,7 @@ class Ops:
         return (out, st) if stats else out
 
     def linear(self, x, w, bias=None, *, act=L.ACT_NONE, residual=None, pro=None, pro_act=L.PRO_NONE, cin=None, in_off=0,
-               n_img=None, out_bf16=False, bounded=False, x_amax=None, x2=None):
+               n_img=None, out_bf16=False, bounded=False, x_amax=None, x2=None, ln=None):
         """x [M,ld] (or any [...,ld]) @ w[Cout,Cin]^T.  ``n_img``: the rows are n_img independent images (frames, clips) of
         M/n_img rows each -- the unit of the per-image prologue AND of the library's plan (kernel tile / split-K are chosen
         from the per-image row count, so a clip's result never depends on its batch-mates).  Default: the leading axis of a
@@ -325,8 +331,14 @@ class Ops:
         x24 = None if x2 is None else x2.reshape(n_img, M // n_img, 1, x2.shape[-1])
         res4 = None if residual is None else residual.reshape(n_img, M // n_img, 1, residual.shape[-1])
         y = self.conv(x4, w, bias, stride=1, pad=0, ksize=1, pro=pro, pro_act=pro_act, act=act, residual=res4, cin=cin,
-                      in_off=in_off, out_bf16=out_bf16, bounded=bounded, x_amax=x_amax, x2=x24)
+                      in_off=in_off, out_bf16=out_bf16, bounded=bounded, x_amax=x_amax, x2=x24, ln=ln)
         return y.reshape(*shp[:-1], w.shape[0])
+
+    def ln_fusable(self, w, rows_per_image):
+        """Can ``linear(x, w, ln=...)`` run its LayerNorm in the GEMM's epilogue?  (x3 policy with a split twin of ``w``, 128 output
+        channels, K a multiple of 32, whole 128-row tiles per image -- a rule that never looks at the batch.)"""
+        return (FUSE_LN and self.mma == L.MMA_X3 and w.shape[0] == 128 and w.shape[-1] % 32 == 0 and rows_per_image % 128 == 0
+                and self.x3_twin(w) is not None)
 
     # ------------------------------------------------------------------ normalisation
     @staticmethod

@@ -30,7 +30,7 @@ extern "C" {
  * the fields a shorter known layout lacks as zero), keep_sizeof_*_args(), keep_argmax_gather takes the non-finite status word,
  * keep_nonfinite_flag.  v13: keep_conv2d_args.upsample accepts KEEP_UPSAMPLE_X2_PHASES (same layout; a v12 library refuses the
  * value, so the binding asks for 13). */
-#define KEEP_ABI_VERSION 15
+#define KEEP_ABI_VERSION 16
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -152,6 +152,16 @@ typedef struct {
   int32_t pad_mode; /* KEEP_PAD_ZERO (default) | KEEP_PAD_REFLECT: pixels outside the (post-upsample) input mirror it like
                        nn.ReflectionPad2d(pad) (wm_facelib/parsing/parsenet.py:97,104: every ParseNet convolution); needs
                        pad_t == pad_l < min(H, W) and KEEP_MMA_F32 or KEEP_MMA_X3 */
+  /* v16, optional: LayerNorm over the Cout channels of every output row, fused into the epilogue of the KEEP_MMA_X3 GEMM form:
+   * out = LayerNorm(in . W^T + bias; ln_gamma, ln_beta, ln_eps) + residual -- the `merge -> norm1` and `mlp.2 -> norm2` pairs of a
+   * GMFlow transformer layer (GM/transformer.py:170-187) as one launch.  Needs a 1x1 stride-1 convolution without prologue /
+   * activation / aux / split-K / statistics, Cout == out_ld == 128 (one wave holds whole rows: tile <4,1,1,4>) and
+   * N*Ho*Wo %% 128 == 0; keep_conv2d_plan answers KEEP_EUNSUP otherwise.  Two-pass statistics (mean, then centred squares),
+   * biased variance like nn.LayerNorm.  NULL: no LayerNorm. */
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
+  int32_t reserved1; /* 0 */
 } keep_conv2d_args;
 /* smallest struct_size the library accepts: the v12 layout up to and including in2_cin1 (fields appended later are optional) */
 #define KEEP_CONV2D_ARGS_V12_SIZE 256

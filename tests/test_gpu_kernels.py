@@ -1288,6 +1288,47 @@ def test_linear_x3_at_the_gemm_shapes_of_the_step(name, M, K, N, act, bias, two,
     assert err64(y.reshape(M, N), ref) <= 2e-6 * scale, (name, err64(y.reshape(M, N), ref), scale)
 
 
+@pytest.mark.parametrize("name,M,K,res,bias,img", [
+    ('merge+norm1+res', 19 * 4096, 128, True, False, 0),      # GMFlow self-attention block: LN(merge(o)) + source
+    ('merge+norm1', 6 * 4096, 128, False, True, 0),           # cross-attention block: LN(merge(o)) feeds the FFN
+    ('mlp.2+norm2+res', 5 * 4096, 1024, True, True, 0),       # LN(mlp.2(h)) + source
+    ('ranges', 4 * 4096, 128, True, True, 4)])                # per-image range scales on the GEMM input
+def test_linear_x3_layernorm_epilogue(name, M, K, res, bias, img):
+    """keep_conv2d ln_gamma (ABI v16): LayerNorm over the 128 output channels in the epilogue of the x3 GEMM form (tile <4,1,1,4>: one
+    half-wave holds a whole row), applied BEFORE the residual -- GM/transformer.py:170-187.  Against float64 and against the two-launch
+    form (GEMM, then keep_layernorm); refused loudly for any geometry it cannot run."""
+    N = 128
+    x = rnd(f'ln_x_{name}', (M, K), 3.0 if img else 1.0)
+    w = rnd(f'ln_w_{name}', (N, K), 0.05)
+    b = rnd(f'ln_b_{name}', (N,), 0.3) if bias else None
+    g, be = 1.0 + 0.3 * rnd(f'ln_g_{name}', (N,)), rnd(f'ln_be_{name}', (N,), 0.2)
+    r = rnd(f'ln_r_{name}', (M, N), 2.0) if res else None
+    if img:
+        x = x * torch.tensor([1.0, 40.0, 0.01, 7.0]).repeat_interleave(M // img).view(-1, 1)
+    wd = dev(w)
+    wx3, asc = x3w(wd)
+    n_img = max(img, 1)
+    kw = dict(mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, pad=0, ksize=1, bounded=not img)
+    xd, bd, gd, bed = dev(x).view(n_img, M // n_img, 1, K), None if b is None else dev(b), dev(g), dev(be)
+    rd = None if r is None else dev(r).view(n_img, M // n_img, 1, N)
+    y = ops.conv(xd, wd, bd, residual=rd, ln=(gd, bed, 1e-5), **kw).reshape(M, N)
+    z = x.double() @ w.double().t() + (0 if b is None else b.double())
+    ref = torch.nn.functional.layer_norm(z, (N,), g.double(), be.double(), 1e-5) + (0 if r is None else r.double())
+    m = ops.conv(xd, wd, bd, **kw).reshape(M, N)
+    two = ops.layernorm(m, gd, bed, res=None if r is None else dev(r))
+    e_f, e_2 = err64(y, ref), err64(two, ref)
+    print(f'{name}: fused {e_f:.3e}  two launches {e_2:.3e}  fused vs two {(y - two).abs().max().item():.3e}')
+    assert e_f <= max(2.0 * e_2, 3e-6), (name, e_f, e_2)
+    assert (y - two).abs().max().item() <= 1e-5
+    with pytest.raises(L.KeepHipError):      # 256 output channels: a row does not fit one half-wave's tile
+        w2 = dev(rnd('ln_w256', (256, K), 0.05))
+        wx, a2 = x3w(w2)
+        ops.conv(xd, w2, None, ln=(dev(rnd('ln_g256', (256,))), dev(rnd('ln_b256', (256,))), 1e-5),
+                 **dict(kw, wx3=wx, x3_acc_scale=a2))
+    with pytest.raises(L.KeepHipError):      # the exact-f32 policy has no LayerNorm epilogue
+        ops.conv(xd, wd, bd, ln=(gd, bed, 1e-5), pad=0, ksize=1, bounded=True)
+
+
 def test_linear_x3_k_concatenated_inputs():
     """keep_conv2d in2 (x3 GEMM form): cat([a, b], -1) @ W^T without materialising the concatenation (GM/transformer.py:182);
     equals the concat path bit for bit (same K order, same kernel), ragged M; rejected loudly outside the x3 policy."""

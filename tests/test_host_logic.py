@@ -375,6 +375,35 @@ def test_plan_is_batch_invariant_in_the_parity_policies():
         assert len(seen) == 1, (H, W, Cin, Cout, k, seen)
 
 
+def test_plan_layernorm_epilogue_rules():
+    """keep_conv2d_plan (host-side C): ln_gamma is accepted only where the LayerNorm epilogue exists -- the x3 GEMM form with
+    128 output channels and whole 128-row tiles -- and refused with KEEP_EUNSUP (-2) everywhere else, never silently dropped."""
+    from comfyui_keep_amd.engine import hiplib
+    lib = ctypes.CDLL(hiplib.LIB_PATH)
+    lib.keep_conv2d_plan.restype = ctypes.c_int32
+    lib.keep_last_error.restype = ctypes.c_char_p
+    buf = (ctypes.c_float * 4096)()
+    ptr = (ctypes.addressof(buf) + 63) // 64 * 64
+
+    def plan(**kw):
+        base = dict(struct_size=ctypes.sizeof(hiplib.ConvArgs), N=2, H=4096, W=1, Cin=128, Cout=128, KH=1, KW=1, stride=1, pad_t=0,
+                    pad_l=0, Ho=4096, Wo=1, in_ld=128, out_ld=128, mma=hiplib.MMA_X3, inp=ptr, out=ptr, weight=ptr, weight_x3=ptr,
+                    x3_acc_scale=1.0, ln_gamma=ptr, ln_beta=ptr, ln_eps=1e-5)
+        base.update(kw)
+        out = hiplib.ConvPlanOut()
+        rc = lib.keep_conv2d_plan(ctypes.byref(hiplib.ConvArgs(**base)), ctypes.byref(out))
+        return rc, out.kernel.decode(), out.split_k
+
+    rc, kernel, sk = plan()
+    assert rc == 0 and 'LayerNorm' in kernel and '<4, 1, 1, 4' in kernel and sk == 1, (rc, kernel, lib.keep_last_error())
+    assert plan(Cin=1024, in_ld=1024)[0] == 0
+    assert plan(ln_gamma=None, ln_beta=None)[1].startswith('conv_x3_kernel<2, 2, 2, 2')         # unchanged without it
+    for bad in (dict(Cout=256, out_ld=256), dict(H=4000, Ho=4000), dict(epi_act=hiplib.ACT_GELU), dict(mma=hiplib.MMA_F32),
+                dict(KH=3, KW=3, pad_t=1, pad_l=1, H=64, W=64, Ho=64, Wo=64), dict(split_k=2), dict(ln_beta=None)):
+        rc, kernel, _ = plan(**bad)
+        assert rc == -2 and b'ln_gamma' in lib.keep_last_error(), (bad, rc, kernel)
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, 'comfyui-keep_amd')
     for dirpath, _, files in os.walk(pkg):

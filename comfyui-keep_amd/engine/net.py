@@ -29,6 +29,7 @@ _KNOWN_KW = set(DEFAULT_ARCH) | {
 
 
 FUSED_GM_MLP = os.environ.get('KEEP_NO_FUSED_MLP') is None     # dev switch
+GM_DEDUP_L0 = os.environ.get('KEEP_GM_DEDUP_L0', '1') != '0'    # GMFlow layer-0 self-attention once per frame instead of once per pair member (A/B: 0)
 # 'x3': split-fp16 operands on the 16-bit matrix pipe (fp32-grade products, csrc/keep_conv_x3.hip) -- the default: it
 # passes the same <= 1e-3 parity tests as 'fp32' (exact f32 MFMA everywhere) at several times its speed.
 CHECK_X3_RANGE = os.environ.get('KEEP_X3_NO_RANGE_CHECK') is None
@@ -539,23 +540,38 @@ class KeepNet:
             first = [b * T + t + 1 for b in range(B) for t in range(T - 1)]
             second = [b * T + t for b in range(B) for t in range(T - 1)]
             self._const[key] = torch.tensor(first + second, device=feat.device, dtype=torch.long)
+        if GM_DEDUP_L0:
+            return self._gmflow_pairs(None, B * (T - 1), uniq=(feat, self._const[key]))
         return self._gmflow_pairs(feat.index_select(0, self._const[key]), B * (T - 1))
 
-    def _gmflow_pairs(self, feat, P):
-        """feat [2P,h8,w8,C]: features of the P first images followed by the P second images -> flow [P,H,W,2]."""
+    def _gmflow_pairs(self, feat, P, uniq=None):
+        """feat [2P,h8,w8,C]: features of the P first images followed by the P second images -> flow [P,H,W,2].
+        ``uniq=(frame features [F,h8,w8,C], pair index [2P])``: the clip form.  The position table and the self-attention block of
+        layer 0 see one image at a time and nothing of its pair, so they run once per FRAME (an interior frame sits in two pairs:
+        47 % fewer images at T = 20) and their outputs are gathered into pair order -- the same values (per-image arithmetic, per-image
+        plans), `test_gmflow_clip_layer0_runs_once_per_frame`."""
         w = self.w
         pfx = 'flownet.model'
-        n_img, h8, w8, C = feat.shape
+        n_img, (_, h8, w8, C) = 2 * P, (feat if uniq is None else uniq[0]).shape
         Ltok = h8 * w8
-        table, grid = self._gm_consts(h8, w8, feat.device)
-        c0 = ops.add_bcast(feat, table).view(n_img * Ltok, C)
+        table, grid = self._gm_consts(h8, w8, (feat if uniq is None else uniq[0]).device)
+        s_att0 = None
+        if uniq is None:
+            c0 = ops.add_bcast(feat, table).view(n_img * Ltok, C)
+        else:
+            fu, sel = uniq
+            F_ = fu.shape[0]
+            cu = ops.add_bcast(fu, table).view(F_ * Ltok, C)
+            su = self._gm_layer(cu, cu, f'{pfx}.transformer.layers.0.self_attn', False, h8, w8, 0, 0, F_)
+            c0 = cu.view(F_, Ltok * C).index_select(0, sel).view(n_img * Ltok, C)
+            s_att0 = su.view(F_, Ltok * C).index_select(0, sel).view(n_img * Ltok, C)
         wsz = h8 // 2
         for i in range(GMFLOW['num_layers']):
             shift = wsz // 2 if i % 2 == 1 else 0
             lp = f'{pfx}.transformer.layers.{i}'
             # the cross-attention target is the swapped INPUT of this block (concat1 is refreshed only after
             # the block, GM/transformer.py:308-317), not the output of its self-attention
-            s_att = self._gm_layer(c0, c0, f'{lp}.self_attn', False, h8, w8, shift, 0, n_img)
+            s_att = s_att0 if (i == 0 and s_att0 is not None) else self._gm_layer(c0, c0, f'{lp}.self_attn', False, h8, w8, shift, 0, n_img)
             c0 = self._gm_layer(s_att, c0, f'{lp}.cross_attn_ffn', True, h8, w8, shift, P, n_img)
         f0 = c0[:P * Ltok]
         f1 = c0[P * Ltok:]

@@ -101,6 +101,21 @@ def test_gmflow_vs_golden(gpu_net):
     close(nchw(flow), OPS['gmflow64'], 5e-4, 'gmflow 64x64')
 
 
+def test_gmflow_clip_layer0_runs_once_per_frame(gpu_net, monkeypatch):
+    """KeepNet._gmflow_clip: the position table and the self-attention block of GMFlow's layer 0 see one image and nothing of its
+    pair, so the clip form runs them once per frame and gathers into pair order (an interior frame sits in two pairs).  Same bits
+    as running them on every pair member (per-image arithmetic and plans), and as the pair-at-a-time entry point."""
+    from comfyui_keep_amd.engine import net as net_mod
+    x = synth.synth_clip(T=4, B=2, size=64, seed=7).cuda()
+    monkeypatch.setattr(net_mod, 'GM_DEDUP_L0', True)
+    f_once = gpu_net._gmflow_clip(x)
+    monkeypatch.setattr(net_mod, 'GM_DEDUP_L0', False)
+    f_pairs = gpu_net._gmflow_clip(x)
+    assert f_once.shape == (2 * 3, 64, 64, 2) and torch.equal(f_once, f_pairs)
+    solo = gpu_net._gmflow(x[1, 2:3], x[1, 1:2])                      # clip 1, pair (frame 2, frame 1)
+    assert torch.equal(solo[0], f_once[3 + 1])
+
+
 def test_encoder_and_generator_stacks_vs_golden(gpu_net):
     z, _ = gpu_net._vq_stack(nhwc(op_input('encoder64', (1, 3, 64, 64))), 'encoder', encoder_blocks(DEFAULT_ARCH))
     close(nchw(z), OPS['encoder64'], 5e-4, 'encoder 64x64')

@@ -11,6 +11,17 @@
 // the streaming halo kernel, round 3's halo kernel, the gather / GEMM kernel.  Measured per family on the whole step (DESIGN 5.4,
 // tools/dev/lib_ab.py): nt on the GEMM family -0.3 %, on round 3's halo kernel another -0.3 %, on the streaming kernel 0.0 % in time but
 // -6.5 % of its fetched HBM bytes (PMC: the written lines no longer evict the halo rows the neighbouring tiles re-read).
+// (dev A/B) cache policy of loads that are read exactly once: the halo pieces of the streaming kernel (re-read 1.33 x by the
+// neighbouring tiles: expected to lose), its residual rows, the A rows of a GEMM with one column block
+#ifndef KEEP_LD_AUX_XS
+#define KEEP_LD_AUX_XS 0
+#endif
+#ifndef KEEP_LD_AUX_RES
+#define KEEP_LD_AUX_RES 0
+#endif
+#ifndef KEEP_LD_AUX_GEMM_A1
+#define KEEP_LD_AUX_GEMM_A1 0
+#endif
 #ifndef KEEP_ST_AUX_XS
 #define KEEP_ST_AUX_XS 2
 #endif

@@ -924,10 +924,16 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
           continue;
         }
         const bool second = p.in2 && c0 >= p.cin1;                      // wave-uniform
-        const u32x4 v0 = second ? __builtin_amdgcn_raw_buffer_load_b128(a2_rsrc, a2_voff[it], (c0 - p.cin1) * 4, 0)
-                                : __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[it], c0 * 4, 0);
-        const u32x4 v1 = second ? __builtin_amdgcn_raw_buffer_load_b128(a2_rsrc, a2_voff[it] + 16, (c0 - p.cin1) * 4, 0)
-                                : __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[it] + 16, c0 * 4, 0);
+        u32x4 v0, v1;
+        if (KEEP_LD_AUX_GEMM_A1 != 0 && BN >= 128 && p.Cout <= BN && !p.in2) {      // one column block: every A row is read exactly once
+          v0 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[it], c0 * 4, KEEP_LD_AUX_GEMM_A1);
+          v1 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[it] + 16, c0 * 4, KEEP_LD_AUX_GEMM_A1);
+        } else {
+          v0 = second ? __builtin_amdgcn_raw_buffer_load_b128(a2_rsrc, a2_voff[it], (c0 - p.cin1) * 4, 0)
+                      : __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[it], c0 * 4, 0);
+          v1 = second ? __builtin_amdgcn_raw_buffer_load_b128(a2_rsrc, a2_voff[it] + 16, (c0 - p.cin1) * 4, 0)
+                      : __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[it] + 16, c0 * 4, 0);
+        }
         R.a_raw[it][0] = __uint_as_float(v0.x); R.a_raw[it][1] = __uint_as_float(v0.y);
         R.a_raw[it][2] = __uint_as_float(v0.z); R.a_raw[it][3] = __uint_as_float(v0.w);
         R.a_raw[it][4] = __uint_as_float(v1.x); R.a_raw[it][5] = __uint_as_float(v1.y);

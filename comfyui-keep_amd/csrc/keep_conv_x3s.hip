@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3s_kernel(ConvP p, int t
       cv[2] = AFF ? __builtin_fmaf(hreg[k].z, csc[2], csh[2]) : hreg[k].z * rs;
       cv[3] = AFF ? __builtin_fmaf(hreg[k].w, csc[3], csh[3]) : hreg[k].w * rs;
       if (XS_ABL != 11) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(okF ? in_rsrc : null_rsrc, h_voff[k], chF * 64, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(okF ? in_rsrc : null_rsrc, h_voff[k], chF * 64, KEEP_LD_AUX_XS);
         hreg[k] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
       }
       if (AFF && k == HALO_IT - 1 && XS_ABL != 11) {           // the affine of this chunk has been read for the last time: the next chunk's
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3s_kernel(ConvP p, int t
     u32x4 rpre[HAS_RES ? 16 : 1];
     if (HAS_RES) {
 #pragma unroll
-      for (int q16 = 0; q16 < 16; ++q16) rpre[q16] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, v_res, dpix_of(q16) * p.res_ld * 4, 0);
+      for (int q16 = 0; q16 < 16; ++q16) rpre[q16] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, v_res, dpix_of(q16) * p.res_ld * 4, KEEP_LD_AUX_RES);
     }
 #pragma unroll
     for (int rd = 0; rd < 4; ++rd) {           // rows 16 rd .. 16 rd + 15 of the wave's 64 pixels: accumulator tile rd / 2, registers 8 (rd % 2) ..
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3s_kernel(ConvP p, int t
   setup_F();
 #pragma unroll
   for (int k = 0; k < HALO_IT; ++k) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, h_voff[k], 0, 0);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, h_voff[k], 0, KEEP_LD_AUX_XS);
     hreg[k] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
   }
   if (AFF) {

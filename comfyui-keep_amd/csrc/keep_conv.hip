@@ -1788,6 +1788,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   p.out_amax = nullptr;
   p.reflect = a->pad_mode == KEEP_PAD_REFLECT ? 1 : 0;
   p.tile_cols = 0;
+  p.reverse = 0;
   p.ln_gamma = a->ln_gamma;
   p.ln_beta = a->ln_beta;
   p.ln_eps = a->ln_eps;

@@ -68,6 +68,7 @@ struct ConvP {
   unsigned* out_amax;         // KEEP_MMA_X3: per-image max |output| as raw float bits (atomicMax), or NULL
   int reflect;                // padding pixels mirror the image (nn.ReflectionPad2d, ParseNet) instead of reading zeros
   int tile_cols;              // x3 gather kernel on a 1-D grid: column blocks per row block (0: blockIdx.x / .y are the row / column block)
+  int reverse;                // x3 gather kernel: row blocks in descending order (the rows the producer wrote LAST are read first)
   const float* ln_gamma;      // x3 GEMM form, tile <4,1,1,4>: LayerNorm over the 128 output channels of a row in the epilogue (or NULL)
   const float* ln_beta;
   float ln_eps;

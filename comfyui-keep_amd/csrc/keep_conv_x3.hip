@@ -819,6 +819,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
     bx = lid / p.tile_cols;
     by = lid - bx * p.tile_cols;
   }
+  if (p.reverse) bx = (int)((p.M + BM - 1) / BM) - 1 - bx;
   const long m0 = (long)bx * BM;
   const int n0 = by * BN;
   const int z = blockIdx.z;
@@ -1534,6 +1535,10 @@ int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int tile, hipStre
   const long gx = cdiv(M, bt), gy = cdiv(a->Cout, bt);
   const bool rowmajor = gy > 1 && gx >= 1024 && gx * gy < (1L << 30) && !getenv("KEEP_X3_GEMM_2D");
   p.tile_cols = rowmajor ? (int)gy : 0;
+  {
+    static const int rev = getenv("KEEP_X3_GEMM_REVERSE") ? atoi(getenv("KEEP_X3_GEMM_REVERSE")) : 0;      // dev A/B
+    p.reverse = rev;
+  }
   dim3 grid(rowmajor ? (unsigned)(gx * gy) : (unsigned)gx, rowmajor ? 1u : (unsigned)gy, p.split_k);
   if (tile == 3) {
     hipLaunchKernelGGL((conv_x3_kernel<4, 1, 1, 4, true, true>), grid, block, 0, st, p);

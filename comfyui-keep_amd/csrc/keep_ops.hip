@@ -1387,6 +1387,45 @@ extern "C" int32_t keep_nchw_to_nhwc(const float* x, float* out, int32_t N, int3
   return KEEP_OK;
 }
 
+// GMFlow's first convolution (GM/backbone.py:69: 7x7, stride 2, pad 3 on the normalised RGB frame) as a 4x4 stride-1 convolution on the
+// 2x2 space-to-depth image: out[y][x] reads rows 2y-3 .. 2y+3 = s2d rows y-2 .. y+1 (sub-row dy = (ky + 1) & 1).  One thread per
+// s2d pixel: 12 values (dy, dx, c) + 4 zero channels = one 64-byte row, so the layer runs on the 16-channel MFMA kernels
+// instead of the element-wise gather of a 147-deep K (engine/weights.py packs the matching [64,4,4,16] weights).
+__global__ __launch_bounds__(256) void rgb_s2d_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W) {
+  const int H2 = H >> 1, W2 = W >> 1;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (i >= (long)H2 * W2) return;
+  const int Y = (int)(i / W2), X = (int)(i - (long)Y * W2);
+  float v[16];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
+    const float stdv = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+    const float* src = x + ((long)n * 3 + c) * H * W + (long)(2 * Y) * W + 2 * X;
+    const float2 r0 = *reinterpret_cast<const float2*>(src), r1 = *reinterpret_cast<const float2*>(src + W);
+    const float raw[4] = {r0.x, r0.y, r1.x, r1.y};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {      // the op order of nchw_to_nhwc_kernel mode 1 (GF:56-57 then GM/utils.py:55-63)
+      float t = (raw[q] + 1.f) / 2.f * 255.f;
+      t = (t / 255.f - mean) / stdv;
+      v[q * 3 + c] = t;
+    }
+  }
+  v[12] = v[13] = v[14] = v[15] = 0.f;
+  float4* dst = reinterpret_cast<float4*>(out + (((long)n * H2 + Y) * W2 + X) * 16);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dst[q] = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
+}
+
+extern "C" int32_t keep_rgb_s2d(const float* x, float* out, int32_t N, int32_t H, int32_t W, void* stream) {
+  KEEP_REQUIRE(x && out && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && (uintptr_t)x % 8 == 0 && (uintptr_t)out % 16 == 0,
+               "keep_rgb_s2d: bad args (H=%d W=%d must be even, x 8-byte / out 16-byte aligned)", H, W);
+  hipLaunchKernelGGL(rgb_s2d_kernel, dim3(cdiv((long)(H / 2) * (W / 2), 256), N), dim3(256), 0, (hipStream_t)stream, x, out, H, W);
+  KEEP_LAUNCH_CHECK("keep_rgb_s2d");
+  return KEEP_OK;
+}
+
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int C,
                                                            int HW) {
   extern __shared__ float tile[];  // [256][C | 1]: odd pitch, the per-pixel column reads below are bank-conflict free

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('KEEP_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')   # (KEEP_HIP_LIB: dev A/B builds)
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 F32, BF16 = 0, 1
 MMA_F32, MMA_BF16, MMA_X3 = 0, 1, 2
@@ -75,6 +75,7 @@ _SIGNATURES = {
     'keep_flow_warp': [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     'keep_convex_upsample': [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     'keep_nchw_to_nhwc': [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    'keep_rgb_s2d': [_vp, _vp, _i32, _i32, _i32, _vp],
     'keep_nhwc_to_nchw': [_vp, _vp, _i32, _i32, _i32, _vp],
     'keep_add_bcast': [_vp, _vp, _vp, _i64, _i64, _f32, _vp],
     'keep_concat2': [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],

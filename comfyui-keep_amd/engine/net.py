@@ -29,6 +29,7 @@ _KNOWN_KW = set(DEFAULT_ARCH) | {
 
 
 FUSED_GM_MLP = os.environ.get('KEEP_NO_FUSED_MLP') is None     # dev switch
+GM_S2D_CONV1 = os.environ.get('KEEP_GM_S2D', '1') != '0'         # GMFlow conv1 (7x7 s2) as a 4x4 convolution on the space-to-depth image (A/B: 0)
 GM_DEDUP_L0 = os.environ.get('KEEP_GM_DEDUP_L0', '1') != '0'    # GMFlow layer-0 self-attention once per frame instead of once per pair member (A/B: 0)
 # 'x3': split-fp16 operands on the 16-bit matrix pipe (fp32-grade products, csrc/keep_conv_x3.hip) -- the default: it
 # passes the same <= 1e-3 parity tests as 'fp32' (exact f32 MFMA everywhere) at several times its speed.
@@ -513,8 +514,15 @@ class KeepNet:
         Per-image arithmetic only (InstanceNorm, convolutions), so a frame's features do not depend on its pair."""
         w = self.w
         pfx = 'flownet.model'
-        img = ops.nchw_to_nhwc(img_nchw, mode=1)                                           # [N,H,W,3] normalised
-        f, fst = self.o.conv(img, w[f'{pfx}.backbone.conv1.weight'], None, stride=2, pad=3, ksize=7, stats=True)
+        ws2d = w.get(f'{pfx}.backbone.conv1.weight_s2d') if GM_S2D_CONV1 else None
+        if ws2d is not None and img_nchw.shape[2] % 2 == 0 and img_nchw.shape[3] % 2 == 0:
+            # the 7x7 stride-2 convolution as a 4x4 stride-1 convolution on the 2x2 space-to-depth image (16-channel rows: the MFMA
+            # kernels take it; the 147-deep element-wise gather of the 3-channel form ran at 0.5 TB/s)
+            img = ops.rgb_s2d(img_nchw.contiguous())                                       # [N,H/2,W/2,16] normalised
+            f, fst = self.o.conv(img, ws2d, None, stride=1, pad=2, ksize=4, stats=True, bounded=True, out_hw=img.shape[1:3])
+        else:
+            img = ops.nchw_to_nhwc(img_nchw, mode=1)                                       # [N,H,W,3] normalised
+            f, fst = self.o.conv(img, w[f'{pfx}.backbone.conv1.weight'], None, stride=2, pad=3, ksize=7, stats=True)
         s, hh = self._inorm(f, fst)
         x = torch.empty_like(f)
         L.call('keep_affine_act', f, s, hh, x, f.shape[0], f.shape[1] * f.shape[2], f.shape[3], L.ACT_RELU)

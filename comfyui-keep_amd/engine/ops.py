@@ -176,7 +176,7 @@ class Ops:
     def conv(self, x, w, bias=None, *, stride=1, pad=1, ksize=3, down=False, upsample=False, pro=None, pro_act=L.PRO_NONE,
              act=L.ACT_NONE, residual=None, aux=None, aux_w=1.0, cin=None, in_off=0, out=None, split_k=None, wb=None,
              wx3=None, x3_acc_scale=None, mma=None, stats=False, out_bf16=False, bounded=False, x_amax=None, x2=None,
-             reflect=False, out_ld=None, ln=None):
+             reflect=False, out_ld=None, ln=None, out_hw=None):
         """x [N,H,W,ld] -> [N,Ho,Wo,Cout].  ``w`` packed [Cout,KH,KW,Cin].  ``cin``/``in_off`` select a channel
         slice of a wider input buffer.  ``down`` = VQGAN Downsample geometry (pad right/bottom only, stride 2).
         ``stats=True`` returns ``(out, st)``: ``st`` is a ``Stats`` (epilogue-reduced GroupNorm partials and, under the x3
@@ -202,6 +202,9 @@ class Ops:
             pad_t = pad_l = pad
             Ho = (Hv + 2 * pad - KH) // stride + 1
             Wo = (Wv + 2 * pad - KW) // stride + 1
+        if out_hw is not None:      # fewer output rows / columns than the symmetric padding gives (an even kernel: pad only top / left)
+            assert out_hw[0] <= Ho and out_hw[1] <= Wo
+            Ho, Wo = out_hw
         M = N * Ho * Wo
         mma = self.mma if mma is None else mma
         in_dtype = L.BF16 if x.dtype == torch.bfloat16 else L.F32
@@ -471,6 +474,15 @@ def nchw_to_nhwc(x, mode=0):
     N, C, H, W = x.shape
     out = empty((N, H, W, C), x)
     L.call('keep_nchw_to_nhwc', x, out, N, C, H * W, mode)
+    return out
+
+
+def rgb_s2d(x):
+    """[N,3,H,W] in [-1,1] -> [N,H/2,W/2,16]: GMFlow's input normalisation + 2x2 space-to-depth (keep_rgb_s2d)."""
+    N, C, H, W = x.shape
+    assert C == 3 and H % 2 == 0 and W % 2 == 0
+    out = empty((N, H // 2, W // 2, 16), x)
+    L.call('keep_rgb_s2d', x, out, N, H, W)
     return out
 
 

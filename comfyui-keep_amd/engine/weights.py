@@ -94,7 +94,23 @@ def logical_tensors(sd, cfg=None):
                 # layer runs on the 16-channel-chunk MFMA kernels instead of the generic gather kernel
                 t = torch.nn.functional.pad(t, (0, 16 - t.shape[3] % 16))
         out[name] = t.contiguous()
+    k7 = 'flownet.model.backbone.conv1.weight'
+    if k7 in out and tuple(out[k7].shape[1:]) == (7, 7, 3):
+        out[k7 + '_s2d'] = s2d_weights_7x7(out[k7])
     return out
+
+
+def s2d_weights_7x7(w):
+    """Packed [Cout,7,7,3] weights of a stride-2 pad-3 convolution -> [Cout,4,4,16] weights of the same convolution as a stride-1
+    convolution (pad 2 top / left) on the 2x2 space-to-depth image of keep_rgb_s2d: input row 2y + ky - 3 = 2(y + Ky - 2) + dy with
+    Ky = (ky + 1) // 2, dy = (ky + 1) % 2; channel (dy*2 + dx)*3 + c; (Ky, dy) = (0, 0) and channels 12..15 carry zeros."""
+    cout = w.shape[0]
+    o = torch.zeros(cout, 4, 4, 16, dtype=w.dtype)
+    for ky in range(7):
+        for kx in range(7):
+            Ky, dy, Kx, dx = (ky + 1) // 2, (ky + 1) % 2, (kx + 1) // 2, (kx + 1) % 2
+            o[:, Ky, Kx, (dy * 2 + dx) * 3:(dy * 2 + dx) * 3 + 3] = w[:, ky, kx, :]
+    return o
 
 
 def pack_blob(tensors):

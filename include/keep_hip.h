@@ -30,7 +30,7 @@ extern "C" {
  * the fields a shorter known layout lacks as zero), keep_sizeof_*_args(), keep_argmax_gather takes the non-finite status word,
  * keep_nonfinite_flag.  v13: keep_conv2d_args.upsample accepts KEEP_UPSAMPLE_X2_PHASES (same layout; a v12 library refuses the
  * value, so the binding asks for 13). */
-#define KEEP_ABI_VERSION 16
+#define KEEP_ABI_VERSION 17
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -320,6 +320,12 @@ int32_t keep_bilinear_upscale(const float* x, float* out, int32_t planes, int32_
 /* layout / elementwise helpers */
 /* [N,C,H,W] -> [N,H,W,C];  mode 1 additionally applies GMFlow's input normalisation (GF:56-57, GM/utils.py:55-63) */
 int32_t keep_nchw_to_nhwc(const float* x, float* out, int32_t N, int32_t C, int32_t HW, int32_t mode, void* stream);
+/* v17: x [N,3,H,W] in [-1,1] -> out [N,H/2,W/2,16]: GMFlow's input normalisation (GF:56-57, GM/utils.py:55-63, the op order of mode 1
+ * above) and a 2x2 space-to-depth in one pass; channel (dy*2 + dx)*3 + c = pixel (2Y+dy, 2X+dx) of colour c, channels 12..15 zero.
+ * The 7x7 stride-2 pad-3 first convolution of GMFlow's encoder (GM/backbone.py:69) is then a 4x4 stride-1 convolution with
+ * pad_t = pad_l = 2 on this image (weights repacked by the host: tap ky of the 7x7 kernel = s2d tap (ky + 1) / 2, sub-row
+ * (ky + 1) & 1), which keep_conv2d runs on its 16-channel MFMA kernels.  H, W even. */
+int32_t keep_rgb_s2d(const float* x, float* out, int32_t N, int32_t H, int32_t W, void* stream);
 int32_t keep_nhwc_to_nchw(const float* x, float* out, int32_t N, int32_t C, int32_t HW, void* stream);
 /* out[n,i] = a[n,i] + alpha * t[i % tsize]   (position tables, grid subtraction) */
 int32_t keep_add_bcast(const float* a, const float* t, float* out, int64_t total, int64_t tsize, float alpha,

@@ -1329,6 +1329,31 @@ def test_linear_x3_layernorm_epilogue(name, M, K, res, bias, img):
         ops.conv(xd, wd, bd, ln=(gd, bed, 1e-5), pad=0, ksize=1, bounded=True)
 
 
+def test_rgb_s2d_and_the_4x4_form_of_gmflow_conv1():
+    """keep_rgb_s2d: the normalised frame of keep_nchw_to_nhwc(mode 1), bit for bit, in the 2x2 space-to-depth layout (channel
+    (dy*2 + dx)*3 + c, channels 12..15 zero); and GMFlow's 7x7 stride-2 convolution through it (4x4 stride-1, weights repacked by
+    engine/weights.py:s2d_weights_7x7) against float64 under both parity policies."""
+    from comfyui_keep_amd.engine.weights import s2d_weights_7x7
+    N, H, W = 3, 64, 96
+    x = rnd('s2d_x', (N, 3, H, W)).clamp(-1, 1)
+    xd = dev(x)
+    ref_img = ops.nchw_to_nhwc(xd, mode=1)                                           # [N,H,W,3]
+    got = ops.rgb_s2d(xd)
+    assert got.shape == (N, H // 2, W // 2, 16) and float(got[..., 12:].abs().max()) == 0.0
+    want = ref_img.view(N, H // 2, 2, W // 2, 2, 3).permute(0, 1, 3, 2, 4, 5).reshape(N, H // 2, W // 2, 12)
+    assert torch.equal(got[..., :12], want)
+    w7 = rnd('s2d_w', (64, 3, 7, 7), 0.05)
+    ws = dev(s2d_weights_7x7(w7.permute(0, 2, 3, 1).contiguous()))
+    ref = F.conv2d(nchw(ref_img).double().cpu(), w7.double(), stride=2, padding=3).permute(0, 2, 3, 1)
+    y32 = ops.conv(got, ws, None, stride=1, pad=2, ksize=4, out_hw=(H // 2, W // 2), split_k=1)
+    wx3, asc = x3w(ws)
+    y3 = ops.conv(got, ws, None, stride=1, pad=2, ksize=4, out_hw=(H // 2, W // 2), split_k=1, mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc,
+                  bounded=True)
+    e32, e3 = err64(y32, ref), err64(y3, ref)
+    print(f's2d conv1: exact-f32 {e32:.3e}  x3 {e3:.3e}')
+    assert y32.shape == (N, H // 2, W // 2, 64) and e32 <= 2e-5 and e3 <= max(3.0 * e32, 2e-6)
+
+
 def test_linear_x3_k_concatenated_inputs():
     """keep_conv2d in2 (x3 GEMM form): cat([a, b], -1) @ W^T without materialising the concatenation (GM/transformer.py:182);
     equals the concat path bit for bit (same K order, same kernel), ragged M; rejected loudly outside the x3 policy."""

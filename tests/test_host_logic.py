@@ -243,6 +243,24 @@ def test_strict_load_rejects_bad_state_dict(synth_weights):
         net.load_state_dict(bad, strict=True)
 
 
+def test_gmflow_conv1_as_a_4x4_convolution_on_the_space_to_depth_image():
+    """engine/weights.py:s2d_weights_7x7 + the layout keep_rgb_s2d writes: the 7x7 stride-2 pad-3 convolution of GMFlow's encoder
+    (GM/backbone.py:69) equals a 4x4 stride-1 convolution (pad 2 top / left, 1 bottom / right) on the 2x2 space-to-depth image with
+    channel (dy*2 + dx)*3 + c -- float64, every output."""
+    from comfyui_keep_amd.engine.weights import s2d_weights_7x7
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 20, 28, generator=g, dtype=torch.float64)
+    w = torch.randn(8, 3, 7, 7, generator=g, dtype=torch.float64)
+    ref = torch.nn.functional.conv2d(x, w, stride=2, padding=3)
+    ws = s2d_weights_7x7(w.permute(0, 2, 3, 1).contiguous())                       # packed [Cout,7,7,3] -> [Cout,4,4,16]
+    assert ws.shape == (8, 4, 4, 16) and float(ws[:, 0, :, 0:6].abs().max()) == 0.0 and float(ws[..., 12:].abs().max()) == 0.0
+    N, C, H, W = x.shape
+    s2d = x.view(N, C, H // 2, 2, W // 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(N, 12, H // 2, W // 2)      # channel (dy*2+dx)*3 + c
+    s2d = torch.nn.functional.pad(s2d, (2, 1, 2, 1))
+    got = torch.nn.functional.conv2d(s2d, ws[..., :12].permute(0, 3, 1, 2))
+    assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-12
+
+
 def test_packed_blob_layouts(synth_weights):
     from comfyui_keep_amd.engine.weights import logical_tensors, pack_blob, views
     lt = logical_tensors(synth_weights)
@@ -262,7 +280,9 @@ def test_packed_blob_layouts(synth_weights):
     up, src = lt['flownet.model.upsampler.0.weight'], synth_weights['flownet.model.upsampler.0.weight']
     assert up.shape == (256, 3, 3, 144) and torch.equal(up[..., :130], src.permute(0, 2, 3, 1)) and not up[..., 130:].any()
     n_in = sum(t.numel() for t in synth_weights.values())
-    assert sum(t.numel() for t in lt.values()) == n_in + 256 * 9 * 14
+    # ... and GMFlow's 7x7 stride-2 first convolution a derived [64,4,4,16] twin for the space-to-depth form (keep_rgb_s2d)
+    assert lt['flownet.model.backbone.conv1.weight_s2d'].shape == (64, 4, 4, 16)
+    assert sum(t.numel() for t in lt.values()) == n_in + 256 * 9 * 14 + 64 * 4 * 4 * 16
 
 
 def test_face_tracking_restatement():

@@ -17,6 +17,17 @@
 
 #include "keep_common.h"
 
+// (dev A/B) cache policy of the x3 attention kernel's output rows: -DKEEP_NT_ATTN_O=1 = streaming stores
+#ifndef KEEP_NT_ATTN_O
+#define KEEP_NT_ATTN_O 0
+#endif
+#if KEEP_NT_ATTN_O
+#define KEEP_ATTN_O_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define KEEP_ATTN_O_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
+
 struct AttnP {
   const float* q;
   const float* k;
@@ -1031,7 +1042,7 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 4 && NQ != 16) ? 2 : 1)) voi
 #pragma unroll
       for (int j = 0; j < DVT; ++j) {
         const int dv = dv0 + j * 32 + l31;
-        if (dv < p.Dv) p.o[base + dv] = o[j][r] * il;
+        if (dv < p.Dv) KEEP_ATTN_O_STORE(p.o + base + dv, o[j][r] * il);
       }
     }
   }

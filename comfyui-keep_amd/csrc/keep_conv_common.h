@@ -22,6 +22,9 @@
 #ifndef KEEP_LD_AUX_GEMM_A1
 #define KEEP_LD_AUX_GEMM_A1 0
 #endif
+#ifndef KEEP_NT_C3
+#define KEEP_NT_C3 0      // (dev A/B) streaming stores of the RGB x3 first-conv kernel's 64-channel output rows
+#endif
 #ifndef KEEP_ST_AUX_XS
 #define KEEP_ST_AUX_XS 2
 #endif

@@ -1292,7 +1292,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_x3_kernel(ConvP p, int tile
 #pragma unroll
         for (int q = 0; q < 4; ++q) e[q] = p.fast ? act_apply_fast(e[q], p.epi_act) : act_apply(e[q], p.epi_act);
       }
-      *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
+      if (KEEP_NT_C3)
+        __builtin_nontemporal_store((f32x4){e[0], e[1], e[2], e[3]}, reinterpret_cast<f32x4*>(p.out + m * p.out_ld + co));
+      else
+        *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         s4[q] += e[q];

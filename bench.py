@@ -545,19 +545,14 @@ def main():
             line["config"]["one_clip_in_flight_frames_per_s"] = line["b1"]["value"]      # the literal configs[1], next to the headline
             # the same clip under the latency profile of the plans (KEEP_PLAN_REF_IMAGES=2: split-K chosen for two images per launch
             # instead of 16 -- a deployment-wide numerics setting like the precision policy, DESIGN.md section 6 "batch invariance")
-            keep_env = os.environ.get('KEEP_PLAN_REF_IMAGES')
-            os.environ['KEEP_PLAN_REF_IMAGES'] = '2'
-            net._graphs.clear(); net._graph_seen.clear()
+            keep_ref = net.o.plan_ref_images
+            net.o.plan_ref_images = 2      # (part of the plan-cache and hipGraph keys: nothing to clear)
             try:
                 d1l, _, _, _ = timed(x[:1].contiguous(), 2, 5)
                 line["b1"]["latency_profile"] = {"value": round(T_CLIP * 5 / d1l, 3), "unit": "frames/s", "ms_per_clip": round(d1l / 5 * 1e3, 2),
-                                                 "setting": "KEEP_PLAN_REF_IMAGES=2"}
+                                                 "setting": "KEEP_PLAN_REF_IMAGES=2 (keep_conv2d_args.plan_ref_images)"}
             finally:
-                if keep_env is None:
-                    del os.environ['KEEP_PLAN_REF_IMAGES']
-                else:
-                    os.environ['KEEP_PLAN_REF_IMAGES'] = keep_env
-                net._graphs.clear(); net._graph_seen.clear()
+                net.o.plan_ref_images = keep_ref
             # ---- the same step entered from host memory the way the processor does
             u8 = [torch.randint(0, 256, (T_CLIP, 512, 512, 3), dtype=torch.uint8).pin_memory() for _ in range(B)]
             net.run_clips_u8(u8, max_b=B)

@@ -42,6 +42,7 @@ struct AttnP {
   int mode, T, seg_len;
   int img_h, img_w, ksplit, shift, kv_rot, n_img;
   int nslices;  // dv slices per head
+  unsigned flags;  // keep_attention_args.flags (KEEP_ATTN_NO_*)
 #ifdef KEEP_X3_ABLATE
   int abl;               // dev builds: phase ablation selector (KEEP_ATTN_EXP)
 #endif
@@ -1116,7 +1117,7 @@ __global__ __launch_bounds__(256) void attn_pack_kv_x3_kernel(AttnP p, _Float16*
 
 // packed K / V^T path: worth it when several query blocks stream the same keys
 static long attn_pack_bytes(const AttnP& p, int mma) {
-  if (mma != KEEP_MMA_X3 || (p.D != 128 && p.D != 256) || p.Lq < 256 || getenv("KEEP_NO_ATTN_PACK")) return 0;
+  if (mma != KEEP_MMA_X3 || (p.D != 128 && p.D != 256) || p.Lq < 256 || (p.flags & KEEP_ATTN_NO_PACK)) return 0;
   const int dvs = p.Dv <= 32 ? 32 : (p.Dv <= 64 ? 64 : 128);
   const int nsl = (p.Dv + dvs - 1) / dvs;
   return (long)p.B * p.H * ((p.Lk + 31) / 32) * ((32 * (2 * p.D + 8) + nsl * dvs * 72) * 2L);
@@ -1142,7 +1143,7 @@ static int launch_attn_x3_packed(const AttnP& p, hipStream_t st) {
   }
   dim3 grid(cdiv(p.Lq, 128), p.H * p.nslices, p.B);
 #ifdef KEEP_X3_ABLATE
-  const_cast<AttnP&>(p).abl = getenv("KEEP_ATTN_EXP") ? atoi(getenv("KEEP_ATTN_EXP")) : 0;
+  const_cast<AttnP&>(p).abl = KEEP_DEV_ENV("KEEP_ATTN_EXP") ? atoi(KEEP_DEV_ENV("KEEP_ATTN_EXP")) : 0;
 #endif
   hipLaunchKernelGGL((attn_x3_kernel<4, DVT, NQ, true>), grid, dim3(256), lds, st, p);
   KEEP_LAUNCH_CHECK("keep_attention(x3 packed)");
@@ -1171,7 +1172,7 @@ static int launch_attn_x3_t(const AttnP& p, hipStream_t st) {
   }
   dim3 grid(cdiv(p.Lq, WAVES * 32), p.H * p.nslices, p.B);
 #ifdef KEEP_X3_ABLATE
-  const_cast<AttnP&>(p).abl = getenv("KEEP_ATTN_EXP") ? atoi(getenv("KEEP_ATTN_EXP")) : 0;
+  const_cast<AttnP&>(p).abl = KEEP_DEV_ENV("KEEP_ATTN_EXP") ? atoi(KEEP_DEV_ENV("KEEP_ATTN_EXP")) : 0;
 #endif
   hipLaunchKernelGGL((attn_x3_kernel<WAVES, DVT, NQ>), grid, dim3(64 * WAVES), lds, st, p);
   KEEP_LAUNCH_CHECK("keep_attention(x3)");
@@ -1566,7 +1567,7 @@ __global__ __launch_bounds__(256, 1) void attn_x3_sfull2_kernel(AttnP p) {
 
 static bool attn_sfull2_ok(const AttnP& p) {
   return p.mode == 0 && p.D == 512 && p.Lk <= 256 && p.Dv <= 512 && p.Dv % 4 == 0 && p.v_ts % 4 == 0 && p.v_bs % 4 == 0 &&
-         p.v_hs % 4 == 0 && (uintptr_t)p.v % 16 == 0 && !getenv("KEEP_NO_SFULL2");
+         p.v_hs % 4 == 0 && (uintptr_t)p.v % 16 == 0 && !(p.flags & KEEP_ATTN_NO_SFULL2);
 }
 
 static int launch_attn_x3_sfull2(const AttnP& p, hipStream_t st) {
@@ -1998,10 +1999,10 @@ extern "C" int64_t keep_attention_workspace_bytes(const keep_attention_args* a_i
   if (a->mma != KEEP_MMA_X3 || a->in_dtype == KEEP_BF16 || a->B <= 0 || a->H <= 0 || a->Lk <= 0) return 0;
   const bool x3_ok = (a->D % 16 == 0) && (a->q_ts % 4 == 0) && (a->q_bs % 4 == 0) && (a->q_hs % 4 == 0) && (a->k_ts % 4 == 0) &&
                      (a->k_bs % 4 == 0) && (a->k_hs % 4 == 0) && ((uintptr_t)a->q % 16 == 0) && ((uintptr_t)a->k % 16 == 0) &&
-                     !getenv("KEEP_NO_ATTN_X3");
+                     !(a->flags & KEEP_ATTN_NO_X3);
   if (!x3_ok) return 0;
   AttnP p;
-  p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.D = a->D; p.Dv = a->Dv;
+  p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.D = a->D; p.Dv = a->Dv; p.flags = a->flags;
   return attn_pack_bytes(p, a->mma);
 }
 
@@ -2028,6 +2029,7 @@ extern "C" int32_t keep_attention(const keep_attention_args* a_in, void* stream)
     KEEP_REQUIRE((long)a->img_h * a->img_w <= 65536, "keep_attention: window mode supports maps of at most 65536 tokens");
   }
   AttnP p;
+  p.flags = a->flags;
   p.q = (const float*)a->q; p.k = (const float*)a->k; p.v = (const float*)a->v; p.o = a->o;
   p.q16 = (const unsigned short*)a->q; p.k16 = (const unsigned short*)a->k; p.v16 = (const unsigned short*)a->v;
   p.q_bs = a->q_bs; p.q_ts = a->q_ts; p.q_hs = a->q_hs;
@@ -2074,7 +2076,7 @@ extern "C" int32_t keep_attention(const keep_attention_args* a_in, void* stream)
   // split fp16: fp32 tensors with 16-byte aligned rows, D a multiple of 16; everything else runs on the exact-f32 kernel
   if (a->mma == KEEP_MMA_X3 && (a->D % 16 == 0) && (a->q_ts % 4 == 0) && (a->q_bs % 4 == 0) && (a->q_hs % 4 == 0) &&
       (a->k_ts % 4 == 0) && (a->k_bs % 4 == 0) && (a->k_hs % 4 == 0) && ((uintptr_t)a->q % 16 == 0) &&
-      ((uintptr_t)a->k % 16 == 0) && !getenv("KEEP_NO_ATTN_X3")) {
+      ((uintptr_t)a->k % 16 == 0) && !(a->flags & KEEP_ATTN_NO_X3)) {
     if (a->Lq <= 32) {
       if (dvt == 1) return launch_attn_x3<1, 1>(p, st);
       if (dvt == 2) return launch_attn_x3<1, 2>(p, st);

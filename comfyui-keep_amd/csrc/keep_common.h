@@ -12,6 +12,19 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 void keep_set_error(const char* fmt, ...);
 
+// The product library reads NO environment variable: kernel-selection overrides arrive through `flags` of the argument structs
+// (KEEP_CONV_* / KEEP_ATTN_*, include/keep_hip.h), deployment settings through their fields (plan_ref_images).  Developer A/B switches
+// (tools/dev/README.md) exist only in builds with -DKEEP_DEV_KNOBS (tools/dev/build_ab.sh; implied by -DKEEP_X3_ABLATE).
+#if defined(KEEP_X3_ABLATE) && !defined(KEEP_DEV_KNOBS)
+#define KEEP_DEV_KNOBS 1
+#endif
+#ifdef KEEP_DEV_KNOBS
+#include <stdlib.h>
+#define KEEP_DEV_ENV(name) getenv(name)
+#else
+#define KEEP_DEV_ENV(name) ((const char*)nullptr)
+#endif
+
 #define KEEP_REQUIRE(cond, ...)            \
   do {                                     \
     if (!(cond)) {                         \

@@ -1715,16 +1715,10 @@ static const int kTargetWaves = 1024;
 // at every batch size.  Measured (round 3, x3): reference 16 -> 235 frames/s at B = 16 and 93 at B = 1; 8 -> 230 / 101; 2 -> - /
 // 109: KEEP_PLAN_REF_IMAGES selects a latency profile (a deployment-wide setting like the precision policy -- results are
 // invariant within one setting).
-static long plan_ref_images() {
-  const char* e = getenv("KEEP_PLAN_REF_IMAGES");
-  return e ? atol(e) : 16;
-}
+static long plan_ref_images(const keep_conv2d_args* a) { return a->plan_ref_images > 0 ? a->plan_ref_images : 16; }
 // gather kernels: launches of at most this many output rows use 64x64 tiles (more blocks), larger ones 128x128.  A tuning
-// knob the HOST never mirrors (keep_conv2d_plan reports what follows from it): tests retune it through the environment.
-static long small_m_threshold() {
-  const char* e = getenv("KEEP_GATHER_SMALL_M");
-  return e ? atol(e) : 4096;
-}   // below this many matrix-core waves a launch cannot fill 256 CUs x 4 SIMDs -> split K
+// rule the HOST never mirrors (keep_conv2d_plan reports what follows from it): KEEP_CONV_SMALL_TILES forces the small tile (tests).
+static long small_m_threshold(const keep_conv2d_args* a) { return (a->flags & KEEP_CONV_SMALL_TILES) ? (1L << 62) : 4096; }   // below this many matrix-core waves a launch cannot fill 256 CUs x 4 SIMDs -> split K
 
 static int validate_conv(const keep_conv2d_args* a) {
   KEEP_REQUIRE(a != nullptr, "keep_conv2d: null args");
@@ -1776,7 +1770,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   const long M_real = (long)a->N * a->Ho * a->Wo;
   // rows the HEURISTICS below see (tile, split-K): per-image rows x the fixed reference batch under the parity policies,
   // the real row count under the bf16 speed policy; launches and buffer sizes always use the real M (p.M)
-  const long M = a->mma == KEEP_MMA_BF16 ? M_real : plan_ref_images() * (long)a->Ho * a->Wo;
+  const long M = a->mma == KEEP_MMA_BF16 ? M_real : plan_ref_images(a) * (long)a->Ho * a->Wo;
   p.in = (const float*)a->in;
   p.w = a->weight;
   p.wb = (const unsigned short*)a->weight_bf16;
@@ -1808,7 +1802,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   p.nsteps = a->KH * a->KW * p.cchunks;
   p.in_bf16 = (a->dtype == KEEP_BF16) ? 1 : 0;
   // fast-math activations: bf16 policy always; x3 policy unless KEEP_X3_EXACT_ACT is set (forms of x3 grade, keep_common.h)
-  p.fast = (a->mma == KEEP_MMA_BF16 || (a->mma == KEEP_MMA_X3 && !getenv("KEEP_X3_EXACT_ACT"))) ? 1 : 0;
+  p.fast = (a->mma == KEEP_MMA_BF16 || (a->mma == KEEP_MMA_X3 && !(a->flags & KEEP_CONV_X3_EXACT_ACT))) ? 1 : 0;
   p.out_bf16 = (a->out_dtype == KEEP_BF16) ? 1 : 0;
   p.vec_ok = (a->Cin % 4 == 0 && a->in_ld % 4 == 0 && ((uintptr_t)a->in % 16 == 0)) ? 1 : 0;
   p.vec_epi = (a->Cout % 4 == 0 && a->out_ld % 4 == 0 && (uintptr_t)a->out % 16 == 0 &&
@@ -1836,7 +1830,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   const bool reflect = a->pad_mode == KEEP_PAD_REFLECT;
   if (a->Cout <= 4 && is33s1 && !reflect && !a->upsample && a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && a->Cin % SC_CH == 0 &&
       a->in_ld % 4 == 0 && (uintptr_t)a->in % 16 == 0 && a->Ho == a->H && a->Wo == a->W && a->Ho % SC_TH == 0 &&
-      a->Wo % SC_TW == 0 && !a->residual && !a->aux && a->split_k <= 1 && pro_al && !getenv("KEEP_NO_COUT4")) {
+      a->Wo % SC_TW == 0 && !a->residual && !a->aux && a->split_k <= 1 && pro_al && !(a->flags & KEEP_CONV_NO_COUT4)) {
     pl.path = PATH_COUT4;
     pl.split_k = 1;
     snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_cout4_kernel");
@@ -1846,7 +1840,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   if (mma == KEEP_MMA_BF16 && is33s1 && !a->upsample && a->Cin <= 3 && a->Cout % 4 == 0 && a->Cout >= 32 && a->dtype == KEEP_F32 &&
       a->out_dtype != KEEP_BF16 && a->Ho == a->H && a->Wo == a->W && a->Ho % 8 == 0 && a->Wo % 32 == 0 && no_pro && !a->residual &&
       !a->aux && a->split_k <= 1 && a->out_ld % 4 == 0 && (uintptr_t)a->out % 16 == 0 && (!a->bias || (uintptr_t)a->bias % 16 == 0) &&
-      !getenv("KEEP_NO_C3")) {
+      !(a->flags & KEEP_CONV_NO_C3)) {
     pl.path = PATH_C3;
     pl.split_k = 1;
     pl.stats_rows = 64;
@@ -1860,7 +1854,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
     // RGB first convolutions: persistent im2col-in-LDS kernel, weights split on the fly from the fp32 tensor
     if (is33s1 && !reflect && !a->upsample && a->Cin <= 3 && a->Cout % 4 == 0 && a->Cout >= 32 && a->Ho == a->H && a->Wo == a->W &&
         a->Ho % 8 == 0 && a->Wo % 32 == 0 && no_pro && !a->residual && !a->aux && a->split_k <= 1 && a->out_ld % 4 == 0 &&
-        (uintptr_t)a->out % 16 == 0 && (!a->bias || (uintptr_t)a->bias % 16 == 0) && a->weight && !getenv("KEEP_NO_C3")) {
+        (uintptr_t)a->out % 16 == 0 && (!a->bias || (uintptr_t)a->bias % 16 == 0) && a->weight && !(a->flags & KEEP_CONV_NO_C3)) {
       pl.path = PATH_C3_X3;
       pl.split_k = 1;
       pl.stats_rows = 64;
@@ -1881,7 +1875,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
       snprintf(pl.kernel, sizeof(pl.kernel), "conv3x3_halo_x3_kernel<32, x2 phases>");
       return KEEP_OK;
     }
-    if (have_w && is33s1 && keep_conv_x3_halo_ok(a) && !getenv("KEEP_NO_HALO_X3")) {
+    if (have_w && is33s1 && keep_conv_x3_halo_ok(a) && !(a->flags & KEEP_CONV_NO_HALO_X3)) {
       pl.path = PATH_HALO_X3;
       const long items = (M / 256) * ncb;
       auto_split = items >= 256 ? 1 : (int)max(1L, min(min(512L / items, (long)a->Cin / 32), 16L));
@@ -1898,15 +1892,15 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
     if (a->in2) {      // K-concatenated input: GEMM form of the x3 gather kernel only
       const bool ok2 = have_w && keep_conv_x3_gather_ok(a, p) && keep_conv_x3_gather_is_gemm(a) && no_pro && !a->x3_in_amax &&
                        a->in2_cin1 > 0 && a->in2_cin1 < a->Cin && a->in2_cin1 % 32 == 0 && (a->Cin - a->in2_cin1) % 4 == 0 &&
-                       a->in_ld >= a->in2_cin1 && (uintptr_t)a->in2 % 16 == 0 && !is33s1 && !getenv("KEEP_NO_GATHER_X3");
+                       a->in_ld >= a->in2_cin1 && (uintptr_t)a->in2 % 16 == 0 && !is33s1 && !(a->flags & KEEP_CONV_NO_GATHER_X3);
       if (!ok2) {
         keep_set_error("keep_conv2d: in2 (K-concatenated input) needs KEEP_MMA_X3, a 1x1 stride-1 convolution without prologue / range probe and in2_cin1 %% 32 == 0");
         return KEEP_EUNSUP;
       }
     }
-    if (have_w && keep_conv_x3_gather_ok(a, p) && !getenv("KEEP_NO_GATHER_X3")) {
+    if (have_w && keep_conv_x3_gather_ok(a, p) && !(a->flags & KEEP_CONV_NO_GATHER_X3)) {
       pl.path = PATH_GATHER_X3;
-      pl.tile = (a->Cout <= 64 || M <= small_m_threshold()) ? 1 : 2;
+      pl.tile = (a->Cout <= 64 || M <= small_m_threshold(a)) ? 1 : 2;
       pl.plain = no_pro;
       const int steps = a->KH * a->KW * ((a->Cin + 31) / 32);
       const long blocks = pl.tile == 1 ? (long)cdiv(M, 64) * cdiv(a->Cout, 64) : (long)cdiv(M, 128) * cdiv(a->Cout, 128);
@@ -1948,7 +1942,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   if (mma == KEEP_MMA_F32 && a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && is33s1 && (a->Cin % 16 == 0) &&
       (a->Cout % 32 == 0) && tileable && same_size && pro_al && (a->in_ld % 4 == 0) && ((uintptr_t)a->in % 16 == 0) &&
       ((uintptr_t)a->weight % 16 == 0) && epi_al && (!a->workspace || (uintptr_t)a->workspace % 16 == 0) &&
-      !getenv("KEEP_NO_HALO_F32")) {
+      !(a->flags & KEEP_CONV_NO_HALO_F32)) {
     pl.path = PATH_HALO_F32;
     const long items = (M / 256) * ncb;
     auto_split = items >= 256 ? 1 : (int)max(1L, min(min(512L / items, (long)a->Cin / 32), 16L));
@@ -1959,7 +1953,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
     return KEEP_OK;
   }
   // ---- bf16 policy: LDS-halo kernel (persistent v3; v1 when the prologue is fused into its staging step)
-  static const int halo_ver = getenv("KEEP_HALO_VER") ? atoi(getenv("KEEP_HALO_VER")) : 3;
+  static const int halo_ver = KEEP_DEV_ENV("KEEP_HALO_VER") ? atoi(KEEP_DEV_ENV("KEEP_HALO_VER")) : 3;
   const bool halo_geom = mma == KEEP_MMA_BF16 && is33s1 && (a->Cin % 32 == 0) && (a->Cout % 32 == 0) && tileable && same_size &&
                          (a->in_ld % 8 == 0) && ((uintptr_t)a->in % 16 == 0) && epi_al;
   if (halo_geom) {
@@ -1994,7 +1988,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
     return KEEP_EUNSUP;
   }
   // ---- gather kernels
-  pl.tile = a->Cout <= 32 ? 0 : ((a->Cout <= 64 || M <= small_m_threshold()) ? 1 : 2);
+  pl.tile = a->Cout <= 32 ? 0 : ((a->Cout <= 64 || M <= small_m_threshold(a)) ? 1 : 2);
   const long blocks = pl.tile == 0 ? (long)cdiv(M, 128) * cdiv(a->Cout, 32)
                       : (pl.tile == 1 ? (long)cdiv(M, 64) * cdiv(a->Cout, 64) : (long)cdiv(M, 128) * cdiv(a->Cout, 128));
   const long waves = blocks * 4;
@@ -2002,7 +1996,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   if (mma == KEEP_MMA_BF16) {
     pl.path = PATH_GATHER_BF16;
     p.flatk = (a->Cin < 8 && no_pro) ? 1 : 0;
-    pl.plain = !p.flatk && p.vec_ok && no_pro && !a->upsample && (a->Cin % 8 == 0) && !getenv("KEEP_NO_PLAIN");
+    pl.plain = !p.flatk && p.vec_ok && no_pro && !a->upsample && (a->Cin % 8 == 0) && !(a->flags & KEEP_CONV_NO_PLAIN);
     int steps = p.flatk ? (a->KH * a->KW * a->Cin + BK16 - 1) / BK16 : a->KH * a->KW * ((a->Cin + BK16 - 1) / BK16);
     pl.bk256 = a->bk256 && !p.flatk && pl.tile == 1;
     if (pl.bk256) {
@@ -2021,9 +2015,9 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
     return KEEP_OK;
   }
   pl.path = PATH_GATHER_F32;
-  p.flatk_f32 = (a->Cin < 8 && a->dtype == KEEP_F32 && no_pro && !getenv("KEEP_NO_FLATK_F32")) ? 1 : 0;
+  p.flatk_f32 = (a->Cin < 8 && a->dtype == KEEP_F32 && no_pro && !(a->flags & KEEP_CONV_NO_FLATK_F32)) ? 1 : 0;
   if (p.flatk_f32) p.nsteps = (a->KH * a->KW * a->Cin + BK - 1) / BK;
-  pl.plain = p.vec_ok && a->Cin % 16 == 0 && no_pro && !a->upsample && pl.tile != 0 && !getenv("KEEP_NO_PLAIN");
+  pl.plain = p.vec_ok && a->Cin % 16 == 0 && no_pro && !a->upsample && pl.tile != 0 && !(a->flags & KEEP_CONV_NO_PLAIN);
   auto_split = (waves >= kTargetWaves || p.nsteps < 8) ? 1 : (int)max(1L, min(min((long)kTargetWaves / waves, (long)p.nsteps / 4), 32L));
   pl.split_k = a->split_k > 0 ? a->split_k : auto_split;
   if (pl.split_k > p.nsteps) pl.split_k = p.nsteps;

@@ -1405,16 +1405,16 @@ int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
   const int tiles_x = a->Wo / tw, tiles_y = a->Ho / th, ncb = (a->Cout + 63) / 64;
   const int n_items = a->N * tiles_x * tiles_y * ncb * p.split_k;
   const int n_cu = x3_num_cu();
-  const int per_cu = getenv("KEEP_X3_BLOCKS_PER_CU") ? atoi(getenv("KEEP_X3_BLOCKS_PER_CU")) : 2;      // dev: occupancy scaling probe
+  const int per_cu = KEEP_DEV_ENV("KEEP_X3_BLOCKS_PER_CU") ? atoi(KEEP_DEV_ENV("KEEP_X3_BLOCKS_PER_CU")) : 2;      // dev: occupancy scaling probe
   dim3 grid(n_items < per_cu * n_cu ? n_items : per_cu * n_cu), block(256);
   const bool simple = p.split_k == 1 && !a->aux && a->epi_act == KEEP_ACT_NONE;
   // pipelined single-block-per-CU kernel: wide tiles, no split-K, at least two work items per CU
 #ifdef KEEP_X3_ABLATE
-  if (getenv("KEEP_X3_EXP") && wide && simple && (a->pro_act == KEEP_PRO_SWISH || a->pro_act == KEEP_PRO_NONE)) {
-    const int ex = atoi(getenv("KEEP_X3_EXP"));
+  if (KEEP_DEV_ENV("KEEP_X3_EXP") && wide && simple && (a->pro_act == KEEP_PRO_SWISH || a->pro_act == KEEP_PRO_NONE)) {
+    const int ex = atoi(KEEP_DEV_ENV("KEEP_X3_EXP"));
 static unsigned long long* dbg = nullptr;
     if (!dbg) (void)hipMalloc(&dbg, 128 + 1024 * 16);
-    const bool cyc = getenv("KEEP_X3_CYC") != nullptr;
+    const bool cyc = KEEP_DEV_ENV("KEEP_X3_CYC") != nullptr;
     if (cyc) (void)hipMemsetAsync(dbg, 0, 128, st);
     ConvP q = p;
     q.ws = reinterpret_cast<float*>(dbg);
@@ -1479,7 +1479,7 @@ static unsigned long long* dbg = nullptr;
 #undef KEEP_LAUNCH_ABL
   }
 #endif
-  static const bool wdma = !getenv("KEEP_X3_NO_WDMA");      // weights by LDS-DMA (default); the VGPR-staged form stays for A/B runs
+  static const bool wdma = !KEEP_DEV_ENV("KEEP_X3_NO_WDMA");      // weights by LDS-DMA (default); the VGPR-staged form stays for A/B runs
 #define KEEP_LAUNCH_HX2(TWV, PROV)                                                                                          \
   if (wdma && simple)                                                                                                      \
     hipLaunchKernelGGL((conv3x3_halo_x3_kernel<TWV, PROV, true, 0, true, true>), grid, block, 0, st, p, tiles_x, tiles_y, ncb, n_items);  \
@@ -1536,10 +1536,10 @@ int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int tile, hipStre
   // several column blocks and many row blocks: row-block-major order on a 1-D grid (KEEP_X3_GEMM_2D=1: the 2-D grid, for A/B runs)
   const int bt = big_tile ? 128 : 64;
   const long gx = cdiv(M, bt), gy = cdiv(a->Cout, bt);
-  const bool rowmajor = gy > 1 && gx >= 1024 && gx * gy < (1L << 30) && !getenv("KEEP_X3_GEMM_2D");
+  const bool rowmajor = gy > 1 && gx >= 1024 && gx * gy < (1L << 30) && !KEEP_DEV_ENV("KEEP_X3_GEMM_2D");
   p.tile_cols = rowmajor ? (int)gy : 0;
   {
-    static const int rev = getenv("KEEP_X3_GEMM_REVERSE") ? atoi(getenv("KEEP_X3_GEMM_REVERSE")) : 0;      // dev A/B
+    static const int rev = KEEP_DEV_ENV("KEEP_X3_GEMM_REVERSE") ? atoi(KEEP_DEV_ENV("KEEP_X3_GEMM_REVERSE")) : 0;      // dev A/B
     p.reverse = rev;
   }
   dim3 grid(rowmajor ? (unsigned)(gx * gy) : (unsigned)gx, rowmajor ? 1u : (unsigned)gy, p.split_k);

@@ -558,9 +558,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3s_kernel(ConvP p, int t
 // (Round 4 also tried drawing the items from a global ticket counter instead of the static stride -- block lifetimes of one launch
 // spread by +-20 %, bimodal -- with the ticket prefetched one item ahead: bit-identical results, 1.5 % (64 ch @512^2) to 5 % (128 ch
 // @256^2) SLOWER: the launch is bound by chip-wide throughput, early finishers hand their share to the rest; removed.)  Everything else stays on
-// conv3x3_halo_x3_kernel.  KEEP_X3_NO_STREAM=1: round 3's kernel everywhere (A/B runs).
+// conv3x3_halo_x3_kernel.  flags & KEEP_CONV_NO_STREAM: round 3's kernel everywhere (kernel-vs-kernel tests, A/B runs).
 bool keep_conv_x3_stream_ok(const keep_conv2d_args* a, const ConvP& p, int split_k) {
-  static const bool off = getenv("KEEP_X3_NO_STREAM") != nullptr;
+  const bool off = (a->flags & KEEP_CONV_NO_STREAM) != 0;
   const bool simple = split_k == 1 && !a->aux;      // (an epilogue activation is one uniform branch per row here: ParseNet's LeakyReLU)
   const bool aff = a->pro_scale != nullptr;
   return !off && simple && a->Ho % 8 == 0 && a->Wo % 32 == 0 && a->Cin >= 32 && a->upsample != KEEP_UPSAMPLE_X2_PHASES &&
@@ -573,13 +573,13 @@ int keep_conv2d_x3_stream(const keep_conv2d_args* a, ConvP& p, int n_cu, hipStre
   const int n_items = a->N * tiles_x * tiles_y * ncb;
   dim3 grid(n_items < 2 * n_cu ? n_items : 2 * n_cu), block(256);
   const bool aff = a->pro_scale != nullptr;
-  if (getenv("KEEP_X3_OCC")) {      // dev: resident blocks per CU as the runtime sees them
+  if (KEEP_DEV_ENV("KEEP_X3_OCC")) {      // dev: resident blocks per CU as the runtime sees them
     int nb = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv3x3_halo_x3s_kernel<KEEP_PRO_SWISH, true>, 256, 0);
     fprintf(stderr, "[x3s] occupancy: %d blocks per CU (LDS %d B per block)\n", nb, XS_LDS);
   }
 #ifdef KEEP_X3_ABLATE
-  if (getenv("KEEP_X3_EXP") && atoi(getenv("KEEP_X3_EXP")) == 21 && a->pro_act == KEEP_PRO_SWISH) {      // timeline of wave 0
+  if (KEEP_DEV_ENV("KEEP_X3_EXP") && atoi(KEEP_DEV_ENV("KEEP_X3_EXP")) == 21 && a->pro_act == KEEP_PRO_SWISH) {      // timeline of wave 0
     static unsigned long long* dbg = nullptr;
     if (!dbg) (void)hipMalloc(&dbg, 128 + 1024 * 16);
     (void)hipMemsetAsync(dbg, 0, 128, st);

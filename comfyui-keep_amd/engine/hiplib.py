@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('KEEP_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')   # (KEEP_HIP_LIB: dev A/B builds)
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 F32, BF16 = 0, 1
 MMA_F32, MMA_BF16, MMA_X3 = 0, 1, 2
@@ -20,6 +20,10 @@ PRO_NONE, PRO_SWISH, PRO_RELU = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_GELU, ACT_SIGMOID, ACT_LRELU01, ACT_SILU = 0, 1, 2, 3, 4, 5, 6
 PAD_ZERO, PAD_REFLECT = 0, 1
 UPSAMPLE_X2_PHASES = 2
+# keep_conv2d_args.flags / keep_attention_args.flags (include/keep_hip.h): kernel-selection overrides, 0 = the library's choice
+(CONV_NO_COUT4, CONV_NO_C3, CONV_NO_HALO_F32, CONV_NO_HALO_X3, CONV_NO_GATHER_X3, CONV_NO_PLAIN, CONV_NO_FLATK_F32,
+ CONV_SMALL_TILES, CONV_X3_EXACT_ACT, CONV_NO_STREAM) = (1 << i for i in range(10))
+ATTN_NO_PACK, ATTN_NO_SFULL2, ATTN_NO_X3 = 1, 2, 4
 
 _vp, _i32, _i64, _f32, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
 STATUS_NONFINITE_LOGITS, STATUS_NONFINITE_TENSOR = 1, 2
@@ -28,13 +32,13 @@ STATUS_NONFINITE_LOGITS, STATUS_NONFINITE_TENSOR = 1, 2
 class ConvArgs(C.Structure):
     # field-for-field include/keep_hip.h:keep_conv2d_args ('inp' = `in`, a Python keyword); tests/test_host_logic.py checks the
     # names / order against the header, the size against keep_sizeof_conv2d_args(), and INTEGRATION.md's copy against this list
-    _fields_ = [('struct_size', _u32), ('reserved0', _u32), ('inp', _vp), ('weight', _vp), ('bias', _vp), ('out', _vp), ('pro_scale', _vp), ('pro_shift', _vp),
+    _fields_ = [('struct_size', _u32), ('flags', _u32), ('inp', _vp), ('weight', _vp), ('bias', _vp), ('out', _vp), ('pro_scale', _vp), ('pro_shift', _vp),
                 ('residual', _vp), ('aux', _vp), ('workspace', _vp)] + \
                [(n, _i32) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad_t', 'pad_l', 'Ho', 'Wo',
                                     'in_ld', 'out_ld', 'res_ld', 'upsample', 'pro_act', 'epi_act')] + \
                [('aux_w', _f32), ('split_k', _i32), ('dtype', _i32), ('mma', _i32), ('weight_bf16', _vp), ('stats_out', _vp), ('stats_P', _i32), ('bk256', _i32), ('out_dtype', _i32),
                 ('weight_x3', _vp), ('x3_acc_scale', _f32), ('x3_in_amax', _vp), ('x3_out_amax', _vp), ('x3_out_amax_zeroed', _i32), ('in2', _vp), ('in2_cin1', _i32), ('pad_mode', _i32),
-                ('ln_gamma', _vp), ('ln_beta', _vp), ('ln_eps', _f32), ('reserved1', _i32)]
+                ('ln_gamma', _vp), ('ln_beta', _vp), ('ln_eps', _f32), ('plan_ref_images', _i32)]
 
 
 class ConvPlanOut(C.Structure):
@@ -43,7 +47,7 @@ class ConvPlanOut(C.Structure):
 
 
 class AttnArgs(C.Structure):
-    _fields_ = [('struct_size', _u32), ('reserved0', _u32), ('q', _vp), ('k', _vp), ('v', _vp), ('o', _vp)] + \
+    _fields_ = [('struct_size', _u32), ('flags', _u32), ('q', _vp), ('k', _vp), ('v', _vp), ('o', _vp)] + \
                [(n, _i64) for n in ('q_bs', 'q_ts', 'q_hs', 'k_bs', 'k_ts', 'k_hs', 'v_bs', 'v_ts', 'v_hs',
                                     'o_bs', 'o_ts', 'o_hs')] + \
                [(n, _i32) for n in ('B', 'H', 'Lq', 'Lk', 'D', 'Dv')] + [('scale', _f32), ('mode', _i32)] + \

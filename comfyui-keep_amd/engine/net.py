@@ -672,7 +672,8 @@ class KeepNet:
         rate; a replay submits them in one call.  Every kernel is stream-ordered, allocation-free and deterministic, and
         the host code between launches only computes shapes, so the replay is bit-identical to the eager run."""
         self.o.ensure_arena(self.device)
-        key = (B, T, H, Wd, self.precision, self._dev_blob.data_ptr(), self.o.arena_generation)
+        key = (B, T, H, Wd, self.precision, self._dev_blob.data_ptr(), self.o.arena_generation, self.o.flags, self.o.attn_flags,
+               self.o.plan_ref_images)
         ent = self._graphs.get(key)
         if ent is None:
             # First occurrence of a key: run eagerly (it is also the warm-up: weight twins, constants, plans, allocator).

@@ -26,8 +26,11 @@ HALO_PRENORM_MINPIX = int(os.environ.get('KEEP_HALO_PRENORM_MINPIX', '0'))
 
 DEBUG_SYNC = os.environ.get('KEEP_DEBUG_SYNC') is not None
 _PLAN_CACHE = {}
-_PLAN_ENV = ('KEEP_NO_COUT4', 'KEEP_NO_C3', 'KEEP_NO_HALO_F32', 'KEEP_NO_HALO_X3', 'KEEP_NO_GATHER_X3', 'KEEP_NO_PLAIN',
-             'KEEP_NO_FLATK_F32', 'KEEP_GATHER_SMALL_M', 'KEEP_PLAN_REF_IMAGES')
+# Deployment settings of the library, read ONCE here (the library itself reads no environment variable: they travel in the argument
+# structs).  KEEP_PLAN_REF_IMAGES: the fixed reference batch of the parity policies' plans (default 16; 2 = latency profile for single
+# clips; results are batch-invariant within one value).  KEEP_X3_EXACT_ACT=1: library expf / erff inside the x3 kernels.
+PLAN_REF_IMAGES = int(os.environ.get('KEEP_PLAN_REF_IMAGES', '0') or 0)
+DEFAULT_CONV_FLAGS = L.CONV_X3_EXACT_ACT if os.environ.get('KEEP_X3_EXACT_ACT') else 0
 
 
 class Plan:
@@ -56,7 +59,6 @@ class Stats:
 def _plan(a, key):
     """keep_conv2d_plan for these arguments, cached by everything the decision can depend on (shapes, flags, which
     optional tensors exist, pointer alignment class) -- never by values."""
-    key = key + tuple(os.environ.get(k) for k in _PLAN_ENV)
     pl = _PLAN_CACHE.get(key)
     if pl is None:
         pl = _PLAN_CACHE[key] = Plan(L.conv2d_plan(a))
@@ -90,6 +92,11 @@ class Ops:
         self.amax_pos = 0
         self.status = None         # one device int32: KEEP_STATUS_* bits raised by this forward's kernels (begin_forward zeroes it)
         self.arena_generation = 0  # bumped when the block is (re)allocated: hipGraphs captured before that are stale
+        # keep_conv2d_args.flags / .plan_ref_images and keep_attention_args.flags of every launch of this Ops (kernel-selection
+        # overrides for tests and A/B runs: hiplib.CONV_* / ATTN_*; the plan's reference batch: a per-net numerics setting)
+        self.flags = DEFAULT_CONV_FLAGS
+        self.attn_flags = 0
+        self.plan_ref_images = PLAN_REF_IMAGES
 
     def begin_forward(self, device):
         """Zero this forward's bookkeeping words with ONE fill launch: the status word (non-finite logits / tensors, see
@@ -243,13 +250,13 @@ class Ops:
                 x3_acc_scale=float(x3_acc_scale), x3_in_amax=in_amax, x3_out_amax=None,
                 in2=x2, in2_cin1=0 if x2 is None else ld, pad_mode=L.PAD_REFLECT if reflect else L.PAD_ZERO,
                 ln_gamma=None if ln is None else ln[0], ln_beta=None if ln is None else ln[1],
-                ln_eps=0.0 if ln is None else float(ln[2]))
+                ln_eps=0.0 if ln is None else float(ln[2]), flags=self.flags, plan_ref_images=self.plan_ref_images)
 
         def key_of(dtype, pro_t, pro_a, odt, sk):
             return (N, H, W, ld, Cin, Cout, KH, stride, pad_t, pad_l, Ho, Wo, out_ld, up_mode, pro_a, act, dtype, mma,
                     odt, sk, pro_t is not None, residual is not None, 0 if residual is None else residual.shape[-1],
                     aux is not None, bias is not None, in_off % 8, wx3 is not None, USE_BK256, x2 is not None, bool(reflect),
-                    ln is not None)
+                    ln is not None, self.flags, self.plan_ref_images)
 
         sk_req = 0 if split_k is None else int(split_k)
         odt = L.BF16 if want_bf16_out else L.F32
@@ -412,7 +419,7 @@ class Ops:
                     v_bs=v_str[0], v_ts=v_str[1], v_hs=v_str[2], o_bs=o_str[0], o_ts=o_str[1], o_hs=o_str[2],
                     B=B, H=H, Lq=Lq, Lk=Lk, D=D, Dv=Dv, scale=float(scale), mode=mode, T=T, seg_len=seg_len,
                     img_h=img_h, img_w=img_w, ksplit=ksplit, shift=shift, kv_rot=kv_rot, n_img=n_img, mma=mma,
-                    in_dtype=in_dtype, q_amax=amax[0], k_amax=amax[1], v_amax=amax[2])
+                    in_dtype=in_dtype, q_amax=amax[0], k_amax=amax[1], v_amax=amax[2], flags=self.attn_flags)
         if DEBUG_SYNC:
             torch.cuda.synchronize()
             if not bool(torch.isfinite(o).all()):

@@ -29,8 +29,9 @@ extern "C" {
  * (callers set it to sizeof of the struct THEY were compiled against; the library rejects sizes it does not know and reads
  * the fields a shorter known layout lacks as zero), keep_sizeof_*_args(), keep_argmax_gather takes the non-finite status word,
  * keep_nonfinite_flag.  v13: keep_conv2d_args.upsample accepts KEEP_UPSAMPLE_X2_PHASES (same layout; a v12 library refuses the
- * value, so the binding asks for 13). */
-#define KEEP_ABI_VERSION 17
+ * value, so the binding asks for 13).  v18: the two reserved words of keep_conv2d_args become `flags` / `plan_ref_images`, the one of
+ * keep_attention_args `flags` (same layout and sizes; zero keeps the v17 behaviour) -- the library no longer reads ANY environment variable. */
+#define KEEP_ABI_VERSION 18
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -68,6 +69,24 @@ extern "C" {
 #define KEEP_ACT_SILU 6    /* x * sigmoid(x): Conv / ShuffleV2Block of the YOLOv5-face detectors, yolov5face/models/common.py:39-45,123-146 */
 #define KEEP_ACT_LRELU01 5 /* LeakyReLU(0.1): MobileNetV1 / FPN / SSH of retinaface_mobile0.25, retinaface_net.py:6-34,41-43,74-76 */
 
+/* keep_conv2d_args.flags (v18): kernel-selection overrides, 0 = the library's own choice.  The library reads no environment variable;
+ * what used to be KEEP_NO_* / KEEP_X3_EXACT_ACT / KEEP_GATHER_SMALL_M switches travels with the call.  The NO_* bits take one kernel
+ * family out of the dispatch (the next more general family runs): the kernel-vs-kernel parity tests and A/B runs use them. */
+#define KEEP_CONV_NO_COUT4 (1u << 0)     /* Cout <= 4 exact-fp32 VALU kernel */
+#define KEEP_CONV_NO_C3 (1u << 1)        /* Cin <= 3 first-convolution kernels */
+#define KEEP_CONV_NO_HALO_F32 (1u << 2)  /* exact-f32 LDS-halo 3x3 kernel */
+#define KEEP_CONV_NO_HALO_X3 (1u << 3)   /* x3 LDS-halo 3x3 kernels (both) */
+#define KEEP_CONV_NO_GATHER_X3 (1u << 4) /* x3 implicit-GEMM kernel (-> exact-f32 kernels) */
+#define KEEP_CONV_NO_PLAIN (1u << 5)     /* prologue-free fast staging of the gather kernels */
+#define KEEP_CONV_NO_FLATK_F32 (1u << 6) /* flattened-K form for Cin < 8 */
+#define KEEP_CONV_SMALL_TILES (1u << 7)  /* gather kernels: 64x64 tiles whatever the row count */
+#define KEEP_CONV_X3_EXACT_ACT (1u << 8) /* x3 kernels: library expf / erff instead of the x3-grade fast forms */
+#define KEEP_CONV_NO_STREAM (1u << 9)    /* x3 3x3: the stage-barrier-MFMA halo kernel instead of the streaming one */
+/* keep_attention_args.flags (v18) */
+#define KEEP_ATTN_NO_PACK (1u << 0)   /* x3: never pre-pack K / V^T (keep_attention_workspace_bytes answers 0) */
+#define KEEP_ATTN_NO_SFULL2 (1u << 1) /* x3, D = 512: the 128-query kernel instead of the 32-query one */
+#define KEEP_ATTN_NO_X3 (1u << 2)     /* KEEP_MMA_X3 calls run on the exact-f32 kernel */
+
 /* padding mode of keep_conv2d */
 #define KEEP_UPSAMPLE_X2_PHASES 2
 #define KEEP_PAD_ZERO 0
@@ -96,7 +115,7 @@ int32_t keep_device_ok(int32_t dev);
  */
 typedef struct {
   uint32_t struct_size;   /* sizeof(keep_conv2d_args) of the CALLER's header; keep_sizeof_conv2d_args() is the library's */
-  uint32_t reserved0;     /* 0 */
+  uint32_t flags;         /* KEEP_CONV_* overrides; 0 = default dispatch */
   const void* in;         /* [N,H,W,in_ld]                                   */
   const float* weight;    /* [Cout][KH][KW][Cin] fp32 (packed by the host)   */
   const float* bias;      /* [Cout] or NULL                                  */
@@ -161,7 +180,9 @@ typedef struct {
   const float* ln_gamma;
   const float* ln_beta;
   float ln_eps;
-  int32_t reserved1; /* 0 */
+  int32_t plan_ref_images; /* v18: the fixed reference batch the parity policies plan split-K / statistics partitions for (0 = 16).  A
+                              deployment-wide numerics setting like `mma`: results are bit-identical across batch sizes within one value;
+                              2 = latency profile for single clips */
 } keep_conv2d_args;
 /* smallest struct_size the library accepts: the v12 layout up to and including in2_cin1 (fields appended later are optional) */
 #define KEEP_CONV2D_ARGS_V12_SIZE 256
@@ -205,7 +226,7 @@ int32_t keep_conv2d_plan(const keep_conv2d_args* a, keep_conv2d_plan_out* out);
  */
 typedef struct {
   uint32_t struct_size;   /* sizeof(keep_attention_args) of the caller's header */
-  uint32_t reserved0;     /* 0 */
+  uint32_t flags;         /* KEEP_ATTN_* overrides; 0 = default dispatch */
   const void* q;
   const void* k;
   const void* v;

@@ -19,6 +19,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _reset_default_ops_overrides():
+    """Kernel-vs-kernel tests set ``ops.DEFAULT.flags`` (keep_conv2d_args.flags overrides); a failing test must not leak them."""
+    yield
+    from comfyui_keep_amd.engine import ops
+    ops.DEFAULT.flags, ops.DEFAULT.attn_flags = ops.DEFAULT_CONV_FLAGS, 0
+
+
 @pytest.fixture(scope='session')
 def synth_weights():
     from comfyui_keep_amd.engine import synth

@@ -68,9 +68,9 @@ def test_conv3x3_f32_halo_kernel_vs_gather_kernel(monkeypatch):
         kw = dict(pro=pro, pro_act=L.PRO_SWISH, upsample=up, stats=True, split_k=1)
         y, st = ops.conv(xd, pack(w), dev(b), **kw)
         assert st is not None and st.P == (y.shape[1] * y.shape[2]) // 64
-        monkeypatch.setenv('KEEP_NO_HALO_F32', '1')
+        ops.DEFAULT.flags = L.CONV_NO_HALO_F32
         y_g, _ = ops.conv(xd, pack(w), dev(b), **kw)
-        monkeypatch.delenv('KEEP_NO_HALO_F32')
+        ops.DEFAULT.flags = 0
         hn = F.group_norm(x, 32, gamma, beta, eps=1e-6)
         hn = hn * torch.sigmoid(hn)
         if up:
@@ -252,9 +252,9 @@ def test_conv3x3_small_cout_valu_kernel(monkeypatch):
         xd = dev(nhwc(x))
         pro = ops.norm_affine(xd, dev(gamma), dev(beta), 32, 1e-6)
         y = ops.conv(xd, pack(w), dev(b), pro=pro)
-        monkeypatch.setenv('KEEP_NO_COUT4', '1')
+        ops.DEFAULT.flags = L.CONV_NO_COUT4
         y_g = ops.conv(xd, pack(w), dev(b), pro=pro)
-        monkeypatch.delenv('KEEP_NO_COUT4')
+        ops.DEFAULT.flags = 0
         ref = F.conv2d(F.group_norm(x, 32, gamma, beta, eps=1e-6), w, b, padding=1)
         check(nchw(y), ref, what=f'cout{cout} valu vs torch')
         check(y, y_g, 2e-5, what=f'cout{cout} valu vs gather kernel')
@@ -876,9 +876,9 @@ def test_conv_bf16_rgb_first_conv_kernel(monkeypatch):
         y, st = ops.conv(dev(nhwc(x)), wp, dev(b), mma=L.MMA_BF16, wb=wb, stats=True)
         assert ops.DEFAULT.profile[-1][0] == 'conv3x3_c3_kernel' and st is not None
         ops.DEFAULT.profile = None
-        monkeypatch.setenv('KEEP_NO_C3', '1')
+        ops.DEFAULT.flags = L.CONV_NO_C3
         y_g, _ = ops.conv(dev(nhwc(x)), wp, dev(b), mma=L.MMA_BF16, wb=wb, stats=True)
-        monkeypatch.delenv('KEEP_NO_C3')
+        ops.DEFAULT.flags = 0
         check(nchw(y), F.conv2d(bf16r(x), bf16r(w), b, padding=1), 2e-5, f'rgb conv {cin}->{cout}')
         check(y, y_g, 2e-5, 'rgb conv vs flat-K gather kernel')
         sc, sh = ops.norm_affine(y, None, None, cout, 1e-5, stats=st)
@@ -1009,7 +1009,7 @@ def test_plan_follows_a_retuned_tile_threshold(mma, monkeypatch):
     y0, st0 = ops.conv(dev(nhwc(x)), wp, dev(b), **kw)
     # the plan sees 16 reference images x 48*48 = 36864 rows (batch-invariant plans): a "large" launch -> 128x128 tiles;
     # with the threshold above that it becomes a "small" one -> 64x64 tiles
-    monkeypatch.setenv('KEEP_GATHER_SMALL_M', '65536')
+    monkeypatch.setattr(ops.DEFAULT, 'flags', L.CONV_SMALL_TILES)
     y1, st1 = ops.conv(dev(nhwc(x)), wp, dev(b), **kw)
     names = [r[0] for r in ops.DEFAULT.profile]
     ops.DEFAULT.profile = None

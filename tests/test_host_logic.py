@@ -366,6 +366,43 @@ def test_abi_struct_layouts_match_header_library_and_doc():
     assert out.kernel.decode().startswith('conv3x3_halo_f32_kernel')
 
 
+def test_library_reads_no_environment_variable_and_flags_steer_the_plan(monkeypatch):
+    """the product libkeep_hip.so has no getenv (dev switches exist only under -DKEEP_DEV_KNOBS); what used to be
+    KEEP_NO_* / KEEP_PLAN_REF_IMAGES / KEEP_GATHER_SMALL_M travels in keep_conv2d_args.flags / .plan_ref_images."""
+    import subprocess
+    from comfyui_keep_amd.engine import hiplib
+    csrc = os.path.join(ROOT, 'comfyui-keep_amd', 'csrc')
+    n_getenv = sum(open(os.path.join(csrc, f)).read().count('getenv') for f in os.listdir(csrc) if f.endswith(('.hip', '.h')))
+    assert n_getenv <= 2, n_getenv          # the KEEP_DEV_ENV macro's definition + its comment, both behind #ifdef KEEP_DEV_KNOBS
+    syms = subprocess.run(['nm', '-D', '--undefined-only', hiplib.LIB_PATH], capture_output=True, text=True).stdout
+    assert 'getenv' not in syms, "the default build must not import getenv"
+    lib = ctypes.CDLL(hiplib.LIB_PATH)
+    lib.keep_conv2d_plan.restype = ctypes.c_int32
+    lib.keep_last_error.restype = ctypes.c_char_p
+
+    def plan(**kw):
+        base = dict(struct_size=ctypes.sizeof(hiplib.ConvArgs), N=1, H=64, W=64, Cin=128, Cout=128, KH=3, KW=3, stride=1, pad_t=1,
+                    pad_l=1, Ho=64, Wo=64, in_ld=128, out_ld=128, mma=hiplib.MMA_F32)
+        base.update(kw)
+        out = hiplib.ConvPlanOut()
+        assert lib.keep_conv2d_plan(ctypes.byref(hiplib.ConvArgs(**base)), ctypes.byref(out)) == 0, lib.keep_last_error()
+        return out.kernel.decode(), out.split_k
+
+    ref = plan()
+    assert ref[0].startswith('conv3x3_halo_f32_kernel')
+    for k in ('KEEP_NO_HALO_F32', 'KEEP_NO_HALO_X3', 'KEEP_NO_COUT4', 'KEEP_NO_C3', 'KEEP_NO_PLAIN', 'KEEP_X3_NO_STREAM'):
+        monkeypatch.setenv(k, '1')
+    monkeypatch.setenv('KEEP_PLAN_REF_IMAGES', '1')
+    monkeypatch.setenv('KEEP_GATHER_SMALL_M', '1')
+    assert plan() == ref                                                          # the environment is not looked at
+    assert not plan(flags=hiplib.CONV_NO_HALO_F32)[0].startswith('conv3x3_halo_f32_kernel')      # ... the flag is
+    # the reference batch of the plans: 16 images of 16x16 need no deeper split than 1 image's plan under reference 1
+    g16 = dict(H=16, W=16, Ho=16, Wo=16, Cin=512, Cout=512, in_ld=512, out_ld=512)
+    assert plan(plan_ref_images=1, **g16)[1] > plan(**g16)[1] and plan(plan_ref_images=16, **g16) == plan(**g16)
+    small = dict(H=2304, W=1, Ho=2304, Wo=1, KH=1, KW=1, pad_t=0, pad_l=0, Cin=128, Cout=192, in_ld=128, out_ld=192)
+    assert '2, 2, 2, 2' in plan(**small)[0] and '2, 2, 1, 1' in plan(flags=hiplib.CONV_SMALL_TILES, **small)[0]
+
+
 def test_integration_doc_matches_the_binding():
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import gen_abi_doc

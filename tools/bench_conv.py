@@ -16,6 +16,8 @@ from comfyui_keep_amd.engine import hiplib as L  # noqa: E402
 if os.environ.get('ABL_LIB'):      # dev library (-DKEEP_X3_ABLATE: tools/dev/README.md)
     L.LIB_PATH = os.environ['ABL_LIB']
 from comfyui_keep_amd.engine import ops  # noqa: E402
+if os.environ.get('CONV_FLAGS'):      # keep_conv2d_args.flags overrides (hiplib.CONV_*), e.g. 512 = KEEP_CONV_NO_STREAM
+    ops.DEFAULT.flags = int(os.environ['CONV_FLAGS'])
 
 LAYERS = {  # name: (N, H, W, Cin, Cout, ksize, upsample)
     'c64_512': (4, 512, 512, 64, 64, 3, False),

@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../../comfyui-keep_amd/csrc"
 make -s >/dev/null
 mkdir -p ab
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $2"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DKEEP_DEV_KNOBS $2"
 /opt/rocm/bin/hipcc $F -c keep_conv_x3.hip -o ab/$1_x3.o &
 /opt/rocm/bin/hipcc $F -fno-slp-vectorize -c keep_conv_x3s.hip -o ab/$1_x3s.o &
 ATT=keep_attn.o

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes over tools/bench_conv.py layers (dev): stall attribution of the x3 halo kernels
-#   tools/dev/pmc_conv.sh <out dir under gpurun_out/> <layers...>      env: KEEP_X3_NO_STREAM=1 for round 3's kernel
+#   tools/dev/pmc_conv.sh <out dir under gpurun_out/> <layers...>      env: CONV_FLAGS=512 (KEEP_CONV_NO_STREAM) for round 3's kernel
 OUT=$(pwd)/gpurun_out/$1; shift
 mkdir -p "$OUT"
 REPO=$(pwd)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """A/B of the 32-query full-score-row attention kernel (AttnBlock at 16x16: 256 tokens, one head of d = 512) against the
-128-query one (KEEP_NO_SFULL2=1): error vs an fp64 softmax(QK^T)V and time, B = 1 and 16."""
+128-query one (keep_attention_args.flags = KEEP_ATTN_NO_SFULL2): error vs an fp64 softmax(QK^T)V and time, B = 1 and 16."""
 import os
 import sys
 
@@ -23,9 +23,9 @@ for B in (1, 16):
     ref = torch.softmax(q @ k.transpose(1, 2) * C ** -0.5, -1) @ v
     for mode in ('old', 'new'):
         if mode == 'old':
-            os.environ['KEEP_NO_SFULL2'] = '1'
+            ops.DEFAULT.attn_flags = L.ATTN_NO_SFULL2
         else:
-            os.environ.pop('KEEP_NO_SFULL2', None)
+            ops.DEFAULT.attn_flags = 0
         o = torch.empty(B * Ltok, C, device='cuda')
 
         def run():

@@ -101,6 +101,25 @@ def test_gmflow_vs_golden(gpu_net):
     close(nchw(flow), OPS['gmflow64'], 5e-4, 'gmflow 64x64')
 
 
+def test_gmflow256_physical_regime_vs_reference_golden(gpu_net):
+    """M16-M21 per module at a physical flow scale (tests/golden/gmflow256.npz: the reference's FlowGenerator on frames 0 and 3 of
+    the translating texture at 256x256 -- |flow| median 0.87 px, p90 2.3, p99 6.9, max 88 px), EVERY pixel: within 2e-4 of the flow
+    scale, and the 99th percentile of the per-pixel error relative to max(1 px, |reference flow|) within 1e-3."""
+    g = np.load(os.path.join(GOLDEN, 'gmflow256.npz'))
+    dt = int(g['dt'])
+    a = synth.synth_clip(T=dt + 1, B=1, size=256, seed=int(g['clip_seed']))[0]
+    flow = nchw(gpu_net._gmflow(a[dt:dt + 1].cuda(), a[0:1].cuda())).numpy()
+    ref = g['flow']
+    err = np.abs(flow - ref)
+    mag = np.maximum(1.0, np.sqrt((ref ** 2).sum(1, keepdims=True)))
+    rep = {'max_err_px': float(err.max()), 'p99_rel': float(np.quantile(err / mag, 0.99)), 'rms_px': float(np.sqrt((err ** 2).mean())),
+           'median_flow_px': float(np.median(np.sqrt((ref ** 2).sum(1)))), 'scale_px': float(np.abs(ref).max())}
+    print(f'gmflow256 [{gpu_net.precision}]', rep)
+    assert np.isfinite(flow).all() and 0.5 < rep['median_flow_px'] < 2.0
+    assert rep['max_err_px'] <= 2e-4 * rep['scale_px'], rep
+    assert rep['p99_rel'] <= 1e-3, rep
+
+
 def test_gmflow_clip_layer0_runs_once_per_frame(gpu_net, monkeypatch):
     """KeepNet._gmflow_clip: the position table and the self-attention block of GMFlow's layer 0 see one image and nothing of its
     pair, so the clip form runs them once per frame and gathers into pair order (an interior frame sits in two pairs).  Same bits
@@ -230,7 +249,15 @@ def test_full_forward_T3_vs_oracle_flows_injected(gpu_net, synth_weights):
 
 
 def test_full_forward_T3_vs_reference_golden(gpu_net):
-    _full_forward_check(gpu_net, 'keep_forward_T3.npz', 3)
+    out = _full_forward_check(gpu_net, 'keep_forward_T3.npz', 3)
+    # every pixel of the 128x128 centre crop of all three frames against the REFERENCE itself (keep_forward_T3_pixels.npz,
+    # oracle/make_golden_r5.py), free running: T = 3 agrees on every token (asserted above: agreement >= 0.99 and the flip rule),
+    # so the frames are comparable pixel by pixel
+    g = np.load(os.path.join(GOLDEN, 'keep_forward_T3_pixels.npz'))
+    a, b, c, d = (int(v) for v in g['crop'])
+    err = np.abs(out[0][:, :, a:b, c:d].cpu().numpy() - g['out_crop']).reshape(3, -1).max(1)
+    print(f'T3 every pixel of the centre crop vs the reference [{gpu_net.precision}], per frame:', err)
+    assert float(err[0]) <= 1e-4 and float(err.max()) <= 1e-3, err
 
 
 def test_full_forward_T3_wide_flow_regime_vs_reference_golden(gpu_net):

@@ -83,6 +83,28 @@ def test_gmflow64(synth_weights):
     close(O.gmflow_forward(a[1:2], a[0:1], synth_weights), OPS['gmflow64'])
 
 
+def _flow_report(flow, ref):
+    """Error of a flow field against the reference's, absolute (px) and against the flow scale: max, and the 99th percentile of
+    the per-pixel error relative to max(1 px, that pixel's reference flow)."""
+    err = np.abs(flow - ref)
+    mag = np.maximum(1.0, np.sqrt((ref ** 2).sum(1, keepdims=True)))
+    return {'max_err_px': float(err.max()), 'p99_rel': float(np.quantile(err / mag, 0.99)), 'median_px': float(np.median(np.sqrt((ref ** 2).sum(1)))),
+            'scale_px': float(np.abs(ref).max())}
+
+
+def test_gmflow256_physical_regime(synth_weights):
+    """M16-M21 pinned where a relative bound means something: the reference's FlowGenerator on frames 0 and 3 of
+    the translating texture at 256x256 (|flow| median 0.87 px, p99 6.9 px, max 88 px), EVERY pixel of the field."""
+    g = np.load(os.path.join(GOLDEN, 'gmflow256.npz'))
+    dt = int(g['dt'])
+    a = synth.synth_clip(T=dt + 1, B=1, size=256, seed=int(g['clip_seed']))[0]
+    flow = O.gmflow_forward(a[dt:dt + 1], a[0:1], synth_weights).numpy()
+    rep = _flow_report(flow, g['flow'])
+    print('oracle gmflow256 vs reference', rep)
+    assert 0.5 < rep['median_px'] < 2.0
+    assert rep['max_err_px'] <= 2e-4 * rep['scale_px'] and rep['p99_rel'] <= 2e-4, rep
+
+
 def test_encoder_generator_small(synth_weights):
     z, _ = O.encoder_forward(op_input('encoder64', (1, 3, 64, 64)), synth_weights, 'encoder', arch.DEFAULT_ARCH)
     close(z, OPS['encoder64'])
@@ -118,6 +140,19 @@ def test_full_forward_T3_vs_golden(synth_weights):
     assert np.array_equal(aux['indices'][0].numpy().astype(np.int16)[safe], g['indices'][safe])
     assert np.abs(aux['gains'][0, :, 0].reshape(3, -1).numpy() - g['gains']).max() <= 1e-4
     assert np.abs(_digest(out[0]) - g['out_grid']).max() <= 3e-4
+
+
+@pytest.mark.slow
+def test_full_forward_T3_every_pixel_of_the_centre_crop_vs_reference(synth_weights):
+    """tests/golden/keep_forward_T3_pixels.npz: every pixel of the 128x128 centre crop of all three frames, from the imported
+    reference itself (oracle/make_golden_r5.py)."""
+    g = np.load(os.path.join(GOLDEN, 'keep_forward_T3_pixels.npz'))
+    a, b, c, d = (int(v) for v in g['crop'])
+    x = synth.synth_clip(T=3, B=1, seed=1234)
+    out = O.keep_forward(x, synth_weights)
+    err = np.abs(out[0][:, :, a:b, c:d].numpy() - g['out_crop']).reshape(3, -1).max(1)
+    print('oracle vs reference, every pixel of the centre crop, per frame:', err)
+    assert err.max() <= 3e-4, err
 
 
 @pytest.mark.slow

@@ -112,6 +112,8 @@ class KeepNet:
         self._aux_top1 = []
         self._pinned_in = {}       # pinned upload staging buffers of run_clips_u8, by (shape, slot)
         self._pinned = None        # pinned host copy of the packed blob (made at the first upload)
+        self.weights_generation = 0   # bumped whenever the packed blob changes (load_state_dict / adopt_packed): a worker pool that
+                                      # received an older blob is stale and is closed (engine/pool.py)
         self.precision = 'fp32'
         self.set_precision(os.environ.get('KEEP_AMD_PRECISION', DEFAULT_PRECISION))
 
@@ -122,8 +124,11 @@ class KeepNet:
         self._sd = {k: v.detach().to(torch.float32).cpu() for k, v in state_dict.items()}
         self._blob, self._index = pack_blob(logical_tensors(self._sd, self.cfg))
         self._dev_blob, self.w, self._pinned = None, None, None
+        self.weights_generation += 1
+        self.close_pool()           # its workers hold the previous weights; .to('cuda') starts a fresh one (KEEP_AMD_GPUS)
         if self.device.type == 'cuda':
             self._upload()
+            self._maybe_start_pool()
         return self
 
     def state_dict(self):
@@ -201,10 +206,7 @@ class KeepNet:
             if self._blob is not None and changed:
                 with torch.cuda.device(device):
                     self._upload()
-            if self.pool is None and self._dev_blob is not None:
-                from . import pool as kpool
-                if kpool.wanted_gpus() > 1 and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
-                    self.start_pool(kpool.wanted_gpus())         # KEEP_AMD_GPUS=N: N - 1 worker processes, one weight broadcast
+            self._maybe_start_pool()
         elif RESIDENT and self._dev_blob is not None:
             # residency policy: KEEPModelPack.offload() after every node call would drop 633 MB of packed
             # weights (plus the policy's twin) and the next call would upload and re-derive them; with KEEP_AMD_RESIDENT=1
@@ -212,11 +214,19 @@ class KeepNet:
             pass
         else:
             self.device = device
+            self.close_pool()              # the weights leave the GPU: the workers' copies go with them
             self._dev_blob, self._dev_blob16, self._dev_blobx3, self.w = None, None, None, None
             self.o.set_precision(self.o.mma)        # drop this net's references to the device blobs
             self._const = {}
             self._graphs = {}
         return self
+
+    def _maybe_start_pool(self):
+        """KEEP_AMD_GPUS=N: N - 1 worker processes, one weight broadcast -- whenever weights are resident and no pool is up."""
+        if self.pool is None and self._dev_blob is not None:
+            from . import pool as kpool
+            if kpool.wanted_gpus() > 1 and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+                self.start_pool(kpool.wanted_gpus())
 
     def start_pool(self, n_gpus):
         """Drive ``n_gpus`` GPUs of this node from THIS process (engine/pool.py): spawns n_gpus - 1 workers, broadcasts the packed
@@ -227,6 +237,25 @@ class KeepNet:
         self.pool = GpuPool(self, n_gpus)
         return self.pool
 
+    def close_pool(self):
+        """Stop the worker processes of this net's pool (they hold a copy of the weights in their GPUs' HBM)."""
+        pool, self.pool = self.pool, None
+        if pool is not None:
+            pool.close()
+
+    def pool_config(self):
+        """Everything a pool worker must share with the root for `bit for bit equal to the sequential loop` to hold: the precision
+        policy, the plans' reference batch, the kernel-selection overrides and the hipGraph mode.  ``GpuPool.run`` compares it with
+        what the workers were last told and re-configures them when it moved (``set_precision`` after the pool came up)."""
+        return {'precision': self.precision, 'plan_ref_images': int(self.o.plan_ref_images), 'flags': int(self.o.flags),
+                'attn_flags': int(self.o.attn_flags), 'graph_mode': str(self.graph_mode)}
+
+    def apply_pool_config(self, cfg):
+        """Worker side of ``pool_config``."""
+        self.set_precision(cfg['precision'])
+        self.o.plan_ref_images, self.o.flags, self.o.attn_flags = int(cfg['plan_ref_images']), int(cfg['flags']), int(cfg['attn_flags'])
+        self.graph_mode = str(cfg['graph_mode'])
+
     def packed_blob(self):
         """Device blob (for the RCCL weight broadcast, engine/dist.py)."""
         return self._dev_blob
@@ -235,6 +264,8 @@ class KeepNet:
         """Install a packed blob received from another rank."""
         self._index, self._dev_blob, self._dev_blob16, self._dev_blobx3 = index, dev_blob, None, None
         self._graphs = {}
+        self.weights_generation += 1
+        self.close_pool()
         self.device = dev_blob.device
         self.w = views(dev_blob, index)
 
@@ -816,7 +847,7 @@ class KeepNet:
         return outs
 
     # ------------------------------------------------------------------ device-side pre/post
-    def run_clips_u8(self, clips_u8, max_b=None, gather='root'):
+    def run_clips_u8(self, clips_u8, max_b=None, gather='root', sink=None):
         """list of uint8 BGR crops [T_i,H,W,3] (host or device) -> list of restored uint8 BGR [T_i,H,W,3] on the host.
 
         Replaces the per-frame host conversions either side of the clip loop -- ``img2tensor(face/255., bgr2rgb) +
@@ -830,7 +861,14 @@ class KeepNet:
         clips are sharded round-robin over the ranks -- no data-path collective, clips share no state -- and the restored
         uint8 clips are collected by clip index with ONE fixed-size uint8 tensor gather: ``gather='root'`` (default) rank 0
         returns the full list and every other rank None (the paste-back that follows runs once, on rank 0); ``'all'`` every
-        rank returns the full list; ``'none'`` each rank returns its own clips as {clip index: tensor}."""
+        rank returns the full list; ``'none'`` each rank returns its own clips as {clip index: tensor}.
+
+        ``sink(ids, crops, classes)`` (single process or worker pool; not under a torch.distributed group): instead of collecting
+        every restored clip on the host, each finished batch group is handed over as soon as its range check has passed --
+        ``ids``: the clip indices, ``crops``: the matching list of restored uint8 [T,H,W,3] tensors, ON THIS PROCESS'S GPU for the
+        groups it ran itself (no download at all) and in host memory for a pool worker's, ``classes``: None, or the ParseNet class
+        maps uint8 [T,H,W] a worker computed for its crops (``GpuPool.set_parser``).  The call then returns None.  The processor's
+        sequence path pastes frames from it while the next group is being restored (modules/keep_processor.py)."""
         if self.w is None:
             raise RuntimeError("KeepNet: weights are not on a device (load_state_dict + .to('cuda') first)")
         from . import dist as kdist
@@ -840,10 +878,13 @@ class KeepNet:
                 raise ValueError(f"expected uint8 [T,H,W,3], got {c.dtype} {tuple(c.shape)}")
         if self.pool is not None and self.shard_across_ranks and len(clips_u8) > 1:
             # single-process product (a ComfyUI node): this process is the root of a worker pool, one worker per additional GPU
-            return self.pool.run(clips_u8, max_b)
-        if not self.shard_across_ranks:      # per-rank workloads (BASELINE configs[4]: one video per GPU): nothing to exchange
-            local = self._run_clips_u8_local(dict(enumerate(clips_u8)), max_b)
-            return [torch.from_numpy(local[i]) for i in range(len(clips_u8))]
+            return self.pool.run(self, clips_u8, max_b, sink=sink)
+        grouped = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        if sink is not None and grouped and self.shard_across_ranks:
+            raise ValueError("run_clips_u8(sink=...) is for one process (with or without the worker pool), not a torch.distributed job")
+        if not self.shard_across_ranks or sink is not None:      # per-rank workloads (BASELINE configs[4]: one video per GPU): nothing to exchange
+            local = self._run_clips_u8_local(dict(enumerate(clips_u8)), max_b, sink=sink)
+            return None if sink is not None else [torch.from_numpy(local[i]) for i in range(len(clips_u8))]
         res = kdist.sharded_map(clips_u8, lambda mine: self._run_clips_u8_local(mine, max_b), gather,
                                 shapes=[tuple(c.shape) for c in clips_u8])
         if res is None or isinstance(res, dict):
@@ -862,13 +903,15 @@ class KeepNet:
             buf = self._pinned_in[key] = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
         return buf
 
-    def _run_clips_u8_local(self, mine, max_b=None):
+    def _run_clips_u8_local(self, mine, max_b=None, sink=None):
         """{clip index: uint8 [T,H,W,3]} -> {clip index: restored uint8 numpy [T,H,W,3]} on this rank's GPU.
 
         Three-stage pipeline over the batch groups, two HIP streams: while group g runs its forward on the compute stream,
         the copy stream uploads group g+1 (pinned staging -> device uint8) and downloads group g-1's restored uint8 into
         pinned memory.  The x3 range check of a group (one int32, ``_checked``) is read after its download has been queued,
-        i.e. the host never waits inside a forward; a flagged group is re-run on the f32 kernels before it is handed back."""
+        i.e. the host never waits inside a forward; a flagged group is re-run on the f32 kernels before it is handed back.
+        Clips that already live on this GPU (device tensors) skip the staging and the upload.  With ``sink`` nothing is downloaded:
+        a finished (range-checked) group is handed to ``sink(ids, [uint8 device tensors], None)`` and {} is returned."""
         order = {}
         for n, c in mine.items():
             order.setdefault(tuple(c.shape[:3]), []).append(n)
@@ -885,8 +928,16 @@ class KeepNet:
 
             slot_ev = {}                                        # staging slot -> event of the H2D copy that last read it
 
+            def on_device(c):
+                return isinstance(c, torch.Tensor) and c.device == self.device
+
             def upload(gi):
                 T, H, Wd, grp = groups[gi]
+                if all(on_device(mine[n]) for n in grp):         # crops warped on this GPU (engine/paste.py:crop_faces): no PCIe round trip
+                    dev = torch.stack([mine[n] for n in grp]) if len(grp) > 1 else mine[grp[0]].unsqueeze(0).contiguous()
+                    ev = torch.cuda.Event()
+                    ev.record(comp)
+                    return None, dev, ev
                 if (gi & 1) in slot_ev:                         # group gi - 2 was copied from this pinned buffer: the CPU must not
                     slot_ev[gi & 1].synchronize()               # overwrite it before that copy has finished (satisfied in steady state)
                 host = self._pinned_staging((len(grp), T, H, Wd, 3), gi & 1)
@@ -914,7 +965,13 @@ class KeepNet:
                     y = ops.nchw_to_nhwc(o.view(len(grp) * T, 3, H, Wd))
                     r8 = torch.empty((len(grp) * T, H, Wd, 3), dtype=torch.uint8, device=self.device)
                     L.call('keep_tensor2img', y, r8, len(grp) * T * H * Wd)
-                    r8_host = r8.view(len(grp), T, H, Wd, 3).cpu()
+                    if sink is not None:
+                        r8_host = r8.view(len(grp), T, H, Wd, 3)
+                    else:
+                        r8_host = r8.view(len(grp), T, H, Wd, 3).cpu()
+                if sink is not None:                    # r8_host is the DEVICE tensor here (nothing was downloaded)
+                    sink(list(grp), [r8_host[k] for k in range(len(grp))], None)
+                    return
                 arr = r8_host.numpy()
                 for k, n in enumerate(grp):
                     local[n] = arr[k]
@@ -938,13 +995,16 @@ class KeepNet:
                 st_host.copy_(self.o.status, non_blocking=True)            # this forward's status word, stream-ordered
                 ev_out = torch.cuda.Event()
                 ev_out.record(comp)
-                r8_host = torch.empty((len(grp), T, H, Wd, 3), dtype=torch.uint8, pin_memory=True)
-                with torch.cuda.stream(io):
-                    io.wait_event(ev_out)
-                    r8_host.copy_(r8.view(len(grp), T, H, Wd, 3), non_blocking=True)
-                    r8.record_stream(io)
-                    ev_done = torch.cuda.Event()
-                    ev_done.record(io)
+                if sink is not None:                    # the crops stay on the GPU; only the status word comes back
+                    r8_host, ev_done = r8.view(len(grp), T, H, Wd, 3), ev_out
+                else:
+                    r8_host = torch.empty((len(grp), T, H, Wd, 3), dtype=torch.uint8, pin_memory=True)
+                    with torch.cuda.stream(io):
+                        io.wait_event(ev_out)
+                        r8_host.copy_(r8.view(len(grp), T, H, Wd, 3), non_blocking=True)
+                        r8.record_stream(io)
+                        ev_done = torch.cuda.Event()
+                        ev_done.record(io)
                 del o, y, r8
                 if pending is not None:
                     finish(pending)          # group g-1: its download ran under group g's launches

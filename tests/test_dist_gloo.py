@@ -121,3 +121,159 @@ def test_shard_is_a_partition():
             parts = [shard_clips(n, r, world) for r in range(world)]
             assert sorted(sum(parts, [])) == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------- worker pool
+# engine/pool.py driven on a machine without a GPU: KEEP_POOL_FAKE_NET=1 replaces the engine inside the workers by a stand-in
+# (restored = 255 - crop under 'x3', 254 - crop otherwise; class map = blue channel mod 19), the root side is the stand-in below.
+# Everything else is the product's code: rendezvous, the one broadcast, arenas, sequence numbers, config sync, failure paths.
+class _FakeRootNet:
+    supports_single_frame = True
+
+    def __init__(self):
+        from comfyui_keep_amd.engine.weights import pack_blob
+        self.device = torch.device('cpu')
+        self.cfg = {'tag': 'fake'}
+        self.precision = 'x3'
+        self.weights_generation = 0
+        self.pool = None
+        blob, self._index = pack_blob({'a.weight': torch.arange(4096, dtype=torch.float32).view(64, 64)})
+        self._blob_t = torch.from_numpy(blob)
+        self.local_calls = []
+
+    def packed_blob(self):
+        return self._blob_t
+
+    def pool_config(self):
+        return {'precision': self.precision, 'plan_ref_images': 0, 'flags': 0, 'attn_flags': 0, 'graph_mode': 'auto'}
+
+    def _run_clips_u8_local(self, mine, max_b=None, sink=None):
+        self.local_calls.append(sorted(mine))
+        top = 255 if self.precision == 'x3' else 254
+        out = {}
+        for i, c in mine.items():
+            c = torch.from_numpy(np.stack(c.frames)) if hasattr(c, 'frames') else c
+            out[i] = (top - c.numpy().astype(np.int16)).clip(0, 255).astype(np.uint8)
+        if sink is not None:
+            sink(sorted(out), [torch.from_numpy(out[i]) for i in sorted(out)], None)
+            return {}
+        return out
+
+    def run_clips_u8(self, clips, max_b=None, sink=None):
+        from comfyui_keep_amd.engine.net import _FrameList
+        clips = [c if isinstance(c, torch.Tensor) else _FrameList(c) for c in clips]
+        return self.pool.run(self, clips, max_b, sink=sink)
+
+
+def _pool_env(monkeypatch, **extra):
+    monkeypatch.setenv('KEEP_POOL_FAKE_NET', '1')
+    monkeypatch.delenv('KEEP_DIST_DEVICE', raising=False)
+    for k, v in extra.items():
+        monkeypatch.setenv(k, v)
+
+
+def _ragged_clips(n, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randint(0, 256, (t, 8, 8, 3), generator=g, dtype=torch.uint8) for t in [20, 20, 1, 7, 3, 20, 2, 5, 20, 11, 4][:n]]
+
+
+def test_pool_world4_order_config_sync_parse_and_arenas(monkeypatch):
+    """GpuPool with three workers (world 4, gloo, no GPU): clip c runs on rank c % 4 and comes back in order; a precision change on
+    the root reaches the workers before the next clip does (no clip is restored under a stale policy); ParseNet class
+    maps ride back with a worker's crops; the shared-memory arenas of a worker are allocated once and reused; a weight change
+    makes the pool refuse to run; close() leaves no worker and no shared memory behind."""
+    _pool_env(monkeypatch)
+    from comfyui_keep_amd.engine.pool import GpuPool, PoolError
+    net = _FakeRootNet()
+    pool = net.pool = GpuPool(net, 4, timeout=120, join_timeout=60)
+    try:
+        assert len(pool._procs) == 3 and pool.broadcast_ms > 0 and not torch.distributed.is_initialized()
+        clips = _ragged_clips(11)
+        out = pool.run(net, clips)
+        assert net.local_calls[-1] == [0, 4, 8]
+        assert all(torch.equal(o, 255 - c) for o, c in zip(out, clips))
+        arenas = {r: tuple(m.name for m in pair) for r, pair in pool._arenas.items()}
+        # the root switches policy after the pool came up: the workers follow before they see a clip
+        net.precision = 'fp32'
+        out = pool.run(net, clips)
+        assert all(torch.equal(o, (254 - c.to(torch.int16)).clamp(0, 255).to(torch.uint8)) for o, c in zip(out, clips))
+        assert pool.config['precision'] == 'fp32'
+        assert {r: tuple(m.name for m in pair) for r, pair in pool._arenas.items()} == arenas          # same blocks, no re-allocation
+        # sink + parse: groups arrive as (ids, crops, classes); the root's own share has no classes (the caller parses it on its GPU)
+        net.precision = 'x3'
+        pool.set_parser({'w': torch.zeros(3)})
+        got = {}
+        assert pool.run(net, clips, sink=lambda ids, crops, cls: got.update({i: (c, None if cls is None else cls[k])
+                                                                               for k, (i, c) in enumerate(zip(ids, crops))}), parse=True) is None
+        assert sorted(got) == list(range(11))
+        for i, c in enumerate(clips):
+            assert torch.equal(got[i][0], 255 - c)
+            if i % 4 == 0:
+                assert got[i][1] is None
+            else:
+                assert torch.equal(got[i][1], (255 - c)[..., 0] % 19)
+        # clips given as lists of crops (what the processor holds)
+        from comfyui_keep_amd.engine.net import _FrameList
+        out = pool.run(net, [_FrameList([f.numpy() for f in c]) for c in clips[:5]])
+        assert all(torch.equal(o, 255 - c) for o, c in zip(out, clips[:5]))
+        # new weights on the root: the pool is stale
+        net.weights_generation += 1
+        try:
+            pool.run(net, clips)
+            raise AssertionError("a stale pool must refuse to run")
+        except PoolError as e:
+            assert 'other weights' in str(e)
+        names = [m.name for pair in pool._arenas.values() for m in pair]
+        procs = list(pool._procs)
+    finally:
+        pool.close()
+    assert all(p.poll() is not None for p in procs) and not pool._procs and not pool._arenas
+    from multiprocessing import shared_memory
+    for n in names:
+        try:
+            shared_memory.SharedMemory(name=n)
+            raise AssertionError(f"arena {n} was not unlinked")
+        except FileNotFoundError:
+            pass
+
+
+def test_pool_startup_failures_do_not_hang(monkeypatch):
+    """a worker that dies around the rendezvous must not leave the root waiting in the store for the c10d
+    default timeout.  Stage 'import': the worker reports 'failed' before anyone joins; stage 'join': the worker dies after the
+    handshake -- the root's join times out after `join_timeout` seconds and the error carries the worker's traceback."""
+    import time
+    from comfyui_keep_amd.engine.pool import GpuPool, PoolError
+    for stage, limit in (('import', 60), ('join', 90)):
+        _pool_env(monkeypatch, KEEP_POOL_TEST_FAIL=f'2:{stage}')
+        net = _FakeRootNet()
+        t0 = time.monotonic()
+        try:
+            GpuPool(net, 3, timeout=120, join_timeout=8)
+            raise AssertionError("the pool came up although worker 2 failed")
+        except PoolError as e:
+            assert 'injected failure' in str(e), str(e)
+        assert time.monotonic() - t0 < limit
+        assert not torch.distributed.is_initialized()
+
+
+def test_pool_through_process_image_sequence(monkeypatch):
+    """The node's sequence entry point over the pool (world 4): 47 aligned frames -> clips of 20 + 20 + 7 sharded over root + 3
+    workers -> restored faces in frame order, equal to the one-process result."""
+    _pool_env(monkeypatch)
+    import test_host_logic as H        # installs the ComfyUI stubs
+    from comfyui_keep_amd.engine.pool import GpuPool
+    from comfyui_keep_amd.modules.keep_model_loader import KEEPModelPack
+    from comfyui_keep_amd.modules.keep_processor import KEEPFaceProcessor
+    net = _FakeRootNet()
+    pool = net.pool = GpuPool(net, 4, timeout=120, join_timeout=60)
+    try:
+        proc = KEEPFaceProcessor(KEEPModelPack(net, H._Helper(), None, None, 'KEEP'))
+        proc.return_restored_aligned = True
+        frames = torch.rand(47, 512, 512, 3)
+        out = proc.process_image_sequence(frames, 1.0, True, True, False, max_clip_length=20)
+        u8 = (frames * 255).to(torch.uint8)
+        assert out.shape == (47, 512, 512, 3) and torch.equal(out, (255 - u8).float() / 255.0)
+        assert net.local_calls[-1] == [0]                      # 3 clips over 4 ranks: the root ran clip 0, workers 1 and 2 the others
+        assert len(proc.last_restored_faces) == 47
+    finally:
+        pool.close()

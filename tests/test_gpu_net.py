@@ -103,8 +103,8 @@ def test_gmflow_vs_golden(gpu_net):
 
 def test_gmflow256_physical_regime_vs_reference_golden(gpu_net):
     """M16-M21 per module at a physical flow scale (tests/golden/gmflow256.npz: the reference's FlowGenerator on frames 0 and 3 of
-    the translating texture at 256x256 -- |flow| median 0.87 px, p90 2.3, p99 6.9, max 88 px), EVERY pixel: within 2e-4 of the flow
-    scale, and the 99th percentile of the per-pixel error relative to max(1 px, |reference flow|) within 1e-3."""
+    the translating texture at 256x256 -- |flow| median 0.87 px, p90 2.3, p99 6.9, max 88 px), EVERY pixel: within 2e-3 px
+    (2e-5 of the flow scale), and the 99th percentile of the per-pixel error relative to max(1 px, |reference flow|) within 3e-4."""
     g = np.load(os.path.join(GOLDEN, 'gmflow256.npz'))
     dt = int(g['dt'])
     a = synth.synth_clip(T=dt + 1, B=1, size=256, seed=int(g['clip_seed']))[0]
@@ -116,8 +116,9 @@ def test_gmflow256_physical_regime_vs_reference_golden(gpu_net):
            'median_flow_px': float(np.median(np.sqrt((ref ** 2).sum(1)))), 'scale_px': float(np.abs(ref).max())}
     print(f'gmflow256 [{gpu_net.precision}]', rep)
     assert np.isfinite(flow).all() and 0.5 < rep['median_flow_px'] < 2.0
-    assert rep['max_err_px'] <= 2e-4 * rep['scale_px'], rep
-    assert rep['p99_rel'] <= 1e-3, rep
+    # measured on MI355X (round 5): max 5.4e-4 / 4.5e-4 px (x3 / fp32), p99 relative 7.8e-5 / 8.2e-5, rms 4.3e-5 px
+    assert rep['max_err_px'] <= 2e-5 * rep['scale_px'] and rep['max_err_px'] <= 2e-3, rep
+    assert rep['p99_rel'] <= 3e-4, rep
 
 
 def test_gmflow_clip_layer0_runs_once_per_frame(gpu_net, monkeypatch):
@@ -257,7 +258,7 @@ def test_full_forward_T3_vs_reference_golden(gpu_net):
     a, b, c, d = (int(v) for v in g['crop'])
     err = np.abs(out[0][:, :, a:b, c:d].cpu().numpy() - g['out_crop']).reshape(3, -1).max(1)
     print(f'T3 every pixel of the centre crop vs the reference [{gpu_net.precision}], per frame:', err)
-    assert float(err[0]) <= 1e-4 and float(err.max()) <= 1e-3, err
+    assert float(err[0]) <= 5e-5 and float(err.max()) <= 2e-4, err       # measured 3.9e-6 ... 1.3e-5 (x3), 4.9e-6 ... 3.0e-5 (fp32)
 
 
 def test_full_forward_T3_wide_flow_regime_vs_reference_golden(gpu_net):

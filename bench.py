@@ -349,6 +349,53 @@ def pipeline_leg(net, n_frames, H, W, faces, batch=20):
                     "paste-back -> uint8 frames in host memory, every stage on the MI355X; synthetic face geometry"}
 
 
+def product_leg(net, n_frames, H, W, faces):
+    """BASELINE configs[2] / [3] through the PRODUCT's own sequence entry point: ``KEEPFaceProcessor.process_image_sequence`` (the
+    node's call: float IMAGE tensor in host memory -> float IMAGE tensor in host memory) and ``process_frames_u8`` (the same between
+    the two ComfyUI converters: uint8 frames -> uint8 frames, comparable with ``pipeline_leg``).  The reference's
+    FaceRestoreHelper needs cv2 and the reference tree, neither of which exists on the GPU box: ``tools/synth_facehelper.py`` stands in
+    for it -- same calls from the processor, the engine's RetinaFace / ParseNet behind it, synthetic landmarks (a detector with
+    random weights finds no faces), Umeyama instead of cv2.estimateAffinePartial2D.  Everything else is the shipped code path:
+    batched detection pre-pass, tracking + smoothing (modules/face_tracks.py), device crop warp, the streamed clip loop + ParseNet +
+    paste-back (``_restore_and_paste_streamed``)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import synth_facehelper as SF
+    proc, helper = SF.make_processor(net, (H, W), faces)
+    g = torch.Generator().manual_seed(faces)
+    frames_u8 = torch.randint(0, 256, (n_frames, H, W, 3), generator=g, dtype=torch.uint8)
+    frames_list = [frames_u8[i].numpy() for i in range(n_frames)]
+
+    def run_u8():
+        helper.begin_sequence()
+        t0 = time.perf_counter()
+        out = proc.process_frames_u8(frames_list, 1.0, False, faces == 1, False, max_clip_length=20)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, out
+
+    run_u8()                                                  # warm: allocator, plan caches, pinned buffers
+    d8, out8 = run_u8()
+    assert tuple(out8.shape) == (n_frames, H, W, 3) and out8.dtype == torch.uint8
+    assert int((out8 != frames_u8).any(-1).sum()) > n_frames * 1000          # faces were pasted
+    rec = {"value": round(n_frames / d8, 2), "unit": "video frames/s", "frames": n_frames, "frame_size": [H, W], "faces_per_frame": faces,
+           "restored_faces_per_s": round(n_frames * faces / d8, 2), "seconds": round(d8, 3),
+           "entry_point": "KEEPFaceProcessor.process_frames_u8 (= process_image_sequence between its two ComfyUI converters)",
+           "what": "uint8 frames in host memory -> batched RetinaFace pre-pass -> tracks -> device crop warp -> streamed KEEP clip loop + "
+                   "ParseNet + paste-back -> uint8 frames in host memory; the product's code path with tools/synth_facehelper.py standing "
+                   "in for the reference's cv2-based FaceRestoreHelper (synthetic landmarks)"}
+    frames_f = frames_u8.float() / 255.0
+    helper.begin_sequence()
+    t0 = time.perf_counter()
+    outf = proc.process_image_sequence(frames_f, 1.0, False, faces == 1, False, max_clip_length=20)
+    torch.cuda.synchronize()
+    df = time.perf_counter() - t0
+    assert tuple(outf.shape) == (n_frames, H, W, 3) and outf.dtype == torch.float32
+    rec["process_image_sequence"] = {"value": round(n_frames / df, 2), "unit": "video frames/s", "seconds": round(df, 3),
+                                     "what": "the node's call: float32 RGB IMAGE tensor in host memory -> float32 IMAGE tensor in host "
+                                             "memory (adds the reference's comfy_image_to_cv2 per frame on the host and 4x the "
+                                             "download bytes)"}
+    return rec
+
+
 def processor_leg(net, n_crops, faces):
     """BASELINE configs[2] / [3] as the hot path sees them: `n_crops` crops stacked frame-major (`faces` crops per frame,
     interleaved: keep_processor.py:252-253) and cut into max_clip_length = 20 chunks by the processor's own code."""
@@ -574,6 +621,9 @@ def main():
             # ---- BASELINE configs[2] / [3] end to end: frames -> frames, every stage on the engine
             line["end_to_end"] = {"config3_300_frames_720p_1_face": pipeline_leg(net, 300, 720, 1280, 1),
                                   "config4_300_frames_1080p_3_faces": pipeline_leg(net, 300, 1080, 1920, 3)}
+            # ---- the same two configurations through the product's own sequence entry point
+            line["end_to_end_product"] = {"config3_300_frames_720p_1_face": product_leg(net, 300, 720, 1280, 1),
+                                          "config4_300_frames_1080p_3_faces": product_leg(net, 300, 1080, 1920, 3)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_frames)
         print(json.dumps(line))

@@ -146,6 +146,8 @@ class KeepNet:
             raise NotImplementedError("KeepNet is an inference engine (the reference trains with BasicSR)")
         return self.eval()
 
+    supports_sink = True      # run_clips_u8(sink=...): finished groups are handed over on the GPU (the processor's streamed paste-back)
+
     # frame 0 of a clip depends on no other frame (no flow, no Kalman update, no CFA for i == 0), so a lone crop can be
     # restored as a T = 1 clip instead of the reference's T = 2 duplicate (keep_processor.py:173-178) with the same result
     supports_single_frame = True
@@ -847,7 +849,7 @@ class KeepNet:
         return outs
 
     # ------------------------------------------------------------------ device-side pre/post
-    def run_clips_u8(self, clips_u8, max_b=None, gather='root', sink=None):
+    def run_clips_u8(self, clips_u8, max_b=None, gather='root', sink=None, parse=False):
         """list of uint8 BGR crops [T_i,H,W,3] (host or device) -> list of restored uint8 BGR [T_i,H,W,3] on the host.
 
         Replaces the per-frame host conversions either side of the clip loop -- ``img2tensor(face/255., bgr2rgb) +
@@ -878,7 +880,7 @@ class KeepNet:
                 raise ValueError(f"expected uint8 [T,H,W,3], got {c.dtype} {tuple(c.shape)}")
         if self.pool is not None and self.shard_across_ranks and len(clips_u8) > 1:
             # single-process product (a ComfyUI node): this process is the root of a worker pool, one worker per additional GPU
-            return self.pool.run(self, clips_u8, max_b, sink=sink)
+            return self.pool.run(self, clips_u8, max_b, sink=sink, parse=bool(parse) and sink is not None)
         grouped = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
         if sink is not None and grouped and self.shard_across_ranks:
             raise ValueError("run_clips_u8(sink=...) is for one process (with or without the worker pool), not a torch.distributed job")

@@ -130,6 +130,23 @@ class ParseNetEngine:
         self.w = None
         self.o = ops.Ops()
 
+    def packed(self):
+        """(packed fp32 blob, index, in_size, out_size, precision): what ``from_packed`` rebuilds the engine from in another process
+        (engine/pool.py: the workers of the GPU pool parse the crops they restored)."""
+        return self._blob, self._index, self.in_size, self.out_size, self.precision
+
+    @classmethod
+    def from_packed(cls, blob, index, in_size=512, out_size=512, precision='x3'):
+        self = cls.__new__(cls)
+        self.in_size, self.out_size = in_size, out_size
+        self.blocks = parsenet_spec(in_size=in_size, out_size=out_size)
+        self._blob, self._index = np.ascontiguousarray(blob), index
+        self.precision = precision
+        self.device = torch.device('cpu')
+        self.w = None
+        self.o = ops.Ops()
+        return self
+
     def to(self, device):
         device = torch.device(device)
         if device.type != 'cuda':

@@ -278,14 +278,14 @@ class GpuPool:
         self._broadcast_request(lambda r, seq: ('configure', seq, cfg))
         self.config = cfg
 
-    def set_parser(self, state_dict):
-        """Give every worker the ParseNet weights (name -> tensor / array of ``engine/parsenet.py``'s engine): ``run(parse=True)`` then
-        also returns the class maps of the crops a worker restored.  Sent once per state dict object."""
-        if self._parser_sent is state_dict:
+    def set_parser(self, engine):
+        """Give every worker the ParseNet weights -- ``engine``: the root's ``engine/parsenet.py:ParseNetEngine`` (its packed blob is
+        what travels) -- so that ``run(parse=True)`` also returns the class maps of the crops a worker restored.  Sent once per engine."""
+        if self._parser_sent is engine:
             return
-        sd = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in state_dict.items()}
-        self._broadcast_request(lambda r, seq: ('parsenet', seq, sd))
-        self._parser_sent = state_dict       # (identity: the ~20 MB dict stays alive with the pool)
+        packed = tuple(engine.packed()) if hasattr(engine, 'packed') else engine
+        self._broadcast_request(lambda r, seq: ('parsenet', seq, packed))
+        self._parser_sent = engine
 
     def _arena(self, r, need_in, need_out):
         """The worker's pair of shared-memory arenas, grown (never shrunk) to the sizes this call needs."""

@@ -8,7 +8,7 @@ the group and then serves numbered requests:
   ('run', seq, arena names | None, ids, shapes, max_b, parse)   uint8 crops in the input arena -> ``KeepNet._run_clips_u8_local`` on
         this GPU -> restored uint8 crops (and, with ``parse``, the ParseNet class maps of those crops) into the output arena
   ('configure', seq, cfg)      ``KeepNet.apply_pool_config``: precision policy, plan reference batch, kernel overrides, graph mode
-  ('parsenet', seq, state)     build ``engine/parsenet.py:ParseNetEngine`` from the root's ParseNet weights
+  ('parsenet', seq, packed)    rebuild ``engine/parsenet.py:ParseNetEngine`` from the root engine's packed blob (``ParseNetEngine.packed()``)
 
 The engine is imported by path, without the ComfyUI node surface (``comfyui-keep_amd/__init__.py`` is never executed here): a
 worker needs neither ComfyUI nor the face helper.  ``KEEP_POOL_FAKE_NET=1``: a stand-in engine (restored = 255 - crop, class map =
@@ -137,7 +137,7 @@ def main():
                     parser = 'fake'
                 else:
                     (PN,) = _engine('parsenet')
-                    parser = PN.ParseNetEngine({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in msg[2].items()}).to(device)
+                    parser = PN.ParseNetEngine.from_packed(*msg[2]).to(device)
                 conn.send(('ok', seq))
                 continue
             _, _, names, ids, shapes, max_b, parse = msg

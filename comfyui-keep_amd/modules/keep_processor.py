@@ -19,6 +19,13 @@ GPUs.  Clips share no state and the kernel plans are batch-invariant (tiles / sp
 DESIGN.md section 6), so the result equals the sequential one-clip-at-a-time loop BIT FOR BIT
 (tests/test_gpu_net.py::test_config3_config4_clip_mixes_equal_sequential).
 The paste-back compositing can run on the GPU (``KEEP_AMD_GPU_PASTE``, ``_paste`` below).
+
+Round 5 -- the sequence path STREAMS steps 3 and 4 (``_restore_and_paste_streamed``): with the engine's net, its ParseNet and the
+GPU paste available, crops that were warped on the GPU stay there, the clip loop hands every finished batch group over on the
+device (``run_clips_u8(sink=...)``), ParseNet runs on batches of up to 32 faces ACROSS frames (the reference: one face per call,
+face_restoration_helper.py:418-424), and the frames whose faces are all restored are composited and downloaded on a second HIP
+stream while the next group is being restored.  Same arithmetic, same order per frame: the output equals the per-frame path bit
+for bit (tests/test_gpu_paste.py::test_streamed_sequence_equals_the_per_frame_path); every other configuration keeps that path.
 """
 import os
 
@@ -100,6 +107,26 @@ class _ReplayDetector:
 
     def detect_faces(self, image, conf_threshold=0.8, *args, **kwargs):
         return self.result
+
+
+class _DeviceFaces:
+    """``last_restored_faces`` of the streamed path: the restored crops stay where they were produced (the GPU, or host memory for a
+    pool worker's) and are fetched on access -- nothing downloads 236 MB per 300 crops for a list only tests and tools read."""
+
+    def __init__(self, items):
+        self._items = list(items)
+
+    def __len__(self):
+        return len(self._items)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self._items)))]
+        t = self._items[i]
+        return np.ascontiguousarray(t.cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t))
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self._items)))
 
 
 def split_clips(num_faces: int, max_clip_length: int):
@@ -257,7 +284,7 @@ class KEEPFaceProcessor:
                 self.gpu_paste = False
         return self.gpu_paste
 
-    def _align_warp(self, helper):
+    def _align_warp(self, helper, keep_on_device=False):
         """``helper.align_warp_face()`` (face_restoration_helper.py:256-320).  With the GPU cv path and the default configuration
         (no pad_blur, constant border) only the similarity fit stays on the host (``cv2.estimateAffinePartial2D``, :305); the
         ``cv2.warpAffine`` that produces the 512 x 512 crops (:316-318) runs on the device (``keep_warp_affine_u8``)."""
@@ -265,11 +292,17 @@ class KEEPFaceProcessor:
                 or getattr(helper.input_img, 'dtype', None) != np.uint8):       # (16-bit sources are float64 after read_image)
             return helper.align_warp_face()
         from ..engine.paste import crop_faces
-        cv2 = _cv2()
-        mats = [cv2.estimateAffinePartial2D(lm, helper.face_template, method=cv2.LMEDS)[0] for lm in helper.all_landmarks_5]
-        crops = crop_faces(helper.input_img, mats, tuple(helper.face_size), self.device).cpu().numpy()
+        fit = getattr(helper, 'estimate_similarity', None)          # (a helper may bring its own fit: bench.py's cv2-free stand-in)
+        cv2 = _cv2() if fit is None else None
+        mats = [fit(lm) if fit is not None else cv2.estimateAffinePartial2D(lm, helper.face_template, method=cv2.LMEDS)[0]
+                for lm in helper.all_landmarks_5]
+        crops = crop_faces(helper.input_img, mats, tuple(helper.face_size), self.device)
         helper.affine_matrices.extend(mats)
-        helper.cropped_faces.extend(crops[i] for i in range(len(mats)))
+        if keep_on_device:                                          # the streamed sequence path: no PCIe round trip of the crops
+            helper.cropped_faces.extend(crops[i] for i in range(len(mats)))
+        else:
+            crops = crops.cpu().numpy()
+            helper.cropped_faces.extend(crops[i] for i in range(len(mats)))
 
     def _gpu_paste_applies(self, helper, bg, draw_box):
         faces, mats = getattr(helper, 'restored_faces', None), getattr(helper, 'inverse_affine_matrices', None)
@@ -324,6 +357,143 @@ class KEEPFaceProcessor:
             classes = torch.stack(classes)
         out = self._paster.paste(bg, faces, list(helper.inverse_affine_matrices), classes, getattr(helper, 'upscale_factor', 1), draw_box)
         return out.cpu().numpy()
+
+    # ------------------------------------------------------------------ streamed restore + paste (round 5)
+    def _stream_applies(self, helper, frames_bgr, crops, draw_box):
+        """The streamed form of steps 3 + 4 needs: the engine's net (``run_clips_u8`` with ``sink``), not inside a torch.distributed
+        job, the GPU cv path (``_gpu_cv_path``), the parse-mask composite with ParseNet on the engine, no face upsampler, uint8
+        colour frames of one size and 512 x 512 crops -- i.e. the configuration ``_gpu_paste_applies`` admits frame by frame, decided
+        once for the sequence.  ``KEEP_AMD_STREAM_PASTE=0`` keeps the per-frame path."""
+        net = self.keep_net
+        if os.environ.get('KEEP_AMD_STREAM_PASTE', '1') == '0' or not getattr(net, 'supports_sink', False):
+            return False
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            return False
+        if self.face_upscale_model is not None or not getattr(helper, 'use_parse', False):
+            return False
+        if getattr(getattr(helper, 'face_parse', None), 'engine', None) is None or not self._gpu_cv_path():
+            return False
+        f0 = frames_bgr[0]
+        if any(not isinstance(f, np.ndarray) or f.dtype != np.uint8 or f.ndim != 3 or f.shape != f0.shape or f.shape[2] != 3
+               for f in frames_bgr):
+            return False
+        if tuple(getattr(helper, 'face_size', (512, 512))) != (512, 512):
+            return False
+        return crops is None or all(tuple(c.shape) == (512, 512, 3) for c in crops)
+
+    def _restore_and_paste_streamed(self, frames_bgr, crops, affines, faces_per_frame, max_clip_length, factor, draw_box, pbar,
+                                    as_u8):
+        """Steps 3 and 4 of ``process_image_sequence`` (keep_processor.py:263-304) as ONE pipeline on the GPU.
+
+        ``run_clips_u8(sink=...)`` restores the clips in batch groups and hands each finished, range-checked group over as device
+        tensors (a pool worker's share arrives in host memory, with its ParseNet class maps).  Whenever the next frames in order
+        have all their faces, they are processed on a second stream: ParseNet over up to 32 faces across frames, then per frame the
+        reference's arithmetic in the reference's order -- inverse affine from the helper (``get_inverse_affine``), face after face
+        blended into the background (engine/paste.py) -- and the download of the finished frame (converted to the ComfyUI float RGB
+        layout on the device unless ``as_u8``).  The compute stream meanwhile runs the next group's forward."""
+        from ..engine import hiplib as L
+        from ..engine.paste import GpuPaster
+        helper, net, dev = self.face_helper, self.keep_net, torch.device(self.device)
+        if dev.index is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
+        if self._paster is None:
+            self._paster = GpuPaster(dev)
+        paster, engine = self._paster, helper.face_parse.engine
+        n_frames, n_crops = len(frames_bgr), len(crops)
+        spans = split_clips(n_crops, max_clip_length)
+        first = [0]
+        for k in faces_per_frame:
+            first.append(first[-1] + k)
+        clips = []
+        for s, e in spans:
+            part = crops[s:e]
+            if all(isinstance(c, torch.Tensor) and c.is_cuda for c in part):
+                clips.append(torch.stack(part))                       # warped on this GPU: restored without leaving it
+            else:
+                clips.append([c.cpu().numpy() if isinstance(c, torch.Tensor) else np.asarray(c) for c in part])
+        pool = getattr(net, 'pool', None)
+        if pool is not None and hasattr(pool, 'set_parser'):          # the workers parse what they restore
+            pool.set_parser(engine)
+        ready, classes = [None] * n_crops, [None] * n_crops
+        ps = getattr(self, '_paste_stream', None)
+        if ps is None:
+            ps = self._paste_stream = torch.cuda.Stream(device=dev)
+        st = {'next': 0, 'out': None, 'aff': 0}
+
+        def on_dev(t):
+            return t if (isinstance(t, torch.Tensor) and t.is_cuda) else torch.as_tensor(t).to(dev, non_blocking=True)
+
+        def emit(t, frame_dev):
+            """finished frame t (uint8 BGR [H,W,3] on the device) -> the output tensor in host memory"""
+            if st['out'] is None:
+                shape = (n_frames,) + tuple(frame_dev.shape)
+                try:
+                    st['out'] = torch.empty(shape, dtype=torch.uint8 if as_u8 else torch.float32, pin_memory=True)
+                except RuntimeError:                                  # more than the host will pin: pageable memory, slower copies
+                    st['out'] = torch.empty(shape, dtype=torch.uint8 if as_u8 else torch.float32)
+            if as_u8:
+                st['out'][t].copy_(frame_dev, non_blocking=True)
+            else:                                                      # cv2_to_comfy_image on the device: RGB, float32(u8) / 255
+                st['out'][t].copy_(frame_dev.flip(-1).to(torch.float32).div_(255.0), non_blocking=True)
+
+        def advance():
+            f0 = f1 = st['next']
+            while f1 < n_frames and all(ready[i] is not None for i in range(first[f1], first[f1 + 1])):
+                f1 += 1
+            if f1 == f0:
+                return
+            with torch.cuda.device(dev), torch.cuda.stream(ps):
+                need = [i for i in range(first[f0], first[f1]) if classes[i] is None]
+                for b0 in range(0, len(need), 32):                     # ParseNet across frames, <= 32 faces per call
+                    idx = need[b0:b0 + 32]
+                    fb = torch.stack([on_dev(ready[i]) for i in idx])
+                    x = torch.empty(fb.shape, dtype=torch.float32, device=dev)
+                    L.call('keep_img2tensor', fb, x, fb.numel() // 3)     # :418-422 BGR u8 -> RGB float (x / 255 - 0.5) / 0.5
+                    cl = engine.classes(x)
+                    for k, i in enumerate(idx):
+                        classes[i] = cl[k]
+                for t in range(f0, f1):
+                    bg = self._final_background(frames_bgr[t], factor)
+                    k = faces_per_frame[t]
+                    if k == 0:
+                        emit(t, on_dev(np.ascontiguousarray(bg)))
+                        continue
+                    helper.affine_matrices = affines[st['aff']:st['aff'] + k]
+                    helper.upscale_factor = factor
+                    helper.get_inverse_affine(None)
+                    st['aff'] += k
+                    ids = range(first[t], first[t + 1])
+                    faces = torch.stack([on_dev(ready[i]) for i in ids])
+                    cls = torch.stack([on_dev(classes[i]) for i in ids])
+                    emit(t, paster.paste(bg, faces, list(helper.inverse_affine_matrices), cls, factor, draw_box))
+                    pbar.update(1)
+            st['next'] = f1
+
+        def sink(ids, crops_list, classes_list):
+            for j, cid in enumerate(ids):
+                s, e = spans[cid]
+                for k in range(e - s):
+                    ready[s + k] = crops_list[j][k]
+                    if classes_list is not None:
+                        classes[s + k] = classes_list[j][k]
+            advance()
+
+        max_b = None
+        groups = int(os.environ.get('KEEP_AMD_STREAM_GROUPS', '0') or 0)      # >= 2: at least that many batch groups (more overlap, smaller batches)
+        if groups >= 2 and hasattr(net, 'clips_per_call'):
+            cap = net.clips_per_call(max_clip_length, 512, 512)
+            max_b = max(1, min(cap, -(-len(clips) // groups)))
+        try:
+            net.run_clips_u8(clips, max_b=max_b, sink=sink, parse=True)
+        except TypeError:                                              # a net whose run_clips_u8 takes no max_b / parse
+            net.run_clips_u8(clips, sink=sink)
+        advance()                                                      # frames without faces behind the last restored one
+        ps.synchronize()
+        if st['next'] != n_frames:
+            raise RuntimeError(f"streamed paste-back: {n_frames - st['next']} frame(s) never became ready")
+        pbar.update(n_frames)
+        self.last_restored_faces = _DeviceFaces(ready)
+        return st['out']
 
     # ------------------------------------------------------------------ sequence
     def _detect_all(self, frames_bgr, only_center_face):
@@ -380,11 +550,14 @@ class KEEPFaceProcessor:
             h, w = img.shape[:2]
             if resize is not None and min(h, w) > resize:
                 scale = resize / min(h, w)
-                img = _resize(img, int(w * scale), int(h * scale), 'INTER_AREA' if scale < 1 else 'INTER_LINEAR')
-            imgs.append(np.ascontiguousarray(img))
-        if any(im.shape != imgs[0].shape or im.dtype != np.uint8 for im in imgs):
+                own = getattr(helper, 'resize_for_detector', None)      # (a helper may bring its own resize: bench.py's cv2-free stand-in)
+                img = (own(img, int(w * scale), int(h * scale)) if own is not None
+                       else _resize(img, int(w * scale), int(h * scale), 'INTER_AREA' if scale < 1 else 'INTER_LINEAR'))
+            imgs.append(img if isinstance(img, torch.Tensor) else np.ascontiguousarray(img))
+        if any(tuple(im.shape) != tuple(imgs[0].shape) or im.dtype not in (np.uint8, torch.uint8) for im in imgs):
             return states, None
-        return states, det.detect_batch(np.stack(imgs), 0.97)
+        batch = torch.stack(imgs) if isinstance(imgs[0], torch.Tensor) else np.stack(imgs)
+        return states, det.detect_batch(batch, 0.97)
 
     @torch.no_grad()
     def process_image_sequence(self, image_sequence_tensor: torch.Tensor, final_upscale_factor: float,
@@ -393,8 +566,27 @@ class KEEPFaceProcessor:
         n_frames = image_sequence_tensor.shape[0]
         if n_frames == 0:
             return image_sequence_tensor
-        pbar = ProgressBar(n_frames * 4)
         frames_bgr = [comfy_image_to_cv2(image_sequence_tensor[i].unsqueeze(0)) for i in range(n_frames)]
+        out = self._process_frames(frames_bgr, final_upscale_factor, has_aligned_frames, only_center_face, draw_box,
+                                   max_clip_length, as_u8=False)
+        if out is None:
+            return None
+        return out if isinstance(out, torch.Tensor) else (torch.cat([cv2_to_comfy_image(f) for f in out], dim=0) if out
+                                                           else image_sequence_tensor)
+
+    @torch.no_grad()
+    def process_frames_u8(self, frames_bgr, final_upscale_factor: float = 1.0, has_aligned_frames: bool = False,
+                          only_center_face: bool = True, draw_box: bool = False, max_clip_length: int = 20):
+        """``process_image_sequence`` between its two ComfyUI converters: list of uint8 BGR frames -> uint8 BGR frames
+        (a [N,H',W',3] tensor from the streamed path, a list of arrays otherwise).  What a video tool that already holds
+        uint8 frames calls, and what bench.py times next to the float entry point."""
+        return self._process_frames(list(frames_bgr), final_upscale_factor, has_aligned_frames, only_center_face, draw_box,
+                                    max_clip_length, as_u8=True)
+
+    def _process_frames(self, frames_bgr, final_upscale_factor, has_aligned_frames, only_center_face, draw_box,
+                        max_clip_length, as_u8):
+        n_frames = len(frames_bgr)
+        pbar = ProgressBar(n_frames * 4)
         helper = self.face_helper
 
         # -- 1. landmarks per frame -> temporally smoothed tracks
@@ -409,6 +601,7 @@ class KEEPFaceProcessor:
 
         # -- 2. crops, flat and frame-major
         crops, affines, faces_per_frame = [], [], []
+        stream_ok = (not has_aligned_frames) and self._stream_applies(helper, frames_bgr, None, draw_box)
         for i in tqdm(range(n_frames), desc="Cropping and aligning faces"):
             if has_aligned_frames:
                 frame_crops, frame_aff = [_resize(frames_bgr[i], 512, 512, 'INTER_LINEAR')], []
@@ -419,14 +612,20 @@ class KEEPFaceProcessor:
                     helper.clean_all()
                     helper.read_image(frames_bgr[i])
                     helper.all_landmarks_5 = active
-                    self._align_warp(helper)
+                    self._align_warp(helper, keep_on_device=stream_ok)
                     frame_crops = list(helper.cropped_faces)
                     frame_aff = list(helper.affine_matrices)
             faces_per_frame.append(len(frame_crops))
             crops.extend(frame_crops)
             affines.extend(frame_aff)
 
+        # -- 3 + 4 streamed: restore group g+1 while group g is parsed, pasted and downloaded (round 5)
+        if crops and not has_aligned_frames and self._stream_applies(helper, frames_bgr, crops, draw_box):
+            return self._restore_and_paste_streamed(frames_bgr, crops, affines, faces_per_frame, max_clip_length,
+                                                    final_upscale_factor, draw_box, pbar, as_u8)
+
         # -- 3. restore: the hot path
+        crops = [c.cpu().numpy() if isinstance(c, torch.Tensor) else c for c in crops]
         restored_faces = []
         if crops:
             restored_faces = self._restore_crops_u8(crops, max_clip_length)
@@ -463,5 +662,4 @@ class KEEPFaceProcessor:
             aff_ptr += k
             pbar.update(1)
 
-        tensors = [cv2_to_comfy_image(f) for f in out_frames]
-        return torch.cat(tensors, dim=0) if tensors else image_sequence_tensor
+        return out_frames

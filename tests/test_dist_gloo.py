@@ -201,7 +201,7 @@ def test_pool_world4_order_config_sync_parse_and_arenas(monkeypatch):
         assert {r: tuple(m.name for m in pair) for r, pair in pool._arenas.items()} == arenas          # same blocks, no re-allocation
         # sink + parse: groups arrive as (ids, crops, classes); the root's own share has no classes (the caller parses it on its GPU)
         net.precision = 'x3'
-        pool.set_parser({'w': torch.zeros(3)})
+        pool.set_parser(('fake parser',))
         got = {}
         assert pool.run(net, clips, sink=lambda ids, crops, cls: got.update({i: (c, None if cls is None else cls[k])
                                                                                for k, (i, c) in enumerate(zip(ids, crops))}), parse=True) is None

@@ -1,5 +1,8 @@
 """GPU: paste-back compositing kernels (csrc/keep_paste.hip through engine/paste.py) against the numpy restatement
 oracle/paste_oracle.py -- bit for bit, on the 1080p / 3-face case of BASELINE configs[3]."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -168,3 +171,41 @@ def test_processor_paste_hook_runs_on_the_device_when_opted_in():
     out_g = proc._paste(helper2, frame, False)
     assert helper2.own_calls == 0
     assert np.array_equal(out_g, P.paste_faces(frame, [np.repeat(g[:, :, None], 3, axis=2) for g in grey], list(mats), list(classes)))
+
+
+def test_streamed_sequence_equals_the_per_frame_path(gpu_net, monkeypatch):
+    """the product's own sequence entry point.  ``process_image_sequence`` with steps 3 + 4 streamed (crops stay on
+    the device, finished batch groups handed over by ``run_clips_u8(sink=...)``, ParseNet over up to 32 faces across frames, paste +
+    download on a second stream under the next group's forward) against the per-frame path (``KEEP_AMD_STREAM_PASTE=0``: restored
+    crops to the host, one frame's faces per ParseNet call, one paste and one download per frame): the same frames BIT FOR BIT --
+    float (the node's IMAGE tensor) and uint8 (``process_frames_u8``).  10 frames of 360 x 480 with 2 face tracks -> 20 crops ->
+    5 clips of 4, forced into >= 2 batch groups."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import synth_facehelper as SF
+    H, W, faces, n = 360, 480, 2, 10
+    proc, helper = SF.make_processor(gpu_net, (H, W), faces)
+    g = torch.Generator().manual_seed(5)
+    frames = torch.rand((n, H, W, 3), generator=g)
+
+    def run(stream, u8=False):
+        monkeypatch.setenv('KEEP_AMD_STREAM_PASTE', '1' if stream else '0')
+        monkeypatch.setenv('KEEP_AMD_STREAM_GROUPS', '3')
+        helper.begin_sequence()
+        if u8:
+            from comfyui_keep_amd.modules.utils import comfy_image_to_cv2
+            return proc.process_frames_u8([comfy_image_to_cv2(frames[i]) for i in range(n)], 1.0, False, False, False, max_clip_length=4)
+        return proc.process_image_sequence(frames, 1.0, False, False, False, max_clip_length=4)
+
+    ref = run(False)
+    ref_faces = [np.asarray(f) for f in proc.last_restored_faces]
+    got = run(True)
+    assert type(proc.last_restored_faces).__name__ == '_DeviceFaces' and len(proc.last_restored_faces) == n * faces
+    assert got.shape == ref.shape == (n, H, W, 3) and got.dtype == torch.float32
+    assert all(np.array_equal(a, b) for a, b in zip(proc.last_restored_faces, ref_faces))          # the restored crops themselves
+    assert torch.equal(got, ref)
+    assert float((ref - frames).abs().max()) > 0.1                                                # (faces were really pasted)
+    u8 = run(True, u8=True)
+    assert u8.dtype == torch.uint8 and torch.equal(u8.flip(-1).float() / 255.0, ref)
+    ref8 = run(False, u8=True)
+    assert all(np.array_equal(u8[i].numpy(), ref8[i]) for i in range(n))
+    assert helper.detector_calls == 0                       # the batched detection pre-pass ran (no per-frame detector call)

@@ -35,6 +35,11 @@ GM_DEDUP_L0 = os.environ.get('KEEP_GM_DEDUP_L0', '1') != '0'    # GMFlow layer-0
 # passes the same <= 1e-3 parity tests as 'fp32' (exact f32 MFMA everywhere) at several times its speed.
 CHECK_X3_RANGE = os.environ.get('KEEP_X3_NO_RANGE_CHECK') is None
 GRAPH_MAX_CLIPS = int(os.environ.get('KEEP_AMD_GRAPH_MAX_CLIPS', '2'))
+# two-stream order of the forward (GMFlow + Kalman gains on a second stream under the frame recurrence) for calls of at most this
+# many clips (0 = never); the first chunk of pairs / the following chunks (pairs per GMFlow launch group)
+STREAM_OVERLAP_MAX_CLIPS = int(os.environ.get('KEEP_AMD_OVERLAP_MAX_CLIPS', '2'))
+STREAM_OVERLAP_FIRST = int(os.environ.get('KEEP_AMD_OVERLAP_FIRST', '3'))
+STREAM_OVERLAP_CHUNK = int(os.environ.get('KEEP_AMD_OVERLAP_CHUNK', '4'))
 GRAPH_CACHE = 4
 RESIDENT = os.environ.get('KEEP_AMD_RESIDENT', '0') == '1'      # keep the packed weights on the device across offload()
 PRECISIONS = ('fp32', 'x3', 'bf16')
@@ -742,12 +747,35 @@ class KeepNet:
         self._aux_top1 = []
         # K1: flows for all T-1 pairs (KA:976-986): flownet(x[:,1:], x[:,:-1])
         flows = None
+        # Few clips in flight (the literal configs[1]: ONE): the frame recurrence below is a chain of ~8 000 small launches that
+        # leaves most of the chip idle, while K1 (GMFlow) and K3 (Kalman gains) are wide, batched and needed only from frame 1 on
+        # (frame i reads the flow of pair i - 1 and gains[i]).  They run on a SECOND stream, GMFlow in chunks of pairs, each chunk
+        # fenced by an event the frame loop waits for just before its first use -- the batched stages fill the CUs the chain leaves
+        # empty.  Same kernels on the same data (per-image arithmetic and plans: chunking the pair batch changes no bit), so the
+        # result is bit-identical to the one-stream order; hipGraph capture records the fork / join.
+        overlap = (STREAM_OVERLAP_MAX_CLIPS >= B and T > 2 and force_flows is None and not ops.DEBUG_SYNC and self.o.profile is None)
+        flow_parts, ev_gain, side, main = None, None, None, None
         if force_flows is not None:      # parity tests: inject the oracle's flows [B,T-1,2,H,W] (isolates GMFlow drift)
             flows = force_flows.to(device=self.device, dtype=torch.float32).permute(0, 1, 3, 4, 2).contiguous()
-        elif T > 1:
+        elif T > 1 and not overlap:
             with _Range('K1 gmflow'):
                 flows = self._gmflow_clip(x)
             flows = flows.view(B, T - 1, H, Wd, 2)
+        elif T > 1:
+            main = torch.cuda.current_stream()
+            side = self._side_stream = getattr(self, '_side_stream', None) or torch.cuda.Stream(device=self.device)
+            side.wait_stream(main)                                       # fork (also orders the side pool's reuse behind the last forward)
+            cuts = [0] + list(range(min(STREAM_OVERLAP_FIRST, T - 1), T - 1, STREAM_OVERLAP_CHUNK)) + [T - 1]
+            cuts = sorted(set(cuts))
+            flow_parts = []                                              # (first pair, one past the last, flows [B,n,H,W,2], event)
+
+            def flow_chunk(a, b):
+                with torch.cuda.stream(side), _Range('K1 gmflow (side stream)'):
+                    f = self._gmflow_clip(x[:, a:b + 1]).view(B, b - a, H, Wd, 2)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                flow_parts.append((a, b, f, ev))
+            flow_chunk(cuts[0], cuts[1])                                 # the first pairs: under K2 and frame 0
         # K2: LQ encoder over all B*T frames, stash CFT taps
         xn = ops.nchw_to_nhwc(x.view(B * T, 3, H, Wd))
         taps = [FUSE_ENCODER_BLOCK[s] for s in cfg['cft_list']]
@@ -757,8 +785,19 @@ class KeepNet:
         zc = z.view(B, T, *z.shape[1:])
         # K3: Kalman gains over the whole clip.  They only enter frames i >= 1 (KA:1067-1070), so a T = 1 "clip" (the
         # single-image fast path: frame 0 depends on neither the flows nor the gains nor the other frames) skips them.
-        with _Range('K3 kalman_gain'):
-            gains = self._kalman_gain(z, B, T).view(B, T, -1) if T > 1 else None
+        if side is not None:
+            ev_z = torch.cuda.Event()
+            ev_z.record(main)
+            with torch.cuda.stream(side), _Range('K3 kalman_gain (side stream)'):
+                side.wait_event(ev_z)
+                gains = self._kalman_gain(z, B, T).view(B, T, -1)
+                ev_gain = torch.cuda.Event()
+                ev_gain.record(side)
+            for a, b in zip(cuts[1:-1], cuts[2:]):                       # the remaining pairs, behind the gains, under the frame loop
+                flow_chunk(a, b)
+        else:
+            with _Range('K3 kalman_gain'):
+                gains = self._kalman_gain(z, B, T).view(B, T, -1) if T > 1 else None
         cft_at = {FUSE_GENERATOR_BLOCK[s]: s for s in cfg['cft_list']}
         cfa_at = {FUSE_GENERATOR_BLOCK[s]: s for s in cfg['cfa_list']}
         gblocks = generator_blocks(cfg)
@@ -776,7 +815,16 @@ class KeepNet:
             else:                                                        # K4 (KA:1067-1070)
                 with _Range('K4 warp + hq_encoder + kalman_update'):
                     warped = torch.empty_like(prev_out)
-                    L.call('keep_flow_warp', prev_out, self._frame(flows, i - 1), warped, B, H, Wd, 3)
+                    if flow_parts is not None:                           # two-stream order: this pair's chunk (and, once, the gains)
+                        a, b, fpart, ev = next(p for p in flow_parts if p[0] <= i - 1 < p[1])
+                        if i - 1 == a:
+                            main.wait_event(ev)
+                        if i == 1:
+                            main.wait_event(ev_gain)
+                        flow_i = self._frame(fpart, i - 1 - a)
+                    else:
+                        flow_i = self._frame(flows, i - 1)
+                    L.call('keep_flow_warp', prev_out, flow_i, warped, B, H, Wd, 3)
                     z_prime, _ = self._vq_stack(warped, 'hq_encoder', encoder_blocks(cfg))
                     z_hat = torch.empty_like(z_i)
                     L.call('keep_kalman_update', z_i, z_prime, self._frame(gains, i), z_hat, B,
@@ -802,6 +850,10 @@ class KeepNet:
                 y, _ = self._vq_stack(quant, 'generator', gblocks, hook=hook)
             prev_out = y
             out_nhwc[:, i].copy_(y)
+        if side is not None:
+            main.wait_stream(side)                                       # join (every chunk has been waited for; this closes a capture)
+            if return_aux:
+                flows = torch.cat([p[2] for p in flow_parts], dim=1)
         out = ops.nhwc_to_nchw(out_nhwc.view(B * T, H, Wd, 3)).view(B, T, 3, H, Wd)
         if self.precision == 'x3' and CHECK_X3_RANGE:
             L.call('keep_nonfinite_flag', out, out.numel(), self.o.status)

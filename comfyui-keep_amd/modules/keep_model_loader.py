@@ -47,8 +47,20 @@ class KEEPModelPack:
         if helper is not None:
             helper.device = device
             for attr in ('face_detector', 'face_parse'):
-                if hasattr(helper, attr):
-                    getattr(helper, attr).to(device)
+                obj = getattr(helper, attr, None)
+                if obj is None:
+                    continue
+                if hasattr(obj, 'to'):
+                    obj.to(device)
+                    continue
+                # YoloDetector (detection/yolov5face/face_detector.py:21-46) is a plain class with no .to(): the upstream pack
+                # raises AttributeError here as soon as a YOLO detector is selected.  Its network is `.detector` (the engine's
+                # EngineYoloModel or the torch Model) and `.device` is what its pre-processing uploads to.
+                inner = getattr(obj, 'detector', None)
+                if inner is not None and hasattr(inner, 'to'):
+                    inner.to(device)
+                if hasattr(obj, 'device'):
+                    obj.device = device
 
     def load_device(self):
         """Everything onto the compute device (the engine uploads its packed weight blob)."""

@@ -298,7 +298,9 @@ def test_retina_decode_on_the_device_equals_the_host_decoder():
     for a, b in zip(on_device, on_host):
         assert a.shape == b.shape and len(a) > 3 and np.array_equal(tie_canon(a), tie_canon(b))
         ties += int(not np.array_equal(a, b))
-    print(f'keep_retina_nms: {ties} of 3 frames differ from the numpy order -- only inside runs of equal scores (anchors of one pixel)')
+    # round 5: a frame in which two survivors share a score bit pattern is handed back to the host decoder (numpy's own
+    # introsort order applies there), so device and host results are the same rows in the same order on EVERY frame
+    assert ties == 0, f'{ties} of 3 frames differ from the numpy order'
     eng.max_survivors = 8                                   # overflow of the compact list: the frame is decoded on the host
     few = eng.detect_batch(frames, 0.6)
     eng.max_survivors = 4096

@@ -366,6 +366,33 @@ def test_hipgraph_replay_is_bit_identical_to_eager(gpu_net):
         gpu_net.graph_mode = mode
 
 
+def test_two_stream_order_of_the_forward_is_bit_identical(gpu_net, monkeypatch):
+    """Round 5: with at most KEEP_AMD_OVERLAP_MAX_CLIPS clips in flight GMFlow (in chunks of pairs) and the Kalman gains run on a
+    second stream under the frame recurrence.  Same kernels on the same data -- per-image arithmetic and plans, so chunking the pair
+    batch changes nothing: output, flows, gains and indices equal the one-stream order BIT FOR BIT, eagerly and through a captured
+    hipGraph (fork / join recorded), for one clip and for two, with chunk boundaries that do and do not divide T - 1."""
+    from comfyui_keep_amd.engine import net as net_mod
+    mode = gpu_net.graph_mode
+    try:
+        for B, T, first, chunk in ((1, 6, 3, 4), (2, 5, 1, 2), (1, 4, 2, 1)):
+            x = synth.synth_clip(T=T, B=B, seed=77 + T).cuda()
+            gpu_net.graph_mode = '0'
+            monkeypatch.setattr(net_mod, 'STREAM_OVERLAP_MAX_CLIPS', 0)
+            ref, raux = gpu_net(x, return_aux=True)
+            monkeypatch.setattr(net_mod, 'STREAM_OVERLAP_MAX_CLIPS', 2)
+            monkeypatch.setattr(net_mod, 'STREAM_OVERLAP_FIRST', first)
+            monkeypatch.setattr(net_mod, 'STREAM_OVERLAP_CHUNK', chunk)
+            got, aux = gpu_net(x, return_aux=True)
+            assert torch.equal(aux['flows'], raux['flows']) and torch.equal(aux['gains'], raux['gains'])
+            assert torch.equal(aux['indices'], raux['indices']) and torch.equal(got, ref)
+            gpu_net.graph_mode = '1'
+            g1 = gpu_net(x)            # captures the two-stream order
+            g2 = gpu_net(x)            # replays it
+            assert torch.equal(g1, ref) and torch.equal(g2, ref)
+    finally:
+        gpu_net.graph_mode = mode
+
+
 def test_graph_survives_a_policy_switch_and_auto_captures_on_second_use(gpu_net):
     """(a) The per-forward bookkeeping block (status word + max|out| arena) lives as long as the net's Ops: a captured x3
     graph must replay correctly after forwards under another policy (round 2 freed the arena on a policy switch and the

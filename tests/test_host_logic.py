@@ -298,6 +298,31 @@ def test_face_tracking_restatement():
     assert sm[0].shape == (3, 5, 2) and not np.isnan(sm[0]).any()
 
 
+def test_model_pack_moves_a_yolo_detector_that_has_no_to():
+    """the reference's YoloDetector is a plain class without .to(); load_device() / offload() must move its network
+    (`.detector`) and retarget `.device` instead of raising AttributeError."""
+    class _Net:
+        def __init__(self):
+            self.where = None
+
+        def to(self, d):
+            self.where = d
+            return self
+
+    class _Yolo:
+        def __init__(self):
+            self.detector, self.device = _Net(), 'cpu'
+
+    helper = _Helper()
+    helper.face_detector, helper.face_parse = _Yolo(), _Net()
+    pack = KEEPModelPack(None, helper, None, None, 'KEEP')
+    pack.load_device()
+    assert helper.face_detector.detector.where == pack.device and helper.face_detector.device == pack.device
+    assert helper.face_parse.where == pack.device and helper.device == pack.device
+    pack.offload()
+    assert helper.face_detector.detector.where == pack.offload_device and helper.face_detector.device == pack.offload_device
+
+
 def test_c_abi_exports_every_declared_symbol():
     from comfyui_keep_amd.engine import hiplib
     header = open(os.path.join(ROOT, 'include', 'keep_hip.h')).read()

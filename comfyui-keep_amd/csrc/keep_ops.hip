@@ -890,7 +890,7 @@ extern "C" int32_t keep_retina_decode(const float* heads, const float* priors, f
 // equal scores is handed back to the host: see below), suppresses greedily with
 // the float32 IoU arithmetic of engine/retinaface.py:nms (areas (x2 - x1) * (y2 - y1), inter / (a_i + a_j - inter) > threshold, no
 // contraction) and writes the kept rows, in order, to out[n, 0 .. out_counts[n]).  counts[n] > cap (the compact list overflowed), or two
-// survivors with the same score: out_counts[n] = -1, the caller decodes that frame on the host.  Bitonic sort of (key, row) pairs in LDS, cap <= 4096.
+// survivors with the same score (out_counts[n] = -2): the caller finishes that frame on the host.  Bitonic sort of (key, row) pairs in LDS, cap <= 4096.
 #define NMS_MAX 4096
 __global__ __launch_bounds__(1024) void retina_nms_kernel(const float* __restrict__ dets, const int* __restrict__ counts,
                                                           float* __restrict__ out, int* __restrict__ out_counts, int cap, float thr) {
@@ -938,14 +938,15 @@ __global__ __launch_bounds__(1024) void retina_nms_kernel(const float* __restric
     }
   // Equal score BIT PATTERNS (a softmax saturating at exactly 1.0f): `scores.argsort()[::-1]` orders them by numpy's introsort, which is
   // not stable above 16 elements -- which of two overlapping equal-score boxes survives is numpy's to decide.  Such a frame is handed
-  // back (out_counts = -1: the caller decodes it on the host with numpy itself) instead of being ordered by a rule of our own.
+  // back (out_counts = -2: the caller orders and suppresses the frame's device-decoded survivors with numpy itself) instead of being
+  // ordered by a rule of our own.
   scan[tid] = 0;
   __syncthreads();
   for (int i = tid; i + 1 < n; i += 1024)
     if ((keys[i] >> 32) == (keys[i + 1] >> 32)) scan[0] = 1;          // (benign race: every writer stores 1)
   __syncthreads();
   if (scan[0]) {
-    if (tid == 0) out_counts[f] = -1;
+    if (tid == 0) out_counts[f] = -2;      // (-1: the compact list overflowed; -2: equal scores -- the survivors in `dets` are valid)
     return;
   }
   __syncthreads();

@@ -66,6 +66,7 @@ _SIGNATURES = {
     'keep_affine_act': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     'keep_gm_mlp': [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     'keep_token_linear': [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    'keep_gm_ffn_x3': [_vp, _vp, _vp, _f32, _vp, _f32, _vp, _vp, _f32, _vp, _i64, _i32, _i32, _i32, _vp],
     'keep_norm_act_bf16': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     'keep_gm_join': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     'keep_bilinear_upscale': [_vp, _vp, _i32, _i32, _i32, _i32, _vp],

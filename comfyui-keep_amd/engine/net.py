@@ -29,6 +29,7 @@ _KNOWN_KW = set(DEFAULT_ARCH) | {
 
 
 FUSED_GM_MLP = os.environ.get('KEEP_NO_FUSED_MLP') is None     # dev switch
+FUSED_GM_FFN_X3 = os.environ.get('KEEP_X3_FUSED_FFN', '1') != '0'   # x3 policy: GMFlow mlp.0 + GELU + mlp.2 + norm2 + residual as one kernel (A/B: 0)
 GM_S2D_CONV1 = os.environ.get('KEEP_GM_S2D', '1') != '0'         # GMFlow conv1 (7x7 s2) as a 4x4 convolution on the space-to-depth image (A/B: 0)
 GM_DEDUP_L0 = os.environ.get('KEEP_GM_DEDUP_L0', '1') != '0'    # GMFlow layer-0 self-attention once per frame instead of once per pair member (A/B: 0)
 # 'x3': split-fp16 operands on the 16-bit matrix pipe (fp32-grade products, csrc/keep_conv_x3.hip) -- the default: it
@@ -185,6 +186,10 @@ class KeepNet:
             if self._dev_blobx3 is None:
                 self._make_x3()
             self.o.set_precision(L.MMA_X3, self._dev_blob, None, self._dev_blobx3, 1.0, x3_scales=self._x3_scales)
+            if FUSED_GM_FFN_X3:     # permuted x3 twins of the GMFlow mlp.2 weights (keep_gm_ffn_x3): built here, never inside a stream capture
+                for n_ in self.w:
+                    if n_.startswith('flownet.') and n_.endswith('.mlp.2.weight') and self.w[n_].shape[0] == 128:
+                        self.o.ffn_w2_twin(self.w[n_])
             if ops.UP2_PHASES:      # phase kernels of the generator's Upsample convolutions: built here, never inside a stream capture
                 for i, (kind, _, _) in enumerate(generator_blocks(self.cfg)):
                     if kind == 'up':
@@ -534,6 +539,9 @@ class KeepNet:
             m = self.o.linear(o, w[f'{p}.merge.weight'], bounded=True, n_img=n_img, ln=n1)
         else:
             m = ops.layernorm(self.o.linear(o, w[f'{p}.merge.weight'], bounded=True, n_img=n_img), n1[0], n1[1])
+        if (self.o.mma == L.MMA_X3 and C == 128 and FUSED_GM_FFN_X3 and self.o.x3_twin(w[f'{p}.mlp.0.weight']) is not None):
+            # mlp.0 -> GELU -> mlp.2 -> norm2 -> + src as ONE launch: the [M, 8C] intermediate (10 GB at 16 clips) stays in registers
+            return self.o.gm_ffn_x3(src, m, w[f'{p}.mlp.0.weight'], w[f'{p}.mlp.2.weight'], w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], 1e-5)
         if self.o.mma == L.MMA_BF16 and C == 128 and FUSED_GM_MLP:
             m2 = self.o.gm_mlp(src, m, w[f'{p}.mlp.0.weight'], w[f'{p}.mlp.2.weight'])      # [M,8C] never leaves the CU
         else:

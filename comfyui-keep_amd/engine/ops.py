@@ -159,6 +159,29 @@ class Ops:
             tw = self._up2[key] = (split_x3(w4.reshape(-1, w.shape[-1]), sc).view(-1), 1.0 / sc)
         return tw
 
+    def ffn_w2_twin(self, w2):
+        """(weight_x3, acc_scale) of ``w2`` [C, hidden] for ``keep_gm_ffn_x3``: every group of 16 hidden units in the order
+        [0-3, 8-11, 4-7, 12-15] (``ffn_w2_perm``), split with the tensor's own power-of-two scale.  Built once per weight tensor
+        (outside any stream capture: ``KeepNet._activate_precision``) and kept with the up2 twins for the lifetime of the blob."""
+        key = ('ffn_w2', w2.data_ptr(), tuple(w2.shape))
+        tw = self._up2.get(key)
+        if tw is None:
+            wp = ffn_w2_perm(w2)
+            sc = x3_scale_for(float(wp.abs().max()))
+            tw = self._up2[key] = (split_x3(wp, sc).view(-1), 1.0 / sc)
+        return tw
+
+    def gm_ffn_x3(self, src, msg, w0, w2, gamma, beta, eps):
+        """GMFlow FFN + norm2 + residual as one launch (x3 policy): LayerNorm(W2 . gelu(W0 . cat[src | msg])) + src; src, msg [M, C]
+        fp32, w0 [8C, 2C] / w2 [C, 8C] fp32 views of the packed blob (their x3 twins are used)."""
+        C = src.shape[-1]
+        M = src.numel() // C
+        out = empty((M, C), src)
+        w2p, asc2 = self.ffn_w2_twin(w2)
+        L.call('keep_gm_ffn_x3', src, msg, self.x3_twin(w0), float(self.x3_scale_of(w0)), w2p, float(asc2), gamma, beta, float(eps), out,
+               M, C, w0.shape[0], 1 if (self.flags & L.CONV_X3_EXACT_ACT) else 0)
+        return out.view(src.shape)
+
     def x3_twin(self, w):
         """split-fp16 copy of an fp32 weight view (row slices of a [Cout, .., Cin] tensor keep their layout), or None
         when the policy has no x3 blob / the tensor's Cin is not a multiple of 16 (such layers run on the f32 kernels)."""
@@ -509,6 +532,18 @@ def split_x3(w2d, scale):
     lo = (ws - hi.float()).to(torch.float16)
     out = torch.stack((hi.view(rows, cin // 16, 16), lo.view(rows, cin // 16, 16)), dim=2)
     return out.contiguous().view(torch.int16)
+
+
+FFN_W2_PERM = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
+
+
+def ffn_w2_perm(w2):
+    """[C, hidden] -> the same matrix with every group of 16 hidden units reordered [0-3, 8-11, 4-7, 12-15]: the order in which the
+    accumulator layout of v_mfma_f32_32x32x16_f16 hands a lane (half g) its hidden units {4g + (r & 3) + 8 (r >> 2)} -- the K order of
+    the second product inside keep_gm_ffn_x3 (csrc/keep_ffn_x3.hip)."""
+    C, Hd = w2.shape
+    idx = torch.tensor(FFN_W2_PERM, device=w2.device)
+    return w2.float().view(C, Hd // 16, 16).index_select(2, idx).reshape(C, Hd).contiguous()
 
 
 def up2_phase_weights(w):

@@ -415,12 +415,17 @@ class RetinaFaceEngine:
                     kc = kcnt.cpu().numpy()
                     kmax = int(kc.max(initial=0))
                     rows = kept[:, :kmax, :15].cpu().numpy() if kmax > 0 else np.zeros((n, 0, 15), np.float32)
-                    over = [i for i in range(n) if kc[i] < 0]
+                    over = [i for i in range(n) if kc[i] == -1]
                     if over:
                         flat_over = heads[over].float().cpu().numpy()
+                    tied = [i for i in range(n) if kc[i] == -2]
+                    if tied:             # two survivors with the same score bits: numpy's own (unstable) argsort decides their order
+                        cnt_t = counts.cpu().numpy()
                     for i in range(n):
-                        if kc[i] < 0:        # more survivors than the compact list holds: that frame's heads go to the host decoder
+                        if kc[i] == -1:      # more survivors than the compact list holds: that frame's heads go to the host decoder
                             results.append(self._host_decode(flat_over[over.index(i)], priors, scale, scale1, conf_threshold, nms_threshold))
+                        elif kc[i] == -2:
+                            results.append(self._host_order_nms(dets[i, :cnt_t[i]].cpu().numpy(), nms_threshold))
                         else:
                             results.append(np.ascontiguousarray(rows[i, :kc[i]]))
                     continue
@@ -434,14 +439,19 @@ class RetinaFaceEngine:
                 if cnt[i] > cap:
                     results.append(self._host_decode(flat_over[over.index(i)], priors, scale, scale1, conf_threshold, nms_threshold))
                     continue
-                r = rows[i, :cnt[i]]
-                r = r[np.argsort(r[:, 15], kind='stable')]                         # anchor order: what np.where(scores > thr) yields
-                order = r[:, 4].argsort()[::-1]                                    # retinaface.py:240: scores.argsort()[::-1]
-                r = r[order]
-                dets_i = np.ascontiguousarray(r[:, :5])
-                keep = nms(dets_i, nms_threshold) if len(dets_i) else []
-                results.append(np.concatenate((dets_i[keep, :], r[keep, 5:15]), axis=1) if len(dets_i) else np.zeros((0, 15), np.float32))
+                results.append(self._host_order_nms(rows[i, :cnt[i]], nms_threshold))
         return results
+
+    @staticmethod
+    def _host_order_nms(r, nms_threshold):
+        """Device-decoded survivors of one frame [k, 16] (x1 y1 x2 y2 score lm x 10 anchor) -> ordered + suppressed [k', 15] with numpy,
+        exactly as the reference's host code does (retinaface.py:240-246)."""
+        r = r[np.argsort(r[:, 15], kind='stable')]                                 # anchor order: what np.where(scores > thr) yields
+        order = r[:, 4].argsort()[::-1]                                            # retinaface.py:240: scores.argsort()[::-1]
+        r = r[order]
+        dets_i = np.ascontiguousarray(r[:, :5])
+        keep = nms(dets_i, nms_threshold) if len(dets_i) else []
+        return np.concatenate((dets_i[keep, :], r[keep, 5:15]), axis=1) if len(dets_i) else np.zeros((0, 15), np.float32)
 
     def _host_decode(self, flat, priors, scale, scale1, conf_threshold, nms_threshold):
         """One frame's head rows [P, 32] through the numpy decoder (the path of rounds 2-3; kept for frames with more survivors

@@ -281,6 +281,16 @@ int32_t keep_norm_act_bf16(const void* x, const float* scale, const float* shift
  * W2 bf16 [C,8C], no biases, C = 128; the [M,8C] intermediate stays on the CU. */
 int32_t keep_gm_mlp(const float* a, const float* b, const void* w0_bf16, const void* w2_bf16, float* out, int64_t M,
                     int32_t C, void* stream);
+/* v18, KEEP_MMA_X3 policy: the whole feed-forward block of a GMFlow cross-attention layer (GM/transformer.py:137-142,182-187) as one launch,
+ *   out[M,C] = LayerNorm( W2 . gelu( W0 . cat[src[M,C] | msg[M,C]] ); ln_gamma, ln_beta, ln_eps ) + src,   C = 128, hidden %% 32 == 0,
+ * with x3 products (three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate) and the [M, hidden] intermediate kept in registers
+ * (csrc/keep_ffn_x3.hip).  w0_x3: split-fp16 twin of W0 [hidden, 2C] in the keep_conv2d `weight_x3` layout ([row][Cin/16][hi16|lo16]),
+ * w0_acc_scale its 2^-e; w2p_x3: the same for W2 [C, hidden] with every group of 16 hidden units stored in the order
+ * [0-3, 8-11, 4-7, 12-15] (engine/ops.py:ffn_w2_perm -- the order in which an MFMA's accumulator layout hands a lane its hidden units).
+ * GELU: the x3-grade fast form (erf to 1.5e-7), or the library erff with exact_act != 0.  No biases (GMFlow's mlp has none). */
+int32_t keep_gm_ffn_x3(const float* src, const float* msg, const void* w0_x3, float w0_acc_scale, const void* w2p_x3, float w2_acc_scale,
+                       const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int64_t M, int32_t C, int32_t hidden,
+                       int32_t exact_act, void* stream);
 /* GM/transformer.py:148-176 projections at M ~ 1e6 tokens (bf16 policy): out[M,N] = x[M,128] . W[N,128]^T (+ bias),
  * W bf16, N in {128,256,384}, out fp32 or bf16 (out_dtype); persistent blocks keep W in LDS and stream the token rows. */
 int32_t keep_token_linear(const float* x, const void* w_bf16, const float* bias, void* out, int64_t M, int32_t K, int32_t N,

@@ -1367,3 +1367,48 @@ def test_linear_x3_k_concatenated_inputs():
     assert torch.equal(y_cat, y_two)
     with pytest.raises(L.KeepHipError):
         ops.conv(a.view(1, M, 1, C), w, None, x2=b.view(1, M, 1, C), pad=0, ksize=1, bounded=True)      # exact-f32 policy
+
+
+@pytest.mark.parametrize("M", [256, 777, 4096])
+def test_gm_ffn_x3_fused_kernel(M):
+    """keep_gm_ffn_x3 (round 5): LayerNorm(W2 . gelu(W0 . cat[src | msg])) + src in ONE launch, the [M, 1024] intermediate kept in
+    registers (GM/transformer.py:137-142,182-187) -- against float64 (exact erf GELU) and against the two-launch form it replaces
+    (x3 GEMM with the K-concatenated input + GELU epilogue, then x3 GEMM with the LayerNorm epilogue): its error vs float64 must not
+    exceed twice the two-launch form's, and the two forms agree to 2e-5 (same products; the second GEMM sums its K axis in another
+    order).  M = 777: a ragged last block (rows beyond M are neither read nor written)."""
+    C, Hd = 128, 1024
+    src, msg = rnd(f'ffn_src{M}', (M, C), 1.5), rnd(f'ffn_msg{M}', (M, C), 1.0)
+    w0, w2 = rnd('ffn_w0', (Hd, 2 * C), 0.08), rnd('ffn_w2', (C, Hd), 0.05)
+    g, be = 1.0 + 0.3 * rnd('ffn_g', (C,)), rnd('ffn_be', (C,), 0.2)
+    x = torch.cat([src, msg], 1).double()
+    h = x @ w0.double().t()
+    h = 0.5 * h * (1.0 + torch.erf(h / 2.0 ** 0.5))
+    ref = torch.nn.functional.layer_norm(h @ w2.double().t(), (C,), g.double(), be.double(), 1e-5) + src.double()
+    sd, md, w0d, w2d, gd, bed = dev(src), dev(msg), dev(w0), dev(w2), dev(g), dev(be)
+    wx0, a0 = x3w(w0d)
+    w2p = ops.ffn_w2_perm(w2d)
+    wx2p, a2p = x3w(w2p)
+    guard = torch.full((64, C), 123.0, device='cuda')
+    out = torch.cat([torch.empty((M, C), device='cuda'), guard])           # rows behind M must stay untouched
+    L.call('keep_gm_ffn_x3', sd, md, wx0, float(a0), wx2p, float(a2p), gd, bed, 1e-5, out, M, C, Hd, 0)
+    assert torch.equal(out[M:], guard)
+    fused = out[:M]
+    kw = dict(mma=L.MMA_X3, pad=0, ksize=1, bounded=True)
+    if M % 128 == 0:
+        wx2, a2 = x3w(w2d)
+        hm = ops.conv(sd.view(1, M, 1, C), w0d, None, act=L.ACT_GELU, x2=md.view(1, M, 1, C), wx3=wx0, x3_acc_scale=a0, **kw)
+        two = ops.conv(hm, w2d, None, residual=sd.view(1, M, 1, C), ln=(gd, bed, 1e-5), wx3=wx2, x3_acc_scale=a2, **kw).reshape(M, C)
+        e_f, e_2 = err64(fused, ref), err64(two, ref)
+        print(f'gm_ffn_x3 M={M}: fused {e_f:.3e}  two launches {e_2:.3e}  fused vs two {(fused - two).abs().max().item():.3e}')
+        assert e_f <= max(2.0 * e_2, 5e-6), (e_f, e_2)
+        assert (fused - two).abs().max().item() <= 2e-5
+    else:
+        e_f = err64(fused, ref)
+        print(f'gm_ffn_x3 M={M}: fused {e_f:.3e}')
+        assert e_f <= 2e-5
+    # exact-erf variant (flags & KEEP_CONV_X3_EXACT_ACT)
+    out2 = torch.empty((M, C), device='cuda')
+    L.call('keep_gm_ffn_x3', sd, md, wx0, float(a0), wx2p, float(a2p), gd, bed, 1e-5, out2, M, C, Hd, 1)
+    assert err64(out2, ref) <= 2e-5
+    with pytest.raises(L.KeepHipError):
+        L.call('keep_gm_ffn_x3', sd, md, wx0, float(a0), wx2p, float(a2p), gd, bed, 1e-5, out2, M, 64, Hd, 0)

@@ -1,2 +1,2 @@
-cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_paste.py -x -q -m gpu 2>&1 | grep -v "^$" | cut -c1-300 | tail -12
+python -m pytest tests -m gpu -x -q -k "streamed_sequence" 2>&1 | grep -v "it/s\]" | tail -60
+python tools/dev/planref_ab.py

@@ -156,14 +156,8 @@ __global__ __launch_bounds__(512, 1) void gm_ffn_x3_kernel(FfnP p) {
   const int a2_hi = FFN_W0_B + l31 * 64 + ((g ^ sw_r) * 16);    // + s * 8192 + t * 2048
   const int a2_lo = FFN_W0_B + l31 * 64 + (((2 + g) ^ sw_r) * 16);
 
-  for (int c = 0; c < nchunks; ++c) {
-    const int stage = c & 1;
-    __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): this wave's pieces of chunk c have landed (and, first time, its X rows)
-    __syncthreads();                           // every wave's pieces are visible; every wave has left chunk c - 1 (stage ^ 1 is free)
-    if (c + 1 < nchunks) dma_chunk(c + 1, stage ^ 1);
-    const unsigned char* st = lds + stage * FFN_STAGE;
-    // ---- GEMM 1: C1[hidden 32 x tokens 32] over K = 2C
-    f32x16 c1;
+  // GEMM 1 of chunk `c` out of LDS stage `st`: C1[hidden 32 x tokens 32] over K = 2C
+  auto gemm1 = [&](const unsigned char* st, f32x16& c1) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) c1[r] = 0.f;
 #pragma unroll
@@ -172,7 +166,10 @@ __global__ __launch_bounds__(512, 1) void gm_ffn_x3_kernel(FfnP p) {
       const f16x8 al = *reinterpret_cast<const f16x8*>(st + a1_lo + j * 2048);
       FFN_MMA_X3(c1, ah, al, xh[j], xl[j])
     }
-    // ---- scale, GELU, split: the lane's 16 hidden values are GEMM 2's B operand for two K-steps (k-slot e of step s = register 8 s + e)
+  };
+  // scale, GELU, split (the lane's 16 hidden values are GEMM 2's B operand for two K-steps: k-slot e of step s = register 8 s + e),
+  // then GEMM 2: Y^T[out 128 x tokens 32] += W2p[:, chunk] . H^T
+  auto gelu_gemm2 = [&](const unsigned char* st, const f32x16& c1) __attribute__((always_inline)) {
     f16x8 hh[2], hl[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -184,7 +181,6 @@ __global__ __launch_bounds__(512, 1) void gm_ffn_x3_kernel(FfnP p) {
       }
       ffn_split8(v, hh[s], hl[s]);
     }
-    // ---- GEMM 2: Y^T[out 128 x tokens 32] += W2p[:, chunk] . H^T
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -193,6 +189,21 @@ __global__ __launch_bounds__(512, 1) void gm_ffn_x3_kernel(FfnP p) {
         const f16x8 al = *reinterpret_cast<const f16x8*>(st + a2_lo + s * 8192 + t * 2048);
         FFN_MMA_X3(y[t], ah, al, hh[s], hl[s])
       }
+  };
+
+  // (Round 5 also built a SKEWED form -- the two waves of a SIMD half a chunk apart through a third LDS stage and two barriers per chunk, so
+  // that one wave's GELU always meets the other's first product on the matrix pipe: bit-identical, and 4.5 % SLOWER (6.54 vs 6.26 ms at
+  // 2.49 M tokens, profiles/r05_ffn_skew_ab.txt): the waves do not run in lockstep to begin with, and the kernel is bound by its LDS
+  // fragment reads -- every wave reads the whole W0 chunk, 0.67 ds_read_b128 per MFMA -- next to the matrix pipe, not by VALU.)
+  for (int c = 0; c < nchunks; ++c) {
+    const int stage = c & 1;
+    __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): this wave's pieces of chunk c have landed (and, first time, its X rows)
+    __syncthreads();                           // every wave's pieces are visible; every wave has left chunk c - 1 (stage ^ 1 is free)
+    if (c + 1 < nchunks) dma_chunk(c + 1, stage ^ 1);
+    const unsigned char* st = lds + stage * FFN_STAGE;
+    f32x16 c1;
+    gemm1(st, c1);
+    gelu_gemm2(st, c1);
   }
 
   // ---- epilogue: LayerNorm over the token's 128 outputs (64 here, 64 in lane ^ 32), + src, store

@@ -1543,6 +1543,25 @@ extern "C" int32_t keep_img2tensor(const uint8_t* x, float* out, int64_t npix, v
   return KEEP_OK;
 }
 
+// modules/utils.py:cv2_to_comfy_image (reference utils.py:162-166) on the device: uint8 BGR -> float32 RGB, float32(u8) / 255.0f as ONE
+// correctly rounded IEEE division (numpy's `rgb.astype(np.float32) / 255.0`; a multiply by the rounded reciprocal -- what a tensor / scalar
+// division compiles to in torch -- differs from it in the last bit for 126 of the 256 values).
+__global__ void bgr_u8_to_comfy_kernel(const uint8_t* __restrict__ x, float* __restrict__ out, long npix) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[i * 3 + c] = __fdiv_rn((float)x[i * 3 + (2 - c)], 255.0f);
+  }
+}
+
+extern "C" int32_t keep_bgr_u8_to_comfy(const uint8_t* x, float* out, int64_t npix, void* stream) {
+  KEEP_REQUIRE(x && out && npix > 0, "keep_bgr_u8_to_comfy: bad args");
+  int blocks = cdiv(npix, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(bgr_u8_to_comfy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)npix);
+  KEEP_LAUNCH_CHECK("keep_bgr_u8_to_comfy");
+  return KEEP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ range probe (KEEP_MMA_X3)
 // amax[n] = max |x| over image n: the fp16 split of an un-normalised tensor needs its range (keep_conv2d x3_in_amax,
 // keep_attention q/k/v_amax).  |x| as raw bits is monotonic in the value, so a plain unsigned atomicMax is exact and

@@ -86,6 +86,7 @@ _SIGNATURES = {
     'keep_concat2': [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
     'keep_tensor2img': [_vp, _vp, _i64, _vp],
     'keep_img2tensor': [_vp, _vp, _i64, _vp],
+    'keep_bgr_u8_to_comfy': [_vp, _vp, _i64, _vp],
     'keep_channel_argmax': [_vp, _vp, _i64, _i32, _i32, _vp],
     'keep_maxpool3s2': [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     'keep_dwconv3x3': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],

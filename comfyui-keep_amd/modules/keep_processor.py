@@ -433,8 +433,10 @@ class KEEPFaceProcessor:
                     st['out'] = torch.empty(shape, dtype=torch.uint8 if as_u8 else torch.float32)
             if as_u8:
                 st['out'][t].copy_(frame_dev, non_blocking=True)
-            else:                                                      # cv2_to_comfy_image on the device: RGB, float32(u8) / 255
-                st['out'][t].copy_(frame_dev.flip(-1).to(torch.float32).div_(255.0), non_blocking=True)
+            else:                                                      # cv2_to_comfy_image on the device (keep_bgr_u8_to_comfy: one IEEE division)
+                ff = torch.empty(frame_dev.shape, dtype=torch.float32, device=dev)
+                L.call('keep_bgr_u8_to_comfy', frame_dev.contiguous(), ff, frame_dev.numel() // 3)
+                st['out'][t].copy_(ff, non_blocking=True)
 
         def advance():
             f0 = f1 = st['next']

@@ -367,6 +367,9 @@ int32_t keep_concat2(const float* a, const float* b, float* out, int64_t M, int3
 int32_t keep_tensor2img(const float* x, uint8_t* out, int64_t npix, void* stream);
 /* keep_processor.py:258-259: uint8 BGR [N,H,W,3] -> fp32 NHWC RGB (float32(u8/255.) - 0.5)/0.5 */
 int32_t keep_img2tensor(const uint8_t* x, float* out, int64_t npix, void* stream);
+/* v18: modules/utils.py:cv2_to_comfy_image (reference utils.py:162-166) on the device: uint8 BGR [N,H,W,3] -> the ComfyUI IMAGE layout,
+ * fp32 RGB in [0,1] = float32(u8) / 255 (one correctly rounded division, bit-equal to numpy's) */
+int32_t keep_bgr_u8_to_comfy(const uint8_t* x, float* out, int64_t npix, void* stream);
 
 
 /* ---- face parsing (wm_facelib/parsing/parsenet.py on keep_conv2d with KEEP_PAD_REFLECT, engine/parsenet.py) ----

@@ -1412,3 +1412,16 @@ def test_gm_ffn_x3_fused_kernel(M):
     assert err64(out2, ref) <= 2e-5
     with pytest.raises(L.KeepHipError):
         L.call('keep_gm_ffn_x3', sd, md, wx0, float(a0), wx2p, float(a2p), gd, bed, 1e-5, out2, M, 64, Hd, 0)
+
+
+def test_bgr_u8_to_comfy_equals_the_host_converter_on_every_value():
+    """keep_bgr_u8_to_comfy == modules/utils.py:cv2_to_comfy_image (reference utils.py:162-166): RGB order, float32(u8) / 255 as one
+    correctly rounded division -- all 256 values in all three channels, bit for bit (a tensor / scalar division in torch multiplies by
+    the rounded reciprocal and misses the last bit on about half of them)."""
+    from comfyui_keep_amd.modules.utils import cv2_to_comfy_image
+    v = np.arange(256, dtype=np.uint8)
+    img = np.stack([v, np.roll(v, 85), np.roll(v, 170)], -1).reshape(16, 16, 3)
+    img = np.ascontiguousarray(np.concatenate([img, img[::-1, ::-1]], 0))
+    out = torch.empty((32, 16, 3), dtype=torch.float32, device='cuda')
+    L.call('keep_bgr_u8_to_comfy', torch.from_numpy(img).cuda(), out, 32 * 16)
+    assert torch.equal(out.cpu(), cv2_to_comfy_image(img)[0])

@@ -297,6 +297,8 @@ class KeepNet:
                              pro_act=L.PRO_SWISH, stats=True, out_bf16=h16)
         sc = x
         if f'{p}.conv_out.weight' in w:
+            # (round 5 ran this 1x1 shortcut on a second stream next to conv1 -- it reads only x: 1.3 % SLOWER at 16 clips, nothing at
+            # one; the same for the q|k and v projections of the code transformer and q / kv of CFA: profiles/r05_small_forks_ab.txt)
             sc = self.o.linear(x, w[f'{p}.conv_out.weight'], w[f'{p}.conv_out.bias'], n_img=x.shape[0],
                                x_amax=None if st is None else st.amax)
         return self.o.conv(h, w[f'{p}.conv2.weight'], w[f'{p}.conv2.bias'], pro=self._gn(h, f'{p}.norm2', hst),

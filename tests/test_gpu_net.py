@@ -763,3 +763,33 @@ def test_weights_stay_resident_across_offload(monkeypatch, synth_weights):
     monkeypatch.setattr(netmod, 'RESIDENT', False)
     n.to('cpu')
     assert n._dev_blob is None and n.w is None
+
+
+def test_bench_multi_rank_line_shape(tmp_path):
+    """the driver's SCALE run must not fail on plumbing.  `python bench.py --gpus 2` (self-launched under
+    torch.distributed.run on the loopback address; KEEP_DIST_DEVICE=0 puts both ranks on this box's one GPU, gloo wire) prints ONE JSON
+    line with the contract's keys and the multi-rank extras (broadcast_ms, frames_per_s_per_rank, config5_one_video_per_gpu)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KEEP_DIST_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--clips', '2',
+                        '--no-extras', '--no-cpu-baseline'], capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'broadcast_ms', 'broadcast_mb', 'frames_per_s_per_rank', 'config5_one_video_per_gpu'):
+        assert k in line, k
+    assert line['n_gpus'] == 2 and line['steps'] == 1 and line['warmup'] == 1 and line['scaling'] == 'weak' and line['higher_is_better'] is True
+    assert line['dtype'] == 'f16x3' and line['data'] == 'synthetic' and line['vs_baseline'] is None and line['unit'] == 'frames/s'
+    assert line['config']['clips_per_gpu'] == 2 and line['config']['parallelism'] == 'dp2 over clips' and 'workload' in line['config']
+    assert len(line['frames_per_s_per_rank']) == 2 and all(v > 0 for v in line['frames_per_s_per_rank'])
+    assert abs(line['value'] - 2 * 2 * 20 / (line['ms_per_step'] * 1e-3)) <= 0.01 * line['value']        # whole-job frames / max-over-ranks time
+    assert line['broadcast_ms'] > 0 and 600 < line['broadcast_mb'] < 700
+    c5 = line['config5_one_video_per_gpu']
+    assert c5['crops_per_gpu'] == 300 and c5['clips_per_gpu'] == 15 and c5['value'] > 0
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in line['roofline'], k

@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace_${POL}_b$B" -o t -- python "$REPO/tools/run_step.py" $POL $B 2 > "$OUT/trace_${POL}_b$B.log" 2>&1
-for C in FETCH_SIZE WRITE_SIZE; do
+for C in ${PMC_COUNTERS:-FETCH_SIZE WRITE_SIZE}; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${POL}_b$B" -o ${POL}_$C -- python "$REPO/tools/run_step.py" $POL $B 1 > "$OUT/pmc_${POL}_${C}.log" 2>&1 || echo "PMC pass $C failed/timeout"
 done
 cd "$REPO"

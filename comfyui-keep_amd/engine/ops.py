@@ -178,8 +178,16 @@ class Ops:
         M = src.numel() // C
         out = empty((M, C), src)
         w2p, asc2 = self.ffn_w2_twin(w2)
+        if self.profile is not None:            # bench.py's roofline leg: the fused block counts with the conv / GEMM path it replaces
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            Hd = w0.shape[0]
+            self.profile.append(('gm_ffn_x3_kernel', 2.0 * M * (2 * C * Hd + Hd * C), 1, e0, e1,
+                                 3 * M * C * 4 + (2 * C * Hd + Hd * C) * 4, (M // 4096 if M % 4096 == 0 else 1, M, 1, 2 * C, C, 1, 1, 0, False)))
+            e0.record()
         L.call('keep_gm_ffn_x3', src, msg, self.x3_twin(w0), float(self.x3_scale_of(w0)), w2p, float(asc2), gamma, beta, float(eps), out,
                M, C, w0.shape[0], 1 if (self.flags & L.CONV_X3_EXACT_ACT) else 0)
+        if self.profile is not None:
+            self.profile[-1][4].record()
         return out.view(src.shape)
 
     def x3_twin(self, w):

@@ -1,1 +1,5 @@
-python -X faulthandler -m pytest tests -m gpu -x -q -v 2>&1 | grep -v "it/s\]" > gpurun_out/r5_fullsuite.log; grep -n "PASSED\|FAILED\|ERROR" gpurun_out/r5_fullsuite.log | tail -5; grep -n -i "fatal\|abort\|segfault\|Current thread" -A 12 gpurun_out/r5_fullsuite.log | head -60; tail -5 gpurun_out/r5_fullsuite.log
+bash tools/profile_step.sh x3 16 r5p_x3_b16 > gpurun_out/r5p_prof16.log 2>&1; tail -3 gpurun_out/r5p_prof16.log
+KEEP_AMD_GRAPH=0 KEEP_AMD_OVERLAP_MAX_CLIPS=0 PMC_COUNTERS= bash tools/profile_step.sh x3 1 r5p_x3_b1 > gpurun_out/r5p_prof1.log 2>&1; tail -3 gpurun_out/r5p_prof1.log
+python tools/dev/conv_census.py 16 conv_x3_kernel > gpurun_out/r5p_census_b16.txt 2>&1
+python tools/dev/conv_census.py 16 halo > gpurun_out/r5p_census_halo_b16.txt 2>&1
+python bench.py > gpurun_out/r5p_bench.json 2> gpurun_out/r5p_bench.err; tail -c 1500 gpurun_out/r5p_bench.json; tail -5 gpurun_out/r5p_bench.err

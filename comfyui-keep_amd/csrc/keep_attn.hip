@@ -1604,6 +1604,224 @@ static int launch_attn_x3_sfull(const AttnP& p, hipStream_t st) {
   return KEEP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ x3, small heads, latency form
+// Multi-head attention over at most 256 keys with D = Dv = 64 (the code transformer's nn.MultiheadAttention, KA:385-439: 8 heads x 256
+// tokens): attn_x3_kernel walks the 8 key tiles of a (head, 128-query) block one after the other (stage -> barrier -> MFMA -> barrier:
+// 40 us for 0.13 GFLOP, 16 blocks per image).  Here a block owns 32 queries of one head and its four waves own 64 KEYS each: a wave
+// requests its Q, K and V rows up front (Q / K straight into the MFMA fragment layout: lane = token, 8 consecutive d), computes its
+// partial S^T = K.Q^T (two 32 x 32 tiles), the block agrees on the row maximum through LDS (one barrier), every wave exponentiates,
+// multiplies its P with its V slice (V^T staged wave-privately, key-permuted like attn_bf16_kernel) and parks (O_w, l_w); after the
+// second barrier O = (O_0 + O_1 + O_2 + O_3) / (l_0 + l_1 + l_2 + l_3), waves in order.  Plain (not online) softmax with the global
+// row maximum: exact fp32, deterministic, one decomposition at every batch size (per-image rule) -- bits never depend on batch-mates.
+__global__ __launch_bounds__(256) void attn_x3_small_kernel(AttnP p) {
+  constexpr int DV = 64, VP = 72, OP = 68;
+  __shared__ __attribute__((aligned(16))) _Float16 vt_s[4 * DV * VP];       // per wave: V^T tile [64 dv][32 hi | 32 lo | pad]; later O_w [32 q][68]
+  __shared__ float red_m[4 * 32], red_l[4 * 32];
+  static_assert(32 * OP * 4 <= DV * VP * 2, "the wave's O tile fits its V^T region");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {      // the query blocks of one (batch, head) share K / V: neighbours in one XCD's L2 (see attn_x3_kernel)
+    const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+    const int lid = bx + gx * (by + gy * bz);
+    const int qd = total >> 3, rm = total & 7, xcd = lid & 7, slot = lid >> 3;
+    const int logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + slot;
+    bx = logical % gx;
+    const int rest = logical / gx;
+    by = rest % gy;
+    bz = rest / gy;
+  }
+  const int b = bz, head = by, q0 = bx * 32, key0 = wave * 64;
+  float sq = 1.f, sk = 1.f, sv = 1.f, inv_qk = 1.f, inv_sv = 1.f;
+  if (p.q_amax) {
+    float iq, ik;
+    attn_range_scale(p.q_amax[b], sq, iq);
+    attn_range_scale(p.k_amax[b], sk, ik);
+    attn_range_scale(p.v_amax[b], sv, inv_sv);
+    inv_qk = iq * ik;
+  }
+  // ---- every load of the wave, issued back to back
+  float4 qraw[4][2], kraw[2][4][2], vraw[2][4][2];
+  {
+    const int tq = q0 + l31;
+    const float* qp = p.q + (long)b * p.q_bs + (long)tq * p.q_ts + (long)head * p.q_hs + lhi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qraw[ks][0] = qraw[ks][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tq < p.Lq) {
+        qraw[ks][0] = *reinterpret_cast<const float4*>(qp + ks * 16);
+        qraw[ks][1] = *reinterpret_cast<const float4*>(qp + ks * 16 + 4);
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int tk = key0 + kt * 32 + l31;
+      const float* kp = p.k + (long)b * p.k_bs + (long)tk * p.k_ts + (long)head * p.k_hs + lhi * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        kraw[kt][ks][0] = kraw[kt][ks][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tk < p.Lk) {
+          kraw[kt][ks][0] = *reinterpret_cast<const float4*>(kp + ks * 16);
+          kraw[kt][ks][1] = *reinterpret_cast<const float4*>(kp + ks * 16 + 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {      // (key pair, 4-dv group) items: 16 pairs x 16 groups per 32-key tile
+        const int i = lane + u * 64;
+        const int pair = i >> 4, dv = (i & 15) << 2;
+        const int t = key0 + kt * 32 + pair * 2;
+        const float* vp = p.v + (long)b * p.v_bs + (long)t * p.v_ts + (long)head * p.v_hs + dv;
+        vraw[kt][u][0] = vraw[kt][u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < p.Lk) vraw[kt][u][0] = *reinterpret_cast<const float4*>(vp);
+        if (t + 1 < p.Lk) vraw[kt][u][1] = *reinterpret_cast<const float4*>(vp + p.v_ts);
+      }
+  }
+  auto split8 = [&](const float4 a, const float4 c, float sc, af16x8& hi, af16x8& lo) {
+    const float f[8] = {a.x * sc, a.y * sc, a.z * sc, a.w * sc, c.x * sc, c.y * sc, c.z * sc, c.w * sc};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const _Float16 h = (_Float16)f[j];
+      hi[j] = h;
+      lo[j] = (_Float16)(f[j] - (float)h);
+    }
+  };
+  // ---- partial scores S^T[key][query] of this wave's 64 keys
+  f32x16 s[2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    af16x8 qh8, ql8;
+    split8(qraw[ks][0], qraw[ks][1], sq, qh8, ql8);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      af16x8 kh8, kl8;
+      split8(kraw[kt][ks][0], kraw[kt][ks][1], sk, kh8, kl8);
+      s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh8, s[kt], 0, 0, 0);
+      s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, ql8, s[kt], 0, 0, 0);
+      s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qh8, s[kt], 0, 0, 0);
+    }
+  }
+  const float qk_scale = p.scale * inv_qk;
+  float m = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const float val = key < p.Lk ? s[kt][r] * qk_scale : -INFINITY;
+      s[kt][r] = val;
+      m = fmaxf(m, val);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32));
+  if (lane < 32) red_m[wave * 32 + l31] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red_m[l31], red_m[32 + l31]), fmaxf(red_m[64 + l31], red_m[96 + l31]));
+  float lsum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = expf(s[kt][r] - m);
+      s[kt][r] = pv;
+      lsum += pv;
+    }
+  lsum += __shfl_xor(lsum, 32);
+  if (lane < 32) red_l[wave * 32 + l31] = lsum;
+  // ---- O_w = P_w . V_w
+  _Float16* Vt = vt_s + wave * DV * VP;
+  f32x16 o[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    if (kt) __builtin_amdgcn_s_waitcnt(0xc07f);      // the previous tile's fragment reads are done (wave-private region)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = lane + u * 64;
+      const int pair = i >> 4, dv = (i & 15) << 2;
+      const float4 va = vraw[kt][u][0], vb = vraw[kt][u][1];
+      const float fa[4] = {va.x * sv, va.y * sv, va.z * sv, va.w * sv}, fb[4] = {vb.x * sv, vb.y * sv, vb.z * sv, vb.w * sv};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        af16x2 hi, lo;
+        const _Float16 ha = (_Float16)fa[j], hb = (_Float16)fb[j];
+        hi[0] = ha; hi[1] = hb;
+        lo[0] = (_Float16)(fa[j] - (float)ha); lo[1] = (_Float16)(fb[j] - (float)hb);
+        _Float16* dd = Vt + (dv + j) * VP + vt_pos(pair * 2);     // vt_pos(k0 + 1) = vt_pos(k0) + 1 for even k0
+        *reinterpret_cast<af16x2*>(dd) = hi;
+        *reinterpret_cast<af16x2*>(dd + 32) = lo;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      af16x8 ph, pl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const _Float16 h = (_Float16)s[kt][st * 8 + j];
+        ph[j] = h;
+        pl[j] = (_Float16)(s[kt][st * 8 + j] - (float)h);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const _Float16* vrow = Vt + (j * 32 + l31) * VP + (st * 2 + lhi) * 8;
+        const af16x8 vh8 = *reinterpret_cast<const af16x8*>(vrow), vl8 = *reinterpret_cast<const af16x8*>(vrow + 32);
+        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh8, o[j], 0, 0, 0);
+        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl8, o[j], 0, 0, 0);
+        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh8, o[j], 0, 0, 0);
+      }
+    }
+  }
+  // ---- park O_w [32 queries][64 dv] over the wave's V^T region, then the wave-ordered sum
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  float* ow = reinterpret_cast<float*>(Vt);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ow[((r & 3) + 8 * (r >> 2) + 4 * lhi) * OP + j * 32 + l31] = o[j][r];
+  __syncthreads();
+  {
+    const int qrow = tid >> 3, c8 = (tid & 7) * 8;
+    const int t = q0 + qrow;
+    float acc8[8];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* src = reinterpret_cast<const float*>(vt_s + w * DV * VP) + qrow * OP + c8;
+      const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
+      const float f[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc8[j] = w == 0 ? f[j] : acc8[j] + f[j];
+    }
+    const float lt = ((red_l[qrow] + red_l[32 + qrow]) + red_l[64 + qrow]) + red_l[96 + qrow];
+    const float il = inv_sv / lt;
+    if (t < p.Lq) {
+      float* dst = p.o + (long)b * p.o_bs + (long)t * p.o_ts + (long)head * p.o_hs + c8;
+      *reinterpret_cast<float4*>(dst) = make_float4(acc8[0] * il, acc8[1] * il, acc8[2] * il, acc8[3] * il);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(acc8[4] * il, acc8[5] * il, acc8[6] * il, acc8[7] * il);
+    }
+  }
+}
+
+static bool attn_small_ok(const AttnP& p) {
+  return p.mode == 0 && p.D == 64 && p.Dv == 64 && p.Lk <= 256 && p.Lq >= 64 && p.v_ts % 4 == 0 && p.v_bs % 4 == 0 && p.v_hs % 4 == 0 &&
+         (uintptr_t)p.v % 16 == 0 && p.o_ts % 4 == 0 && p.o_bs % 4 == 0 && p.o_hs % 4 == 0 && (uintptr_t)p.o % 16 == 0 &&
+         !(p.flags & KEEP_ATTN_NO_SMALL);
+}
+
+static int launch_attn_x3_small(const AttnP& p, hipStream_t st) {
+  hipLaunchKernelGGL(attn_x3_small_kernel, dim3(cdiv(p.Lq, 32), p.H, p.B), dim3(256), 0, st, p);
+  KEEP_LAUNCH_CHECK("keep_attention(x3, small heads, latency form)");
+  return KEEP_OK;
+}
+
 template <int WAVES, int DVT>
 static int launch_attn_x3(const AttnP& p, hipStream_t st) {
   if (p.D <= 128) return launch_attn_x3_t<WAVES, DVT, 8>(p, st);
@@ -2077,6 +2295,7 @@ extern "C" int32_t keep_attention(const keep_attention_args* a_in, void* stream)
   if (a->mma == KEEP_MMA_X3 && (a->D % 16 == 0) && (a->q_ts % 4 == 0) && (a->q_bs % 4 == 0) && (a->q_hs % 4 == 0) &&
       (a->k_ts % 4 == 0) && (a->k_bs % 4 == 0) && (a->k_hs % 4 == 0) && ((uintptr_t)a->q % 16 == 0) &&
       ((uintptr_t)a->k % 16 == 0) && !(a->flags & KEEP_ATTN_NO_X3)) {
+    if (attn_small_ok(p)) return launch_attn_x3_small(p, st);
     if (a->Lq <= 32) {
       if (dvt == 1) return launch_attn_x3<1, 1>(p, st);
       if (dvt == 2) return launch_attn_x3<1, 2>(p, st);

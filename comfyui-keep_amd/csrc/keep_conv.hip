@@ -1678,6 +1678,9 @@ int keep_conv2d_x3_c3(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 bool keep_conv_x3_halo_ok(const keep_conv2d_args* a);
 bool keep_conv_x3_stream_ok(const keep_conv2d_args* a, const ConvP& p, int split_k);
 bool keep_conv_x3_gather_ok(const keep_conv2d_args* a, const ConvP& p);
+bool keep_gemm_x3l_ok(const keep_conv2d_args* a);
+int keep_gemm_x3l_waves(const keep_conv2d_args* a);
+int keep_conv2d_x3_gemm_lat(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 
 enum ConvPath {
   PATH_COUT4 = 0, PATH_C3, PATH_HALO_F32, PATH_HALO_BF16, PATH_HALO_BF16_V1, PATH_GATHER_BF16, PATH_GATHER_F32, PATH_HALO_X3,
@@ -1786,6 +1789,7 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
   p.ln_gamma = a->ln_gamma;
   p.ln_beta = a->ln_beta;
   p.ln_eps = a->ln_eps;
+  p.kslice_steps = 0;
   p.bias = a->bias;
   p.out = (float*)a->out;
   p.pro_scale = a->pro_scale;
@@ -1897,6 +1901,19 @@ static int plan_conv(const keep_conv2d_args* a, ConvP& p, ConvPlan& pl) {
         keep_set_error("keep_conv2d: in2 (K-concatenated input) needs KEEP_MMA_X3, a 1x1 stride-1 convolution without prologue / range probe and in2_cin1 %% 32 == 0");
         return KEEP_EUNSUP;
       }
+    }
+    // GEMM form with few rows per image (token GEMMs of the frame recurrence): the latency form, K cut into canonical slices
+    // (keep_gemm_x3l.hip).  A per-image rule -- the sums it defines are the same at every batch size.
+    if (have_w && keep_gemm_x3l_ok(a) && keep_conv_x3_gather_ok(a, p) && keep_conv_x3_gather_is_gemm(a) &&
+        !(a->flags & (KEEP_CONV_NO_GATHER_X3 | KEEP_CONV_NO_GEMM_LAT))) {
+      pl.path = PATH_GATHER_X3;
+      pl.tile = 4;
+      pl.plain = no_pro;
+      pl.split_k = 1;
+      pl.stats_rows = 0;
+      pl.amax_ok = true;
+      snprintf(pl.kernel, sizeof(pl.kernel), "gemm_x3l_kernel<%d>", keep_gemm_x3l_waves(a));
+      return KEEP_OK;
     }
     if (have_w && keep_conv_x3_gather_ok(a, p) && !(a->flags & KEEP_CONV_NO_GATHER_X3)) {
       pl.path = PATH_GATHER_X3;
@@ -2136,7 +2153,7 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a_in, void* stream) {
       if (rc != KEEP_OK) return rc;
       break;
     case PATH_GATHER_X3:
-      rc = keep_conv2d_x3_gather(a, p, pl.tile, st);
+      rc = pl.tile == 4 ? keep_conv2d_x3_gemm_lat(a, p, st) : keep_conv2d_x3_gather(a, p, pl.tile, st);
       if (rc != KEEP_OK) return rc;
       break;
     case PATH_HALO_F32: {

@@ -75,6 +75,7 @@ struct ConvP {
   const float* ln_gamma;      // x3 GEMM form, tile <4,1,1,4>: LayerNorm over the 128 output channels of a row in the epilogue (or NULL)
   const float* ln_beta;
   float ln_eps;
+  int kslice_steps;           // x3 GEMM form: K steps (of 32 channels) per canonical slice of keep_gemm_x3l.hip's sums; 0 = one sequential sum
 };
 
 

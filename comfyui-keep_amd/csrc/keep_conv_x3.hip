@@ -1059,13 +1059,37 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
     stage(0, R0);
     __syncthreads();
     int buf = 0;
+    // canonical K slices (p.kslice_steps > 0: the throughput form of keep_gemm_x3l.hip's sums): every slice of kslice_steps K steps is
+    // accumulated from zero and the slice totals are added in order -- bit for bit what the latency form's waves + LDS reduction produce
+    f32x16 tot[TM][TN];
+    int ksl_left = p.kslice_steps;
+    bool ksl_first = true;
     for (int s = s_begin; s < s_end; ++s) {
       const bool more = (s + 1 < s_end);
       if (more) fetch(s + 1, R0);
       mma_step(buf);
+      if (p.kslice_steps > 0 && --ksl_left == 0) {
+        ksl_left = p.kslice_steps;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              tot[i][j][r] = ksl_first ? acc[i][j][r] : tot[i][j][r] + acc[i][j][r];
+              acc[i][j][r] = 0.f;
+            }
+        ksl_first = false;
+      }
       if (more) stage(buf ^ 1, R0);
       __syncthreads();
       buf ^= 1;
+    }
+    if (p.kslice_steps > 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = tot[i][j];
     }
   }
   if (XG_ABL == 2 && acc[0][0][0] != 1234.5f) return;
@@ -1516,8 +1540,11 @@ static unsigned long long* dbg = nullptr;
 // tile: plan_conv's choice (1: 64x64 block tiles, 2: 128x128, 3: 128x128 as four 32-row waves with the LayerNorm epilogue) --
 // the launch never re-derives it
 int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int tile, hipStream_t st) {
-  const int big_tile = tile >= 2;
   const long M = p.M;
+  // the plan's tile follows the reference batch because the statistics partition does; a launch WITHOUT statistics may take the small
+  // tile when the real row count is small (one clip in flight: 4 x the blocks) -- the K order of a row's sum does not depend on the tile
+  if (tile == 2 && !p.stats && M <= 4096) tile = 1;
+  const int big_tile = tile >= 2;
   const int steps = a->KH * a->KW * ((a->Cin + XBK - 1) / XBK);
   if (p.split_k > steps) p.split_k = steps;
   const bool plain = !a->pro_scale && a->pro_act == KEEP_PRO_NONE;

@@ -1,0 +1,239 @@
+// keep_conv2d, KEEP_MMA_X3, GEMM form (1x1, stride 1) with FEW ROWS PER IMAGE: the latency form.
+//
+// The token GEMMs of the frame recurrence (code transformer KA:385-439, AttnBlock projections VQ:219-243, CFA KA:519-541) have
+// 256 .. 1024 rows per image and K = 256 .. 2048.  With one clip in flight (the literal configs[1]) conv_x3_kernel spends 18 .. 57 us
+// on each of them whatever the FLOP count: 32 .. 128 blocks walk K in steps of 32 with one step of prefetch, i.e. 16 .. 64 DEPENDENT
+// round trips to L2 / HBM (the weights of a frame do not fit any cache: 633 MB per frame).  Here the K axis is cut into NW
+// CANONICAL SLICES, one per wave of a block: a wave requests its whole slice of A (fp32 rows, straight into the MFMA fragment
+// layout: lane = row, 8 consecutive channels) and of B (the pre-split weight rows, [hi16 | lo16] per 16-channel chunk) up front --
+// one round trip -- splits A in registers, runs its 3 * KS / 16 MFMAs per 32 x 32 tile from a ZERO accumulator and parks the partial
+// tile in LDS; after one barrier the block adds the NW partials in slice order 0, 1, .., NW - 1 and runs the epilogue (accumulator
+// scale, bias, activation, residual, fused max|out|) with 16-byte row-contiguous stores.  No LDS operand staging, no K loop barrier.
+//
+// Numerics: the value of an output element is defined by the slicing alone (NW = 8 for K >= 512, 4 below; slice s covers channels
+// [s K / NW, (s + 1) K / NW) in order) -- NOT by the row tile (TM), the grid order or the batch: plan_conv selects this kernel from the
+// per-image geometry, so a clip's bits never depend on its batch-mates, and the launch is free to pick TM / the XCD order from the real M.
+#include "keep_conv_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define GL_G 4                      // k-steps (of 16 channels) per register group: 64 channels
+#define GL_EP 36                    // floats per parked row: 32 + 4 pad
+#define GL_MAX_TILES 512            // launches of more 32 x 32 output tiles run on conv_x3_kernel with canonical slices (same bits)
+
+template <int NW, int TM, bool PLAIN>
+__global__ __launch_bounds__(NW * 64) void gemm_x3l_kernel(ConvP p, int m_fast) {
+  constexpr int BM = TM * 32, NT = NW * 64;
+  __shared__ __attribute__((aligned(16))) float part[NW * BM * GL_EP];
+  __shared__ __attribute__((aligned(16))) float pro_s[PLAIN ? 4 : 2 * 2048];      // GroupNorm (scale | shift) of the tile's image
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  // the faster grid index walks the LARGER operand's tiles: each of the 8 XCDs (dealt round-robin by linear block id) fetches 1/8 of it
+  const int bm = m_fast ? blockIdx.x : blockIdx.y, bn = m_fast ? blockIdx.y : blockIdx.x;
+  const long m0 = (long)bm * BM;
+  const int n0 = bn * 32;
+  const int hw = p.Ho * p.Wo;
+  const int n_img = (int)(m0 / hw);                      // hw % BM == 0 (plan): the tile lies in one image
+  const int K = p.Cin, KS = K / NW, NG = KS / (16 * GL_G);
+  const int k0 = wave * KS;
+
+  const long rows_here = (p.M - m0) < BM ? (p.M - m0) : BM;
+  auto make_rsrc = [&](const void* ptr, long bytes) {
+    const unsigned long long b = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.in + m0 * p.in_ld, ((rows_here - 1) * p.in_ld + K) * 4);
+  const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.wx3 + (long)n0 * K * 2, 32L * K * 4);
+  const int a_voff = (l31 * p.in_ld + lhi * 8) * 4;      // + i * 32 rows; channel offset in the scalar operand
+  const int b_voff = l31 * K * 4 + lhi * 16;             // weight row = K/16 chunks of [hi16 | lo16] = 64 B
+
+  struct Grp {
+    u32x4 a[TM][GL_G][2];
+    u32x4 b[GL_G][2];
+  };
+  auto fetch = [&](int g, Grp& R) {
+    const int kc = k0 + g * 16 * GL_G;                   // first channel of the group (wave-uniform)
+#pragma unroll
+    for (int ks = 0; ks < GL_G; ++ks) {
+      R.b[ks][0] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff, (kc + ks * 16) * 4, 0);
+      R.b[ks][1] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff + 32, (kc + ks * 16) * 4, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int ks = 0; ks < GL_G; ++ks) {
+        R.a[i][ks][0] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff + i * 32 * p.in_ld * 4, (kc + ks * 16) * 4, 0);
+        R.a[i][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff + i * 32 * p.in_ld * 4 + 16, (kc + ks * 16) * 4, 0);
+      }
+  };
+
+  Grp R0, R1;
+  fetch(0, R0);
+  if (NG > 1) fetch(1, R1);
+  float a_s = 1.f, a_inv = 1.f;
+  if (p.in_amax) x3_range_scale(p.in_amax[n_img], a_s, a_inv);
+  if (!PLAIN) {      // the image's (scale, shift) rows: global -> LDS under the operand loads
+    for (int c = tid; c < K; c += NT) {
+      pro_s[c] = p.pro_scale ? p.pro_scale[(long)n_img * K + c] : 1.f;
+      pro_s[2048 + c] = p.pro_shift ? p.pro_shift[(long)n_img * K + c] : 0.f;
+    }
+    __syncthreads();
+  }
+
+  f32x16 acc[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  auto compute = [&](int g, Grp& R) {
+    const int kc = k0 + g * 16 * GL_G + lhi * 8;
+#pragma unroll
+    for (int ks = 0; ks < GL_G; ++ks) {
+      const f16x8 bh = __builtin_bit_cast(f16x8, R.b[ks][0]);
+      const f16x8 bl = __builtin_bit_cast(f16x8, R.b[ks][1]);
+      float sc[8], sh[8];
+      if (!PLAIN) {
+        const float4 s0 = *reinterpret_cast<const float4*>(&pro_s[kc + ks * 16]);
+        const float4 s1 = *reinterpret_cast<const float4*>(&pro_s[kc + ks * 16 + 4]);
+        const float4 h0 = *reinterpret_cast<const float4*>(&pro_s[2048 + kc + ks * 16]);
+        const float4 h1 = *reinterpret_cast<const float4*>(&pro_s[2048 + kc + ks * 16 + 4]);
+        sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+        sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float v[8];
+        v[0] = __uint_as_float(R.a[i][ks][0].x); v[1] = __uint_as_float(R.a[i][ks][0].y);
+        v[2] = __uint_as_float(R.a[i][ks][0].z); v[3] = __uint_as_float(R.a[i][ks][0].w);
+        v[4] = __uint_as_float(R.a[i][ks][1].x); v[5] = __uint_as_float(R.a[i][ks][1].y);
+        v[6] = __uint_as_float(R.a[i][ks][1].z); v[7] = __uint_as_float(R.a[i][ks][1].w);
+        if (!PLAIN) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            v[j] = v[j] * sc[j] + sh[j];
+            if (p.pro_act != KEEP_PRO_NONE) v[j] = p.fast ? pro_apply_x3(v[j], p.pro_act) : pro_apply(v[j], p.pro_act);
+          }
+        }
+        f16x8 ah, al;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const f32x2 vs = f32x2{v[j], v[j + 1]} * a_s;
+          const f16x2 h = __builtin_convertvector(vs, f16x2);
+          const f16x2 l = __builtin_convertvector(vs - __builtin_convertvector(h, f32x2), f16x2);
+          ah[j] = h.x; ah[j + 1] = h.y;
+          al[j] = l.x; al[j + 1] = l.y;
+        }
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
+      }
+    }
+  };
+
+  for (int g = 0; g < NG; g += 2) {
+    compute(g, R0);
+    if (g + 2 < NG) fetch(g + 2, R0);
+    if (g + 1 < NG) {
+      compute(g + 1, R1);
+      if (g + 3 < NG) fetch(g + 3, R1);
+    }
+  }
+
+  // park the slice's partial tile: part[wave][row][col]
+  float* mine = part + wave * BM * GL_EP;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * GL_EP + l31] = acc[i][r];
+  __syncthreads();
+
+  // slice-ordered sum + epilogue: one float4 (row, 4 channels) per thread and pass
+  const float post = p.acc_scale * a_inv;
+  float amx = 0.f;
+  constexpr int UNITS = BM * 8;
+#pragma unroll
+  for (int u0 = 0; u0 < UNITS; u0 += NT) {
+    const int u = u0 + tid;
+    if (UNITS % NT != 0 && u >= UNITS) break;
+    const int row = u >> 3, c4 = (u & 7) * 4;
+    float4 v = *reinterpret_cast<const float4*>(part + row * GL_EP + c4);
+#pragma unroll
+    for (int s = 1; s < NW; ++s) {
+      const float4 t = *reinterpret_cast<const float4*>(part + (s * BM + row) * GL_EP + c4);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const long m = m0 + row;
+    const int co = n0 + c4;
+    if (m >= p.M) continue;
+    float e[4] = {v.x * post, v.y * post, v.z * post, v.w * post};
+    if (p.bias) {
+      const float4 b4 = *reinterpret_cast<const float4*>(p.bias + co);
+      e[0] += b4.x; e[1] += b4.y; e[2] += b4.z; e[3] += b4.w;
+    }
+    if (p.epi_act != KEEP_ACT_NONE) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e[q] = p.fast ? act_apply_fast(e[q], p.epi_act) : act_apply(e[q], p.epi_act);
+    }
+    if (p.res) {
+      const float4 r4 = *reinterpret_cast<const float4*>(p.res + m * p.res_ld + co);
+      e[0] += r4.x; e[1] += r4.y; e[2] += r4.z; e[3] += r4.w;
+    }
+    *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) amx = fmaxf(amx, fabsf(e[q]));
+  }
+  if (p.out_amax) wave_amax_commit(p.out_amax + n_img, amx);
+}
+
+// Geometry of the latency form (a per-image rule: nothing here looks at N).
+bool keep_gemm_x3l_ok(const keep_conv2d_args* a) {
+  const long hw = (long)a->Ho * a->Wo;
+  const int K = a->Cin;
+  const int nw = K >= 512 ? 8 : 4;
+  return a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad_t == 0 && a->pad_l == 0 && a->Ho == a->H && a->Wo == a->W && !a->upsample &&
+         hw >= 64 && hw <= 1024 && hw % 64 == 0 && K >= 256 && K <= 2048 && K % (nw * 16 * GL_G) == 0 && a->Cout % 32 == 0 && !a->in2 && !a->aux &&
+         !a->ln_gamma && a->split_k <= 1 && a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && a->in_ld % 4 == 0 && (uintptr_t)a->in % 16 == 0 &&
+         a->out_ld % 4 == 0 && (uintptr_t)a->out % 16 == 0 && (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&
+         (!a->bias || (uintptr_t)a->bias % 16 == 0) && (long)a->in_ld * 4 * 64 + (long)K * 4 < (1L << 31) && (long)K * 4 * 32 < (1L << 31);
+}
+
+int keep_gemm_x3l_waves(const keep_conv2d_args* a) { return a->Cin >= 512 ? 8 : 4; }
+
+int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int tile, hipStream_t st);
+
+// The sums are defined by the K slicing; WHICH kernel evaluates them follows the real row count (bit-neutral): the latency form while
+// its 32 x 32 tiles leave CUs idle, conv_x3_kernel with canonical slices (p.kslice_steps: 64 x 64 or 128 x 128 block tiles, operands
+// staged through LDS -- 4 x less L2 -> CU traffic per FLOP) beyond.
+int keep_conv2d_x3_gemm_lat(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
+  const long M = p.M;
+  const bool plain = !a->pro_scale && a->pro_act == KEEP_PRO_NONE;
+  const int nw = keep_gemm_x3l_waves(a);
+  const long tiles32 = (M / 32) * (a->Cout / 32);
+  const bool by_tiles = (a->flags & KEEP_CONV_GEMM_LAT_TILES) || (tiles32 > GL_MAX_TILES && !(a->flags & KEEP_CONV_GEMM_LAT_WAVES));
+  if (by_tiles) {
+    p.kslice_steps = a->Cin / nw / 32;
+    p.split_k = 1;
+    return keep_conv2d_x3_gather(a, p, (a->Cout <= 64 || M <= 4096) ? 1 : 2, st);
+  }
+  const int gm = cdiv(M, 32), gn = a->Cout / 32;
+  const int m_fast = (long)M > (long)a->Cout ? 1 : 0;       // the faster index walks the LARGER operand: each XCD sees 1/8 of it
+  dim3 grid(m_fast ? gm : gn, m_fast ? gn : gm);
+#define KEEP_LAUNCH_GL(NWV)                                                                                \
+  if (!plain)                                                                                              \
+    hipLaunchKernelGGL((gemm_x3l_kernel<NWV, 1, false>), grid, dim3(NWV * 64), 0, st, p, m_fast);          \
+  else                                                                                                     \
+    hipLaunchKernelGGL((gemm_x3l_kernel<NWV, 1, true>), grid, dim3(NWV * 64), 0, st, p, m_fast);
+  if (nw == 8) {
+    KEEP_LAUNCH_GL(8)
+  } else {
+    KEEP_LAUNCH_GL(4)
+  }
+#undef KEEP_LAUNCH_GL
+  KEEP_LAUNCH_CHECK("keep_conv2d(gemm x3 latency form)");
+  return KEEP_OK;
+}

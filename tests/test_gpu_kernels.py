@@ -1425,3 +1425,96 @@ def test_bgr_u8_to_comfy_equals_the_host_converter_on_every_value():
     out = torch.empty((32, 16, 3), dtype=torch.float32, device='cuda')
     L.call('keep_bgr_u8_to_comfy', torch.from_numpy(img).cuda(), out, 32 * 16)
     assert torch.equal(out.cpu(), cv2_to_comfy_image(img)[0])
+
+
+@pytest.mark.parametrize("name,hw,K,N,act,bias,res,gn,ranged", [
+    ('v / out_proj', 256, 512, 512, False, True, True, False, False),      # code transformer (KA:385-439): 512 -> 512 + residual
+    ('linear1', 256, 512, 1024, True, True, False, False, False),          # 512 -> 1024 + GELU
+    ('linear2', 256, 1024, 512, False, True, True, False, False),          # 1024 -> 512 + residual: two register groups per slice
+    ('feat_emb', 256, 256, 512, False, True, False, False, False),         # 256 -> 512: four slices
+    ('attn qkv', 256, 512, 1536, False, True, False, True, False),         # AttnBlock (VQ:219-243): GroupNorm prologue
+    ('cfa ff', 1024, 2048, 512, False, True, False, False, True),          # CFA feed-forward at 32 x 32: four groups, per-image range scale
+    ('cfa kv', 1024, 256, 2048, False, False, False, False, True)])
+def test_gemm_x3_latency_form(name, hw, K, N, act, bias, res, gn, ranged):
+    """gemm_x3l_kernel (keep_gemm_x3l.hip): the x3 GEMM form for <= 1024 rows per image.  Against float64 (the bound of the
+    throughput kernel: 2e-6 of sum |x| |w|), against conv_x3_kernel's one sequential sum (KEEP_CONV_NO_GEMM_LAT), and BIT-EQUAL
+    between one image per launch (the latency kernel: one wave per K slice, LDS reduction) and 20 images per launch (conv_x3_kernel
+    with canonical slices, ConvP.kslice_steps): the K slicing alone defines the sums, the launch follows the real row count."""
+    n_img = 20
+    M = n_img * hw
+    x = rnd(f'gl_x_{name}', (n_img, hw, K), 2.0)
+    if ranged:
+        x = x * torch.tensor([1.0, 300.0, 0.01, 7.0, 2000.0]).repeat(4).view(-1, 1, 1)
+    w = rnd(f'gl_w_{name}', (N, K), 0.05)
+    b = rnd(f'gl_b_{name}', (N,), 0.3) if bias else None
+    r = rnd(f'gl_r_{name}', (n_img, hw, N), 1.5) if res else None
+    pro = None
+    x_eff = x.double()
+    if gn:
+        sc, sh = rnd(f'gl_sc_{name}', (n_img, K)) * 0.3 + 1.0, rnd(f'gl_sh_{name}', (n_img, K)) * 0.2
+        pro = (dev(sc), dev(sh))
+        x_eff = x.double() * sc.double()[:, None] + sh.double()[:, None]
+    wx3, asc = x3w(dev(w))
+    kw = dict(mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, pad=0, ksize=1, act=L.ACT_GELU if act else L.ACT_NONE, bounded=not ranged,
+              pro=pro, stats=True)
+    xd, wd, bd = dev(x), dev(w), None if b is None else dev(b)
+    rd = None if r is None else dev(r).view(n_img, hw, 1, N)
+    y, st = ops.conv(xd.view(n_img, hw, 1, K), wd, bd, residual=rd, **kw)
+    pl = [k for k in ops._PLAN_CACHE.values() if k.kernel.startswith('gemm_x3l_kernel')]
+    assert pl, 'the latency form was not selected'
+    ref = x_eff.reshape(M, K) @ w.double().t() + (0 if b is None else b.double())
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    if r is not None:
+        ref = ref + r.double().reshape(M, N)
+    scale = (x_eff.abs().reshape(n_img, hw, K) @ w.double().abs().t()).flatten(1).max(1).values       # per image: the ranges differ
+    e = (y.double().cpu().reshape(n_img, hw * N) - ref.reshape(n_img, hw * N)).abs().max(1).values
+    assert bool((e <= 2e-6 * scale).all()), (name, e / scale)
+    # fused max|out| per image
+    assert st is not None and st.amax is not None
+    assert torch.equal(st.amax.cpu(), y.abs().reshape(n_img, -1).max(1).values.cpu())
+    # one image per launch: same bits
+    for i in (0, 7, 19):
+        yi = ops.conv(xd[i:i + 1].view(1, hw, 1, K), wd, bd, residual=None if rd is None else rd[i:i + 1],
+                      **{**kw, 'pro': None if pro is None else (pro[0][i:i + 1], pro[1][i:i + 1]), 'stats': False})
+        assert torch.equal(yi.reshape(hw, N), y[i].reshape(hw, N)), (name, i)
+    # the throughput kernel computes the same product in another order
+    ops.DEFAULT.flags |= L.CONV_NO_GEMM_LAT
+    y0 = ops.conv(xd.view(n_img, hw, 1, K), wd, bd, residual=rd, **{**kw, 'stats': False})
+    e0 = (y0.double().cpu().reshape(n_img, hw * N) - ref.reshape(n_img, hw * N)).abs().max(1).values
+    assert bool((e <= 2.0 * e0 + 1e-7 * scale).all()), (name, e / scale, e0 / scale)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,amp,peak", [(3, 8, 256, 256, 1.0, 3.0), (2, 4, 250, 200, 1.0, 3.0), (2, 8, 256, 256, 1e5, 3.0),
+                                                (1, 2, 96, 64, 1.0, 60.0), (2, 3, 70, 37, 1.0, 3.0)])
+def test_attention_x3_small_heads_latency_form(B, H, Lq, Lk, amp, peak):
+    """attn_x3_small_kernel (D = Dv = 64, <= 256 keys: the code transformer's multi-head attention, KA:385-439): four waves x 64 keys
+    per 32-query block, global row maximum through LDS, wave-ordered sum of the partial outputs.  Against float64 (not worse than
+    attn_x3_kernel, the tile-by-tile online-softmax form it replaces), ragged Lq / Lk (masked keys, a wave without keys), packed q|k
+    rows, probed ranges, peaked scores -- and bit-equal between one batch element per launch and all of them."""
+    D = Dv = 64
+    qk = rnd('asq', (B, max(Lq, Lk), 2 * H * D)) * amp                    # q | k packed like in_proj's output (strided heads)
+    v = rnd('asv', (B, Lk, H * Dv)) * amp
+    scale = D ** -0.5 * peak / amp
+    q4, k4, v4 = qk[:, :Lq, :H * D].reshape(B, Lq, H, D), qk[:, :Lk, H * D:].reshape(B, Lk, H, D), v.reshape(B, Lk, H, Dv)
+    ref = torch.softmax(torch.einsum('bqhd,bkhd->bhqk', q4.double(), k4.double()) * scale, -1)
+    ref = torch.einsum('bhqk,bkhd->bqhd', ref, v4.double())
+    Lm = max(Lq, Lk)
+    qkd, vd = dev(qk), dev(v)
+
+    def run(flags, b0=0, nb=B):
+        o = torch.empty((nb, Lq, H, Dv), device='cuda')
+        ops.DEFAULT.attn_flags = flags
+        x = qkd[b0:b0 + nb]
+        ops.attention(x, ops.offset(x, H * D), vd[b0:b0 + nb], o, B=nb, H=H, Lq=Lq, Lk=Lk, D=D, Dv=Dv, scale=scale,
+                      q_str=(Lm * 2 * H * D, 2 * H * D, D), k_str=(Lm * 2 * H * D, 2 * H * D, D), v_str=(Lk * H * Dv, H * Dv, Dv),
+                      o_str=(Lq * H * Dv, H * Dv, Dv), mma=L.MMA_X3, probe=amp > 1)
+        return o
+    o_new, o_old = run(0), run(L.ATTN_NO_SMALL)
+    assert torch.isfinite(o_new).all()
+    sc = ref.abs().max().item()
+    e_new, e_old = err64(o_new, ref), err64(o_old, ref)
+    assert e_new <= max(2.0 * e_old, 2e-6 * sc), f'latency form {e_new:.3e} vs attn_x3_kernel {e_old:.3e} (scale {sc:.3g})'
+    assert not torch.equal(o_new, o_old) or Lq < 64, 'both flag settings ran the same kernel'
+    for b0 in range(B):
+        assert torch.equal(run(0, b0, 1)[0], o_new[b0]), f'batch element {b0} differs between B = 1 and B = {B}'

@@ -1,3 +1,5 @@
-python -X faulthandler -m pytest tests -m gpu -x -q -s 2>&1 | grep -v "it/s\]" > gpurun_out/r5_fullsuite_a.log; tail -3 gpurun_out/r5_fullsuite_a.log; grep -c "Fatal\|Segmentation\|Aborted" gpurun_out/r5_fullsuite_a.log
-grep -n "max_top1_logit_err_up_to_first_flip" gpurun_out/r5_fullsuite_a.log | sed "s/.*\(keep_forward[^ ]*\) \(\[[a-z0-9]*\]\).*'first_frame_with_a_flip': \([0-9]*\).*'max_top1_logit_err_up_to_first_flip': \([0-9.e-]*\).*/\1 \2 first_flip \3 logit_err \4/" | head -20
-python -X faulthandler -m pytest tests -m gpu -x -q 2>&1 | grep -v "it/s\]" > gpurun_out/r5_fullsuite_b.log; tail -3 gpurun_out/r5_fullsuite_b.log; grep -c "Fatal\|Segmentation\|Aborted" gpurun_out/r5_fullsuite_b.log
+set -x
+cd /root/repo
+timeout 600 python tools/dev/conv_split_bench.py 0x8 2>&1 | tail -12
+timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu 2>&1 | tail -5
+timeout 600 python tools/dev/flag_ab.py 1 new=0 2>&1 | tail -3

@@ -793,7 +793,8 @@ __device__ __forceinline__ void x3_gather_epilogue(const ConvP& p, f32x16 (&acc)
 
 // ONE: 1x1 stride-1 unpadded convolution == a row-major GEMM: the A rows are fetched with block-relative buffer loads (rows
 // beyond M read zeros through the descriptor's range check), no im2col index arithmetic.
-template <int WGM, int WGN, int TM, int TN, bool PLAIN, bool ONE = false>
+// KSL: canonical K slices (p.kslice_steps > 0, keep_gemm_x3l.hip) -- its own instantiations: the slice totals cost TM * TN * 16 registers.
+template <int WGM, int WGN, int TM, int TN, bool PLAIN, bool ONE = false, bool KSL = false>
 __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
   constexpr int BM = WGM * TM * 32;
   constexpr int BN = WGN * TN * 32;
@@ -864,8 +865,6 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
     int a_c;
     float u_sc[8], u_sh[8];
   };
-  StepRegs R0;
-  R0.a_c = 0;
   const long m_last = (m0 + BM - 1 < p.M) ? (m0 + BM - 1) : (long)p.M - 1;
   const bool uni_n = !PLAIN && p.pro_scale && ((m0 / hw) == (m_last / hw));
   const long uni_off = (m0 / hw) * (long)p.Cin;
@@ -1053,47 +1052,58 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
   };
 
   if (s_begin < s_end) {
-    // (A two-deep register pipeline -- loads issued two MFMA phases ahead, 248 VGPRs -- measured no gain: 2119 vs 2045 us on
-    // 256 -> 1024 at 0.62 M rows, 760 vs 734 us on 1024 -> 128: the K loop is not waiting for its loads.)
-    fetch(s_begin, R0);
-    stage(0, R0);
+    // Register prefetch ring of PD K steps.  Large tiles (128 x 128: many blocks in flight, the K loop does not wait for its loads --
+    // a two-deep ring measured 2119 vs 2045 us on 256 -> 1024 at 0.62 M rows) keep PD = 1.  The 64 x 64 tile serves the launches that
+    // CANNOT fill the chip with blocks (token GEMMs of <= 4096 rows, stride-2 convolutions of one clip): their K loop is a chain of
+    // dependent L2 / HBM round trips (20 us for 4096 x 512 x 512 whatever the FLOPs), and a step in flight costs only 18 VGPRs there.
+    constexpr int PD = (TM * TN == 1) ? (PLAIN ? 4 : 2) : 1;      // (the prologue form carries 16 scale / shift registers per step in flight)
+    StepRegs R[PD];
+#pragma unroll
+    for (int u = 0; u < PD; ++u)
+      if (s_begin + u < s_end) fetch(s_begin + u, R[u]);
+    stage(0, R[0]);
     __syncthreads();
     int buf = 0;
     // canonical K slices (p.kslice_steps > 0: the throughput form of keep_gemm_x3l.hip's sums): every slice of kslice_steps K steps is
     // accumulated from zero and the slice totals are added in order -- bit for bit what the latency form's waves + LDS reduction produce
-    f32x16 tot[TM][TN];
+    f32x16 tot[KSL ? TM : 1][KSL ? TN : 1];
     int ksl_left = p.kslice_steps;
     bool ksl_first = true;
-    for (int s = s_begin; s < s_end; ++s) {
-      const bool more = (s + 1 < s_end);
-      if (more) fetch(s + 1, R0);
-      mma_step(buf);
-      if (p.kslice_steps > 0 && --ksl_left == 0) {
-        ksl_left = p.kslice_steps;
+    for (int s0 = s_begin; s0 < s_end; s0 += PD) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+      for (int u = 0; u < PD; ++u) {
+        const int s = s0 + u;
+        if (s < s_end) {      // (uniform)
+          if (s + PD < s_end) fetch(s + PD, R[u]);            // R[u] held step s: staged one iteration ago
+          mma_step(buf);
+          if (KSL && --ksl_left == 0) {
+            ksl_left = p.kslice_steps;
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              tot[i][j][r] = ksl_first ? acc[i][j][r] : tot[i][j][r] + acc[i][j][r];
-              acc[i][j][r] = 0.f;
-            }
-        ksl_first = false;
+              for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  tot[KSL ? i : 0][KSL ? j : 0][r] = ksl_first ? acc[i][j][r] : tot[KSL ? i : 0][KSL ? j : 0][r] + acc[i][j][r];
+                  acc[i][j][r] = 0.f;
+                }
+            ksl_first = false;
+          }
+          if (s + 1 < s_end) stage(buf ^ 1, R[(u + 1) % PD]);
+          __syncthreads();
+          buf ^= 1;
+        }
       }
-      if (more) stage(buf ^ 1, R0);
-      __syncthreads();
-      buf ^= 1;
     }
-    if (p.kslice_steps > 0) {
+    if (KSL) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = tot[i][j];
+        for (int j = 0; j < TN; ++j) acc[i][j] = tot[KSL ? i : 0][KSL ? j : 0];
     }
   }
   if (XG_ABL == 2 && acc[0][0][0] != 1234.5f) return;
-  if (XG_ABL == 3) acc[0][0][0] = (float)R0.b_raw[0].x + R0.a_raw[0][0] + (float)As[0][threadIdx.x];
+  if (XG_ABL == 3) acc[0][0][0] = (float)As[0][threadIdx.x];
   const float asc = p.acc_scale;
   if (p.in_amax) {          // undo the per-image range scale: accumulator register r of tile i holds output row ...
 #pragma unroll
@@ -1552,7 +1562,11 @@ int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int tile, hipStre
   // 1x1 stride-1 unpadded convolutions (token GEMMs): block-relative buffer-load fetch, no im2col index arithmetic
   const bool one = keep_conv_x3_gather_is_gemm(a);
 #define KEEP_LAUNCH_GX(A, B, C, D)                                                                 \
-  if (plain && one)                                                                                \
+  if (p.kslice_steps > 0 && plain)                                                                 \
+    hipLaunchKernelGGL((conv_x3_kernel<A, B, C, D, true, true, true>), grid, block, 0, st, p);     \
+  else if (p.kslice_steps > 0)                                                                     \
+    hipLaunchKernelGGL((conv_x3_kernel<A, B, C, D, false, true, true>), grid, block, 0, st, p);    \
+  else if (plain && one)                                                                           \
     hipLaunchKernelGGL((conv_x3_kernel<A, B, C, D, true, true>), grid, block, 0, st, p);           \
   else if (plain)                                                                                  \
     hipLaunchKernelGGL((conv_x3_kernel<A, B, C, D, true, false>), grid, block, 0, st, p);          \

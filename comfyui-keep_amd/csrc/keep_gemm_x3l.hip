@@ -1,7 +1,7 @@
-// keep_conv2d, KEEP_MMA_X3, GEMM form (1x1, stride 1) with FEW ROWS PER IMAGE: the latency form.
+// keep_conv2d, KEEP_MMA_X3, GEMM form (1x1, stride 1) with FEW ROWS PER IMAGE (<= 256): the latency form.
 //
 // The token GEMMs of the frame recurrence (code transformer KA:385-439, AttnBlock projections VQ:219-243, CFA KA:519-541) have
-// 256 .. 1024 rows per image and K = 256 .. 2048.  With one clip in flight (the literal configs[1]) conv_x3_kernel spends 18 .. 57 us
+// 256 rows per image and K = 256 .. 2048.  With one clip in flight (the literal configs[1]) conv_x3_kernel spends 18 .. 57 us
 // on each of them whatever the FLOP count: 32 .. 128 blocks walk K in steps of 32 with one step of prefetch, i.e. 16 .. 64 DEPENDENT
 // round trips to L2 / HBM (the weights of a frame do not fit any cache: 633 MB per frame).  Here the K axis is cut into NW
 // CANONICAL SLICES, one per wave of a block: a wave requests its whole slice of A (fp32 rows, straight into the MFMA fragment
@@ -10,7 +10,7 @@
 // tile in LDS; after one barrier the block adds the NW partials in slice order 0, 1, .., NW - 1 and runs the epilogue (accumulator
 // scale, bias, activation, residual, fused max|out|) with 16-byte row-contiguous stores.  No LDS operand staging, no K loop barrier.
 //
-// Numerics: the value of an output element is defined by the slicing alone (NW = 8 for K >= 512, 4 below; slice s covers channels
+// Numerics: the value of an output element is defined by the slicing alone (NW = 8 for K >= 1024, 4 below; slice s covers channels
 // [s K / NW, (s + 1) K / NW) in order) -- NOT by the row tile (TM), the grid order or the batch: plan_conv selects this kernel from the
 // per-image geometry, so a clip's bits never depend on its batch-mates, and the launch is free to pick TM / the XCD order from the real M.
 #include "keep_conv_common.h"
@@ -22,6 +22,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define GL_G 4                      // k-steps (of 16 channels) per register group: 64 channels
 #define GL_EP 36                    // floats per parked row: 32 + 4 pad
+// rows per image the family takes: the 16 x 16 token maps (code transformer, AttnBlock).  The 32 x 32 maps (CFA: 135 launches per clip)
+// were measured too: -0.5 ms per clip with one clip in flight, +1.8 ms per 16-clip step (64 x 64 tiles with slice totals against the
+// 128 x 128 tile of the sequential sum) -- left on conv_x3_kernel.
+#define GL_MAX_HW 256
 #define GL_MAX_TILES 512            // launches of more 32 x 32 output tiles run on conv_x3_kernel with canonical slices (same bits)
 
 template <int NW, int TM, bool PLAIN>
@@ -194,15 +198,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_x3l_kernel(ConvP p, int m_fast) 
 bool keep_gemm_x3l_ok(const keep_conv2d_args* a) {
   const long hw = (long)a->Ho * a->Wo;
   const int K = a->Cin;
-  const int nw = K >= 512 ? 8 : 4;
+  const int nw = K >= 1024 ? 8 : 4;
   return a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad_t == 0 && a->pad_l == 0 && a->Ho == a->H && a->Wo == a->W && !a->upsample &&
-         hw >= 64 && hw <= 1024 && hw % 64 == 0 && K >= 256 && K <= 2048 && K % (nw * 16 * GL_G) == 0 && a->Cout % 32 == 0 && !a->in2 && !a->aux &&
+         hw >= 64 && hw <= GL_MAX_HW && hw % 64 == 0 && K >= 256 && K <= 2048 && K % (nw * 16 * GL_G) == 0 && a->Cout % 32 == 0 && !a->in2 && !a->aux &&
          !a->ln_gamma && a->split_k <= 1 && a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && a->in_ld % 4 == 0 && (uintptr_t)a->in % 16 == 0 &&
          a->out_ld % 4 == 0 && (uintptr_t)a->out % 16 == 0 && (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&
          (!a->bias || (uintptr_t)a->bias % 16 == 0) && (long)a->in_ld * 4 * 64 + (long)K * 4 < (1L << 31) && (long)K * 4 * 32 < (1L << 31);
 }
 
-int keep_gemm_x3l_waves(const keep_conv2d_args* a) { return a->Cin >= 512 ? 8 : 4; }
+// slices of 128 channels for K = 512 .. 1024 (4 / 8 waves), 256 for K = 2048, 64 for K = 256: the throughput form folds a slice total
+// every 4 K steps at least where the launches are many (conv_x3_kernel KSL: 16 adds per 24 MFMAs and wave)
+int keep_gemm_x3l_waves(const keep_conv2d_args* a) { return a->Cin >= 1024 ? 8 : 4; }
 
 int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int tile, hipStream_t st);
 
@@ -218,7 +224,7 @@ int keep_conv2d_x3_gemm_lat(const keep_conv2d_args* a, ConvP& p, hipStream_t st)
   if (by_tiles) {
     p.kslice_steps = a->Cin / nw / 32;
     p.split_k = 1;
-    return keep_conv2d_x3_gather(a, p, (a->Cout <= 64 || M <= 4096) ? 1 : 2, st);
+    return keep_conv2d_x3_gather(a, p, 1, st);      // 64 x 64 tiles at every row count: the slice totals of a 128 x 128 tile leave one block per CU
   }
   const int gm = cdiv(M, 32), gn = a->Cout / 32;
   const int m_fast = (long)M > (long)a->Cout ? 1 : 0;       // the faster index walks the LARGER operand: each XCD sees 1/8 of it

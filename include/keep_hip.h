@@ -82,7 +82,7 @@ extern "C" {
 #define KEEP_CONV_SMALL_TILES (1u << 7)  /* gather kernels: 64x64 tiles whatever the row count */
 #define KEEP_CONV_X3_EXACT_ACT (1u << 8) /* x3 kernels: library expf / erff instead of the x3-grade fast forms */
 #define KEEP_CONV_NO_STREAM (1u << 9)    /* x3 3x3: the stage-barrier-MFMA halo kernel instead of the streaming one */
-#define KEEP_CONV_NO_GEMM_LAT (1u << 10) /* x3 GEMM form with <= 1024 rows per image: one sequential sum (conv_x3_kernel) instead of canonical K slices */
+#define KEEP_CONV_NO_GEMM_LAT (1u << 10) /* x3 GEMM form with <= 256 rows per image: one sequential sum (conv_x3_kernel) instead of canonical K slices */
 #define KEEP_CONV_GEMM_LAT_WAVES (1u << 11) /* canonical K slices: the one-wave-per-slice kernel (gemm_x3l_kernel) whatever the row count (same bits) */
 #define KEEP_CONV_GEMM_LAT_TILES (1u << 12) /* canonical K slices: conv_x3_kernel with slice totals whatever the row count (same bits) */
 /* keep_attention_args.flags (v18) */

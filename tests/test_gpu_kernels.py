@@ -1433,10 +1433,10 @@ def test_bgr_u8_to_comfy_equals_the_host_converter_on_every_value():
     ('linear2', 256, 1024, 512, False, True, True, False, False),          # 1024 -> 512 + residual: two register groups per slice
     ('feat_emb', 256, 256, 512, False, True, False, False, False),         # 256 -> 512: four slices
     ('attn qkv', 256, 512, 1536, False, True, False, True, False),         # AttnBlock (VQ:219-243): GroupNorm prologue
-    ('cfa ff', 1024, 2048, 512, False, True, False, False, True),          # CFA feed-forward at 32 x 32: four groups, per-image range scale
-    ('cfa kv', 1024, 256, 2048, False, False, False, False, True)])
+    ('wide ff', 256, 2048, 512, False, True, False, False, True),          # K = 2048: four groups per slice, per-image range scale
+    ('ragged rows', 192, 512, 2048, False, False, False, False, True)])
 def test_gemm_x3_latency_form(name, hw, K, N, act, bias, res, gn, ranged):
-    """gemm_x3l_kernel (keep_gemm_x3l.hip): the x3 GEMM form for <= 1024 rows per image.  Against float64 (the bound of the
+    """gemm_x3l_kernel (keep_gemm_x3l.hip): the x3 GEMM form for <= 256 rows per image.  Against float64 (the bound of the
     throughput kernel: 2e-6 of sum |x| |w|), against conv_x3_kernel's one sequential sum (KEEP_CONV_NO_GEMM_LAT), and BIT-EQUAL
     between one image per launch (the latency kernel: one wave per K slice, LDS reduction) and 20 images per launch (conv_x3_kernel
     with canonical slices, ConvP.kslice_steps): the K slicing alone defines the sums, the launch follows the real row count."""

@@ -1604,6 +1604,160 @@ static int launch_attn_x3_sfull(const AttnP& p, hipStream_t st) {
   return KEEP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ x3, D = Dv = 512, two passes
+// The VQGAN AttnBlock on a 16 x 16 map (VQ:219-243: one head of d = 512 over 256 tokens) as TWO launches in the latency form of
+// keep_gemm_x3l.hip -- every wave owns a K slice, requests its whole operand slices up front, the block adds the partial tiles in wave
+// order through LDS:
+//   attn_scores_x3l_kernel   S[q][key] = scale * sum_d Q K : 32 x 32 tiles, four waves x 128 channels; BOTH operands are fp32 rows split
+//                            in registers (lane = token, 8 consecutive channels: the MFMA fragment layout straight from global memory);
+//   attn_pv_x3l_kernel       O = softmax(S) V : 32 queries x 32 dv tiles, four waves x 64 keys; the row maximum / sum of the block's
+//                            32 queries is agreed through LDS (every block sees whole score rows), P = exp(S - m) is split in
+//                            registers as the A operand, V is the B operand read as a GATHER (lane = dv column, one dword per key:
+//                            32 consecutive dv of one key per half-wave = whole 128-byte lines, no transpose pass).
+// 64 + 128 blocks per image instead of attn_x3_sfull2_kernel's 8 (each walking 8 key tiles twice): 77 -> ~16 us with one clip in
+// flight.  One decomposition per image at every batch size: bits never depend on batch-mates.
+__global__ __launch_bounds__(256) void attn_scores_x3l_kernel(AttnP p, float* __restrict__ sc_out) {
+  __shared__ __attribute__((aligned(16))) float part[4 * 32 * 36];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int key0 = blockIdx.x * 32, q0 = blockIdx.y * 32, bh = blockIdx.z, b = bh / p.H, head = bh - b * p.H;
+  const int c0 = wave * 128 + lhi * 8;
+  const float* qp = p.q + (long)b * p.q_bs + (long)head * p.q_hs + (long)(q0 + l31) * p.q_ts + c0;
+  const float* kp = p.k + (long)b * p.k_bs + (long)head * p.k_hs + (long)(key0 + l31) * p.k_ts + c0;
+  float4 qa[8][2], ka[8][2];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    qa[ks][0] = *reinterpret_cast<const float4*>(qp + ks * 16);
+    qa[ks][1] = *reinterpret_cast<const float4*>(qp + ks * 16 + 4);
+    ka[ks][0] = *reinterpret_cast<const float4*>(kp + ks * 16);
+    ka[ks][1] = *reinterpret_cast<const float4*>(kp + ks * 16 + 4);
+  }
+  __builtin_amdgcn_sched_barrier(0);      // every load is in flight before the first split (the scheduler would interleave them to save registers)
+  auto split8 = [&](const float4 a, const float4 c, af16x8& hi, af16x8& lo) {
+    const float f[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const _Float16 h = (_Float16)f[j];
+      hi[j] = h;
+      lo[j] = (_Float16)(f[j] - (float)h);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    af16x8 qh8, ql8, kh8, kl8;
+    split8(qa[ks][0], qa[ks][1], qh8, ql8);
+    split8(ka[ks][0], ka[ks][1], kh8, kl8);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql8, kh8, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh8, kl8, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh8, kh8, acc, 0, 0, 0);
+  }
+  float* mine = part + wave * 32 * 36;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 36 + l31] = acc[r];
+  __syncthreads();
+  const int row = tid >> 3, c4 = (tid & 7) * 4;
+  float4 v = *reinterpret_cast<const float4*>(part + row * 36 + c4);
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const float4 t = *reinterpret_cast<const float4*>(part + (w * 32 + row) * 36 + c4);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  *reinterpret_cast<float4*>(sc_out + ((long)bh * p.Lq + q0 + row) * p.Lk + key0 + c4) =
+      make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
+}
+
+__global__ __launch_bounds__(256) void attn_pv_x3l_kernel(AttnP p, const float* __restrict__ sc_in) {
+  __shared__ __attribute__((aligned(16))) float part[4 * 32 * 36];
+  __shared__ float red_m[4 * 32], red_l[4 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int dv0 = blockIdx.x * 32, q0 = blockIdx.y * 32, bh = blockIdx.z, b = bh / p.H, head = bh - b * p.H;
+  const int k0 = wave * 64 + lhi * 8;
+  const float* sp = sc_in + ((long)bh * p.Lq + q0 + l31) * p.Lk + k0;
+  const float* vp = p.v + (long)b * p.v_bs + (long)head * p.v_hs + (long)k0 * p.v_ts + dv0 + l31;
+  float4 sa[4][2];
+  float vb[4][8];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    sa[ks][0] = *reinterpret_cast<const float4*>(sp + ks * 16);
+    sa[ks][1] = *reinterpret_cast<const float4*>(sp + ks * 16 + 4);
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vb[ks][j] = vp[(long)(ks * 16 + j) * p.v_ts];
+  __builtin_amdgcn_sched_barrier(0);
+  // row maximum over all 256 keys: this lane's 32 values, its half-wave twin, the other three waves
+  float sv[4][8];
+  float m = -INFINITY;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    sv[ks][0] = sa[ks][0].x; sv[ks][1] = sa[ks][0].y; sv[ks][2] = sa[ks][0].z; sv[ks][3] = sa[ks][0].w;
+    sv[ks][4] = sa[ks][1].x; sv[ks][5] = sa[ks][1].y; sv[ks][6] = sa[ks][1].z; sv[ks][7] = sa[ks][1].w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, sv[ks][j]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 32));
+  if (lane < 32) red_m[wave * 32 + l31] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red_m[l31], red_m[32 + l31]), fmaxf(red_m[64 + l31], red_m[96 + l31]));
+  float lsum = 0.f;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    af16x8 ph, pl, vh, vl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float pv = expf(sv[ks][j] - m);
+      lsum += pv;
+      const _Float16 h = (_Float16)pv;
+      ph[j] = h;
+      pl[j] = (_Float16)(pv - (float)h);
+      const _Float16 g = (_Float16)vb[ks][j];
+      vh[j] = g;
+      vl[j] = (_Float16)(vb[ks][j] - (float)g);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, acc, 0, 0, 0);
+  }
+  lsum += __shfl_xor(lsum, 32);
+  if (lane < 32) red_l[wave * 32 + l31] = lsum;
+  float* mine = part + wave * 32 * 36;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 36 + l31] = acc[r];
+  __syncthreads();
+  const int row = tid >> 3, c4 = (tid & 7) * 4;
+  float4 v = *reinterpret_cast<const float4*>(part + row * 36 + c4);
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const float4 t = *reinterpret_cast<const float4*>(part + (w * 32 + row) * 36 + c4);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  const float il = 1.0f / (((red_l[row] + red_l[32 + row]) + red_l[64 + row]) + red_l[96 + row]);
+  *reinterpret_cast<float4*>(p.o + (long)b * p.o_bs + (long)head * p.o_hs + (long)(q0 + row) * p.o_ts + dv0 + c4) =
+      make_float4(v.x * il, v.y * il, v.z * il, v.w * il);
+}
+
+static bool attn_two_pass_ok(const AttnP& p) {
+  return p.mode == 0 && p.D == 512 && p.Dv == 512 && p.Lq == 256 && p.Lk == 256 && !p.q_amax && p.o_ts % 4 == 0 && p.o_bs % 4 == 0 &&
+         p.o_hs % 4 == 0 && (uintptr_t)p.o % 16 == 0 && !(p.flags & KEEP_ATTN_NO_TWO_PASS);
+}
+static long attn_two_pass_bytes(const AttnP& p) { return (long)p.B * p.H * p.Lq * p.Lk * 4; }
+
+static int launch_attn_x3_two_pass(const AttnP& p, float* scores, hipStream_t st) {
+  hipLaunchKernelGGL(attn_scores_x3l_kernel, dim3(p.Lk / 32, p.Lq / 32, p.B * p.H), dim3(256), 0, st, p, scores);
+  KEEP_LAUNCH_CHECK("keep_attention(x3, two passes: scores)");
+  hipLaunchKernelGGL(attn_pv_x3l_kernel, dim3(p.Dv / 32, p.Lq / 32, p.B * p.H), dim3(256), 0, st, p, (const float*)scores);
+  KEEP_LAUNCH_CHECK("keep_attention(x3, two passes: softmax . V)");
+  return KEEP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ x3, small heads, latency form
 // Multi-head attention over at most 256 keys with D = Dv = 64 (the code transformer's nn.MultiheadAttention, KA:385-439: 8 heads x 256
 // tokens): attn_x3_kernel walks the 8 key tiles of a (head, 128-query) block one after the other (stage -> barrier -> MFMA -> barrier:
@@ -2221,6 +2375,8 @@ extern "C" int64_t keep_attention_workspace_bytes(const keep_attention_args* a_i
   if (!x3_ok) return 0;
   AttnP p;
   p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.D = a->D; p.Dv = a->Dv; p.flags = a->flags;
+  p.mode = a->mode; p.q_amax = a->q_amax; p.o = a->o; p.o_ts = a->o_ts; p.o_bs = a->o_bs; p.o_hs = a->o_hs;
+  if (attn_two_pass_ok(p)) return attn_two_pass_bytes(p);      // the score matrix between the two launches
   return attn_pack_bytes(p, a->mma);
 }
 
@@ -2296,6 +2452,8 @@ extern "C" int32_t keep_attention(const keep_attention_args* a_in, void* stream)
       (a->k_ts % 4 == 0) && (a->k_bs % 4 == 0) && (a->k_hs % 4 == 0) && ((uintptr_t)a->q % 16 == 0) &&
       ((uintptr_t)a->k % 16 == 0) && !(a->flags & KEEP_ATTN_NO_X3)) {
     if (attn_small_ok(p)) return launch_attn_x3_small(p, st);
+    if (attn_two_pass_ok(p) && a->workspace && a->workspace_bytes >= attn_two_pass_bytes(p) && (uintptr_t)a->workspace % 16 == 0)
+      return launch_attn_x3_two_pass(p, (float*)a->workspace, st);
     if (a->Lq <= 32) {
       if (dvt == 1) return launch_attn_x3<1, 1>(p, st);
       if (dvt == 2) return launch_attn_x3<1, 2>(p, st);

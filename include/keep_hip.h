@@ -89,6 +89,7 @@ extern "C" {
 #define KEEP_ATTN_NO_PACK (1u << 0)   /* x3: never pre-pack K / V^T (keep_attention_workspace_bytes answers 0) */
 #define KEEP_ATTN_NO_SFULL2 (1u << 1) /* x3, D = 512: the 128-query kernel instead of the 32-query one */
 #define KEEP_ATTN_NO_X3 (1u << 2)     /* KEEP_MMA_X3 calls run on the exact-f32 kernel */
+#define KEEP_ATTN_NO_TWO_PASS (1u << 4) /* x3, D = Dv = 512, 256 tokens: attn_x3_sfull2_kernel instead of scores + softmax.V in the latency form */
 #define KEEP_ATTN_NO_SMALL (1u << 3)  /* x3, D = Dv = 64, <= 256 keys: attn_x3_kernel instead of the latency form (attn_x3_small_kernel) */
 
 /* padding mode of keep_conv2d */

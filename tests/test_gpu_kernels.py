@@ -1518,3 +1518,33 @@ def test_attention_x3_small_heads_latency_form(B, H, Lq, Lk, amp, peak):
     assert not torch.equal(o_new, o_old) or Lq < 64, 'both flag settings ran the same kernel'
     for b0 in range(B):
         assert torch.equal(run(0, b0, 1)[0], o_new[b0]), f'batch element {b0} differs between B = 1 and B = {B}'
+
+
+def test_attention_x3_two_pass_latency_form():
+    """attn_scores_x3l_kernel + attn_pv_x3l_kernel (the VQGAN AttnBlock on a 16 x 16 map, VQ:219-243: d = 512, 256 tokens) on q|k|v packed
+    in one [tokens, 3C] buffer like the qkv projection writes them: against float64 (not worse than attn_x3_sfull2_kernel), peaked
+    scores, and bit-equal between one image per launch and all of them."""
+    B, H, L_, D = 3, 1, 256, 512
+    for peak in (3.0, 40.0):
+        qkv = rnd(f'tp_qkv{peak}', (B, L_, 3 * D))
+        q4, k4, v4 = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        scale = D ** -0.5 * peak
+        ref = torch.softmax(torch.einsum('bqd,bkd->bqk', q4.double(), k4.double()) * scale, -1) @ v4.double()
+        qd = dev(qkv)
+
+        def run(flags, b0=0, nb=B):
+            o = torch.empty((nb, L_, D), device='cuda')
+            ops.DEFAULT.attn_flags = flags
+            x = qd[b0:b0 + nb]
+            s3 = (L_ * 3 * D, 3 * D, 0)
+            ops.attention(x, ops.offset(x, D), ops.offset(x, 2 * D), o, B=nb, H=H, Lq=L_, Lk=L_, D=D, Dv=D, scale=scale,
+                          q_str=s3, k_str=s3, v_str=s3, o_str=(L_ * D, D, 0), mma=L.MMA_X3)
+            return o
+        o_new, o_old = run(0), run(L.ATTN_NO_TWO_PASS)
+        assert torch.isfinite(o_new).all()
+        sc = ref.abs().max().item()
+        e_new, e_old = err64(o_new, ref), err64(o_old, ref)
+        assert e_new <= max(2.0 * e_old, 2e-6 * sc), f'two passes {e_new:.3e} vs attn_x3_sfull2_kernel {e_old:.3e} (scale {sc:.3g})'
+        assert not torch.equal(o_new, o_old), 'both flag settings ran the same kernel'
+        for b0 in range(B):
+            assert torch.equal(run(0, b0, 1)[0], o_new[b0]), f'batch element {b0} differs between B = 1 and B = {B}'

@@ -794,7 +794,10 @@ __device__ __forceinline__ void x3_gather_epilogue(const ConvP& p, f32x16 (&acc)
 // ONE: 1x1 stride-1 unpadded convolution == a row-major GEMM: the A rows are fetched with block-relative buffer loads (rows
 // beyond M read zeros through the descriptor's range check), no im2col index arithmetic.
 // KSL: canonical K slices (p.kslice_steps > 0, keep_gemm_x3l.hip) -- its own instantiations: the slice totals cost TM * TN * 16 registers.
-template <int WGM, int WGN, int TM, int TN, bool PLAIN, bool ONE = false, bool KSL = false>
+// DEEP: the 64 x 64 tile's register prefetch ring (below); the im2col form at large row counts runs without it (bit-neutral).
+// KAL: KSL with slices of exactly PD = 4 K steps (K = 512, 1024: every token GEMM of the code transformer) -- slice boundaries are compile-time
+// positions of the unrolled ring: the first MFMA of a slice takes the inline constant 0 as C, the fold is 16 adds, nothing is zeroed.
+template <int WGM, int WGN, int TM, int TN, bool PLAIN, bool ONE = false, bool KSL = false, bool DEEP = true, bool KAL = false>
 __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
   constexpr int BM = WGM * TM * 32;
   constexpr int BN = WGN * TN * 32;
@@ -1025,7 +1028,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
   const int a_f0 = (wm * TM * 32 + l31) * XP + lhi * 8;
   const int b_f0 = (wn * TN * 32 + l31) * XP + lhi * 8;
 
-  auto mma_step = [&](int buf) {
+  auto mma_step = [&](int buf, bool zc = false) {
     if (XG_ABL == 3) return;
     const _Float16* Ab = As[buf];
     const _Float16* Bb = Bs[buf];
@@ -1046,7 +1049,14 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          MMA_X3(acc[i][j], ah[i], al[i], bh[j], bl[j])
+          if (KAL && zc && ks == 0) {
+            const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], z16, 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          } else {
+            MMA_X3(acc[i][j], ah[i], al[i], bh[j], bl[j])
+          }
         }
     }
   };
@@ -1056,7 +1066,8 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
     // a two-deep ring measured 2119 vs 2045 us on 256 -> 1024 at 0.62 M rows) keep PD = 1.  The 64 x 64 tile serves the launches that
     // CANNOT fill the chip with blocks (token GEMMs of <= 4096 rows, stride-2 convolutions of one clip): their K loop is a chain of
     // dependent L2 / HBM round trips (20 us for 4096 x 512 x 512 whatever the FLOPs), and a step in flight costs only 18 VGPRs there.
-    constexpr int PD = (TM * TN == 1) ? (PLAIN ? 4 : 2) : 1;      // (the prologue form carries 16 scale / shift registers per step in flight)
+    // The im2col form at LARGE row counts (16 x 512 x 512 stride-2: 656 -> 735 us with the ring: 4 -> 3 blocks per CU) keeps PD = 1 (DEEP = false).
+    constexpr int PD = (TM * TN == 1 && DEEP) ? (PLAIN ? 4 : 2) : 1;      // (the prologue form carries 16 scale / shift registers per step in flight)
     StepRegs R[PD];
 #pragma unroll
     for (int u = 0; u < PD; ++u)
@@ -1075,8 +1086,28 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvP p) {
         const int s = s0 + u;
         if (s < s_end) {      // (uniform)
           if (s + PD < s_end) fetch(s + PD, R[u]);            // R[u] held step s: staged one iteration ago
-          mma_step(buf);
-          if (KSL && --ksl_left == 0) {
+          if (KAL) {
+            mma_step(buf, u == 0);
+            if (u == PD - 1) {
+              if (ksl_first) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                  for (int j = 0; j < TN; ++j) tot[KSL ? i : 0][KSL ? j : 0] = acc[i][j];
+              } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                  for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tot[KSL ? i : 0][KSL ? j : 0][r] += acc[i][j][r];
+              }
+              ksl_first = false;
+            }
+          } else {
+            mma_step(buf);
+          }
+          if (KSL && !KAL && --ksl_left == 0) {
             ksl_left = p.kslice_steps;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -1562,12 +1593,16 @@ int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int tile, hipStre
   // 1x1 stride-1 unpadded convolutions (token GEMMs): block-relative buffer-load fetch, no im2col index arithmetic
   const bool one = keep_conv_x3_gather_is_gemm(a);
 #define KEEP_LAUNCH_GX(A, B, C, D)                                                                 \
-  if (p.kslice_steps > 0 && plain)                                                                 \
+  if (p.kslice_steps == 4 && plain && C * D == 1 && steps % 4 == 0)                                \
+    hipLaunchKernelGGL((conv_x3_kernel<A, B, C, D, true, true, true, true, C * D == 1>), grid, block, 0, st, p); \
+  else if (p.kslice_steps > 0 && plain)                                                            \
     hipLaunchKernelGGL((conv_x3_kernel<A, B, C, D, true, true, true>), grid, block, 0, st, p);     \
   else if (p.kslice_steps > 0)                                                                     \
     hipLaunchKernelGGL((conv_x3_kernel<A, B, C, D, false, true, true>), grid, block, 0, st, p);    \
   else if (plain && one)                                                                           \
     hipLaunchKernelGGL((conv_x3_kernel<A, B, C, D, true, true>), grid, block, 0, st, p);           \
+  else if (plain && C * D == 1 && M > 262144)                                                      \
+    hipLaunchKernelGGL((conv_x3_kernel<A, B, C, D, true, false, false, false>), grid, block, 0, st, p); \
   else if (plain)                                                                                  \
     hipLaunchKernelGGL((conv_x3_kernel<A, B, C, D, true, false>), grid, block, 0, st, p);          \
   else if (one)                                                                                    \

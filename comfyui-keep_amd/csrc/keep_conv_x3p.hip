@@ -1,0 +1,279 @@
+// keep_conv2d, KEEP_MMA_X3, 3x3 stride 1 on SMALL maps with a split-K plan, FEW images per launch: the partial producer in small tiles.
+//
+// The 16 x 16 stages of the frame recurrence (VQ ResBlocks of 512 channels, KA:1062-1127) run split 4 .. 8 ways over the input channels
+// at every batch size (plan_conv: a per-image rule), conv3x3_halo_x3_kernel<16> writing one partial per (256-pixel tile, 64 couts, z)
+// block and conv_splitk_reduce_kernel adding them in z order.  With ONE clip in flight that is 32 blocks of four waves walking 8
+// chunks x 108 MFMAs each: 40 us for 1.2 GFLOP on a chip with 1024 SIMDs.  This kernel produces THE SAME partials -- the same channel
+// chunks per z (halo_decode's rule), per chunk the same prologue arithmetic (GroupNorm affine, x3-grade swish, range scale, split) and
+// the nine taps in the same order with the same three-MFMA product into a zero-initialised accumulator: bit-identical values in the
+// same workspace layout, the reducer is unchanged -- from blocks of 64 pixels (4 x 16) x 64 couts: four times the blocks, each wave
+// ONE 32 x 32 tile (27 MFMAs per chunk).  Operand staging is the halo kernel's: the fp32 halo (6 x 18 pixels x 16 channels) goes
+// register -> VALU -> LDS rows [hi16 | lo16 | pad], the 9 x 64 pre-split weight rows go L2 -> register -> LDS in the DMA kernel's image (64-byte rows, XOR-swizzled
+// 16-byte slots); three operand stages in LDS: a chunk costs one barrier and its loads are issued two chunks ahead (a wave's 27
+// MFMAs per chunk are shorter than an HBM round trip of the weights: with two stages every chunk waited ~1.5 us for its DMA).
+// keep_conv2d_x3_halo picks it from the REAL item count (bit-neutral); large batches keep the 256-pixel kernel.
+#include "keep_conv_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define XPP 40                         // fp16 per halo row: 16 hi + 16 lo + 8 pad (80 B), as in keep_conv_x3.hip
+#define XP_HW 18                       // halo width of a 16-column tile
+#define XP_HPIX (6 * XP_HW)            // 4 + 2 rows
+#define XP_HBYTES (XP_HPIX * XPP * 2)  // 8640
+#define XP_WBYTES (9 * 64 * 64)        // 36864: 9 taps x 64 couts x 64 B
+
+#define XP_ST 3                        // operand stages in LDS: the loads of chunk c + 2 are issued before the MFMAs of chunk c
+// NCH > 0: the block's chunk count, known at compile time -- the ring is straight-line code and the compiler's wait counts are exact (inside
+// a loop it orders every LDS read of a stage behind vmcnt(0): the DMA that filled the stage came through the back edge); 0: any count.
+template <int PRO, bool HAS_SC, int NCH>
+__global__ __launch_bounds__(256) void conv3x3_x3p_kernel(ConvP p, int tiles_x, int tiles_y, int ncb, int n_items) {
+  // one LDS object per weight stage: the compiler's wait-count pass orders a ds_read behind every LDS-DMA write that MAY alias it -- with
+  // one array the fragment reads of stage u waited (vmcnt(1)) for the DMA of stage u + 2, i.e. for the whole prefetch distance
+  __shared__ __attribute__((aligned(1024))) unsigned char ws0[XP_WBYTES];
+  __shared__ __attribute__((aligned(1024))) unsigned char ws1[XP_WBYTES];
+  __shared__ __attribute__((aligned(1024))) unsigned char ws2[XP_WBYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char hs_raw[XP_ST * XP_HBYTES];
+  static_assert(XP_ST == 3, "three weight stages");
+#define XP_WS(i) ((i) == 0 ? ws0 : ((i) == 1 ? ws1 : ws2))
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int ph = wave >> 1, chf = wave & 1;      // pixel rows {2 ph, 2 ph + 1} of the tile, cout half
+  const int g = tid & 3;
+  // item -> (z, image, tile, cout block): the pixel tiles of one (cout block, z) -- they share the weight rows -- are neighbours in one XCD
+  const int lid = xcd_remap(blockIdx.x, n_items);
+  const int npt = p.N * tiles_y * tiles_x;
+  const int pt = lid % npt, cbz = lid / npt;
+  const int cb = cbz % ncb, z = cbz / ncb;
+  const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, n = pt / (tiles_x * tiles_y);
+  const int oy0 = ty * 4, ox0 = tx * 16, n0 = cb * 64;
+  const int nchunks = p.Cin >> 4;
+  const int per = (nchunks + p.split_k - 1) / p.split_k;      // halo_decode<TW, 4>
+  const int ch_begin = z * per, ch_end = min(nchunks, ch_begin + per);
+  constexpr bool has_pro = HAS_SC || PRO != KEEP_PRO_NONE;
+
+  float in_s = 1.f, in_inv = 1.f;
+  if (p.in_amax) x3_range_scale(p.in_amax[n], in_s, in_inv);
+  int h_voff[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int hp = (tid >> 2) + k * 64;
+    h_voff[k] = -16;
+    if (hp < XP_HPIX) {
+      const int hy = hp / XP_HW, hx = hp - hy * XP_HW;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) h_voff[k] = ((iy * p.W + ix) * p.in_ld + g * 4) * 4;
+    }
+  }
+  auto make_rsrc = [&](const void* ptr, int bytes) {
+    const unsigned long long b = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(p.in + (long)n * p.H * p.W * p.in_ld, p.H * p.W * p.in_ld * 4);
+  const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.wx3, p.Cout * 9 * p.Cin * 4);
+  const long sc_off = (long)n * p.Cin + g * 4;
+  // weight DMA (conv3x3_halo_x3_kernel, WDMA): instruction q = 9 wave + t fills LDS rows q * 16 .. + 15 = tap q / 4, couts (q % 4) * 16 + lane / 4;
+  // the lane's physical slot lane & 3 holds logical piece (lane & 3) ^ ((lane >> 4) & 3) of its 64-byte row
+  int dma_voff[4];
+  {
+    const int lp = (lane & 3) ^ ((lane >> 4) & 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = n0 + ((wave + j) & 3) * 16 + (lane >> 2);
+      dma_voff[j] = co < p.Cout ? co * 9 * p.Cin * 4 + lp * 16 : -16;
+    }
+  }
+  float4 hregs[XP_ST][2];
+  u32x4 wregs[XP_ST][9];      // weight pieces in flight (register -> ds_write_b128 in stage(): plain loads, so the compiler's wait counts are exact --
+                              // behind LDS-DMA writes it ordered every LDS access with vmcnt(0), i.e. behind the whole prefetch distance)
+  float4 sc4s[XP_ST], sh4s[XP_ST];
+#pragma unroll
+  for (int i = 0; i < XP_ST; ++i) {
+    sc4s[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+    sh4s[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  auto fetch = [&](int ch, int buf) {
+    float4 (&hreg)[2] = hregs[buf];
+    float4 &sc4 = sc4s[buf], &sh4 = sh4s[buf];
+    const int c0 = ch << 4;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, h_voff[k], c0 * 4, 0);
+      hreg[k] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+    if (HAS_SC) {
+      sc4 = *reinterpret_cast<const float4*>(p.pro_scale + sc_off + c0);
+      sh4 = *reinterpret_cast<const float4*>(p.pro_shift + sc_off + c0);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {      // the piece LDS-DMA instruction q = 9 wave + t of conv3x3_halo_x3_kernel would move for this lane
+      const int q = __builtin_amdgcn_readfirstlane(wave) * 9 + t;
+      wregs[buf][t] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, dma_voff[t & 3], ((q >> 2) * p.Cin + c0) * 4, 0);
+    }
+  };
+  // GroupNorm affine + activation + range scale + split of this thread's pieces: the expressions of conv3x3_halo_x3_kernel::stage
+  auto stage = [&](int buf) {
+    const float4 (&hreg)[2] = hregs[buf];
+    const float4 sc4 = sc4s[buf], sh4 = sh4s[buf];
+    {
+      unsigned char* wbase = XP_WS(buf);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int q = __builtin_amdgcn_readfirstlane(wave) * 9 + t;
+        *reinterpret_cast<u32x4*>(wbase + q * 1024 + lane * 16) = wregs[buf][t];
+      }
+    }
+    _Float16* Hs = reinterpret_cast<_Float16*>(hs_raw + buf * XP_HBYTES);
+    const f32x2 sc01 = {sc4.x, sc4.y}, sc23 = {sc4.z, sc4.w}, sh01 = {sh4.x, sh4.y}, sh23 = {sh4.z, sh4.w};
+    const f32x2 nsc01 = sc01 * -1.4426950408889634f, nsc23 = sc23 * -1.4426950408889634f;
+    const f32x2 nsh01 = sh01 * -1.4426950408889634f, nsh23 = sh23 * -1.4426950408889634f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int hp = (tid >> 2) + k * 64;
+      if (hp < XP_HPIX) {
+        _Float16* dst = &Hs[hp * XPP + g * 4];
+        if (!has_pro || h_voff[k] >= 0) {
+          f32x2 v01 = {hreg[k].x, hreg[k].y}, v23 = {hreg[k].z, hreg[k].w};
+          if (has_pro) {
+            const f32x2 y01 = v01 * sc01 + sh01, y23 = v23 * sc23 + sh23;
+            if (PRO == KEEP_PRO_SWISH) {
+              const f32x2 z01 = v01 * nsc01 + nsh01, z23 = v23 * nsc23 + nsh23;
+              f32x2 d01 = {__builtin_amdgcn_exp2f(z01.x), __builtin_amdgcn_exp2f(z01.y)};
+              f32x2 d23 = {__builtin_amdgcn_exp2f(z23.x), __builtin_amdgcn_exp2f(z23.y)};
+              d01 += 1.0f;
+              d23 += 1.0f;
+              const f32x2 r01 = {__builtin_amdgcn_rcpf(d01.x), __builtin_amdgcn_rcpf(d01.y)};
+              const f32x2 r23 = {__builtin_amdgcn_rcpf(d23.x), __builtin_amdgcn_rcpf(d23.y)};
+              v01 = y01 * r01;
+              v23 = y23 * r23;
+            } else {
+              v01 = y01;
+              v23 = y23;
+            }
+          }
+          if (PRO == KEEP_PRO_NONE && p.in_amax) {
+            v01 *= in_s;
+            v23 *= in_s;
+          }
+          const f16x2 h01 = __builtin_convertvector(v01, f16x2), h23 = __builtin_convertvector(v23, f16x2);
+          const f16x2 l01 = __builtin_convertvector(v01 - __builtin_convertvector(h01, f32x2), f16x2);
+          const f16x2 l23 = __builtin_convertvector(v23 - __builtin_convertvector(h23, f32x2), f16x2);
+          const f16x4 hi = {h01.x, h01.y, h23.x, h23.y}, lo = {l01.x, l01.y, l23.x, l23.y};
+          *reinterpret_cast<f16x4*>(dst) = hi;
+          *reinterpret_cast<f16x4*>(dst + 16) = lo;
+        } else {      // zero padding applies to the normalised + activated tensor
+          const f16x4 zero = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+          *reinterpret_cast<f16x4*>(dst) = zero;
+          *reinterpret_cast<f16x4*>(dst + 16) = zero;
+        }
+      }
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int a_base = ((2 * ph + (l31 >> 4)) * XP_HW + (l31 & 15)) * XPP + lhi * 8;
+  const int b_base = l31 * 32 + ((lhi ^ ((l31 >> 2) & 3)) * 8);
+  auto mma = [&](int buf) {
+    const _Float16* Ws = reinterpret_cast<const _Float16*>(XP_WS(buf));
+    const _Float16* Hs = reinterpret_cast<const _Float16*>(hs_raw + buf * XP_HBYTES);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const _Float16* src = &Hs[a_base + (kh * XP_HW + kw) * XPP];
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(src), al = *reinterpret_cast<const f16x8*>(src + 16);
+        const int o = b_base + ((kh * 3 + kw) * 64 + chf * 32) * 32;
+        const f16x8 bh = *reinterpret_cast<const f16x8*>(&Ws[o]), bl = *reinterpret_cast<const f16x8*>(&Ws[o ^ 16]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+      }
+  };
+
+// (a __syncthreads() carries vmcnt(0): it would wait for the loads of chunk c + 2 as well; LDS writes are complete at lgkmcnt(0))
+#define XP_BARRIER()                  \
+  __builtin_amdgcn_s_waitcnt(0xc07f); \
+  __builtin_amdgcn_s_barrier();
+  if (NCH > 0 || ch_begin < ch_end) {
+    const bool two = NCH > 0 ? NCH > 1 : ch_begin + 1 < ch_end;
+    fetch(ch_begin, 0);
+    if (two) fetch(ch_begin + 1, 1);
+    stage(0);
+    XP_BARRIER()
+    if (NCH > 0) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {      // chunk ch_begin + c lives in stage c % XP_ST
+        if (c + 2 < NCH) fetch(ch_begin + c + 2, (c + 2) % XP_ST);
+        mma(c % XP_ST);
+        if (c + 1 < NCH) {
+          stage((c + 1) % XP_ST);
+          XP_BARRIER()
+        }
+      }
+    } else {
+      for (int c0 = ch_begin; c0 < ch_end; c0 += XP_ST) {
+#pragma unroll
+        for (int u = 0; u < XP_ST; ++u) {      // chunk c0 + u lives in stage u (the ring advances by XP_ST per outer iteration)
+          const int ch = c0 + u;
+          if (ch < ch_end) {
+            if (ch + 2 < ch_end) fetch(ch + 2, (u + 2) % XP_ST);
+            mma(u);
+            if (ch + 1 < ch_end) {
+              stage((u + 1) % XP_ST);
+            }
+            XP_BARRIER()
+          }
+        }
+      }
+    }
+  }
+#undef XP_BARRIER
+  // the partial of this (tile, cout block, z): ws[z][m][co], scaled like the halo kernel's split-K epilogue (v * asc)
+  const float asc = p.acc_scale * in_inv;
+  const int hw_o = p.Ho * p.Wo;
+  const int co = n0 + chf * 32 + l31;
+  if (co < p.Cout) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const long m = (long)n * hw_o + (oy0 + 2 * ph + (rr >> 4)) * p.Wo + ox0 + (rr & 15);
+      p.ws[((long)z * p.M + m) * p.Cout + co] = acc[r] * asc;
+    }
+  }
+}
+
+// Geometry / epilogue this producer covers (everything else of a split-K plan stays on conv3x3_halo_x3_kernel: same partials).
+bool keep_conv_x3p_ok(const keep_conv2d_args* a, const ConvP& p, int split_k) {
+  const long items_old = (long)a->N * ((a->Ho * a->Wo) / 256) * ((a->Cout + 63) / 64) * split_k;
+  return split_k > 1 && !a->upsample && a->pad_mode == KEEP_PAD_ZERO && a->Ho % 4 == 0 && a->Wo % 16 == 0 && (a->Ho * a->Wo) % 256 == 0 &&
+         a->Cout % 64 == 0 && a->Cin % 16 == 0 && items_old <= 128 && a->workspace &&
+         (a->pro_act == KEEP_PRO_NONE || (a->pro_act == KEEP_PRO_SWISH && p.fast)) && !(a->flags & KEEP_CONV_NO_SMALL_PARTIALS);
+}
+
+int keep_conv2d_x3_partials(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
+  const int tiles_x = a->Wo / 16, tiles_y = a->Ho / 4, ncb = a->Cout / 64;
+  const int n_items = a->N * tiles_x * tiles_y * ncb * p.split_k;
+  const bool sc = a->pro_scale != nullptr;
+  const int nchunks = a->Cin / 16, per = (nchunks + p.split_k - 1) / p.split_k;
+  const int nch = (nchunks % p.split_k == 0 && (per == 4 || per == 8 || per == 16)) ? per : 0;      // every z walks `per` chunks
+#define KEEP_LAUNCH_XP(PROV, SCV)                                                                                                     \
+  {                                                                                                                                   \
+    if (nch == 4) hipLaunchKernelGGL((conv3x3_x3p_kernel<PROV, SCV, 4>), dim3(n_items), dim3(256), 0, st, p, tiles_x, tiles_y, ncb, n_items);        \
+    else if (nch == 8) hipLaunchKernelGGL((conv3x3_x3p_kernel<PROV, SCV, 8>), dim3(n_items), dim3(256), 0, st, p, tiles_x, tiles_y, ncb, n_items);   \
+    else if (nch == 16) hipLaunchKernelGGL((conv3x3_x3p_kernel<PROV, SCV, 16>), dim3(n_items), dim3(256), 0, st, p, tiles_x, tiles_y, ncb, n_items); \
+    else hipLaunchKernelGGL((conv3x3_x3p_kernel<PROV, SCV, 0>), dim3(n_items), dim3(256), 0, st, p, tiles_x, tiles_y, ncb, n_items);                 \
+  }
+  if (a->pro_act == KEEP_PRO_SWISH && sc) KEEP_LAUNCH_XP(KEEP_PRO_SWISH, true)
+  else if (a->pro_act == KEEP_PRO_SWISH) KEEP_LAUNCH_XP(KEEP_PRO_SWISH, false)
+  else if (sc) KEEP_LAUNCH_XP(KEEP_PRO_NONE, true)
+  else KEEP_LAUNCH_XP(KEEP_PRO_NONE, false)
+#undef KEEP_LAUNCH_XP
+  KEEP_LAUNCH_CHECK("keep_conv2d(halo x3, small-tile partials)");
+  return KEEP_OK;
+}

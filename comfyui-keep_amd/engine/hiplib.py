@@ -22,7 +22,7 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 UPSAMPLE_X2_PHASES = 2
 # keep_conv2d_args.flags / keep_attention_args.flags (include/keep_hip.h): kernel-selection overrides, 0 = the library's choice
 (CONV_NO_COUT4, CONV_NO_C3, CONV_NO_HALO_F32, CONV_NO_HALO_X3, CONV_NO_GATHER_X3, CONV_NO_PLAIN, CONV_NO_FLATK_F32,
- CONV_SMALL_TILES, CONV_X3_EXACT_ACT, CONV_NO_STREAM, CONV_NO_GEMM_LAT, CONV_GEMM_LAT_WAVES, CONV_GEMM_LAT_TILES) = (1 << i for i in range(13))
+ CONV_SMALL_TILES, CONV_X3_EXACT_ACT, CONV_NO_STREAM, CONV_NO_GEMM_LAT, CONV_GEMM_LAT_WAVES, CONV_GEMM_LAT_TILES, CONV_NO_SMALL_PARTIALS) = (1 << i for i in range(14))
 ATTN_NO_PACK, ATTN_NO_SFULL2, ATTN_NO_X3, ATTN_NO_SMALL, ATTN_NO_TWO_PASS = 1, 2, 4, 8, 16
 
 _vp, _i32, _i64, _f32, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32

@@ -84,6 +84,7 @@ extern "C" {
 #define KEEP_CONV_NO_STREAM (1u << 9)    /* x3 3x3: the stage-barrier-MFMA halo kernel instead of the streaming one */
 #define KEEP_CONV_NO_GEMM_LAT (1u << 10) /* x3 GEMM form with <= 256 rows per image: one sequential sum (conv_x3_kernel) instead of canonical K slices */
 #define KEEP_CONV_GEMM_LAT_WAVES (1u << 11) /* canonical K slices: the one-wave-per-slice kernel (gemm_x3l_kernel) whatever the row count (same bits) */
+#define KEEP_CONV_NO_SMALL_PARTIALS (1u << 13) /* x3 3x3 split-K plans with few images: conv3x3_halo_x3_kernel's 256-pixel blocks instead of conv3x3_x3p_kernel (same partials) */
 #define KEEP_CONV_GEMM_LAT_TILES (1u << 12) /* canonical K slices: conv_x3_kernel with slice totals whatever the row count (same bits) */
 /* keep_attention_args.flags (v18) */
 #define KEEP_ATTN_NO_PACK (1u << 0)   /* x3: never pre-pack K / V^T (keep_attention_workspace_bytes answers 0) */

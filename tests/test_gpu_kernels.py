@@ -1548,3 +1548,44 @@ def test_attention_x3_two_pass_latency_form():
         assert not torch.equal(o_new, o_old), 'both flag settings ran the same kernel'
         for b0 in range(B):
             assert torch.equal(run(0, b0, 1)[0], o_new[b0]), f'batch element {b0} differs between B = 1 and B = {B}'
+
+
+@pytest.mark.parametrize("n,h,wd,cin,cout,sk,gn,res,ranged", [
+    (1, 16, 16, 512, 512, None, True, True, False),      # the 16 x 16 ResBlock convolutions of the frame recurrence (plan: split 4)
+    (2, 16, 16, 256, 512, 4, False, False, True),        # no prologue: probed range scale per image
+    (1, 16, 16, 1024, 512, None, True, False, False),    # CFT encode_enc conv1 on cat[enc, dec]
+    (1, 32, 32, 256, 256, 4, True, True, False),         # a wide map under a latency-profile split
+    (1, 16, 16, 80, 64, 2, True, False, False),          # five chunks over two splits: uneven channel ranges
+    (1, 20, 16, 64, 128, 2, False, True, False)])        # 20 rows: five 4-row tiles, a map the 256-pixel kernel cannot tile -> never selected
+def test_conv_x3_small_tile_partials_are_the_256_pixel_kernels(n, h, wd, cin, cout, sk, gn, res, ranged):
+    """conv3x3_x3p_kernel (keep_conv_x3p.hip): the split-K partials of a 3x3 x3 convolution from 64-pixel blocks when few images are in
+    flight -- BIT-EQUAL to conv3x3_halo_x3_kernel's 256-pixel blocks (KEEP_CONV_NO_SMALL_PARTIALS): same channel ranges, same prologue
+    arithmetic, same MFMA order, same reducer."""
+    if (h * wd) % 256:
+        pytest.skip('not a map of the halo path')
+    x = rnd('sp_x', (n, cin, h, wd), 2.0) + 0.3
+    if ranged:
+        x = x * torch.tensor([1.0, 900.0][:n]).view(-1, 1, 1, 1)
+    w, b = rnd('sp_w', (cout, cin, 3, 3), 0.05), rnd('sp_b', (cout,))
+    r = rnd('sp_r', (n, cout, h, wd)) if res else None
+    xd, wp, bd = dev(nhwc(x)), pack(w), dev(b)
+    wx3, asc = x3w(wp)
+    pro = None
+    if gn:
+        pro = ops.norm_affine(xd, dev(rnd('sp_g', (cin,)) * 0.2 + 1), dev(rnd('sp_bt', (cin,)) * 0.2), 16, 1e-6)
+    kw = dict(mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, pro=pro, pro_act=L.PRO_SWISH if gn else L.PRO_NONE, split_k=sk,
+              residual=None if r is None else dev(nhwc(r)), bounded=not ranged)
+    outs = []
+    for fl in (0, L.CONV_NO_SMALL_PARTIALS):
+        ops.DEFAULT.flags = fl
+        outs.append(ops.conv(xd, wp, bd, **kw))
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+    # and it is a convolution (fp32-grade)
+    xe = x.double()
+    if gn:
+        xe = xe * pro[0].cpu().double().view(n, cin, 1, 1) + pro[1].cpu().double().view(n, cin, 1, 1)
+        xe = xe * torch.sigmoid(xe)
+    ref = F.conv2d(xe, w.double(), b.double(), padding=1) + (0 if r is None else r.double())
+    scale = F.conv2d(xe.abs(), w.double().abs(), padding=1).flatten(1).max(1).values.view(n, 1, 1, 1)
+    assert bool(((nchw(outs[0]).double().cpu() - ref).abs() <= 3e-6 * scale).all())

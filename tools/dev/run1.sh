@@ -1,5 +1,4 @@
 set -x
 cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "gemm_x3_latency or linear or downsample or conv_x3_gather" 2>&1 | tail -5
-timeout 600 python tools/dev/gemm_lat_bench.py 2>&1 | grep -E " 16:| hw K" | head -8
-timeout 600 python tools/dev/flag_ab.py 16 2>&1 | tail -6
+timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "small_tile_partials or halo or splitk" 2>&1 | tail -8
+timeout 600 python tools/dev/flag_ab.py 1 new=0 old=0x2000 2>&1 | tail -6

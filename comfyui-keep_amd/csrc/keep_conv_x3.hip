@@ -1448,6 +1448,8 @@ bool keep_conv_x3_gather_is_gemm(const keep_conv2d_args* a) {
 }
 
 bool keep_conv_x3p_ok(const keep_conv2d_args* a, const ConvP& p, int split_k);
+bool keep_conv_x3q_ok(const keep_conv2d_args* a, const ConvP& p, int split_k);
+int keep_conv2d_x3_small_full(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 int keep_conv2d_x3_partials(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 bool keep_conv_x3_stream_ok(const keep_conv2d_args* a, const ConvP& p, int split_k);
 int keep_conv2d_x3_stream(const keep_conv2d_args* a, ConvP& p, int n_cu, hipStream_t st);
@@ -1467,6 +1469,7 @@ int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
   const int nchunks = a->Cin / 16;
   if (p.split_k > nchunks) p.split_k = nchunks;
   if (keep_conv_x3p_ok(a, p, p.split_k)) return keep_conv2d_x3_partials(a, p, st);                        // keep_conv_x3p.hip (few images: 64-pixel tiles, same partials)
+  if (keep_conv_x3_stream_ok(a, p, p.split_k) && keep_conv_x3q_ok(a, p, p.split_k)) return keep_conv2d_x3_small_full(a, p, st);      // few items: 64-pixel blocks, the streaming kernel's values
   if (keep_conv_x3_stream_ok(a, p, p.split_k)) return keep_conv2d_x3_stream(a, p, x3_num_cu(), st);      // keep_conv_x3s.hip
   const bool wide = (a->Ho % 8 == 0 && a->Wo % 32 == 0);
   const int tw = wide ? 32 : 16, th = 256 / tw;

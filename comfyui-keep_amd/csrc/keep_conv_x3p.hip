@@ -248,6 +248,216 @@ __global__ __launch_bounds__(256) void conv3x3_x3p_kernel(ConvP p, int tiles_x, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ un-split plans: the whole convolution
+// The same blocks for plans WITHOUT split-K on wide maps (32 x 32 .. 128 x 128 of one clip: 16 .. 128 items of conv3x3_halo_x3s_kernel on
+// 256 CUs, each wave 108 MFMAs per chunk): this kernel reproduces THAT kernel's values -- its conversion arithmetic (fma(v, sc, sh);
+// exp2(fma(y, -log2 e, pad)); + 1; rcp; y * r; hi = f16(y), lo = f16(y - hi)), its product order (a_lo b_hi, a_hi b_hi, a_hi b_lo),
+// chunks and taps in order, e = fma(acc, acc_scale, bias) (+ residual), the per-image max|out| (a maximum: order-free) -- and
+// conv_stats_replica_kernel (keep_conv_x3s.hip) re-reads the written tile in the streaming kernel's epilogue order for the GroupNorm
+// partials.  Bit-equal outputs and statistics; the launch follows the REAL item count.
+template <int PRO, bool AFF, int NCH>
+__global__ __launch_bounds__(256) void conv3x3_x3q_kernel(ConvP p, int tiles_x, int tiles_y, int ncb, int n_items) {
+  static_assert(AFF || PRO == KEEP_PRO_NONE, "an activation prologue comes with its GroupNorm affine");
+  __shared__ __attribute__((aligned(1024))) unsigned char ws0[XP_WBYTES];
+  __shared__ __attribute__((aligned(1024))) unsigned char ws1[XP_WBYTES];
+  __shared__ __attribute__((aligned(1024))) unsigned char ws2[XP_WBYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char hs_raw[XP_ST * XP_HBYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int ph = wave >> 1, chf = wave & 1;
+  const int g = tid & 3;
+  const int lid = xcd_remap(blockIdx.x, n_items);
+  const int npt = p.N * tiles_y * tiles_x;
+  const int pt = lid % npt, cb = lid / npt;
+  const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, n = pt / (tiles_x * tiles_y);
+  const int oy0 = ty * 4, ox0 = tx * 16, n0 = cb * 64;
+  const int nch = p.Cin >> 4;
+
+  float in_s = 1.f, in_inv = 1.f;
+  if (p.in_amax) x3_range_scale(p.in_amax[n], in_s, in_inv);
+  const float rs = (PRO == KEEP_PRO_NONE && p.in_amax) ? in_s : 1.f;
+  int h_voff[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int hp = (tid >> 2) + k * 64;
+    h_voff[k] = -16;
+    if (hp < XP_HPIX) {
+      const int hy = hp / XP_HW, hx = hp - hy * XP_HW;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) h_voff[k] = ((iy * p.W + ix) * p.in_ld + g * 4) * 4;
+    }
+  }
+  auto make_rsrc = [&](const void* ptr, int bytes) {
+    const unsigned long long b = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(p.in + (long)n * p.H * p.W * p.in_ld, p.H * p.W * p.in_ld * 4);
+  const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.wx3, p.Cout * 9 * p.Cin * 4);
+  const long sc_off = (long)n * p.Cin + g * 4;
+  int dma_voff[4];
+  {
+    const int lp = (lane & 3) ^ ((lane >> 4) & 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = n0 + ((wave + j) & 3) * 16 + (lane >> 2);
+      dma_voff[j] = co < p.Cout ? co * 9 * p.Cin * 4 + lp * 16 : -16;
+    }
+  }
+  float4 hregs[XP_ST][2];
+  u32x4 wregs[XP_ST][9];
+  float4 sc4s[XP_ST], sh4s[XP_ST];
+#pragma unroll
+  for (int i = 0; i < XP_ST; ++i) {
+    sc4s[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+    sh4s[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  auto fetch = [&](int ch, int buf) {
+    const int c0 = ch << 4;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, h_voff[k], c0 * 4, 0);
+      hregs[buf][k] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+    if (AFF) {
+      sc4s[buf] = *reinterpret_cast<const float4*>(p.pro_scale + sc_off + c0);
+      sh4s[buf] = *reinterpret_cast<const float4*>(p.pro_shift + sc_off + c0);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int q = __builtin_amdgcn_readfirstlane(wave) * 9 + t;
+      wregs[buf][t] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, dma_voff[t & 3], ((q >> 2) * p.Cin + c0) * 4, 0);
+    }
+  };
+  auto stage = [&](int buf) {      // conv3x3_halo_x3s_kernel::conv_step, all steps of a piece at once
+    {
+      unsigned char* wbase = XP_WS(buf);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int q = __builtin_amdgcn_readfirstlane(wave) * 9 + t;
+        *reinterpret_cast<u32x4*>(wbase + q * 1024 + lane * 16) = wregs[buf][t];
+      }
+    }
+    _Float16* Hs = reinterpret_cast<_Float16*>(hs_raw + buf * XP_HBYTES);
+    const float csc[4] = {sc4s[buf].x, sc4s[buf].y, sc4s[buf].z, sc4s[buf].w}, csh[4] = {sh4s[buf].x, sh4s[buf].y, sh4s[buf].z, sh4s[buf].w};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int hp = (tid >> 2) + k * 64;
+      if (hp < XP_HPIX) {
+        const float hv[4] = {hregs[buf][k].x, hregs[buf][k].y, hregs[buf][k].z, hregs[buf][k].w};
+        const float padf = (AFF && h_voff[k] < 0) ? 1e30f : 0.f;
+        float cv[4], cw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          cv[j] = AFF ? __builtin_fmaf(hv[j], csc[j], csh[j]) : hv[j] * rs;
+          if (PRO == KEEP_PRO_SWISH) {
+            cw[j] = __builtin_fmaf(cv[j], -1.4426950408889634f, padf);
+            cw[j] = __builtin_amdgcn_exp2f(cw[j]);
+            cw[j] += 1.0f;
+            cw[j] = __builtin_amdgcn_rcpf(cw[j]);
+            cv[j] *= cw[j];
+          } else if (AFF) {
+            cv[j] *= rs;
+            cv[j] = padf != 0.f ? 0.f : cv[j];
+          }
+        }
+        const f16x2 h01 = __builtin_convertvector(f32x2{cv[0], cv[1]}, f16x2), h23 = __builtin_convertvector(f32x2{cv[2], cv[3]}, f16x2);
+        const float l0 = __builtin_fmaf((float)h01.x, -1.0f, cv[0]), l1 = __builtin_fmaf((float)h01.y, -1.0f, cv[1]);
+        const float l2 = __builtin_fmaf((float)h23.x, -1.0f, cv[2]), l3 = __builtin_fmaf((float)h23.y, -1.0f, cv[3]);
+        const f16x2 q01 = __builtin_convertvector(f32x2{l0, l1}, f16x2), q23 = __builtin_convertvector(f32x2{l2, l3}, f16x2);
+        const f16x4 hi = {h01.x, h01.y, h23.x, h23.y}, lo = {q01.x, q01.y, q23.x, q23.y};
+        _Float16* dst = &Hs[hp * XPP + g * 4];
+        *reinterpret_cast<f16x4*>(dst) = hi;
+        *reinterpret_cast<f16x4*>(dst + 16) = lo;
+      }
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int a_base = ((2 * ph + (l31 >> 4)) * XP_HW + (l31 & 15)) * XPP + lhi * 8;
+  const int b_base = l31 * 32 + ((lhi ^ ((l31 >> 2) & 3)) * 8);
+  auto mma = [&](int buf) {
+    const _Float16* Ws = reinterpret_cast<const _Float16*>(XP_WS(buf));
+    const _Float16* Hs = reinterpret_cast<const _Float16*>(hs_raw + buf * XP_HBYTES);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const _Float16* src = &Hs[a_base + (kh * XP_HW + kw) * XPP];
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(src), al = *reinterpret_cast<const f16x8*>(src + 16);
+        const int o = b_base + ((kh * 3 + kw) * 64 + chf * 32) * 32;
+        const f16x8 bh = *reinterpret_cast<const f16x8*>(&Ws[o]), bl = *reinterpret_cast<const f16x8*>(&Ws[o ^ 16]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);      // the streaming kernel's term order
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+      }
+  };
+#define XP_BARRIER()                  \
+  __builtin_amdgcn_s_waitcnt(0xc07f); \
+  __builtin_amdgcn_s_barrier();
+  {
+    const bool two = NCH > 0 ? NCH > 1 : nch > 1;
+    fetch(0, 0);
+    if (two) fetch(1, 1);
+    stage(0);
+    XP_BARRIER()
+    if (NCH > 0) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (c + 2 < NCH) fetch(c + 2, (c + 2) % XP_ST);
+        mma(c % XP_ST);
+        if (c + 1 < NCH) {
+          stage((c + 1) % XP_ST);
+          XP_BARRIER()
+        }
+      }
+    } else {
+      for (int c0 = 0; c0 < nch; c0 += XP_ST) {
+#pragma unroll
+        for (int u = 0; u < XP_ST; ++u) {
+          const int ch = c0 + u;
+          if (ch < nch) {
+            if (ch + 2 < nch) fetch(ch + 2, (u + 2) % XP_ST);
+            mma(u);
+            if (ch + 1 < nch) stage((u + 1) % XP_ST);
+            XP_BARRIER()
+          }
+        }
+      }
+    }
+  }
+  // ---- epilogue: the wave parks its 32 x 32 tile (over halo stage 0 + 1: every wave is past its last fragment read) and writes rows of 32 channels
+  XP_BARRIER()
+#undef XP_BARRIER
+  float* et = reinterpret_cast<float*>(hs_raw) + wave * 32 * 36;      // 4 waves x 4608 B <= 2 stages x 8640 B
+#pragma unroll
+  for (int r = 0; r < 16; ++r) et[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 36 + l31] = acc[r];
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  const float asc = p.acc_scale * in_inv;
+  const int hw_o = p.Ho * p.Wo;
+  const int c4 = (lane & 7) * 4, co = n0 + chf * 32 + c4;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
+  float amx = 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int rr = it * 8 + (lane >> 3);
+    const long m = (long)n * hw_o + (oy0 + 2 * ph + (rr >> 4)) * p.Wo + ox0 + (rr & 15);
+    const float4 v = *reinterpret_cast<const float4*>(et + rr * 36 + c4);
+    float e[4] = {__builtin_fmaf(v.x, asc, bias4.x), __builtin_fmaf(v.y, asc, bias4.y), __builtin_fmaf(v.z, asc, bias4.z),
+                  __builtin_fmaf(v.w, asc, bias4.w)};
+    if (p.res) {
+      const float4 r4 = *reinterpret_cast<const float4*>(p.res + m * p.res_ld + co);
+      e[0] += r4.x; e[1] += r4.y; e[2] += r4.z; e[3] += r4.w;
+    }
+    *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) amx = fmaxf(amx, fabsf(e[q]));
+  }
+  if (p.out_amax) wave_amax_commit(p.out_amax + n, amx);
+}
+
 // Geometry / epilogue this producer covers (everything else of a split-K plan stays on conv3x3_halo_x3_kernel: same partials).
 bool keep_conv_x3p_ok(const keep_conv2d_args* a, const ConvP& p, int split_k) {
   const long items_old = (long)a->N * ((a->Ho * a->Wo) / 256) * ((a->Cout + 63) / 64) * split_k;
@@ -275,5 +485,40 @@ int keep_conv2d_x3_partials(const keep_conv2d_args* a, ConvP& p, hipStream_t st)
   else KEEP_LAUNCH_XP(KEEP_PRO_NONE, false)
 #undef KEEP_LAUNCH_XP
   KEEP_LAUNCH_CHECK("keep_conv2d(halo x3, small-tile partials)");
+  return KEEP_OK;
+}
+
+void keep_conv_stats_replica(const ConvP& p, int n_img, hipStream_t st);      // keep_conv_x3s.hip
+
+// Un-split plans on wide maps (what conv3x3_halo_x3s_kernel takes) with few items: the 64-pixel blocks, same values.
+bool keep_conv_x3q_ok(const keep_conv2d_args* a, const ConvP& p, int split_k) {
+  const long items_s = (long)a->N * (a->Ho / 8) * (a->Wo / 32) * ((a->Cout + 63) / 64);
+  const bool aff = a->pro_scale != nullptr;
+  return split_k == 1 && !a->upsample && a->pad_mode == KEEP_PAD_ZERO && a->Ho % 8 == 0 && a->Wo % 32 == 0 && a->Cout % 64 == 0 &&
+         a->Cin % 16 == 0 && a->Cin >= 32 && items_s <= 64 && !a->aux && a->epi_act == KEEP_ACT_NONE &&
+         ((a->pro_act == KEEP_PRO_SWISH && aff && p.fast) || a->pro_act == KEEP_PRO_NONE) && (!p.stats || a->out_ld == a->Cout) &&
+         !(a->flags & (KEEP_CONV_NO_SMALL_PARTIALS | KEEP_CONV_NO_STREAM));
+}
+
+int keep_conv2d_x3_small_full(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
+  const int tiles_x = a->Wo / 16, tiles_y = a->Ho / 4, ncb = a->Cout / 64;
+  const int n_items = a->N * tiles_x * tiles_y * ncb;
+  const bool aff = a->pro_scale != nullptr;
+  const int nchunks = a->Cin / 16;
+  const int nch = (nchunks == 4 || nchunks == 8 || nchunks == 16 || nchunks == 32) ? nchunks : 0;
+#define KEEP_LAUNCH_XQ(PROV, AFFV)                                                                                                    \
+  {                                                                                                                                   \
+    if (nch == 4) hipLaunchKernelGGL((conv3x3_x3q_kernel<PROV, AFFV, 4>), dim3(n_items), dim3(256), 0, st, p, tiles_x, tiles_y, ncb, n_items);        \
+    else if (nch == 8) hipLaunchKernelGGL((conv3x3_x3q_kernel<PROV, AFFV, 8>), dim3(n_items), dim3(256), 0, st, p, tiles_x, tiles_y, ncb, n_items);   \
+    else if (nch == 16) hipLaunchKernelGGL((conv3x3_x3q_kernel<PROV, AFFV, 16>), dim3(n_items), dim3(256), 0, st, p, tiles_x, tiles_y, ncb, n_items); \
+    else if (nch == 32) hipLaunchKernelGGL((conv3x3_x3q_kernel<PROV, AFFV, 32>), dim3(n_items), dim3(256), 0, st, p, tiles_x, tiles_y, ncb, n_items); \
+    else hipLaunchKernelGGL((conv3x3_x3q_kernel<PROV, AFFV, 0>), dim3(n_items), dim3(256), 0, st, p, tiles_x, tiles_y, ncb, n_items);                 \
+  }
+  if (a->pro_act == KEEP_PRO_SWISH) KEEP_LAUNCH_XQ(KEEP_PRO_SWISH, true)
+  else if (aff) KEEP_LAUNCH_XQ(KEEP_PRO_NONE, true)
+  else KEEP_LAUNCH_XQ(KEEP_PRO_NONE, false)
+#undef KEEP_LAUNCH_XQ
+  KEEP_LAUNCH_CHECK("keep_conv2d(halo x3, small tiles)");
+  if (p.stats) keep_conv_stats_replica(p, a->N, st);
   return KEEP_OK;
 }

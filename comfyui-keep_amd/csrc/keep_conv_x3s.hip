@@ -552,6 +552,68 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3s_kernel(ConvP p, int t
 #undef XS_T
 }
 
+// ------------------------------------------------------------------------------------------------ statistics of a written tile
+// GroupNorm partials of an output tensor another kernel wrote (keep_conv_x3p.hip: the 64-pixel blocks of one clip in flight), reduced in
+// EXACTLY the order of the epilogue above -- a block per (8 x 32 tile, 64 couts), lane (prow, c4) walks the wave's 16 pixel groups in
+// order, the two lane-swap sums, the four waves in order -- so that the partials are the bits conv3x3_halo_x3s_kernel would have written.
+__global__ __launch_bounds__(256) void conv_stats_replica_kernel(ConvP p, int tiles_x, int tiles_y, int ncb) {
+  __shared__ float red[4 * 64 * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cb = blockIdx.x % ncb;
+  int t = blockIdx.x / ncb;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y, n = t / tiles_y;
+  const int c4 = (lane & 15) * 4, prow = lane >> 4, n0 = cb * 64;
+  const int co = n0 + c4;
+  const int hw_o = p.Ho * p.Wo;
+  const int pix_b = (ty * 8 + 2 * wave) * p.Wo + tx * 32 + prow;
+  const float* src = p.out + ((long)n * hw_o + pix_b) * p.out_ld + co;
+  float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (co < p.Cout) {
+#pragma unroll
+    for (int g16 = 0; g16 < 16; ++g16) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (long)((g16 >> 3) * p.Wo + (g16 & 7) * 4) * p.out_ld);
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s4[q] += e[q];
+        ss4[q] += e[q] * e[q];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    s4[q] = xs_xor32_sum(xs_xor16_sum(s4[q]));
+    ss4[q] = xs_xor32_sum(xs_xor16_sum(ss4[q]));
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      red[(wave * 64 + c4 + q) * 2 + 0] = s4[q];
+      red[(wave * 64 + c4 + q) * 2 + 1] = ss4[q];
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float a = 0.f, b2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      a += red[(w * 64 + lane) * 2 + 0];
+      b2 += red[(w * 64 + lane) * 2 + 1];
+    }
+    if (n0 + lane < p.Cout) {
+      float* dst = p.stats + (((long)n * p.stats_P + ty * tiles_x + tx) * p.Cout + n0 + lane) * 2;
+      dst[0] = a;
+      dst[1] = b2;
+    }
+  }
+}
+
+void keep_conv_stats_replica(const ConvP& p, int n_img, hipStream_t st) {
+  const int tiles_x = p.Wo / 32, tiles_y = p.Ho / 8, ncb = (p.Cout + 63) / 64;
+  hipLaunchKernelGGL(conv_stats_replica_kernel, dim3(n_img * tiles_x * tiles_y * ncb), dim3(256), 0, st, p, tiles_x, tiles_y, ncb);
+}
+
 // ------------------------------------------------------------------------------------------------ dispatch
 // Geometry of the streaming kernel inside what keep_conv_x3_halo_ok() already admits: 8x32 tiles, whole-item K ranges of at least two
 // chunks, no split-K / aux tensor (bias / activation / residual / statistics / max|out| epilogue), the fast activation forms.

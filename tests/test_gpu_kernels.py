@@ -1589,3 +1589,39 @@ def test_conv_x3_small_tile_partials_are_the_256_pixel_kernels(n, h, wd, cin, co
     ref = F.conv2d(xe, w.double(), b.double(), padding=1) + (0 if r is None else r.double())
     scale = F.conv2d(xe.abs(), w.double().abs(), padding=1).flatten(1).max(1).values.view(n, 1, 1, 1)
     assert bool(((nchw(outs[0]).double().cpu() - ref).abs() <= 3e-6 * scale).all())
+
+
+@pytest.mark.parametrize("n,h,wd,cin,cout,gn,res,ranged", [
+    (1, 32, 32, 256, 256, True, True, False),       # ResBlock convolutions of the 32 x 32 stage (16 chunks)
+    (1, 64, 64, 256, 256, True, True, False),       # 64 x 64 stage: 64 items of the streaming kernel -> 1024 small blocks
+    (1, 32, 32, 512, 256, True, False, False),      # 32 chunks
+    (1, 64, 64, 128, 256, True, True, False),       # 8 chunks
+    (2, 32, 32, 256, 512, False, False, True),      # no prologue, probed range scale per image
+    (1, 64, 64, 144, 256, False, True, False),      # 9 chunks: the loop form of the ring
+    (1, 32, 64, 64, 64, True, False, False)])       # 4 chunks, a non-square map
+def test_conv_x3_small_tiles_equal_the_streaming_kernel(n, h, wd, cin, cout, gn, res, ranged):
+    """conv3x3_x3q_kernel + conv_stats_replica_kernel (un-split plans on wide maps, few items): output, GroupNorm partials and max|out|
+    BIT-EQUAL to conv3x3_halo_x3s_kernel's (KEEP_CONV_NO_SMALL_PARTIALS) -- its conversion arithmetic, product order and epilogue order."""
+    x = rnd('sq_x', (n, cin, h, wd), 2.0) + 0.3
+    if ranged:
+        x = x * torch.tensor([1.0, 900.0][:n]).view(-1, 1, 1, 1)
+    w, b = rnd('sq_w', (cout, cin, 3, 3), 0.05), rnd('sq_b', (cout,))
+    r = rnd('sq_r', (n, cout, h, wd)) if res else None
+    xd, wp, bd = dev(nhwc(x)), pack(w), dev(b)
+    wx3, asc = x3w(wp)
+    pro = None
+    if gn:
+        pro = ops.norm_affine(xd, dev(rnd('sq_g', (cin,)) * 0.2 + 1), dev(rnd('sq_bt', (cin,)) * 0.2), 16, 1e-6)
+    kw = dict(mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, pro=pro, pro_act=L.PRO_SWISH if gn else L.PRO_NONE,
+              residual=None if r is None else dev(nhwc(r)), bounded=not ranged, stats=True, split_k=1)
+    got = []
+    for fl in (0, L.CONV_NO_SMALL_PARTIALS):
+        ops.DEFAULT.flags = fl
+        ops.DEFAULT.amax_arena = None          # fresh (zeroed by the library) max|out| slots per call
+        y, st = ops.conv(xd, wp, bd, **kw)
+        got.append((y.clone(), st.part.clone(), st.amax.clone()))
+    assert torch.isfinite(got[0][0]).all()
+    assert torch.equal(got[0][0], got[1][0]), 'outputs differ'
+    assert torch.equal(got[0][1], got[1][1]), 'GroupNorm partials differ'
+    assert torch.equal(got[0][2], got[1][2]), 'max|out| differs'
+    assert torch.equal(got[0][2].cpu(), got[0][0].abs().flatten(1).max(1).values.cpu())

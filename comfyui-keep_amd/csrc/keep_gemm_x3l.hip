@@ -199,7 +199,9 @@ bool keep_gemm_x3l_ok(const keep_conv2d_args* a) {
   const long hw = (long)a->Ho * a->Wo;
   const int K = a->Cin;
   const int nw = K >= 1024 ? 8 : 4;
-  return a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad_t == 0 && a->pad_l == 0 && a->Ho == a->H && a->Wo == a->W && !a->upsample &&
+  // (GEMMs with a GroupNorm prologue -- the AttnBlock qkv projection, 117 launches per clip -- stay on conv_x3_kernel's sequential sum: the
+  // latency form gains 0.8 ms per clip there, the slice totals of the prologue form cost the 16-clip step 5.5 ms: 46.8 -> 91 us per launch)
+  return !a->pro_scale && a->pro_act == KEEP_PRO_NONE && a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad_t == 0 && a->pad_l == 0 && a->Ho == a->H && a->Wo == a->W && !a->upsample &&
          hw >= 64 && hw <= GL_MAX_HW && hw % 64 == 0 && K >= 256 && K <= 2048 && K % (nw * 16 * GL_G) == 0 && a->Cout % 32 == 0 && !a->in2 && !a->aux &&
          !a->ln_gamma && a->split_k <= 1 && a->dtype == KEEP_F32 && a->out_dtype != KEEP_BF16 && a->in_ld % 4 == 0 && (uintptr_t)a->in % 16 == 0 &&
          a->out_ld % 4 == 0 && (uintptr_t)a->out % 16 == 0 && (!a->residual || (a->res_ld % 4 == 0 && (uintptr_t)a->residual % 16 == 0)) &&

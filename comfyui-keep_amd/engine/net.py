@@ -39,6 +39,7 @@ GRAPH_MAX_CLIPS = int(os.environ.get('KEEP_AMD_GRAPH_MAX_CLIPS', '2'))
 # two-stream order of the forward (GMFlow + Kalman gains on a second stream under the frame recurrence) for calls of at most this
 # many clips (0 = never); the first chunk of pairs / the following chunks (pairs per GMFlow launch group)
 STREAM_OVERLAP_MAX_CLIPS = int(os.environ.get('KEEP_AMD_OVERLAP_MAX_CLIPS', '2'))
+CFA_FREE_RANGES = os.environ.get('KEEP_CFA_FREE_RANGES', '1') != '0'   # x3: CFA range scales from producers' fused maxima instead of probes (A/B: 0)
 STREAM_OVERLAP_FIRST = int(os.environ.get('KEEP_AMD_OVERLAP_FIRST', '3'))
 STREAM_OVERLAP_CHUNK = int(os.environ.get('KEEP_AMD_OVERLAP_CHUNK', '4'))
 GRAPH_CACHE = 4
@@ -400,21 +401,26 @@ class KeepNet:
         return self.o.conv(ss, w[f'{p}.shift.2.weight'], w[f'{p}.shift.2.bias'], cin=C, in_off=C, residual=dec,
                            aux=scale, aux_w=self.cfg['cond'], stats=True, x_amax=ss_amax)
 
-    def _cfa(self, curr, prev, p):
-        """KA:519-541 (post-norm): a = attn(curr, prev); y = LN(a)+curr; LN(ff(y))+y."""
+    def _cfa(self, curr, prev, p, curr_amax=None):
+        """KA:519-541 (post-norm): a = attn(curr, prev); y = LN(a)+curr; LN(ff(y))+y.
+        x3 range scales: five of the nine probes of a call come for free -- ``curr_amax`` (the producing convolution's fused max|out|),
+        the q / kv projections' own fused maxima (max over k AND v bounds either), and |attention output| <= max|v|."""
         w, cfg = self.w, self.cfg
         B, H, Wd, C = curr.shape
         Ltok = H * Wd
         nh, dh = cfg['cfa_nhead'], cfg['cfa_dim']
         inner = nh * dh
         c = curr.view(B * Ltok, C)
-        q = self.o.linear(c, w[f'{p}.attn.to_q.weight'], out_bf16=True, n_img=B)
-        kv = self.o.linear(prev.view(B * Ltok, C), w[f'{p}.attn.to_kv.weight'], out_bf16=True, n_img=B)
+        free = CFA_FREE_RANGES and self.o.mma == L.MMA_X3
+        q, q_amax = self.o.linear(c, w[f'{p}.attn.to_q.weight'], out_bf16=True, n_img=B, x_amax=curr_amax if free else None, want_amax=True)
+        kv, kv_amax = self.o.linear(prev.view(B * Ltok, C), w[f'{p}.attn.to_kv.weight'], out_bf16=True, n_img=B, want_amax=True)
+        have = free and q_amax is not None and kv_amax is not None
         o = ops.empty((B * Ltok, inner), curr)
         self.o.attention(q, kv, ops.offset(kv, inner), o, B=B, H=nh, Lq=Ltok, Lk=Ltok, D=dh, Dv=dh, scale=dh ** -0.5,
                       q_str=(Ltok * inner, inner, dh), k_str=(Ltok * 2 * inner, 2 * inner, dh),
-                      v_str=(Ltok * 2 * inner, 2 * inner, dh), o_str=(Ltok * inner, inner, dh), probe=True)
-        a = self.o.linear(o, w[f'{p}.attn.to_out.0.weight'], w[f'{p}.attn.to_out.0.bias'], n_img=B)
+                      v_str=(Ltok * 2 * inner, 2 * inner, dh), o_str=(Ltok * inner, inner, dh), probe=True,
+                      amax=(q_amax, kv_amax, kv_amax) if have else None)
+        a = self.o.linear(o, w[f'{p}.attn.to_out.0.weight'], w[f'{p}.attn.to_out.0.bias'], n_img=B, x_amax=kv_amax if have else None)
         y = ops.layernorm(a, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], res=c)
         f = ops.geglu(self.o.linear(y, w[f'{p}.ff.net.0.proj.weight'], w[f'{p}.ff.net.0.proj.bias'], n_img=B))
         f = self.o.linear(f, w[f'{p}.ff.net.2.weight'], w[f'{p}.ff.net.2.bias'], n_img=B)
@@ -852,7 +858,7 @@ class KeepNet:
                 if j in cfa_at:
                     s = cfa_at[j]
                     if i > 0:
-                        y, yst = self._cfa(y, cross_prev[s], f'cfa.{s}'), None
+                        y, yst = self._cfa(y, cross_prev[s], f'cfa.{s}', None if yst is None else yst.amax), None
                     cross_prev[s] = y
                 return y, yst
 

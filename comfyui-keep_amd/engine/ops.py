@@ -314,9 +314,9 @@ class Ops:
         if ws is not None:
             a.workspace = ws.data_ptr()
         st = None
-        if stats and (pl.stats_P or pl.out_amax_ok):
+        if stats and ((pl.stats_P and stats != 'amax') or pl.out_amax_ok):
             st = Stats()
-            if pl.stats_P:
+            if pl.stats_P and stats != 'amax':      # ('amax': only the fused max|out| -- a GEMM whose consumer needs a range, not a GroupNorm)
                 st.part, st.P = empty((N, pl.stats_P, Cout, 2), x), pl.stats_P
                 a.stats_out, a.stats_P = st.part.data_ptr(), pl.stats_P
             if pl.out_amax_ok:
@@ -353,7 +353,7 @@ class Ops:
         return (out, st) if stats else out
 
     def linear(self, x, w, bias=None, *, act=L.ACT_NONE, residual=None, pro=None, pro_act=L.PRO_NONE, cin=None, in_off=0,
-               n_img=None, out_bf16=False, bounded=False, x_amax=None, x2=None, ln=None):
+               n_img=None, out_bf16=False, bounded=False, x_amax=None, x2=None, ln=None, want_amax=False):
         """x [M,ld] (or any [...,ld]) @ w[Cout,Cin]^T.  ``n_img``: the rows are n_img independent images (frames, clips) of
         M/n_img rows each -- the unit of the per-image prologue AND of the library's plan (kernel tile / split-K are chosen
         from the per-image row count, so a clip's result never depends on its batch-mates).  Default: the leading axis of a
@@ -372,7 +372,10 @@ class Ops:
         x24 = None if x2 is None else x2.reshape(n_img, M // n_img, 1, x2.shape[-1])
         res4 = None if residual is None else residual.reshape(n_img, M // n_img, 1, residual.shape[-1])
         y = self.conv(x4, w, bias, stride=1, pad=0, ksize=1, pro=pro, pro_act=pro_act, act=act, residual=res4, cin=cin,
-                      in_off=in_off, out_bf16=out_bf16, bounded=bounded, x_amax=x_amax, x2=x24, ln=ln)
+                      in_off=in_off, out_bf16=out_bf16, bounded=bounded, x_amax=x_amax, x2=x24, ln=ln, stats='amax' if want_amax else False)
+        if want_amax:      # (y, per-image max |y| from the GEMM's epilogue, or None where the launch cannot emit it): the range probe of the consumer
+            y, st = y
+            return y.reshape(*shp[:-1], w.shape[0]), (None if st is None else st.amax)
         return y.reshape(*shp[:-1], w.shape[0])
 
     def ln_fusable(self, w, rows_per_image):
@@ -426,7 +429,7 @@ class Ops:
 
     # ------------------------------------------------------------------ keep_attention
     def attention(self, q, k, v, o, *, B, H, Lq, Lk, D, Dv, scale, q_str, k_str, v_str, o_str, mode=0, T=0, seg_len=0,
-                  img_h=0, img_w=0, ksplit=0, shift=0, kv_rot=0, n_img=0, mma=None, probe=False):
+                  img_h=0, img_w=0, ksplit=0, shift=0, kv_rot=0, n_img=0, mma=None, probe=False, amax=None):
         """Strides are (batch, token, head) element strides.  ``probe=True`` (x3 policy, mode 0): q / k / v are projections
         of an un-normalised tensor -- their ranges are probed and the kernel rescales them into the fp16 window."""
         mma = self.attn_mma if mma is None else mma
@@ -436,8 +439,11 @@ class Ops:
             in_dtype, mma = L.BF16, L.MMA_BF16
         elif mma != L.MMA_F32 and (D % 16 or any(s % 4 for s in (*q_str, *k_str))):
             mma = L.MMA_F32
+        given = amax
         amax = (None, None, None)
-        if probe and mma == L.MMA_X3 and mode == 0 and in_dtype == L.F32:
+        if given is not None and all(t is not None and t.numel() == B for t in given) and mma == L.MMA_X3 and mode == 0 and in_dtype == L.F32:
+            amax = tuple(given)      # per-batch upper bounds of max |q|, |k|, |v| the caller already holds (producers' fused maxima)
+        elif probe and mma == L.MMA_X3 and mode == 0 and in_dtype == L.F32:
             # rows of batch b: tokens x (H heads x D) starting at b*bs; heads are contiguous slices of one row here
             amax = (absmax(q, B, Lq, H * D, q_str[1], q_str[0], self), absmax(k, B, Lk, H * D, k_str[1], k_str[0], self),
                     absmax(v, B, Lk, H * Dv, v_str[1], v_str[0], self))

@@ -1432,7 +1432,7 @@ def test_bgr_u8_to_comfy_equals_the_host_converter_on_every_value():
     ('linear1', 256, 512, 1024, True, True, False, False, False),          # 512 -> 1024 + GELU
     ('linear2', 256, 1024, 512, False, True, True, False, False),          # 1024 -> 512 + residual: two register groups per slice
     ('feat_emb', 256, 256, 512, False, True, False, False, False),         # 256 -> 512: four slices
-    ('attn qkv', 256, 512, 1536, False, True, False, True, False),         # AttnBlock (VQ:219-243): GroupNorm prologue
+    ('proj_out', 256, 512, 1536, False, True, True, False, False),         # wide N
     ('wide ff', 256, 2048, 512, False, True, False, False, True),          # K = 2048: four groups per slice, per-image range scale
     ('ragged rows', 192, 512, 2048, False, False, False, False, True)])
 def test_gemm_x3_latency_form(name, hw, K, N, act, bias, res, gn, ranged):

@@ -15,6 +15,8 @@ if [ -f $G/r5p_x3_b16/x3_b16_pmc.json ]; then
   { echo "# rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace --output-format csv -- python tools/run_step.py x3 16 1"; echo "# KiB per launch as reported; FETCH_SIZE is doubled on gfx950 in r05_pmc_traffic.json (MI355X_MICROARCH.md, HBM section)"; cat $G/r5p_x3_b16/x3_b16_pmc.txt; } > profiles/r05_pmc_step_x3_b16.txt
 fi
 [ -f $G/r5p_bench.json ] && grep '^{' $G/r5p_bench.json | tail -1 > profiles/r05_bench_default.json
-[ -f $G/r5p_census_b16.txt ] && cp $G/r5p_census_b16.txt profiles/r05_conv_census_x3_b16.txt
-[ -f $G/r5p_census_halo_b16.txt ] && cp $G/r5p_census_halo_b16.txt profiles/r05_conv_census_halo_x3_b16.txt
+[ -f $G/r5p_census_b16.txt ] && grep -v "^/opt" $G/r5p_census_b16.txt > profiles/r05_conv_census_x3_b16.txt
+[ -f $G/r5p_census_halo_b16.txt ] && grep -v "^/opt" $G/r5p_census_halo_b16.txt > profiles/r05_conv_census_halo_x3_b16.txt
+[ -f $G/r5p_census_b1.txt ] && grep -v "^/opt" $G/r5p_census_b1.txt > profiles/r05_conv_census_x3_b1.txt
+[ -f $G/r5p_gemm_forms.txt ] && { echo "# python tools/dev/gemm_lat_bench.py: us per launch (hipGraph replay of 40 launches) of the token GEMMs by form and images per launch --"; echo "# seq: one sequential sum (KEEP_CONV_NO_GEMM_LAT); waves: gemm_x3l_kernel at every row count; tiles: conv_x3_kernel with canonical slices at every row count"; grep -v "^/opt" $G/r5p_gemm_forms.txt; } > profiles/r05_gemm_forms.txt
 ls -la profiles/r05_* 2>/dev/null

@@ -16,5 +16,5 @@ DB=$(find "$OUT/trace_${POL}_b$B" -name "*results.db" | head -1)
 python profiles/summarize_rocpd.py "$DB" 2 > "$OUT/${POL}_b${B}_kernel_stats.txt"
 python profiles/summarize_pmc.py $(find "$OUT/pmc_${POL}_b$B" -name "*counter_collection.csv") > "$OUT/${POL}_b${B}_pmc.txt" 2>/dev/null
 python profiles/pmc_to_json.py $POL $B "$OUT/pmc_${POL}_b$B" > "$OUT/${POL}_b${B}_pmc.json" 2>/dev/null
-find "$OUT" -name "*.db" -size +40M -delete
+find "$OUT" -name "*.db" -delete
 head -30 "$OUT/${POL}_b${B}_kernel_stats.txt"

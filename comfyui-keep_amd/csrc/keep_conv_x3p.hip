@@ -248,6 +248,9 @@ __global__ __launch_bounds__(256) void conv3x3_x3p_kernel(ConvP p, int tiles_x, 
   }
 }
 
+#ifndef XQ_ABL
+#define XQ_ABL 0      // dev: 1 no staging after the first chunk, 2 no MFMAs, 3 no operand fetch after the prologue, 4 no fragment reads
+#endif
 // ------------------------------------------------------------------------------------------------ un-split plans: the whole convolution
 // The same blocks for plans WITHOUT split-K on wide maps (32 x 32 .. 128 x 128 of one clip: 16 .. 128 items of conv3x3_halo_x3s_kernel on
 // 256 CUs, each wave 108 MFMAs per chunk): this kernel reproduces THAT kernel's values -- its conversion arithmetic (fma(v, sc, sh);
@@ -388,9 +391,13 @@ __global__ __launch_bounds__(256) void conv3x3_x3q_kernel(ConvP p, int tiles_x, 
         const f16x8 ah = *reinterpret_cast<const f16x8*>(src), al = *reinterpret_cast<const f16x8*>(src + 16);
         const int o = b_base + ((kh * 3 + kw) * 64 + chf * 32) * 32;
         const f16x8 bh = *reinterpret_cast<const f16x8*>(&Ws[o]), bl = *reinterpret_cast<const f16x8*>(&Ws[o ^ 16]);
+        if (XQ_ABL == 2) {
+          acc[0] += (float)al[0] + (float)bh[0] + (float)ah[1] + (float)bl[1];
+        } else {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);      // the streaming kernel's term order
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+        }
       }
   };
 #define XP_BARRIER()                  \
@@ -405,10 +412,10 @@ __global__ __launch_bounds__(256) void conv3x3_x3q_kernel(ConvP p, int tiles_x, 
     if (NCH > 0) {
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        if (c + 2 < NCH) fetch(c + 2, (c + 2) % XP_ST);
+        if (c + 2 < NCH && XQ_ABL != 3) fetch(c + 2, (c + 2) % XP_ST);
         mma(c % XP_ST);
         if (c + 1 < NCH) {
-          stage((c + 1) % XP_ST);
+          if (XQ_ABL != 1) stage((c + 1) % XP_ST);
           XP_BARRIER()
         }
       }

@@ -1,8 +1,4 @@
-set -x
 cd /root/repo
-python bench.py > gpurun_out/r5p_bench.json 2> gpurun_out/r5p_bench.err
-python tools/dev/conv_census.py 16 conv_x3_kernel > gpurun_out/r5p_census_b16.txt 2>&1
-python tools/dev/conv_census.py 16 halo > gpurun_out/r5p_census_halo_b16.txt 2>&1
-python tools/dev/conv_census.py 1 "" > gpurun_out/r5p_census_b1.txt 2>&1
-python tools/dev/gemm_lat_bench.py > gpurun_out/r5p_gemm_forms.txt 2>&1
-grep '^{' gpurun_out/r5p_bench.json | tail -1 | cut -c1-700
+timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "gemm_x3_latency or linear" 2>&1 | tail -3
+timeout 600 python tools/dev/gemm_lat_bench.py 2>&1 | grep -E " 16:|  8:| hw K" | head -14
+timeout 600 python tools/dev/flag_ab.py 16 new=0 2>&1 | tail -3

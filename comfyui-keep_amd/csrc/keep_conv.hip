@@ -1666,6 +1666,28 @@ __global__ void conv_splitk_reduce_kernel(ConvP p) {
   }
 }
 
+// The same reduction four channels per thread (Cout, out_ld, res_ld multiples of 4, 16-byte aligned tensors: p.vec_epi): float4 loads of
+// the partials in z order, the element-wise epilogue of epilogue_one per lane -- bit-identical to the scalar kernel (every output element
+// sees the same operations in the same order), no 64-bit division per element.
+__global__ void conv_splitk_reduce4_kernel(ConvP p) {
+  const int c4n = p.Cout >> 2;
+  const long total4 = (long)p.M * c4n;
+  const long total = (long)p.M * p.Cout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / c4n;
+    const int co = (int)(i - m * c4n) << 2;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < p.split_k; ++z) {
+      const float4 t = *reinterpret_cast<const float4*>(p.ws + (long)z * total + m * p.Cout + co);
+      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+    float e[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e[q] = epilogue_one(p, v[q], m, co + q);
+    *reinterpret_cast<float4*>(p.out + m * p.out_ld + co) = make_float4(e[0], e[1], e[2], e[3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ plan + dispatch
 // ONE place decides which kernel a keep_conv2d call runs on, its tile, the split-K factor and the layout of the epilogue
 // statistics: plan_conv().  keep_conv2d_plan() exposes that decision to the host, which sizes the workspace / statistics
@@ -2257,6 +2279,13 @@ extern "C" int32_t keep_conv2d(const keep_conv2d_args* a_in, void* stream) {
   }
   if (p.split_k > 1) {
     const long total = M * a->Cout;
+    if (p.vec_epi) {
+      int blocks = cdiv(total / 4, 256);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(conv_splitk_reduce4_kernel, dim3(blocks), dim3(256), 0, st, p);
+      KEEP_LAUNCH_CHECK("keep_conv2d(split-K reduce)");
+      return KEEP_OK;
+    }
     int blocks = cdiv(total, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);

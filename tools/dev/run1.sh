@@ -1,4 +1,3 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "small_tile" 2>&1 | tail -3
-python tools/dev/x3q_time.py 2>&1 | grep -v amdgpu.ids
-timeout 600 python tools/dev/flag_ab.py 1 new=0 co64=0x1000 2>&1 | tail -4
+PMC_COUNTERS= bash tools/profile_step.sh x3 16 r5r_x3_b16 2>&1 | grep -E "splitk|total kernel"
+grep -E "splitk|total kernel" gpurun_out/r5r_x3_b16/x3_b16_kernel_stats.txt

@@ -70,6 +70,33 @@ def test_cft_cfa_vs_golden(gpu_net):
     close(nchw(y), OPS['cfa'], 3e-4, 'cfa')
 
 
+def test_cfa_range_scales_from_producer_maxima(gpu_net):
+    """x3 policy: CFA takes five of its nine range scales from maxima its producers already hold (`curr_amax`: the producing
+    convolution's fused max|out|; the q / kv projections' fused maxima; |attention output| <= max|v|) instead of probing -- with inputs of
+    the Asian config's residual-stream magnitude (1e4 .. 6e4) the result stays the probed path's to fp32 rounding, and a loose but valid
+    bound (4 x) costs at most two bits of the low halves."""
+    from comfyui_keep_amd.engine import net as net_mod, ops
+    net = gpu_net
+    if net.precision != 'x3':
+        pytest.skip('range scales are an x3 matter')
+    curr = nhwc(op_input('cfa_curr', (2, 256, 8, 8))) * torch.tensor([3.0e4, 1.0]).view(2, 1, 1, 1).cuda()
+    prev = nhwc(op_input('cfa_prev', (2, 256, 8, 8))) * torch.tensor([1.0e4, 5.0]).view(2, 1, 1, 1).cuda()
+    amax = curr.abs().flatten(1).max(1).values
+    old = net_mod.CFA_FREE_RANGES
+    try:
+        net_mod.CFA_FREE_RANGES = False
+        ref = net._cfa(curr, prev, 'cfa.32')
+        net_mod.CFA_FREE_RANGES = True
+        got = net._cfa(curr, prev, 'cfa.32', amax.contiguous())
+        loose = net._cfa(curr, prev, 'cfa.32', (amax * 4).contiguous())
+    finally:
+        net_mod.CFA_FREE_RANGES = old
+    assert torch.isfinite(got).all()
+    sc = ref.abs().flatten(1).max(1).values.view(2, 1, 1, 1)
+    assert float(((got - ref).abs() / sc).max()) <= 2e-6
+    assert float(((loose - ref).abs() / sc).max()) <= 1e-5
+
+
 def test_kalman_gain_vs_golden_and_batched(gpu_net, synth_weights):
     z = op_input('kalman_z', (1, 3, 256, 8, 8))
     g = gpu_net._kalman_gain(nhwc(z[0]), 1, 3)

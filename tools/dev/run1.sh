@@ -1,3 +1,2 @@
 cd /root/repo
-PMC_COUNTERS= bash tools/profile_step.sh x3 16 r5r_x3_b16 2>&1 | grep -E "splitk|total kernel"
-grep -E "splitk|total kernel" gpurun_out/r5r_x3_b16/x3_b16_kernel_stats.txt
+timeout 1200 python -m pytest tests/test_gpu_net.py -x -q -m gpu -k "cfa" 2>&1 | tail -8

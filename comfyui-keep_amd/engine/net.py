@@ -715,6 +715,10 @@ class KeepNet:
         self.precision = 'fp32'
         try:
             self._activate_precision()
+            if B > 16 and not return_aux and force_indices is None and force_flows is None:
+                # the exact-f32 policy holds 0.36 GB per frame against 0.22: a call sized for x3 (up to 48 clips) re-runs in parts
+                # (per-image plans: same bits as one call)
+                return torch.cat([self._forward(x[b0:b0 + 16].contiguous(), min(16, B - b0), T, H, Wd, None, False) for b0 in range(0, B, 16)], 0)
             return self._forward(x, B, T, H, Wd, force_indices, return_aux, force_flows)
         finally:
             self.precision = 'x3'
@@ -883,18 +887,20 @@ class KeepNet:
     # ------------------------------------------------------------------ independent clips (hot loop #1)
     def clips_per_call(self, T, H=512, Wd=512):
         """How many equal-length clips ride the batch axis of one net call.  Every batched stage (LQ encoder, GMFlow,
-        Kalman gain) holds all B*T frames at once, so B is bounded by free HBM: ~0.35 GB per 512x512 frame at fp32
-        storage (measured: B=16, T=20 peaks at 71-110 GB by policy).  ``KEEP_AMD_MAX_CLIPS`` caps it (default 16: more
-        adds nothing to throughput, DESIGN.md batch sweep); the node's ``max_clip_length`` therefore still bounds
-        memory: a longer clip means fewer clips per call, never a bigger footprint."""
-        cap = int(os.environ.get('KEEP_AMD_MAX_CLIPS', '16'))
-        per_frame = 0.35e9 * (H * Wd) / (512.0 * 512.0) * (0.7 if self.precision == 'bf16' else 1.0)
+        Kalman gain) holds all B*T frames at once, so B is bounded by free HBM: ~0.22 GB per 512x512 frame at fp32
+        storage under the x3 policy, 0.35 under exact f32 (measured: B=16, T=20 peaks at 70.5 / 110 GB).  ``KEEP_AMD_MAX_CLIPS``
+        caps it (default 48 = what 288 GB hold under x3: 16 / 32 / 48 clips per call run at 279.6 / 287.1 / 290.3 frames/s -- the
+        16 x 16 ... 64 x 64 stages and the token GEMMs fill the chip better; results do not depend on the choice: per-image
+        plans); the node's ``max_clip_length`` therefore still bounds memory: a longer clip means fewer clips per call, never a
+        bigger footprint."""
+        cap = int(os.environ.get('KEEP_AMD_MAX_CLIPS', '48'))
+        per_frame = {'bf16': 0.17e9, 'fp32': 0.36e9}.get(self.precision, 0.23e9) * (H * Wd) / (512.0 * 512.0)
         try:
             free, _ = torch.cuda.mem_get_info(self.device)
             free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)   # cached blocks are reusable
         except Exception:
             free = 64e9
-        return max(1, min(cap, int(0.7 * free / (per_frame * max(T, 1)))))
+        return max(1, min(cap, int(0.8 * free / (per_frame * max(T, 1)))))
 
     def run_clips(self, clips, need_upscale=False, max_b=None):
         """list of [1,T_i,3,H,W] -> list of restored clips.  Clips share no state (KA:1050,1064,1113), so equal-length
@@ -988,6 +994,8 @@ class KeepNet:
         groups = []
         for (T, H, Wd), ids in order.items():
             b = self.clips_per_call(T, H, Wd) if max_b is None else max_b
+            if sink is not None and max_b is None:
+                b = min(b, 16)      # streamed paste-back: several groups, so that the paste of group k runs under the forward of group k + 1
             groups += [(T, H, Wd, ids[s:s + b]) for s in range(0, len(ids), b)]
         local = {}
         if not groups:

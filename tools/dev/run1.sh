@@ -1,2 +1,5 @@
 cd /root/repo
-timeout 1200 python -m pytest tests/test_gpu_net.py -x -q -m gpu -k "cfa" 2>&1 | tail -8
+bash tools/profile_step.sh x3 48 r5p_x3_b48 2>&1 | tail -3
+python tools/dev/conv_census.py 48 halo > gpurun_out/r5p_census_halo_b48.txt 2>&1
+python tools/dev/conv_census.py 48 conv_x3_kernel > gpurun_out/r5p_census_b48.txt 2>&1
+ls gpurun_out/r5p_x3_b48

@@ -1,5 +1,10 @@
 cd /root/repo
-bash tools/profile_step.sh x3 48 r5p_x3_b48 2>&1 | tail -3
-python tools/dev/conv_census.py 48 halo > gpurun_out/r5p_census_halo_b48.txt 2>&1
-python tools/dev/conv_census.py 48 conv_x3_kernel > gpurun_out/r5p_census_b48.txt 2>&1
-ls gpurun_out/r5p_x3_b48
+timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -6
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+python bench.py > gpurun_out/r5p_bench.json 2> gpurun_out/r5p_bench.err; echo rc=$?
+grep '^{' gpurun_out/r5p_bench.json | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print(d['value'], d['ms_per_step'], d['config']['clips_per_gpu'], d['peak_hbm_gb'], d['roofline']['frac'], d['roofline']['conv_path_frac'], d['roofline'].get('traffic'), d['roofline'].get('algorithmic_bytes_per_launch'))
+print(d.get('clips16',{}).get('value'), d['b1']['value'], d['cpu_baseline']['value'])
+"

@@ -254,10 +254,14 @@ def facelib_leg():
                                              "what": "as above (uint8 frames in host memory -> detections on the host); network_only: "
                                                      "depthwise 3x3 kernel + 1x1 GEMMs + LeakyReLU(0.1) epilogues"}
     del det, x
-    # YOLOv5n / YOLOv5l face detectors (detection/__init__.py:42-49): the network behind YoloDetector.detect_faces (its letterbox and
-    # NMS are the reference's host / torch code), frames letterboxed to 640 x 1152 like a 720p frame (face_detector.py:50-62)
+    # YOLOv5n / YOLOv5l face detectors (detection/__init__.py:42-49): YoloDetector.detect_faces on a 720p frame after the helper's resize
+    # (640 x 1137 uint8 in host memory -> letterboxed to 704 x 1152 on the device, face_detector.py:50-62 -> network -> selection + NMS on
+    # the device -> kept rows on the host: engine/yoloface.py:yolo_detect_batch_device); network_only: device tensor in, decoded
+    # [N, anchors, 16] predictions on the device out
+    import types
     from comfyui_keep_amd.engine import yoloface as YF
-    xy = torch.rand((16, 640, 1152, 3), device='cuda')
+    xy = torch.rand((16, 704, 1152, 3), device='cuda')
+    yframes = torch.randint(0, 256, (16, 640, 1137, 3), dtype=torch.uint8)
     for name in ('YOLOv5n', 'YOLOv5l'):
         yolo = YF.YoloFaceEngine(YF.synth_yolo_state_dict(name, seed=0)).to('cuda')
         yolo.forward_nhwc(xy)
@@ -267,9 +271,20 @@ def facelib_leg():
             yolo.forward_nhwc(xy)
         torch.cuda.synchronize()
         dy = (time.perf_counter() - t0) / 3
-        out[f"{name.lower()}_face_640x1152"] = {"network_only_frames_per_s": round(16 / dy, 1), "ms_per_call": round(dy * 1e3, 2), "batch": 16,
-                                                "what": "device tensor in, decoded [N, anchors, 16] predictions on the device out"}
-        del yolo
+        ydet = types.SimpleNamespace(detector=YF.EngineYoloModel(yolo), target_size=None, min_face=10, device='cuda')
+        for _ in range(2):
+            YF.yolo_detect_batch(ydet, yframes, 0.97)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            YF.yolo_detect_batch(ydet, yframes, 0.97)
+        torch.cuda.synchronize()
+        dyh = (time.perf_counter() - t0) / 5
+        out[f"{name.lower()}_face_640x1137"] = {"frames_per_s": round(16 / dyh, 1), "network_only_frames_per_s": round(16 / dy, 1),
+                                                "ms_per_call": round(dyh * 1e3, 2), "batch": 16,
+                                                "what": "uint8 frames in host memory -> detections on the host (letterbox kernel, network, "
+                                                        "selection + NMS on the device; 0.97 threshold of the helper)"}
+        del yolo, ydet
     return out
 
 

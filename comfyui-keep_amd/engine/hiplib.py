@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('KEEP_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')   # (KEEP_HIP_LIB: dev A/B builds)
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 F32, BF16 = 0, 1
 MMA_F32, MMA_BF16, MMA_X3 = 0, 1, 2
@@ -94,6 +94,8 @@ _SIGNATURES = {
     'keep_slice_copy': [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     'keep_channel_shuffle2': [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
     'keep_yolo_decode': [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _i32, _i32, _vp],
+    'keep_yolo_letterbox_u8': [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    'keep_yolo_select': [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp],
     'keep_upsample_add': [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     'keep_act_inplace': [_vp, _i64, _i32, _vp],
     'keep_retina_decode': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _vp],

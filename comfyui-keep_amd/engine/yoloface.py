@@ -3,9 +3,11 @@
 Reference: ``wm_facelib/detection/__init__.py:42-49`` (``YoloDetector(config_name=.../yolov5n.yaml | yolov5l.yaml)``),
 ``yolov5face/models/yolo.py:26-84`` (Detect), ``:87-131`` (Model: ``parse_model`` of the yaml, ``forward_once``),
 ``yolov5face/models/common.py:32-173`` (Conv, StemBlock, Bottleneck, C3, ShuffleV2Block, SPP, Concat) and the two yaml files
-(layer lists restated below as ``YOLO_CFGS``).  ``YoloDetector.detect_faces`` (face_detector.py:113-141: colour conversion, letterbox,
-``non_max_suppression_face``, coordinate rescaling) is host / torch code of the reference and stays what it is: this module is a
-drop-in for its ``self.detector`` -- ``model(images)[0]`` -> ``[N, anchors, 16]`` predictions in pixels of the network input.
+(layer lists restated below as ``YOLO_CFGS``).  This module is a drop-in for ``YoloDetector.detector`` -- ``model(images)[0]`` -> ``[N, anchors, 16]`` predictions in pixels of
+the network input -- and, for the processor's batched pre-pass, ``yolo_detect_batch``: ``YoloDetector.detect_faces``
+(face_detector.py:113-141) with the colour conversion, the letterbox and the float conversion in one kernel (``keep_yolo_letterbox_u8``),
+the candidate selection of ``non_max_suppression_face`` (``keep_yolo_select``) and the suppression (``keep_retina_nms``) on the device:
+uint8 frames go up, the handful of kept rows come back (a 1080p frame has 128 520 prediction rows = 8 MB).
 
 How it maps onto the engine
   * Conv = Conv2d + BatchNorm2d(eval) + SiLU: one ``keep_conv2d`` with the folded weights and the ``KEEP_ACT_SILU`` epilogue;
@@ -19,6 +21,7 @@ How it maps onto the engine
     ``keep_yolo_decode`` writes the level's rows of the ``[N, anchors, 16]`` prediction tensor (sigmoid, grid / anchor decode).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -383,11 +386,127 @@ class EngineYoloModel:
         return self
 
 
+def letterbox_geometry(h, w, stride=32):
+    """Where ``_preprocess`` (face_detector.py:48-62, target_size None) puts a frame: ``check_img_size`` rounds the longer side up to a
+    multiple of the largest stride, ``letterbox(auto=True, scaleup=True)`` (utils/datasets.py:5-33) scales the frame to it and pads both
+    axes to the next multiple of 64 of the REMAINDER (np.mod(d, 64)), half on each side.  -> (rh, rw), (top, left), (H2, W2)."""
+    size = int(math.ceil(max(h, w) / stride) * stride)
+    r = min(size / h, size / w)
+    rw, rh = int(round(w * r)), int(round(h * r))
+    dw, dh = ((size - rw) % 64) / 2, ((size - rh) % 64) / 2
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    return (rh, rw), (top, left), (rh + top + bottom, rw + left + right)
+
+
+def faces_from_kept_rows(rows, net_hw, frame_hw, min_face):
+    """What ``_postprocess`` + ``detect_faces`` make of one frame's suppressed detections (face_detector.py:80-104,133-141;
+    scale_coords / scale_coords_landmarks / clip_coords, utils/general.py:42-63,249-272): rows float32 [k, >= 15]
+    (x1 y1 x2 y2 conf lm x 10, network-input pixels, descending conf) -> int64 [k', 15] rows ``x1 y1 x2 y2 x1 lm x 10`` in frame pixels,
+    or None.  torch CPU float32 arithmetic, as the reference's (its ``det = pred[image_id].cpu()``); the ``.round()`` of :85-86 is not in
+    place and has no effect; ``int()`` truncates."""
+    if rows is None or len(rows) == 0:
+        return None
+    det = torch.as_tensor(np.ascontiguousarray(rows[:, :15]), dtype=torch.float32).clone()
+    (H2, W2), (H, W) = net_hw, frame_hw
+    gain = min(H2 / H, W2 / W)
+    pad_x, pad_y = (W2 - W * gain) / 2, (H2 - H * gain) / 2
+    xs, ys = [0, 2, 5, 7, 9, 11, 13], [1, 3, 6, 8, 10, 12, 14]
+    det[:, xs] = ((det[:, xs] - pad_x) / gain).clamp_(0, W)
+    det[:, ys] = ((det[:, ys] - pad_y) / gain).clamp_(0, H)
+    size = torch.tensor([W, H])
+    box = (det[:, :4] / size.repeat(2)).double() * size.repeat(2).double()          # (/ gn in float32, * width in Python floats)
+    lms = (det[:, 5:15] / size.repeat(5)).double() * size.repeat(5).double()
+    box, lms = box.trunc().long(), lms.trunc().long()
+    big = ~((box[:, 3] - box[:, 1]) < min_face)
+    if not bool(big.any()):
+        return None
+    box, lms = box[big], lms[big]
+    return torch.cat((box, box[:, :1], lms), dim=1).numpy()
+
+
+_YOLO_PINNED = {}
+
+
+def _stage_u8(chunk):
+    key = tuple(chunk.shape)
+    buf = _YOLO_PINNED.get(key)
+    if buf is None:
+        if len(_YOLO_PINNED) >= 2:
+            _YOLO_PINNED.clear()
+        buf = _YOLO_PINNED[key] = torch.empty(chunk.shape, dtype=torch.uint8, pin_memory=True)
+    buf.copy_(chunk)
+    return buf
+
+
+def yolo_detect_batch_device(det, frames_bgr, conf_thres=0.7, iou_thres=0.5, max_frames=16, cap=1024):
+    """``yolo_detect_batch`` with everything between the uint8 frames and the kept detections on the device.  frames: uint8 [N,H,W,3] BGR
+    (numpy or tensor, host or device).  Per chunk of ``max_frames``: pinned H2D of the uint8 frames, ``keep_yolo_letterbox_u8`` (BGR2RGB +
+    resize + 114 border + / 255 -> NHWC float), the network, ``keep_yolo_select`` (objectness and conf thresholds, xywh2xyxy -> compact
+    list), ``keep_retina_nms`` (= torchvision.ops.nms); one D2H of the counts, one of the kept rows.  A frame whose compact list overflowed
+    (more than ``cap`` candidates: a threshold near 0) or that holds two candidates with equal conf is finished on the host from its device
+    tensors with the same arithmetic (``engine/retinaface.py:nms``)."""
+    from .retinaface import nms as host_nms
+    eng = det.detector.engine
+    frames = torch.as_tensor(np.ascontiguousarray(frames_bgr) if isinstance(frames_bgr, np.ndarray) else frames_bgr)
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
+        raise ValueError(f'yolo_detect_batch_device: uint8 [N,H,W,3] frames expected, got {frames.dtype} {tuple(frames.shape)}')
+    N, H, W, _ = frames.shape
+    if eng.w is None:
+        eng.to(frames.device if frames.device.type == 'cuda' else getattr(det, 'device', 'cuda'))
+    dev = eng.device
+    (rh, rw), (top, left), (H2, W2) = letterbox_geometry(H, W, int(max(STRIDES)))
+    min_face = getattr(det, 'min_face', 10)
+    out = []
+    for s0 in range(0, N, max_frames):
+        chunk = frames[s0:s0 + max_frames]
+        if chunk.device.type != 'cuda':
+            chunk = _stage_u8(chunk).to(dev, non_blocking=True)
+        chunk = chunk.contiguous()
+        n = chunk.shape[0]
+        with torch.cuda.device(dev):
+            x = torch.empty((n, H2, W2, 3), dtype=torch.float32, device=dev)
+            L.call('keep_yolo_letterbox_u8', chunk, x, n, H, W, rh, rw, top, left, H2, W2, 1)
+            pred = eng.forward_nhwc(x)
+            P = pred.shape[1]
+            dets = torch.empty((n, cap, 16), dtype=torch.float32, device=dev)
+            counts = torch.zeros((n,), dtype=torch.int32, device=dev)
+            L.call('keep_yolo_select', pred, dets, counts, n, P, cap, float(conf_thres))
+            kept = torch.empty((n, cap, 16), dtype=torch.float32, device=dev)
+            kcnt = torch.empty((n,), dtype=torch.int32, device=dev)
+            L.call('keep_retina_nms', dets, counts, kept, kcnt, n, cap, float(iou_thres))
+            kc = kcnt.cpu().numpy()
+            top_k = int(max(0, kc.max()))
+            rows_all = kept[:, :top_k].cpu().numpy() if top_k else None
+        for i in range(n):
+            if kc[i] >= 0:
+                rows = rows_all[i, :kc[i]] if kc[i] else None
+            else:                   # -1: the list overflowed, -2: equal conf values -> this frame's candidates are ordered / suppressed on the host
+                if kc[i] == -2:
+                    cand = dets[i, :int(counts[i])].cpu().numpy()
+                else:
+                    full = pred[i].cpu().numpy()
+                    full = full[full[:, 4] > np.float32(conf_thres)]
+                    conf = full[:, 15] * full[:, 4]
+                    hw_, hh_ = full[:, 2] / np.float32(2), full[:, 3] / np.float32(2)
+                    cand = np.concatenate((np.stack((full[:, 0] - hw_, full[:, 1] - hh_, full[:, 0] + hw_, full[:, 1] + hh_, conf), 1),
+                                           full[:, 5:15]), 1)[conf > np.float32(conf_thres)]
+                rows = cand[host_nms(cand[:, :5], np.float32(iou_thres))] if len(cand) else None
+            out.append(faces_from_kept_rows(rows, (H2, W2), (H, W), min_face))
+    return out
+
+
 def yolo_detect_batch(det, frames_bgr, conf_thres=0.7, iou_thres=0.5):
-    """``YoloDetector.detect_faces`` (face_detector.py:113-141) for a stack of equally sized frames with ONE network call: the
-    detector's own ``_preprocess`` (letterbox) and ``_postprocess`` (NMS, rescaling, min_face filter) on the whole list, then what
-    ``detect_faces`` assembles from them, per frame: ``[x1, y1, x2, y2, x1, lm x 10]`` rows, or None for a frame without faces
-    (detect_faces called on that frame alone returns None).  ``KEEPFaceProcessor._detect_all`` finds it as ``det.detect_batch``."""
+    """``YoloDetector.detect_faces`` (face_detector.py:113-141) for a stack of equally sized frames with ONE network call per chunk, per
+    frame: ``[x1, y1, x2, y2, x1, lm x 10]`` rows, or None for a frame without faces (detect_faces called on that frame alone returns
+    None).  ``KEEPFaceProcessor._detect_all`` finds it as ``det.detect_batch``.  uint8 frames with the engine's network behind the detector
+    and ``target_size`` None (detection/__init__.py:42-49 never sets it) take ``yolo_detect_batch_device``; ``KEEP_AMD_YOLO_DEVICE=0``,
+    other frame types or a ``target_size`` keep the detector's own ``_preprocess`` (letterbox, cv2) and ``_postprocess`` (NMS, rescaling,
+    min_face filter) on the whole list around the one network call."""
+    dtype = getattr(frames_bgr, 'dtype', None)
+    if (os.environ.get('KEEP_AMD_YOLO_DEVICE', '1') != '0' and isinstance(getattr(det, 'detector', None), EngineYoloModel)
+            and not getattr(det, 'target_size', None) and dtype in (np.uint8, torch.uint8) and len(frames_bgr)):
+        return yolo_detect_batch_device(det, frames_bgr, conf_thres, iou_thres)
     import copy
     import cv2
     images = [cv2.cvtColor(np.ascontiguousarray(img), cv2.COLOR_BGR2RGB) for img in frames_bgr]

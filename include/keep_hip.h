@@ -30,8 +30,8 @@ extern "C" {
  * the fields a shorter known layout lacks as zero), keep_sizeof_*_args(), keep_argmax_gather takes the non-finite status word,
  * keep_nonfinite_flag.  v13: keep_conv2d_args.upsample accepts KEEP_UPSAMPLE_X2_PHASES (same layout; a v12 library refuses the
  * value, so the binding asks for 13).  v18: the two reserved words of keep_conv2d_args become `flags` / `plan_ref_images`, the one of
- * keep_attention_args `flags` (same layout and sizes; zero keeps the v17 behaviour) -- the library no longer reads ANY environment variable. */
-#define KEEP_ABI_VERSION 18
+ * keep_attention_args `flags` (same layout and sizes; zero keeps the v17 behaviour) -- the library no longer reads ANY environment variable.  v19: keep_yolo_letterbox_u8, keep_yolo_select (additions only). */
+#define KEEP_ABI_VERSION 19
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -417,6 +417,18 @@ int32_t keep_channel_shuffle2(const float* a, const float* b, float* out, int64_
  * objectness / class, grid + anchor decode of the box and of the five landmarks, in pixels of the network input. */
 int32_t keep_yolo_decode(const float* raw, float* pred, int32_t N, int32_t ny, int32_t nx, float stride, const float* anchors_wh,
                          int32_t row0, int32_t rows_total, void* stream);
+/* YoloDetector._preprocess on the device (v19; face_detector.py:48-67, utils/datasets.py:5-36): frames uint8 [N,H,W,3] ->
+ * out float32 [N,H2,W2,3] NHWC in [0, 1]: optional channel swap (cv2.cvtColor BGR2RGB, face_detector.py:126), cv2.resize(INTER_LINEAR) to
+ * (rw, rh) when that differs from (W, H) -- OpenCV's 8-bit fixed-point bilinear (11-bit coefficients; an exact 2x reduction, which cv2
+ * turns into INTER_AREA, is refused), placed at (top, left) of a canvas of 114 (cv2.copyMakeBorder), then float / 255. */
+int32_t keep_yolo_letterbox_u8(const uint8_t* frames, float* out, int32_t N, int32_t H, int32_t W, int32_t rh, int32_t rw, int32_t top,
+                               int32_t left, int32_t H2, int32_t W2, int32_t swap_rb, void* stream);
+/* non_max_suppression_face up to its NMS call (v19; utils/general.py:89-143, one class): pred [N,P,16] as keep_yolo_decode wrote it ->
+ * for every row with objectness > conf_threshold and conf = class * objectness > conf_threshold one row of dets [N,cap,16] =
+ * x1 y1 x2 y2 conf lm0..lm9 row-index (xywh2xyxy: x -+ w / 2), appended in arrival order; counts[n] (zeroed by the caller) = survivors
+ * of frame n (may exceed cap: rows beyond cap are dropped).  keep_retina_nms (= torchvision.ops.nms) takes dets / counts from here. */
+int32_t keep_yolo_select(const float* pred, float* dets, int32_t* counts, int32_t N, int32_t P, int32_t cap, float conf_threshold,
+                         void* stream);
 /* FPN top-down step (retinaface_net.py:86-92): out = a + nearest-resize(b [N,hb,wb,C] -> [N,H,W,C]) */
 int32_t keep_upsample_add(const float* a, const float* b, float* out, int32_t N, int32_t H, int32_t W, int32_t hb, int32_t wb,
                           int32_t C, void* stream);

@@ -15,6 +15,17 @@ in the build image; the trunk below restates torchvision's published ResNet-50 v
 convolution, state-dict names ``body.conv1 / bn1 / layer{1..4}.{i}.conv{1,2,3} / bn{1,2,3} / downsample.{0,1}``) and the golden
 generator feeds the SAME restated trunk to the reference's FPN / SSH / heads.  The mobile0.25 configuration has no such gap:
 MobileNetV1 is the reference's own class, and its golden is the output of the reference's modules from image to heads.
+
+  * ``yolo_preprocess`` / ``yolo_postprocess``  YoloDetector._preprocess / _postprocess / detect_faces (yolov5face/face_detector.py:48-141,
+                            utils/datasets.py:5-36 letterbox, utils/general.py:42-165,249-272 scale_coords / non_max_suppression_face)
+
+``tests/golden/yolo_prepost.npz`` holds what the reference's OWN ``YoloDetector.detect_faces`` returns (``make_golden_facelib.py
+--yolo-prepost``) with its two absent dependencies replaced: PARITY UNPINNED for ``cv2.resize(INTER_LINEAR)`` on uint8 (OpenCV is not
+installed; ``cv2_resize_linear_u8`` restates the fixed-point bilinear of OpenCV's modules/imgproc/src/resize.cpp, and the golden run uses
+that same restatement as its ``cv2.resize``) and for ``torchvision.ops.nms`` (greedy IoU suppression, as for RetinaFace).  Everything else
+on that path -- the letterbox geometry, the padding, the thresholds, xywh2xyxy, the rescaling to the frame, clamps, the integer
+truncation, the min_face filter, the assembly of the result -- is the reference's own code in the golden run; the frames whose longer side
+is a multiple of 32 are never resized, so for them the pre-processing golden has no unpinned part.
 """
 import math
 
@@ -231,3 +242,148 @@ def yolo_forward(x, W, layers, anchors, strides):
             return torch.cat(z, 1)
         ys.append(y)
     raise AssertionError('no Detect layer')
+
+
+# ------------------------------------------------------------------------------------- YoloDetector pre / post-processing
+def cv2_resize_linear_u8(img, dw, dh):
+    """cv2.resize(img uint8 [H,W,C], (dw, dh), interpolation=cv2.INTER_LINEAR) -- OpenCV modules/imgproc/src/resize.cpp: resizeGeneric_
+    with HResizeLinear<uchar,int,short> / VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>> (11-bit coefficients).  PARITY
+    UNPINNED (OpenCV absent from the image).  An exact 2x reduction is INTER_AREA inside cv2.resize and is not restated."""
+    H, W = img.shape[:2]
+    if (dw, dh) == (W, H):
+        return img.copy()
+    if H == 2 * dh and W == 2 * dw:
+        raise NotImplementedError('cv2.resize turns an exact 2x INTER_LINEAR reduction into INTER_AREA')
+
+    def coef(dsize, ssize, clamp):
+        scale = 1.0 / (dsize / ssize)                                    # double inv_scale = (double)dsize / ssize; scale = 1. / inv_scale
+        f = ((np.arange(dsize, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        i = np.floor(f).astype(np.int64)
+        f = f - i.astype(np.float32)
+        if clamp:                                                         # columns: the position is clamped and the weight reset
+            lo, hi = i < 0, i >= ssize - 1
+            i = np.where(lo, 0, np.where(hi, ssize - 1, i))
+            f = np.where(lo | hi, np.float32(0), f).astype(np.float32)
+        c0 = np.clip(np.rint((np.float32(1) - f) * np.float32(2048)), -32768, 32767).astype(np.int64)
+        c1 = np.clip(np.rint(f * np.float32(2048)), -32768, 32767).astype(np.int64)
+        return i, c0, c1
+
+    sx, a0, a1 = coef(dw, W, True)
+    sy, b0, b1 = coef(dh, H, False)
+    src = img.astype(np.int64)
+    x1 = np.minimum(sx + 1, W - 1)
+    hor = src[:, sx] * a0[None, :, None] + src[:, x1] * a1[None, :, None]            # [H, dw, C]
+    r0, r1 = hor[np.clip(sy, 0, H - 1)], hor[np.clip(sy + 1, 0, H - 1)]              # rows are clamped, their weights kept
+    out = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def yolo_letterbox_geometry(h, w, stride=32):
+    """check_img_size + letterbox(auto=True, scaleup=True) (face_detector.py:58-59 with target_size None, utils/datasets.py:5-33,
+    utils/general.py:9-19): (resized h, w), (top, left), (H2, W2)."""
+    size = math.ceil(max(h, w) / stride) * stride
+    r = min(size / h, size / w)
+    rw, rh = int(round(w * r)), int(round(h * r))
+    dw, dh = np.mod(size - rw, 64) / 2, np.mod(size - rh, 64) / 2
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    return (rh, rw), (top, left), (rh + top + bottom, rw + left + right)
+
+
+def yolo_preprocess(frames_bgr):
+    """detect_faces' BGR2RGB + _preprocess (target_size None) for uint8 frames of one size -> float32 [N, 3, H2, W2] in [0, 1]."""
+    out = []
+    for img in frames_bgr:
+        img = np.ascontiguousarray(img[:, :, ::-1])
+        (rh, rw), (top, left), (H2, W2) = yolo_letterbox_geometry(*img.shape[:2])
+        canvas = np.full((H2, W2, 3), 114, np.uint8)
+        canvas[top:top + rh, left:left + rw] = cv2_resize_linear_u8(img, rw, rh)
+        out.append(canvas)
+    return torch.from_numpy(np.array(out).transpose(0, 3, 1, 2)).float() / 255.0
+
+
+def _greedy_nms(boxes, scores, thr):
+    """torchvision.ops.nms (PARITY UNPINNED: torchvision absent): descending score, drop when IoU with a kept box > thr; float32."""
+    order = np.argsort(-scores, kind='stable')
+    areas = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    keep, alive = [], np.ones(len(order), bool)
+    for a, i in enumerate(order):
+        if not alive[a]:
+            continue
+        keep.append(int(i))
+        rest = order[a + 1:]
+        w = np.clip(np.minimum(boxes[i, 2], boxes[rest, 2]) - np.maximum(boxes[i, 0], boxes[rest, 0]), 0, None)
+        h = np.clip(np.minimum(boxes[i, 3], boxes[rest, 3]) - np.maximum(boxes[i, 1], boxes[rest, 1]), 0, None)
+        inter = w * h
+        alive[a + 1:] &= ~((inter / (areas[i] + areas[rest] - inter)) > thr)
+    return keep
+
+
+def yolo_postprocess(pred, net_hw, frame_hw, conf_thres=0.7, iou_thres=0.5, min_face=10):
+    """One frame of YoloDetector.detect_faces after the network (face_detector.py:69-104,133-141; general.py:89-165 with one class):
+    pred float32 [P, 16] -> int64 [k, 15] rows ``x1 y1 x2 y2 x1 lm x 10`` in frame pixels, or None without a face."""
+    f32 = np.float32
+    x = pred[pred[:, 4] > f32(conf_thres)].astype(f32)
+    conf = x[:, 15] * x[:, 4]
+    half_w, half_h = x[:, 2] / f32(2), x[:, 3] / f32(2)
+    box = np.stack((x[:, 0] - half_w, x[:, 1] - half_h, x[:, 0] + half_w, x[:, 1] + half_h), 1)
+    sel = conf > f32(conf_thres)
+    box, conf, lm = box[sel], conf[sel], x[sel, 5:15]
+    if not len(box):
+        return None
+    keep = _greedy_nms(box, conf, f32(iou_thres))
+    box, lm = box[keep], lm[keep]
+    H2, W2 = net_hw
+    H, W = frame_hw
+    gain = min(H2 / H, W2 / W)
+    pad = f32((W2 - W * gain) / 2), f32((H2 - H * gain) / 2)
+    g = f32(gain)
+    lim = np.array([W, H], f32)
+    box = (box - np.array([pad[0], pad[1]] * 2, f32)) / g                  # scale_coords: tensor op python scalar = float32 arithmetic
+    lm = (lm - np.array([pad[0], pad[1]] * 5, f32)) / g
+    box = np.clip(box, 0, np.tile(lim, 2))
+    lm = np.clip(lm, 0, np.tile(lim, 5))
+    box = (box / np.tile(lim, 2)).astype(np.float64) * np.tile(np.array([W, H], np.float64), 2)      # / gn (float32), * width in double
+    lm = (lm / np.tile(lim, 5)).astype(np.float64) * np.tile(np.array([W, H], np.float64), 5)
+    box, lm = np.trunc(box).astype(np.int64), np.trunc(lm).astype(np.int64)
+    big = ~(box[:, 3] - box[:, 1] < min_face)
+    box, lm = box[big], lm[big]
+    if not len(box):
+        return None
+    return np.concatenate((box, box[:, :1], lm), axis=1)
+
+
+def yolo_prepost_inputs():
+    """Frames and crafted predictions of the YoloDetector pre / post-processing golden (shared with the tests): two frame sizes -- 100 x 160
+    (longer side a multiple of 32: padding only) and 90 x 150 (resized by 160 / 150, then padded) -- and per size one [2, P, 16] prediction
+    tensor: background rows of low objectness, clusters of overlapping boxes whose objectness / class products straddle the thresholds,
+    a box across the frame border (clamps), a face lower than min_face, one frame of the second pair without any face."""
+    rng = np.random.default_rng(20240517)
+    cases = {}
+    for tag, (h, w) in (('pad', (100, 160)), ('resize', (90, 150))):
+        frames = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+        (rh, rw), (top, left), (H2, W2) = yolo_letterbox_geometry(h, w)
+        P = 3 * sum((H2 // s) * (W2 // s) for s in (8, 16, 32))
+        pred = np.zeros((2, P, 16), np.float32)
+        pred[..., 0] = rng.uniform(0, W2, (2, P))
+        pred[..., 1] = rng.uniform(0, H2, (2, P))
+        pred[..., 2:4] = rng.uniform(4, 60, (2, P, 2))
+        pred[..., 4] = rng.uniform(0.0, 0.6, (2, P))
+        pred[..., 5:15] = rng.uniform(0, W2, (2, P, 10))
+        pred[..., 15] = rng.uniform(0.0, 1.0, (2, P))
+        for n in range(2):
+            if tag == 'resize' and n == 1:
+                continue                                              # a frame without faces
+            centres = [(0.3 * W2, 0.5 * H2, 40.0, 52.0), (0.7 * W2, 0.45 * H2, 30.0, 36.0), (W2 - 6.0, H2 - 20.0, 30.0, 44.0),
+                       (0.5 * W2, 0.2 * H2 + top, 9.0, 7.0)]          # (the last: lower than min_face = 10 after truncation)
+            rows = rng.choice(P, size=12 * len(centres), replace=False)
+            for c, (cx, cy, bw, bh) in enumerate(centres):
+                for k in range(12):
+                    r = rows[c * 12 + k]
+                    jit = rng.normal(0, 2.5, 4)
+                    pred[n, r, 0:4] = (cx + jit[0], cy + jit[1], bw + jit[2], bh + jit[3])
+                    pred[n, r, 4] = rng.uniform(0.6, 1.0) if k >= 6 else rng.uniform(0.975, 1.0)      # (products straddle 0.7 and 0.97)
+                    pred[n, r, 15] = rng.uniform(0.7, 1.0) if k >= 6 else rng.uniform(0.975, 1.0)
+                    pred[n, r, 5:15] = np.tile((cx, cy), 5) + rng.normal(0, 0.3 * bw, 10)
+        cases[tag] = (frames, pred.astype(np.float32))
+    return cases

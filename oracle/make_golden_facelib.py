@@ -160,6 +160,60 @@ def yolo_golden():
     return out
 
 
+def yolo_prepost_golden():
+    """The reference's OWN ``YoloDetector.detect_faces`` (yolov5face/face_detector.py:113-141: BGR2RGB, _preprocess with letterbox, the
+    network call, _postprocess with non_max_suppression_face / scale_coords / scale_coords_landmarks, the assembly) run frame by frame on
+    ``facelib_oracle.yolo_prepost_inputs``; its network is a recorder that keeps the pre-processed tensor and returns the crafted prediction.  Absent
+    dependencies: ``cv2`` = {cvtColor(BGR2RGB): channel flip, copyMakeBorder(constant): np.pad, resize(INTER_LINEAR):
+    facelib_oracle.cv2_resize_linear_u8 -- UNPINNED}, ``torchvision.ops.nms`` = greedy IoU suppression (UNPINNED)."""
+    import types
+    import facelib_oracle as FO
+    deps = os.path.join(REF, 'modules', 'deps')
+    for name, sub in (('wm_facelib', ''), ('wm_facelib.detection', 'detection'), ('wm_facelib.detection.yolov5face', 'detection/yolov5face'),
+                      ('wm_facelib.detection.yolov5face.models', 'detection/yolov5face/models'),
+                      ('wm_facelib.detection.yolov5face.utils', 'detection/yolov5face/utils')):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(deps, 'wm_facelib', sub)]
+            sys.modules[name] = m
+    cv2 = sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+    cv2.INTER_LINEAR, cv2.BORDER_CONSTANT, cv2.COLOR_BGR2RGB = 1, 0, 4
+    cv2.cvtColor = lambda img, code: np.ascontiguousarray(img[:, :, ::-1])
+    cv2.resize = lambda img, dsize, interpolation=1: FO.cv2_resize_linear_u8(img, int(dsize[0]), int(dsize[1]))
+    cv2.copyMakeBorder = lambda img, t, b, l, r, kind, value=(0, 0, 0): np.stack(
+        [np.pad(img[:, :, c], ((t, b), (l, r)), constant_values=value[c]) for c in range(3)], 2)
+    tv = sys.modules.setdefault('torchvision', types.ModuleType('torchvision'))
+    tv.ops = types.SimpleNamespace(nms=lambda boxes, scores, thr: torch.tensor(FO._greedy_nms(boxes.numpy(), scores.numpy(), np.float32(thr)),
+                                                                              dtype=torch.int64))
+    import importlib
+    ver, torch.__version__ = torch.__version__, torch.__version__.split('+')[0]      # (face_detector.py:18 cannot parse a '+rocm' local version)
+    try:
+        fd = importlib.import_module('wm_facelib.detection.yolov5face.face_detector')
+    finally:
+        torch.__version__ = ver
+    out = {}
+    for tag, (frames, pred) in FO.yolo_prepost_inputs().items():
+        for conf, iou, name in ((0.7, 0.5, 'default'), (0.97, 0.5, 'helper')):      # detect_faces' defaults; the helper's 0.97 (face_restoration_helper.py:221)
+            for n in range(2):
+                det = fd.YoloDetector.__new__(fd.YoloDetector)
+                det.target_size, det.min_face, det.device = None, 10, 'cpu'
+                seen = {}
+
+                def network(x, n=n, seen=seen, pred=pred):
+                    seen['x'] = x.clone()
+                    return (torch.from_numpy(pred[n:n + 1].copy()),)
+                network.stride = torch.tensor([8.0, 16.0, 32.0])
+                det.detector = network
+                res = det.detect_faces(frames[n].copy(), conf, iou)
+                if name == 'default':
+                    out[f'{tag}_x{n}'] = np.round(seen['x'][0].numpy() * 255.0).astype(np.uint8)       # (u8 / 255 round-trips exactly)
+                    assert np.array_equal(out[f'{tag}_x{n}'].astype(np.float32) / np.float32(255.0), seen['x'][0].numpy())
+                out[f'{tag}_{name}_det{n}'] = np.zeros((0, 15), np.int64) if res is None else np.asarray(res).astype(np.int64)
+                print(tag, name, n, 'input', tuple(seen['x'].shape), 'faces', None if res is None else res.shape)
+    np.savez_compressed(os.path.join(GOLD, 'yolo_prepost.npz'), **out)
+    print('yolo_prepost.npz:', {k: v.shape for k, v in out.items()})
+
+
 def main():
     ref = _load(os.path.join(REF, 'modules', 'deps', 'wm_facelib', 'parsing', 'parsenet.py'), 'ref_parsenet')
     out = {}
@@ -190,4 +244,7 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    if '--yolo-prepost' in sys.argv:
+        yolo_prepost_golden()
+    else:
+        main()

@@ -310,3 +310,113 @@ def test_retina_decode_on_the_device_equals_the_host_decoder():
     as_float = eng.detect_batch(frames.double().numpy(), 0.9)                     # read_image's float64 frames
     for a, b in zip(as_float, eng.detect_batch(frames, 0.9)):
         assert np.array_equal(a, b)
+
+
+def test_yolo_letterbox_kernel_vs_oracle():
+    """keep_yolo_letterbox_u8 (BGR2RGB + cv2.resize(INTER_LINEAR) + 114 border + / 255, NHWC) bit-exact against the oracle's restatement
+    of ``_preprocess`` and against the golden network inputs of the reference run (tests/golden/yolo_prepost.npz), on the golden frames
+    and on product-like sizes: 640 x 1137 (a 720p frame after the helper's resize: scaled by 1152 / 1137, padded to 704 x 1152), a
+    padding-only size, a tall frame (left / right padding), strong magnification."""
+    from comfyui_keep_amd.engine import yoloface as YF
+    g = np.load(os.path.join(GOLDEN, 'yolo_prepost.npz'))
+    cases = [(tag, frames) for tag, (frames, _) in FO.yolo_prepost_inputs().items()]
+    rng = np.random.default_rng(7)
+    for hw in ((640, 1137), (352, 640), (517, 333), (23, 41), (300, 1000)):
+        cases.append((None, rng.integers(0, 256, (2, *hw, 3), dtype=np.uint8)))
+    smooth = (np.add.outer(np.arange(97), np.arange(131))[..., None] * np.array([1, 2, 3]) % 256).astype(np.uint8)[None]
+    cases.append((None, smooth))
+    for tag, frames in cases:
+        N, H, W, _ = frames.shape
+        (rh, rw), (top, left), (H2, W2) = YF.letterbox_geometry(H, W)
+        out = torch.empty((N, H2, W2, 3), device='cuda')
+        L.call('keep_yolo_letterbox_u8', torch.from_numpy(frames).cuda(), out, N, H, W, rh, rw, top, left, H2, W2, 1)
+        ref = FO.yolo_preprocess(list(frames))
+        got = out.cpu().permute(0, 3, 1, 2)
+        assert torch.equal(got, ref), (tag, H, W, float((got - ref).abs().max()) * 255)
+        if tag is not None:
+            for n in range(N):
+                assert np.array_equal(got[n].numpy(), g[f'{tag}_x{n}'].astype(np.float32) / np.float32(255.0))
+    # swap_rb = 0 keeps the channel order; bad geometry and the 2x reduction (cv2's INTER_AREA path) are refused
+    f = torch.from_numpy(cases[0][1]).cuda()
+    out = torch.empty((2, 160, 160, 3), device='cuda')
+    L.call('keep_yolo_letterbox_u8', f, out, 2, 100, 160, 100, 160, 30, 0, 160, 160, 0)
+    assert torch.equal(out[:, 30:130].cpu(), torch.from_numpy(cases[0][1]).float() / 255.0)
+    with pytest.raises(L.KeepHipError):
+        L.call('keep_yolo_letterbox_u8', f, out, 2, 100, 160, 100, 160, 70, 0, 160, 160, 1)
+    with pytest.raises(L.KeepHipError):
+        L.call('keep_yolo_letterbox_u8', f, out, 2, 100, 160, 50, 80, 0, 0, 160, 160, 1)
+
+
+def _yolo_stub_detector(name='YOLOv5n', pred=None):
+    """A YoloDetector as keep_model_loader leaves it (detector = EngineYoloModel, target_size None, min_face 10), without the reference
+    class: the device path reads exactly these attributes.  ``pred``: replace the network's output (crafted predictions)."""
+    import types
+    from comfyui_keep_amd.engine import yoloface as YF
+    eng = YF.YoloFaceEngine(YF.synth_yolo_state_dict(name, seed=0)).to('cuda')
+    if pred is not None:
+        real = eng.forward_nhwc
+        state = {'i': 0}
+
+        def forward(x):
+            shape = real(x).shape                      # (the network still runs: shapes are checked against it)
+            out = torch.from_numpy(pred[state['i']:state['i'] + x.shape[0]]).cuda()
+            state['i'] += x.shape[0]
+            assert tuple(out.shape) == tuple(shape)
+            return out
+        eng.forward_nhwc = forward
+    return types.SimpleNamespace(detector=YF.EngineYoloModel(eng), target_size=None, min_face=10, device='cuda')
+
+
+def test_yolo_detect_batch_device_vs_reference_golden():
+    """``yolo_detect_batch`` on the device (letterbox kernel -> network -> keep_yolo_select -> keep_retina_nms -> host tail on the kept
+    rows) against what the reference's own ``detect_faces`` returned for the golden frames and crafted predictions, at its default
+    thresholds and at the helper's 0.97; a frame without faces is None; chunks smaller than the batch; the overflow (cap 8) and
+    equal-conf hand-backs finish on the host with the same result."""
+    from comfyui_keep_amd.engine import yoloface as YF
+    g = np.load(os.path.join(GOLDEN, 'yolo_prepost.npz'))
+    for tag, (frames, pred) in FO.yolo_prepost_inputs().items():
+        for conf, name in ((0.7, 'default'), (0.97, 'helper')):
+            want = [g[f'{tag}_{name}_det{n}'] for n in range(2)]
+            for kw in ({}, {'max_frames': 1}, {'cap': 8}):
+                det = _yolo_stub_detector(pred=pred)
+                got = (YF.yolo_detect_batch(det, frames, conf, 0.5) if not kw else YF.yolo_detect_batch_device(det, frames, conf, 0.5, **kw))
+                for n in range(2):
+                    if len(want[n]) == 0:
+                        assert got[n] is None, (tag, name, n, kw)
+                    else:
+                        assert got[n].dtype == np.int64 and np.array_equal(got[n], want[n]), (tag, name, n, kw, got[n], want[n])
+    # two candidates with the same conf: the device hands the frame back (-2) and the host orders them (stable: first row first)
+    frames, pred = FO.yolo_prepost_inputs()['pad']
+    pred = pred.copy()
+    rows = np.flatnonzero(pred[0, :, 4] * pred[0, :, 15] > 0.9)[:2]
+    pred[0, rows[1]] = pred[0, rows[0]]
+    det = _yolo_stub_detector(pred=pred)
+    got = YF.yolo_detect_batch(det, frames, 0.7, 0.5)
+    ref = FO.yolo_postprocess(pred[0], (160, 160), (100, 160), 0.7, 0.5)
+    assert np.array_equal(got[0], ref)
+
+
+def test_yolo_detect_batch_device_on_the_network_vs_oracle_postprocess():
+    """The whole device path on the engine's own predictions (synthetic weights: objectness spans its range, hundreds of candidates
+    at a low threshold): equal to the oracle's post-processing of the same prediction tensor, frame by frame; selection kernel counts =
+    the number of rows above both thresholds."""
+    from comfyui_keep_amd.engine import yoloface as YF
+    rng = np.random.default_rng(11)
+    frames = rng.integers(0, 256, (3, 176, 301, 3), dtype=np.uint8)
+    det = _yolo_stub_detector('YOLOv5n')
+    (rh, rw), (top, left), (H2, W2) = YF.letterbox_geometry(176, 301)
+    x = torch.empty((3, H2, W2, 3), device='cuda')
+    L.call('keep_yolo_letterbox_u8', torch.from_numpy(frames).cuda(), x, 3, 176, 301, rh, rw, top, left, H2, W2, 1)
+    pred = det.detector.engine.forward_nhwc(x)
+    p = pred.cpu().numpy()
+    for conf in (0.5, 0.3):
+        n_cand = [(int(((p[i, :, 4] > np.float32(conf)) & (p[i, :, 15] * p[i, :, 4] > np.float32(conf))).sum())) for i in range(3)]
+        dets = torch.empty((3, 4096, 16), device='cuda')
+        counts = torch.zeros(3, dtype=torch.int32, device='cuda')
+        L.call('keep_yolo_select', pred, dets, counts, 3, p.shape[1], 4096, conf)
+        assert counts.cpu().tolist() == n_cand
+        got = YF.yolo_detect_batch_device(det, frames, conf, 0.5, cap=4096)
+        print(f'yolo device path: conf {conf}: candidates {n_cand}, faces {[0 if r is None else len(r) for r in got]}')
+        for i in range(3):
+            ref = FO.yolo_postprocess(p[i], (H2, W2), (176, 301), conf, 0.5)
+            assert (got[i] is None and ref is None) or np.array_equal(got[i], ref), (conf, i)

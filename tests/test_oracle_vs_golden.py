@@ -269,3 +269,45 @@ def test_retinaface_oracle_and_host_decode_vs_reference_golden():
     # greedy NMS: a cluster of overlapping boxes keeps its best, disjoint boxes all survive, order = descending score
     d = np.array([[0, 0, 10, 10, 0.9], [1, 1, 11, 11, 0.95], [20, 20, 30, 30, 0.5], [0, 0, 10, 10.5, 0.7]], np.float32)
     assert RF.nms(d, 0.4) == [1, 2]
+
+
+def test_yolo_pre_and_post_processing_vs_reference_golden():
+    """oracle/facelib_oracle.py:yolo_preprocess / yolo_postprocess and the product's host logic (engine/yoloface.py:letterbox_geometry,
+    faces_from_kept_rows) against what the reference's OWN ``YoloDetector.detect_faces`` returned frame by frame
+    (tests/golden/yolo_prepost.npz; cv2.resize / torchvision.ops.nms unpinned, see the oracle's header): the network input it built and
+    the face rows it assembled, at detect_faces' default thresholds and at the helper's 0.97."""
+    import facelib_oracle as FO
+    from comfyui_keep_amd.engine import yoloface as YF
+    g = np.load(os.path.join(GOLDEN, 'yolo_prepost.npz'))
+    for hw in ((100, 160), (90, 150), (640, 1137), (1080, 1920), (512, 512), (720, 1280), (333, 517), (517, 333), (64, 2000)):
+        assert YF.letterbox_geometry(*hw) == FO.yolo_letterbox_geometry(*hw), hw
+    for tag, (frames, pred) in FO.yolo_prepost_inputs().items():
+        (rh, rw), (top, left), net_hw = YF.letterbox_geometry(*frames.shape[1:3])
+        x = FO.yolo_preprocess(list(frames))
+        assert tuple(x.shape[2:]) == net_hw == g[f'{tag}_x0'].shape[1:]
+        for n in range(2):
+            assert np.array_equal(x[n].numpy(), g[f'{tag}_x{n}'].astype(np.float32) / np.float32(255.0)), (tag, n)
+            if tag == 'pad':            # no resize on this frame size: the golden input has no unpinned part -- it IS the frame, RGB, inside 114
+                assert np.array_equal(g[f'{tag}_x{n}'][:, top:top + rh, left:left + rw], frames[n][:, :, ::-1].transpose(2, 0, 1))
+                assert (g[f'{tag}_x{n}'][:, :top] == 114).all() and (g[f'{tag}_x{n}'][:, top + rh:] == 114).all()
+            for conf, name in ((0.7, 'default'), (0.97, 'helper')):
+                want = g[f'{tag}_{name}_det{n}']
+                got = FO.yolo_postprocess(pred[n], net_hw, frames.shape[1:3], conf, 0.5)
+                assert np.array_equal(np.zeros((0, 15), np.int64) if got is None else got, want), (tag, name, n)
+                # the product's host tail on the rows the selection + suppression leave (restated here with the oracle's NMS)
+                p = pred[n][pred[n][:, 4] > np.float32(conf)]
+                c = p[:, 15] * p[:, 4]
+                rows = np.concatenate((np.stack((p[:, 0] - p[:, 2] / 2, p[:, 1] - p[:, 3] / 2, p[:, 0] + p[:, 2] / 2, p[:, 1] + p[:, 3] / 2, c), 1),
+                                       p[:, 5:15]), 1)[c > np.float32(conf)]
+                keep = FO._greedy_nms(rows[:, :4], rows[:, 4], np.float32(0.5)) if len(rows) else []
+                got = YF.faces_from_kept_rows(rows[keep] if keep else None, net_hw, frames.shape[1:3], 10)
+                assert np.array_equal(np.zeros((0, 15), np.int64) if got is None else got, want), (tag, name, n, 'host tail')
+    # the resize restatement: identity, constant images, and a 2 x 2 -> 4 x 4 case by hand (coefficients 2048 * {.75, .25})
+    img = np.arange(2 * 2 * 3, dtype=np.uint8).reshape(2, 2, 3) * 20
+    up = FO.cv2_resize_linear_u8(img, 4, 4)
+    assert np.array_equal(up[0, 0], img[0, 0]) and np.array_equal(up[3, 3], img[1, 1])
+    hor = (int(img[0, 0, 0]) * 1536 + int(img[0, 1, 0]) * 512) >> 4          # dx = 1: fx = .25; dy = 0: sy = -1 (clamped to row 0), fy = .75
+    assert int(up[0, 1, 0]) == (((512 * hor) >> 16) + ((1536 * hor) >> 16) + 2) >> 2
+    assert (FO.cv2_resize_linear_u8(np.full((7, 9, 3), 93, np.uint8), 20, 13) == 93).all()
+    with pytest.raises(NotImplementedError):
+        FO.cv2_resize_linear_u8(np.zeros((8, 8, 3), np.uint8), 4, 4)

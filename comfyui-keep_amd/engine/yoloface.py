@@ -425,23 +425,9 @@ def faces_from_kept_rows(rows, net_hw, frame_hw, min_face):
     return torch.cat((box, box[:, :1], lms), dim=1).numpy()
 
 
-_YOLO_PINNED = {}
-
-
-def _stage_u8(chunk):
-    key = tuple(chunk.shape)
-    buf = _YOLO_PINNED.get(key)
-    if buf is None:
-        if len(_YOLO_PINNED) >= 2:
-            _YOLO_PINNED.clear()
-        buf = _YOLO_PINNED[key] = torch.empty(chunk.shape, dtype=torch.uint8, pin_memory=True)
-    buf.copy_(chunk)
-    return buf
-
-
 def yolo_detect_batch_device(det, frames_bgr, conf_thres=0.7, iou_thres=0.5, max_frames=16, cap=1024):
     """``yolo_detect_batch`` with everything between the uint8 frames and the kept detections on the device.  frames: uint8 [N,H,W,3] BGR
-    (numpy or tensor, host or device).  Per chunk of ``max_frames``: pinned H2D of the uint8 frames, ``keep_yolo_letterbox_u8`` (BGR2RGB +
+    (numpy or tensor, host or device).  Per chunk of ``max_frames``: H2D of the uint8 frames, ``keep_yolo_letterbox_u8`` (BGR2RGB +
     resize + 114 border + / 255 -> NHWC float), the network, ``keep_yolo_select`` (objectness and conf thresholds, xywh2xyxy -> compact
     list), ``keep_retina_nms`` (= torchvision.ops.nms); one D2H of the counts, one of the kept rows.  A frame whose compact list overflowed
     (more than ``cap`` candidates: a threshold near 0) or that holds two candidates with equal conf is finished on the host from its device
@@ -460,8 +446,8 @@ def yolo_detect_batch_device(det, frames_bgr, conf_thres=0.7, iou_thres=0.5, max
     out = []
     for s0 in range(0, N, max_frames):
         chunk = frames[s0:s0 + max_frames]
-        if chunk.device.type != 'cuda':
-            chunk = _stage_u8(chunk).to(dev, non_blocking=True)
+        if chunk.device.type != 'cuda':      # pageable -> device directly: 35 MB of frames in 0.63 ms (55 GB/s); a pinned staging copy in front of it
+            chunk = chunk.to(dev)            # (torch's 128-thread copy_) stalls for 70-80 ms every few calls, profiles/r05_h2d_staging.txt
         chunk = chunk.contiguous()
         n = chunk.shape[0]
         with torch.cuda.device(dev):

@@ -470,6 +470,7 @@ def yolo_detect_batch_device(det, frames_bgr, conf_thres=0.7, iou_thres=0.5, max
             else:                   # -1: the list overflowed, -2: equal conf values -> this frame's candidates are ordered / suppressed on the host
                 if kc[i] == -2:
                     cand = dets[i, :int(counts[i])].cpu().numpy()
+                    cand = cand[np.argsort(cand[:, 15], kind='stable')]      # arrival order -> row order: equal conf values keep the prediction's order
                 else:
                     full = pred[i].cpu().numpy()
                     full = full[full[:, 4] > np.float32(conf_thres)]

@@ -388,8 +388,10 @@ def test_yolo_detect_batch_device_vs_reference_golden():
     # two candidates with the same conf: the device hands the frame back (-2) and the host orders them (stable: first row first)
     frames, pred = FO.yolo_prepost_inputs()['pad']
     pred = pred.copy()
-    rows = np.flatnonzero(pred[0, :, 4] * pred[0, :, 15] > 0.9)[:2]
-    pred[0, rows[1]] = pred[0, rows[0]]
+    near = (np.abs(pred[0, :, 0] - 48.0) < 10) & (np.abs(pred[0, :, 1] - 80.0) < 10) & (pred[0, :, 4] > 0.6)      # the cluster around (48, 80)
+    rows = np.flatnonzero(near)[:2]
+    pred[0, rows, 4] = pred[0, rows, 15] = 0.9990234375            # the two best of the frame, the same conf, overlapping, different boxes /
+    assert len(rows) == 2 and not np.array_equal(pred[0, rows[0], :4], pred[0, rows[1], :4])      # landmarks: the order decides which one survives
     det = _yolo_stub_detector(pred=pred)
     got = YF.yolo_detect_batch(det, frames, 0.7, 0.5)
     ref = FO.yolo_postprocess(pred[0], (160, 160), (100, 160), 0.7, 0.5)

@@ -25,6 +25,6 @@ fi
 [ -f $G/r5p_census_halo_b48.txt ] && grep -v "^/opt" $G/r5p_census_halo_b48.txt > profiles/r05_conv_census_halo_x3_b48.txt
 [ -f $G/r5p_census_b16.txt ] && grep -v "^/opt" $G/r5p_census_b16.txt > profiles/r05_conv_census_x3_b16.txt
 [ -f $G/r5p_census_halo_b16.txt ] && grep -v "^/opt" $G/r5p_census_halo_b16.txt > profiles/r05_conv_census_halo_x3_b16.txt
-[ -f $G/r5p_census_b1.txt ] && grep -v "^/opt" $G/r5p_census_b1.txt > profiles/r05_conv_census_x3_b1.txt
+[ -f $G/r5p_census_b1.txt ] && { echo "# kernel names are the PLAN family's (keep_conv_plan): at one clip the launcher of the halo family hands maps of <= 64 / 128 items of the 256-pixel kernels to"; echo "# conv3x3_x3q_kernel (un-split) / conv3x3_x3p_kernel (split-K partials) -- the bit-equal 64-pixel forms of DESIGN 5.6; the times are what ran (r05_x3_b1_kernel_stats.txt names them)"; grep -v "^/opt" $G/r5p_census_b1.txt; } > profiles/r05_conv_census_x3_b1.txt
 [ -f $G/r5p_gemm_forms.txt ] && { echo "# python tools/dev/gemm_lat_bench.py: us per launch (hipGraph replay of 40 launches) of the token GEMMs by form and images per launch --"; echo "# seq: one sequential sum (KEEP_CONV_NO_GEMM_LAT); waves: gemm_x3l_kernel at every row count; tiles: conv_x3_kernel with canonical slices at every row count"; grep -v "^/opt" $G/r5p_gemm_forms.txt; } > profiles/r05_gemm_forms.txt
 ls -la profiles/r05_* 2>/dev/null

@@ -370,41 +370,70 @@ extern "C" int32_t keep_gm_join(const float* a, const float* sa, const float* ha
   return KEEP_OK;
 }
 
+__global__ void absmax_zero_kernel(unsigned* p, int n);      // (defined with the range probe below)
+
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // one wave per row; C <= 1024 (C/64 <= 16 values per lane kept in registers); two-pass mean/variance.
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ res,
                                                         float* __restrict__ out, const float* __restrict__ pos,
-                                                        int pos_rows, float* __restrict__ out2, int M, int C, float eps) {
+                                                        int pos_rows, float* __restrict__ out2, int M, int C, float eps,
+                                                        unsigned* __restrict__ amax_bits = nullptr, int rows_per_img = 1) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const float* xr = x + (long)row * C;
-  float v[16];
-  float s = 0.f;
+  const bool valid = row < M;
+  if (!valid && !amax_bits) return;
+  unsigned mx = 0u;
+  if (valid) {
+    const float* xr = x + (long)row * C;
+    float v[16];
+    float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int c = lane + j * 64;
-    v[j] = c < C ? xr[c] : 0.f;
-    s += v[j];
+    for (int j = 0; j < 16; ++j) {
+      const int c = lane + j * 64;
+      v[j] = c < C ? xr[c] : 0.f;
+      s += v[j];
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = lane + j * 64;
+      const float d = c < C ? v[j] - mean : 0.f;
+      q += d * d;
+    }
+    const float var = wave_sum(q) / (float)C;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = lane + j * 64;
+      if (c < C) {
+        const float y = (v[j] - mean) * rstd * gamma[c] + beta[c];
+        const float o = res ? y + res[(long)row * C + c] : y;
+        out[(long)row * C + c] = o;
+        mx = max(mx, __float_as_uint(o) & 0x7fffffffu);
+        if (out2) out2[(long)row * C + c] = y + pos[(long)(row % pos_rows) * C + c];
+      }
+    }
   }
-  const float mean = wave_sum(s) / (float)C;
-  float q = 0.f;
+  if (amax_bits) {      // keep_layernorm_amax: the consumer's x3 range scale (max |out| per image) without a probe launch; see absmax_kernel.
+    // One atomic per BLOCK when its four rows lie in one image (same-line atomics retire at ~12 ns each), else one per wave.
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int c = lane + j * 64;
-    const float d = c < C ? v[j] - mean : 0.f;
-    q += d * d;
-  }
-  const float var = wave_sum(q) / (float)C;
-  const float rstd = 1.0f / sqrtf(var + eps);
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int c = lane + j * 64;
-    if (c < C) {
-      const float y = (v[j] - mean) * rstd * gamma[c] + beta[c];
-      out[(long)row * C + c] = res ? y + res[(long)row * C + c] : y;
-      if (out2) out2[(long)row * C + c] = y + pos[(long)(row % pos_rows) * C + c];
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    __shared__ unsigned wave_m[4];
+    const int row0 = blockIdx.x * 4, row3 = min(row0 + 3, M - 1);
+    const bool one_img = row0 / rows_per_img == row3 / rows_per_img;
+    if (lane == 0) wave_m[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (one_img) {
+      if (threadIdx.x == 0) {
+        mx = max(max(wave_m[0], wave_m[1]), max(wave_m[2], wave_m[3]));
+        unsigned* dst = amax_bits + row0 / rows_per_img;
+        if (mx > *reinterpret_cast<volatile unsigned*>(dst)) atomicMax(dst, mx);
+      }
+    } else if (valid && lane == 0) {
+      unsigned* dst = amax_bits + row / rows_per_img;
+      if (mx > *reinterpret_cast<volatile unsigned*>(dst)) atomicMax(dst, mx);
     }
   }
 }
@@ -460,6 +489,21 @@ extern "C" int32_t keep_layernorm(const float* x, const float* gamma, const floa
   hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, res, out, pos,
                      pos_rows > 0 ? pos_rows : 1, out2, M, C, eps);
   KEEP_LAUNCH_CHECK("keep_layernorm");
+  return KEEP_OK;
+}
+
+// keep_layernorm (without pos / out2) + amax[n] = max |out| over image n's rows_per_image rows: the range scale of the x3 GEMM that
+// consumes the output, fused (bit patterns of |x| order like the values: an unsigned atomicMax is exact and order-independent).
+extern "C" int32_t keep_layernorm_amax(const float* x, const float* gamma, const float* beta, const float* res, float* out, int32_t M,
+                                       int32_t C, float eps, int32_t rows_per_image, float* amax, int32_t zeroed, void* stream) {
+  KEEP_REQUIRE(x && gamma && beta && out && amax && M > 0 && C > 0 && C <= 1024 && rows_per_image > 0 && M % rows_per_image == 0,
+               "keep_layernorm_amax: bad args (M=%d C=%d rows_per_image=%d)", M, C, rows_per_image);
+  hipStream_t st = (hipStream_t)stream;
+  const int N = M / rows_per_image;
+  if (!zeroed) hipLaunchKernelGGL(absmax_zero_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(amax), N);
+  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, gamma, beta, res, out, (const float*)nullptr, 1,
+                     (float*)nullptr, M, C, eps, reinterpret_cast<unsigned*>(amax), rows_per_image);
+  KEEP_LAUNCH_CHECK("keep_layernorm_amax");
   return KEEP_OK;
 }
 
@@ -1559,6 +1603,47 @@ extern "C" int32_t keep_bgr_u8_to_comfy(const uint8_t* x, float* out, int64_t np
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(bgr_u8_to_comfy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)npix);
   KEEP_LAUNCH_CHECK("keep_bgr_u8_to_comfy");
+  return KEEP_OK;
+}
+
+// keep_geglu + amax[n] = max |out| over image n (grid (bx, N): a block stays inside one image, one atomic per block)
+__global__ __launch_bounds__(256) void geglu_amax_kernel(const float* __restrict__ x, float* __restrict__ out, long per_img, int F,
+                                                         unsigned* __restrict__ amax_bits) {
+  const int n = blockIdx.y;
+  const float* xi = x + (long)n * per_img * 2;
+  float* oi = out + (long)n * per_img;
+  unsigned mx = 0u;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (long)gridDim.x * 256) {
+    const long m = i / F;
+    const int j = (int)(i - m * F);
+    const float h = xi[m * 2 * F + j];
+    const float g = xi[m * 2 * F + F + j];
+    const float o = h * (0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)));
+    oi[i] = o;
+    mx = max(mx, __float_as_uint(o) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+  __shared__ unsigned wave_m[4];
+  if ((threadIdx.x & 63) == 0) wave_m[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = max(max(wave_m[0], wave_m[1]), max(wave_m[2], wave_m[3]));
+    if (mx > *reinterpret_cast<volatile unsigned*>(amax_bits + n)) atomicMax(amax_bits + n, mx);
+  }
+}
+
+extern "C" int32_t keep_geglu_amax(const float* x, float* out, int32_t N, int32_t rows_per_image, int32_t F, float* amax, int32_t zeroed,
+                                   void* stream) {
+  KEEP_REQUIRE(x && out && amax && N > 0 && rows_per_image > 0 && F > 0, "keep_geglu_amax: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (!zeroed) hipLaunchKernelGGL(absmax_zero_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(amax), N);
+  const long per_img = (long)rows_per_image * F;
+  const long work = (per_img + 2047) / 2048;
+  const long cap = 2048 / N > 1 ? 2048 / N : 1;
+  const int bx = (int)(work < 1 ? 1 : (work > cap ? cap : work));
+  hipLaunchKernelGGL(geglu_amax_kernel, dim3(bx, N), dim3(256), 0, st, x, out, per_img, F, reinterpret_cast<unsigned*>(amax));
+  KEEP_LAUNCH_CHECK("keep_geglu_amax");
   return KEEP_OK;
 }
 

@@ -73,6 +73,8 @@ _SIGNATURES = {
     'keep_absmax': [_vp, _vp, _i32, _i64, _i32, _i64, _i64, _i32, _vp],
     'keep_layernorm': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp],
     'keep_geglu': [_vp, _vp, _i32, _i32, _vp],
+    'keep_layernorm_amax': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _i32, _vp],
+    'keep_geglu_amax': [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
     'keep_argmax_gather': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     'keep_nonfinite_flag': [_vp, _i64, _vp, _vp],
     'keep_vq_nearest': [_vp, _vp, _vp, _i32, _i32, _i32, _vp],

@@ -40,6 +40,10 @@ GRAPH_MAX_CLIPS = int(os.environ.get('KEEP_AMD_GRAPH_MAX_CLIPS', '2'))
 # many clips (0 = never); the first chunk of pairs / the following chunks (pairs per GMFlow launch group)
 STREAM_OVERLAP_MAX_CLIPS = int(os.environ.get('KEEP_AMD_OVERLAP_MAX_CLIPS', '2'))
 CFA_FREE_RANGES = os.environ.get('KEEP_CFA_FREE_RANGES', '1') != '0'   # x3: CFA range scales from producers' fused maxima instead of probes (A/B: 0)
+# the CFA block's LayerNorm / GEGLU maxima fused into their kernels up to this many token rows per launch (few clips in flight: the probe launch is
+# the cost); above it the probes stay -- thousands of blocks behind one atomic word per image cost more than the probe (+4 ms per 16-clip step,
+# tools/dev/cfa_ab.py).  The maxima are exact either way: same bits.
+CFA_FUSED_AMAX_ROWS = int(os.environ.get('KEEP_CFA_FUSED_AMAX_ROWS', '4096'))
 STREAM_OVERLAP_FIRST = int(os.environ.get('KEEP_AMD_OVERLAP_FIRST', '3'))
 STREAM_OVERLAP_CHUNK = int(os.environ.get('KEEP_AMD_OVERLAP_CHUNK', '4'))
 GRAPH_CACHE = 4
@@ -401,10 +405,12 @@ class KeepNet:
         return self.o.conv(ss, w[f'{p}.shift.2.weight'], w[f'{p}.shift.2.bias'], cin=C, in_off=C, residual=dec,
                            aux=scale, aux_w=self.cfg['cond'], stats=True, x_amax=ss_amax)
 
-    def _cfa(self, curr, prev, p, curr_amax=None):
+    def _cfa(self, curr, prev, p, curr_amax=None, prev_amax=None, want_amax=False):
         """KA:519-541 (post-norm): a = attn(curr, prev); y = LN(a)+curr; LN(ff(y))+y.
-        x3 range scales: five of the nine probes of a call come for free -- ``curr_amax`` (the producing convolution's fused max|out|),
-        the q / kv projections' own fused maxima (max over k AND v bounds either), and |attention output| <= max|v|."""
+        x3 range scales: none of the nine is probed when the caller supplies ``curr_amax`` / ``prev_amax`` -- ``curr_amax`` (the producing
+        convolution's fused max|out|), the q / kv projections' own fused maxima (max over k AND v bounds either), |attention output| <=
+        max|v|, and the fused maxima of the two LayerNorms and the GEGLU (``keep_layernorm_amax`` / ``keep_geglu_amax``: the feed-forward
+        GEMMs' inputs, and -- ``want_amax``: (z, max|z| per image) -- the NEXT frame's ``prev_amax``)."""
         w, cfg = self.w, self.cfg
         B, H, Wd, C = curr.shape
         Ltok = H * Wd
@@ -413,7 +419,8 @@ class KeepNet:
         c = curr.view(B * Ltok, C)
         free = CFA_FREE_RANGES and self.o.mma == L.MMA_X3
         q, q_amax = self.o.linear(c, w[f'{p}.attn.to_q.weight'], out_bf16=True, n_img=B, x_amax=curr_amax if free else None, want_amax=True)
-        kv, kv_amax = self.o.linear(prev.view(B * Ltok, C), w[f'{p}.attn.to_kv.weight'], out_bf16=True, n_img=B, want_amax=True)
+        kv, kv_amax = self.o.linear(prev.view(B * Ltok, C), w[f'{p}.attn.to_kv.weight'], out_bf16=True, n_img=B,
+                                    x_amax=prev_amax if free else None, want_amax=True)
         have = free and q_amax is not None and kv_amax is not None
         o = ops.empty((B * Ltok, inner), curr)
         self.o.attention(q, kv, ops.offset(kv, inner), o, B=B, H=nh, Lq=Ltok, Lk=Ltok, D=dh, Dv=dh, scale=dh ** -0.5,
@@ -421,11 +428,18 @@ class KeepNet:
                       v_str=(Ltok * 2 * inner, 2 * inner, dh), o_str=(Ltok * inner, inner, dh), probe=True,
                       amax=(q_amax, kv_amax, kv_amax) if have else None)
         a = self.o.linear(o, w[f'{p}.attn.to_out.0.weight'], w[f'{p}.attn.to_out.0.bias'], n_img=B, x_amax=kv_amax if have else None)
+        if free and B * Ltok <= CFA_FUSED_AMAX_ROWS:
+            y, y_amax = self.o.layernorm_amax(a, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], res=c, n_img=B)
+            f, f_amax = self.o.geglu_amax(self.o.linear(y, w[f'{p}.ff.net.0.proj.weight'], w[f'{p}.ff.net.0.proj.bias'], n_img=B, x_amax=y_amax),
+                                          n_img=B)
+            f = self.o.linear(f, w[f'{p}.ff.net.2.weight'], w[f'{p}.ff.net.2.bias'], n_img=B, x_amax=f_amax)
+            z, z_amax = self.o.layernorm_amax(f, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], res=y, n_img=B)
+            return (z.view(B, H, Wd, C), z_amax) if want_amax else z.view(B, H, Wd, C)
         y = ops.layernorm(a, w[f'{p}.norm1.weight'], w[f'{p}.norm1.bias'], res=c)
         f = ops.geglu(self.o.linear(y, w[f'{p}.ff.net.0.proj.weight'], w[f'{p}.ff.net.0.proj.bias'], n_img=B))
         f = self.o.linear(f, w[f'{p}.ff.net.2.weight'], w[f'{p}.ff.net.2.bias'], n_img=B)
         z = ops.layernorm(f, w[f'{p}.norm2.weight'], w[f'{p}.norm2.bias'], res=y)
-        return z.view(B, H, Wd, C)
+        return (z.view(B, H, Wd, C), None) if want_amax else z.view(B, H, Wd, C)
 
     # ------------------------------------------------------------------ Kalman gain (KA:801-821)
     def _kalman_gain(self, z, B, T):
@@ -823,7 +837,7 @@ class KeepNet:
         gblocks = generator_blocks(cfg)
         out_nhwc = ops.empty((B, T, H, Wd, 3), x)
         idx_all, margin_all = [], []
-        cross_prev = {}
+        cross_prev, cross_prev_amax = {}, {}
         prev_out = None
         fi = None
         if force_indices is not None:
@@ -861,9 +875,10 @@ class KeepNet:
                     y, yst = self._cft(self._frame(enc_feat[s], i), y, f'cft.{s}')
                 if j in cfa_at:
                     s = cfa_at[j]
+                    y_amax = None if yst is None else yst.amax                 # (frame 0: the producing convolution's fused max|out|)
                     if i > 0:
-                        y, yst = self._cfa(y, cross_prev[s], f'cfa.{s}', None if yst is None else yst.amax), None
-                    cross_prev[s] = y
+                        (y, y_amax), yst = self._cfa(y, cross_prev[s], f'cfa.{s}', y_amax, cross_prev_amax.get(s), want_amax=True), None
+                    cross_prev[s], cross_prev_amax[s] = y, y_amax
                 return y, yst
 
             with _Range('K7 generator + CFT + CFA'):

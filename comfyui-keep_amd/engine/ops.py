@@ -427,6 +427,33 @@ class Ops:
         L.call('keep_geglu', x, out, M, F)
         return out
 
+    def _amax_slots(self, N, like):
+        """N result words for a fused max|out|: from the per-forward arena (zeroed once in begin_forward) when it has room."""
+        if self.amax_arena is not None and self.amax_pos + N <= self.amax_arena.numel():
+            out = self.amax_arena[self.amax_pos:self.amax_pos + N]
+            self.amax_pos += N
+            return out, 1
+        return torch.empty((N,), dtype=torch.float32, device=like.device), 0
+
+    def layernorm_amax(self, x, gamma, beta, *, n_img, res=None, eps=1e-5):
+        """``layernorm`` (+res) and the per-image max |out| of the result in one launch: (y, amax [n_img]) -- the x3 range scale of the
+        GEMM that reads y (bit-identical y; amax == ``absmax(y)``)."""
+        C = x.shape[-1]
+        M = x.numel() // C
+        out = torch.empty_like(x)
+        am, zeroed = self._amax_slots(n_img, x)
+        L.call('keep_layernorm_amax', x, gamma, beta, res, out, M, C, float(eps), M // n_img, am, zeroed)
+        return out, am
+
+    def geglu_amax(self, x, *, n_img):
+        """``geglu`` and the per-image max |out|: (y, amax [n_img])."""
+        F = x.shape[-1] // 2
+        M = x.numel() // (2 * F)
+        out = empty((*x.shape[:-1], F), x)
+        am, zeroed = self._amax_slots(n_img, x)
+        L.call('keep_geglu_amax', x, out, n_img, M // n_img, F, am, zeroed)
+        return out, am
+
     # ------------------------------------------------------------------ keep_attention
     def attention(self, q, k, v, o, *, B, H, Lq, Lk, D, Dv, scale, q_str, k_str, v_str, o_str, mode=0, T=0, seg_len=0,
                   img_h=0, img_w=0, ksplit=0, shift=0, kv_rot=0, n_img=0, mma=None, probe=False, amax=None):

@@ -30,7 +30,7 @@ extern "C" {
  * the fields a shorter known layout lacks as zero), keep_sizeof_*_args(), keep_argmax_gather takes the non-finite status word,
  * keep_nonfinite_flag.  v13: keep_conv2d_args.upsample accepts KEEP_UPSAMPLE_X2_PHASES (same layout; a v12 library refuses the
  * value, so the binding asks for 13).  v18: the two reserved words of keep_conv2d_args become `flags` / `plan_ref_images`, the one of
- * keep_attention_args `flags` (same layout and sizes; zero keeps the v17 behaviour) -- the library no longer reads ANY environment variable.  v19: keep_yolo_letterbox_u8, keep_yolo_select (additions only). */
+ * keep_attention_args `flags` (same layout and sizes; zero keeps the v17 behaviour) -- the library no longer reads ANY environment variable.  v19: keep_yolo_letterbox_u8, keep_yolo_select, keep_layernorm_amax, keep_geglu_amax (additions only). */
 #define KEEP_ABI_VERSION 19
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
@@ -318,6 +318,13 @@ int32_t keep_layernorm(const float* x, const float* gamma, const float* beta, co
 
 /* GEGLU gate (diffusers FeedForward, KA:495-496,595-596): out[m,j] = x[m,j] * gelu_erf(x[m,F+j]), x is [M,2F] */
 int32_t keep_geglu(const float* x, float* out, int32_t M, int32_t F, void* stream);
+/* keep_layernorm (no pos / out2) and keep_geglu with the consumer's x3 range scale fused (v19): amax[n] = max |out| over the
+ * rows_per_image rows of image n (M = N * rows_per_image), exactly what keep_absmax would return for the output -- the CFA block's
+ * feed-forward GEMMs and the next frame's kv projection take it instead of a probe launch (keep_arch.py:519-541, engine/net.py:_cfa).
+ * zeroed != 0: the caller hands in slots it has zero-filled (a per-forward arena); outputs are bit-identical to keep_layernorm / keep_geglu. */
+int32_t keep_layernorm_amax(const float* x, const float* gamma, const float* beta, const float* res, float* out, int32_t M, int32_t C,
+                            float eps, int32_t rows_per_image, float* amax, int32_t zeroed, void* stream);
+int32_t keep_geglu_amax(const float* x, float* out, int32_t N, int32_t rows_per_image, int32_t F, float* amax, int32_t zeroed, void* stream);
 
 /* KA:1085-1089 + VQ:78-91: idx[m] = argmax_j logits[m,j] (lowest index on ties); out[m,:] = codebook[idx[m],:].
  * force_idx (optional) overrides the argmax (parity tests).  margin (optional) = top1-top2 logit gap.

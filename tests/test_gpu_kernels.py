@@ -1625,3 +1625,33 @@ def test_conv_x3_small_tiles_equal_the_streaming_kernel(n, h, wd, cin, cout, gn,
     assert torch.equal(got[0][1], got[1][1]), 'GroupNorm partials differ'
     assert torch.equal(got[0][2], got[1][2]), 'max|out| differs'
     assert torch.equal(got[0][2].cpu(), got[0][0].abs().flatten(1).max(1).values.cpu())
+
+
+def test_layernorm_and_geglu_with_fused_range_maxima():
+    """keep_layernorm_amax / keep_geglu_amax: outputs bit-identical to keep_layernorm / keep_geglu, amax[n] = max |out| over image n's
+    rows (what keep_absmax returns for the output), with caller-zeroed slots and without; rows per image 1 .. 1024, ragged C."""
+    from comfyui_keep_amd.engine import ops
+    o = ops.Ops()
+    o.begin_forward(torch.device('cuda'))
+    for (n_img, rows, C, with_res) in ((1, 256, 512, True), (3, 64, 256, True), (2, 1024, 256, False), (5, 7, 100, True), (48, 16, 128, False)):
+        x = op_input(f'lnamax_x_{C}_{rows}', (n_img * rows, C), 3.0).cuda() * torch.linspace(0.5, 40.0, n_img).repeat_interleave(rows).view(-1, 1).cuda()
+        g, b = op_input(f'lnamax_g_{C}', (C,)).cuda() + 1.0, op_input(f'lnamax_b_{C}', (C,)).cuda()
+        res = op_input(f'lnamax_r_{C}_{rows}', (n_img * rows, C), 5.0).cuda() if with_res else None
+        ref = ops.Ops.layernorm(x, g, b, res=res)
+        y, am = o.layernorm_amax(x, g, b, res=res, n_img=n_img)
+        assert torch.equal(y, ref) and torch.equal(am, ref.view(n_img, -1).abs().max(1).values), (n_img, rows, C)
+        am2 = torch.full((n_img,), 7e30, device='cuda')           # not zeroed: the entry point clears the slots itself
+        y2 = torch.empty_like(x)
+        L.call('keep_layernorm_amax', x, g, b, res, y2, n_img * rows, C, 1e-5, rows, am2, 0)
+        assert torch.equal(y2, ref) and torch.equal(am2, am)
+    for (n_img, rows, F) in ((1, 256, 1024), (3, 64, 2048), (4, 5, 36), (48, 256, 1024)):
+        x = op_input(f'ggamax_{rows}_{F}', (n_img * rows, 2 * F), 2.0).cuda() * torch.linspace(0.3, 20.0, n_img).repeat_interleave(rows).view(-1, 1).cuda()
+        ref = ops.Ops.geglu(x)
+        y, am = o.geglu_amax(x, n_img=n_img)
+        assert torch.equal(y, ref) and torch.equal(am, ref.view(n_img, -1).abs().max(1).values), (n_img, rows, F)
+        am2 = torch.full((n_img,), 7e30, device='cuda')
+        y2 = torch.empty_like(ref)
+        L.call('keep_geglu_amax', x, y2, n_img, rows, F, am2, 0)
+        assert torch.equal(y2, ref) and torch.equal(am2, am)
+    with pytest.raises(L.KeepHipError):
+        L.call('keep_layernorm_amax', x, g, b, None, y2, 10, 128, 1e-5, 3, am2, 0)

@@ -89,8 +89,13 @@ def test_cfa_range_scales_from_producer_maxima(gpu_net):
         net_mod.CFA_FREE_RANGES = True
         got = net._cfa(curr, prev, 'cfa.32', amax.contiguous())
         loose = net._cfa(curr, prev, 'cfa.32', (amax * 4).contiguous())
+        # the previous frame's maximum handed in as well (what the frame loop does from frame 1 on): the kv projection's probe goes too --
+        # an exact maximum, so the result is the same bits; the returned max|z| is the probe's value
+        pmax = prev.abs().flatten(1).max(1).values.contiguous()
+        got2, z_amax = net._cfa(curr, prev, 'cfa.32', amax.contiguous(), pmax, want_amax=True)
     finally:
         net_mod.CFA_FREE_RANGES = old
+    assert torch.equal(got2, got) and torch.equal(z_amax, got.abs().flatten(1).max(1).values)
     assert torch.isfinite(got).all()
     sc = ref.abs().flatten(1).max(1).values.view(2, 1, 1, 1)
     assert float(((got - ref).abs() / sc).max()) <= 2e-6

@@ -936,8 +936,11 @@ extern "C" int32_t keep_retina_decode(const float* heads, const float* priors, f
 // contraction) and writes the kept rows, in order, to out[n, 0 .. out_counts[n]).  counts[n] > cap (the compact list overflowed), or two
 // survivors with the same score (out_counts[n] = -2): the caller finishes that frame on the host.  Bitonic sort of (key, row) pairs in LDS, cap <= 4096.
 #define NMS_MAX 4096
+// order != NULL (keep_retina_nms_ordered): the caller ordered the frame's survivors itself (order[f, i] = row of rank i) -- the frames the
+// sorting form hands back -- and only the suppression and the compaction run here.
 __global__ __launch_bounds__(1024) void retina_nms_kernel(const float* __restrict__ dets, const int* __restrict__ counts,
-                                                          float* __restrict__ out, int* __restrict__ out_counts, int cap, float thr) {
+                                                          float* __restrict__ out, int* __restrict__ out_counts, int cap, float thr,
+                                                          const int* __restrict__ order) {
   __shared__ unsigned long long keys[NMS_MAX];
   __shared__ unsigned short rows[NMS_MAX];
   __shared__ float4 box[NMS_MAX];
@@ -954,6 +957,10 @@ __global__ __launch_bounds__(1024) void retina_nms_kernel(const float* __restric
   const float* fd = dets + (long)f * cap * 16;
   int npad = 1;
   while (npad < n) npad <<= 1;
+  if (order) {
+    for (int i = tid; i < n; i += 1024) rows[i] = (unsigned short)order[(long)f * cap + i];
+    npad = 0;                              // (no sort, no tie check)
+  }
   for (int i = tid; i < npad; i += 1024) {
     unsigned long long k = ~0ULL;
     if (i < n) {
@@ -986,7 +993,7 @@ __global__ __launch_bounds__(1024) void retina_nms_kernel(const float* __restric
   // ordered by a rule of our own.
   scan[tid] = 0;
   __syncthreads();
-  for (int i = tid; i + 1 < n; i += 1024)
+  for (int i = tid; i + 1 < n && !order; i += 1024)
     if ((keys[i] >> 32) == (keys[i + 1] >> 32)) scan[0] = 1;          // (benign race: every writer stores 1)
   __syncthreads();
   if (scan[0]) {
@@ -1047,8 +1054,19 @@ extern "C" int32_t keep_retina_nms(const float* dets, const int32_t* counts, flo
                                    float iou_threshold, void* stream) {
   KEEP_REQUIRE(dets && counts && out && out_counts && N > 0 && cap > 0 && cap <= NMS_MAX && (uintptr_t)dets % 16 == 0 && (uintptr_t)out % 16 == 0,
                "keep_retina_nms: bad args (cap <= 4096 rows per frame, 16-byte aligned lists)");
-  hipLaunchKernelGGL(retina_nms_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, dets, counts, out, out_counts, cap, iou_threshold);
+  hipLaunchKernelGGL(retina_nms_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, dets, counts, out, out_counts, cap, iou_threshold,
+                     (const int*)nullptr);
   KEEP_LAUNCH_CHECK("keep_retina_nms");
+  return KEEP_OK;
+}
+
+extern "C" int32_t keep_retina_nms_ordered(const float* dets, const int32_t* counts, const int32_t* order, float* out, int32_t* out_counts,
+                                           int32_t N, int32_t cap, float iou_threshold, void* stream) {
+  KEEP_REQUIRE(dets && counts && order && out && out_counts && N > 0 && cap > 0 && cap <= NMS_MAX && (uintptr_t)dets % 16 == 0 &&
+                   (uintptr_t)out % 16 == 0,
+               "keep_retina_nms_ordered: bad args (cap <= 4096 rows per frame, 16-byte aligned lists)");
+  hipLaunchKernelGGL(retina_nms_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, dets, counts, out, out_counts, cap, iou_threshold, order);
+  KEEP_LAUNCH_CHECK("keep_retina_nms_ordered");
   return KEEP_OK;
 }
 

@@ -102,6 +102,7 @@ _SIGNATURES = {
     'keep_act_inplace': [_vp, _i64, _i32, _vp],
     'keep_retina_decode': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _vp],
     'keep_retina_nms': [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp],
+    'keep_retina_nms_ordered': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp],
     'keep_sep_filter': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
     'keep_u8_to_f32': [_vp, _vp, _i64, _vp],
     'keep_f32_round_u8': [_vp, _vp, _i64, _vp],

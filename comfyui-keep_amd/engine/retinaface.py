@@ -419,12 +419,12 @@ class RetinaFaceEngine:
                         flat_over = heads[over].float().cpu().numpy()
                     tied = [i for i in range(n) if kc[i] == -2]
                     if tied:             # two survivors with the same score bits: numpy's own (unstable) argsort decides their order
-                        cnt_t = counts.cpu().numpy()
+                        tied_rows = self._tied_frames(dets, counts, tied, cap, nms_threshold)
                     for i in range(n):
                         if kc[i] == -1:      # more survivors than the compact list holds: that frame's heads go to the host decoder
                             results.append(self._host_decode(flat_over[over.index(i)], priors, scale, scale1, conf_threshold, nms_threshold))
                         elif kc[i] == -2:
-                            results.append(self._host_order_nms(dets[i, :cnt_t[i]].cpu().numpy(), nms_threshold))
+                            results.append(tied_rows[tied.index(i)])
                         else:
                             results.append(np.ascontiguousarray(rows[i, :kc[i]]))
                     continue
@@ -440,6 +440,31 @@ class RetinaFaceEngine:
                     continue
                 results.append(self._host_order_nms(rows[i, :cnt[i]], nms_threshold))
         return results
+
+    def _tied_frames(self, dets, counts, tied, cap, nms_threshold):
+        """Frames with equal score bit patterns (``keep_retina_nms`` -> -2): the ORDER is made on the host exactly as the reference makes it
+        (anchor order, then ``scores.argsort()[::-1]``: numpy's introsort decides the ties, retinaface.py:240) from the scores and anchor
+        indices alone; the permutation goes up and the suppression + compaction run on the device (``keep_retina_nms_ordered``: the
+        arithmetic of ``nms`` below).  One D2H of two columns, one H2D of the permutation, one launch, one D2H of the kept rows for all tied
+        frames of the chunk -- instead of a round trip and an O(n^2) numpy pass per frame.  ``KEEP_AMD_DEVICE_TIED_NMS=0``: the numpy path."""
+        idx = torch.tensor(tied, dtype=torch.int64, device=dets.device)
+        cnt_t = counts[idx].contiguous()
+        cnt = cnt_t.cpu().numpy()
+        if os.environ.get('KEEP_AMD_DEVICE_TIED_NMS', '1') == '0':
+            return [self._host_order_nms(dets[i, :c].cpu().numpy(), nms_threshold) for i, c in zip(tied, cnt)]
+        cmax = int(cnt.max())
+        d_t = dets[idx].contiguous()
+        cols = d_t[:, :cmax, [4, 15]].cpu().numpy()                                   # scores, anchor indices
+        order = np.zeros((len(tied), cap), np.int32)
+        for k, c in enumerate(cnt):
+            by_anchor = np.argsort(cols[k, :c, 1], kind='stable')                      # what np.where(scores > thr) yields
+            order[k, :c] = by_anchor[cols[k, :c, 0][by_anchor].argsort()[::-1]]        # scores.argsort()[::-1] on that list
+        kept = torch.empty_like(d_t)
+        kcnt = torch.empty(len(tied), dtype=torch.int32, device=dets.device)
+        L.call('keep_retina_nms_ordered', d_t, cnt_t, torch.from_numpy(order).to(dets.device), kept, kcnt, len(tied), cap, float(nms_threshold))
+        kc = kcnt.cpu().numpy()
+        rows = kept[:, :int(kc.max(initial=0)), :15].cpu().numpy()
+        return [np.ascontiguousarray(rows[k, :kc[k]]) for k in range(len(tied))]
 
     @staticmethod
     def _host_order_nms(r, nms_threshold):

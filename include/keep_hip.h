@@ -30,7 +30,7 @@ extern "C" {
  * the fields a shorter known layout lacks as zero), keep_sizeof_*_args(), keep_argmax_gather takes the non-finite status word,
  * keep_nonfinite_flag.  v13: keep_conv2d_args.upsample accepts KEEP_UPSAMPLE_X2_PHASES (same layout; a v12 library refuses the
  * value, so the binding asks for 13).  v18: the two reserved words of keep_conv2d_args become `flags` / `plan_ref_images`, the one of
- * keep_attention_args `flags` (same layout and sizes; zero keeps the v17 behaviour) -- the library no longer reads ANY environment variable.  v19: keep_yolo_letterbox_u8, keep_yolo_select, keep_layernorm_amax, keep_geglu_amax (additions only). */
+ * keep_attention_args `flags` (same layout and sizes; zero keeps the v17 behaviour) -- the library no longer reads ANY environment variable.  v19: keep_yolo_letterbox_u8, keep_yolo_select, keep_layernorm_amax, keep_geglu_amax, keep_retina_nms_ordered (additions only). */
 #define KEEP_ABI_VERSION 19
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
@@ -405,6 +405,11 @@ int32_t keep_dwconv3x3(const float* x, const float* w, const float* bias, float*
  * cap <= 4096.  float32 IoU: inter / (area_i + area_j - inter) > iou_threshold, areas (x2 - x1) * (y2 - y1). */
 int32_t keep_retina_nms(const float* dets, const int32_t* counts, float* out, int32_t* out_counts, int32_t N, int32_t cap,
                         float iou_threshold, void* stream);
+/* The same suppression and compaction for frames whose ORDER the caller made (v19): order [N, cap] int32, order[n, i] = the row of dets[n]
+ * of rank i (0 .. counts[n]) -- the frames keep_retina_nms hands back because two survivors share a score (out_counts = -2): the host
+ * orders them as the reference does (`scores.argsort()[::-1]`, numpy's own tie order) and only the permutation goes up. */
+int32_t keep_retina_nms_ordered(const float* dets, const int32_t* counts, const int32_t* order, float* out, int32_t* out_counts, int32_t N,
+                                int32_t cap, float iou_threshold, void* stream);
 /* ---- YOLOv5-face detectors on keep_conv2d (v15; wm_facelib/detection/yolov5face/models/common.py, yolo.py; engine/yoloface.py) ----
  * nn.MaxPool2d(k, stride, padding = pad, ceil_mode) on a channel slice of an NHWC map (padding = -inf): StemBlock's 2x2 stride-2
  * ceil-mode pool (common.py:53) and SPP's k x k stride-1 pools (common.py:160-163).  x rows of in_ld floats, out rows of out_ld

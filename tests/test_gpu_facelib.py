@@ -312,6 +312,49 @@ def test_retina_decode_on_the_device_equals_the_host_decoder():
         assert np.array_equal(a, b)
 
 
+def test_retina_tied_frames_are_ordered_on_the_host_and_suppressed_on_the_device():
+    """Frames whose survivors share score bit patterns (keep_retina_nms -> -2): ``_tied_frames`` (host: the reference's ordering calls on
+    scores + anchor indices; device: keep_retina_nms_ordered) returns what the all-numpy path (``_host_order_nms``) returns, bit for bit --
+    crafted frames with long runs of equal scores inside overlapping clusters (the order of a run decides which box survives), arrival
+    order shuffled, 30 .. 3000 survivors; and through ``detect_batch`` on mobile0.25 with synthetic weights (its softmax saturates at 1.0f)."""
+    from comfyui_keep_amd.engine import retinaface as RF
+    eng = RF.RetinaFaceEngine(RF.synth_retinaface_state_dict(seed=0, backbone='mobile0.25')).to('cuda')
+    rng = np.random.default_rng(5)
+    cap = 4096
+    sizes = [30, 700, 3000, 17]
+    dets = np.zeros((len(sizes), cap, 16), np.float32)
+    for f, n in enumerate(sizes):
+        cx, cy = rng.uniform(50, 600, n // 6 + 1), rng.uniform(50, 400, n // 6 + 1)
+        which = rng.integers(0, len(cx), n)
+        w, h = rng.uniform(30, 60, n), rng.uniform(30, 60, n)
+        x1, y1 = cx[which] + rng.normal(0, 6, n) - w / 2, cy[which] + rng.normal(0, 6, n) - h / 2
+        dets[f, :n, 0:4] = np.stack((x1, y1, x1 + w, y1 + h), 1)
+        dets[f, :n, 4] = rng.choice(np.array([1.0, 0.99999994, 0.9999, 0.98, 0.975], np.float32), n)        # long runs of equal scores
+        dets[f, :n, 5:15] = rng.uniform(0, 640, (n, 10))
+        dets[f, :n, 15] = rng.permutation(20000)[:n]                                                     # anchor indices, arrival order shuffled
+    d = torch.from_numpy(dets).cuda()
+    counts = torch.tensor(sizes, dtype=torch.int32, device='cuda')
+    kept, kcnt = torch.empty_like(d), torch.empty(len(sizes), dtype=torch.int32, device='cuda')
+    L.call('keep_retina_nms', d, counts, kept, kcnt, len(sizes), cap, 0.4)
+    assert kcnt.cpu().tolist() == [-2] * len(sizes)
+    got = eng._tied_frames(d, counts, list(range(len(sizes))), cap, 0.4)
+    for f, n in enumerate(sizes):
+        ref = eng._host_order_nms(dets[f, :n], 0.4)
+        assert got[f].shape == ref.shape and 3 < len(ref) < n and np.array_equal(got[f], ref), (f, got[f].shape, ref.shape)
+    part = eng._tied_frames(d, counts, [2, 0], cap, 0.4)                 # a subset of the chunk's frames, in the caller's order
+    assert np.array_equal(part[0], got[2]) and np.array_equal(part[1], got[0])
+    g = torch.Generator().manual_seed(3)
+    frames = torch.randint(0, 256, (3, 320, 448, 3), generator=g, dtype=torch.uint8)
+    on_device = eng.detect_batch(frames, 0.97)
+    os.environ['KEEP_AMD_DEVICE_TIED_NMS'] = '0'
+    try:
+        on_host = eng.detect_batch(frames, 0.97)
+    finally:
+        del os.environ['KEEP_AMD_DEVICE_TIED_NMS']
+    for a, b in zip(on_device, on_host):
+        assert len(a) > 3 and np.array_equal(a, b)
+
+
 def test_yolo_letterbox_kernel_vs_oracle():
     """keep_yolo_letterbox_u8 (BGR2RGB + cv2.resize(INTER_LINEAR) + 114 border + / 255, NHWC) bit-exact against the oracle's restatement
     of ``_preprocess`` and against the golden network inputs of the reference run (tests/golden/yolo_prepost.npz), on the golden frames

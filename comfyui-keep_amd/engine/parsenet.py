@@ -168,8 +168,11 @@ class ParseNetEngine:
             self.o.set_precision(L.MMA_F32, self._dev, None)
         return self
 
-    def _conv(self, x, name, **kw):
-        return self.o.conv(x, self.w[f'{name}.weight'], self.w[f'{name}.bias'], pad=1, ksize=3, reflect=True, **kw)
+    def _conv(self, x, name, x_amax=None, **kw):
+        """-> (y, per-image max |y| from the launch's epilogue or None): the x3 range scale of the convolutions that read y, so that none
+        of them probes its input (46 ``keep_absmax`` launches = 9 % of a 16-face call otherwise)."""
+        y, st = self.o.conv(x, self.w[f'{name}.weight'], self.w[f'{name}.bias'], pad=1, ksize=3, reflect=True, stats='amax', x_amax=x_amax, **kw)
+        return y, (None if st is None else st.amax)
 
     @torch.no_grad()
     def logits_nhwc(self, x_nhwc):
@@ -179,31 +182,31 @@ class ParseNetEngine:
         with torch.cuda.device(self.device):
             self.o.begin_forward(self.device)
             x = x_nhwc.contiguous()
-            feat = None
+            xa = None                                                  # max |x| per image where a producer's epilogue supplied it
             body_in = None
             n_body = sum(1 for b in self.blocks if b[1] == 'none')
             seen_body = 0
             for name, kind, cin, cout in self.blocks:
                 if kind == 'conv':
-                    x = self._conv(x, name)
+                    x, xa = self._conv(x, name, xa)
                     continue
                 if kind == 'none' and seen_body == 0:
                     body_in = x                                        # feat (parsenet.py:190)
                 if kind == 'down':       # parsenet.py:126-136: shortcut s2; conv1 s1 + BN + LReLU; conv2 s2 + BN; sum
-                    idt = self._conv(x, f'{name}.shortcut', stride=2)
-                    h = self._conv(x, f'{name}.conv1', act=L.ACT_LRELU02)
-                    x = self._conv(h, f'{name}.conv2', stride=2, residual=idt)
+                    idt, _ = self._conv(x, f'{name}.shortcut', xa, stride=2)
+                    h, ha = self._conv(x, f'{name}.conv1', xa, act=L.ACT_LRELU02)
+                    x, xa = self._conv(h, f'{name}.conv2', ha, stride=2, residual=idt)
                 elif kind == 'up':       # shortcut and conv1 read the nearest x2 upsampling; conv2 at the new size
-                    idt = self._conv(x, f'{name}.shortcut', upsample=True)
-                    h = self._conv(x, f'{name}.conv1', upsample=True, act=L.ACT_LRELU02)
-                    x = self._conv(h, f'{name}.conv2', residual=idt)
+                    idt, _ = self._conv(x, f'{name}.shortcut', xa, upsample=True)
+                    h, ha = self._conv(x, f'{name}.conv1', xa, upsample=True, act=L.ACT_LRELU02)
+                    x, xa = self._conv(h, f'{name}.conv2', ha, residual=idt)
                 else:
-                    h = self._conv(x, f'{name}.conv1', act=L.ACT_LRELU02)
+                    h, ha = self._conv(x, f'{name}.conv1', xa, act=L.ACT_LRELU02)
                     seen_body += 1
                     # the last body block also adds `feat` (x = feat + body(feat), parsenet.py:190): one more residual pass
-                    x = self._conv(h, f'{name}.conv2', residual=x)
+                    x, xa = self._conv(h, f'{name}.conv2', ha, residual=x)
                     if seen_body == n_body:
-                        x = ops.add_bcast(x, body_in)
+                        x, xa = ops.add_bcast(x, body_in), None
             return x
 
     def logits(self, x_nchw):

@@ -32,7 +32,7 @@ import numpy as np
 def sect():
     t = {}
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    chunk = det._stage(frames).to('cuda', non_blocking=True); torch.cuda.synchronize(); t['stage+H2D'] = time.perf_counter() - t0; t0 = time.perf_counter()
+    chunk = frames.to('cuda'); torch.cuda.synchronize(); t['H2D'] = time.perf_counter() - t0; t0 = time.perf_counter()
     xx = torch.empty((16, 640, 1138, 3), dtype=torch.float32, device='cuda')
     RF.L.call('keep_u8_to_f32', chunk, xx, chunk.numel()); xx = RF.ops.add_bcast(xx, det._mean, alpha=-1.0)
     heads = det.raw_heads(xx); torch.cuda.synchronize(); t['network'] = time.perf_counter() - t0; t0 = time.perf_counter()

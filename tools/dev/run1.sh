@@ -1,10 +1,4 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_facelib.py -x -q -m gpu 2>&1 | tail -4
-timeout 600 python - <<'PY' 2>&1 | tail -12
-import json, sys
-sys.path.insert(0, '/root/repo')
-import bench
-r = bench.facelib_leg()
-for k, v in r.items():
-    print(k, json.dumps({a: b for a, b in v.items() if a != 'what'}))
-PY
+KEEP_DIST_DEVICE=0 timeout 1500 python bench.py --gpus 2 --steps 2 --warmup 1 > gpurun_out/r5p_bench_2ranks.json 2> gpurun_out/r5p_bench_2ranks.err; echo rc=$?
+grep '^{' gpurun_out/r5p_bench_2ranks.json | tail -1 | cut -c1-900
+tail -3 gpurun_out/r5p_bench_2ranks.err

@@ -17,7 +17,6 @@ for _ in range(2):
     par.classes(x)
 torch.cuda.synchronize()
 par.o.profile = []
-orig = par.o.begin_forward
 par.classes(x)
 torch.cuda.synchronize()
 rec, par.o.profile = par.o.profile, None

@@ -1584,12 +1584,77 @@ static unsigned long long* dbg = nullptr;
   return KEEP_OK;
 }
 
+// The GroupNorm partials of the 128 x 128 tile (x3_gather_epilogue<2, 2, 2, 2>: one partial per 128 output rows) from the WRITTEN output, in
+// that epilogue's order: a wave's lane sums its rows it * 4 + prow (it = 0 .. 15) of 4 columns sequentially, the four prow lanes meet as
+// (p0 + p1) + (p2 + p3), the two row halves of the block as (0 + upper) + lower.  Lets a launch with few rows run the 64 x 64 tile
+// (4 x the blocks, same output bits) and still hand the plan's statistics partition to keep_norm_finalize.  grid (rows / 128, cols / 128).
+__global__ __launch_bounds__(256) void conv_x3_gather_stats_replica_kernel(ConvP p) {
+  __shared__ float red[4 * 64 * 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long m0 = (long)blockIdx.x * 128;
+  const int n0 = blockIdx.y * 128;
+  const int c4 = (lane & 15) * 4, prow = lane >> 4;
+  const int co = n0 + wn * 64 + c4;
+  const bool cok = co < p.Cout;
+  float s4[4] = {0.f, 0.f, 0.f, 0.f}, ss4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const long row = m0 + wm * 64 + it * 4 + prow;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cok) v = *reinterpret_cast<const float4*>(p.out + row * p.out_ld + co);
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s4[q] += e[q];
+      ss4[q] += e[q] * e[q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    s4[q] = xor32_sum(xor16_sum(s4[q]));
+    ss4[q] = xor32_sum(xor16_sum(ss4[q]));
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      red[(wave * 64 + c4 + q) * 2 + 0] = s4[q];
+      red[(wave * 64 + c4 + q) * 2 + 1] = ss4[q];
+    }
+  }
+  __syncthreads();
+  const int hw_o = p.Ho * p.Wo;
+  const int n_img = (int)(m0 / hw_o), p_idx = (int)((m0 % hw_o) / 128);
+  for (int c = threadIdx.x; c < 128; c += 256) {
+    const int wn_c = c >> 6, rem = c & 63;
+    float a = 0.f, b2 = 0.f;
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm) {
+      a += red[((mm * 2 + wn_c) * 64 + rem) * 2 + 0];
+      b2 += red[((mm * 2 + wn_c) * 64 + rem) * 2 + 1];
+    }
+    if (n0 + c < p.Cout) {
+      float* dst = p.stats + (((long)n_img * p.stats_P + p_idx) * p.Cout + n0 + c) * 2;
+      dst[0] = a;
+      dst[1] = b2;
+    }
+  }
+}
+
 // tile: plan_conv's choice (1: 64x64 block tiles, 2: 128x128, 3: 128x128 as four 32-row waves with the LayerNorm epilogue) --
 // the launch never re-derives it
 int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int tile, hipStream_t st) {
   const long M = p.M;
   // the plan's tile follows the reference batch because the statistics partition does; a launch WITHOUT statistics may take the small
-  // tile when the real row count is small (one clip in flight: 4 x the blocks) -- the K order of a row's sum does not depend on the tile
+  // tile when the real row count is small (one clip in flight: 4 x the blocks) -- the K order of a row's sum does not depend on the tile.
+  // WITH statistics (the encoder's stride-2 convolutions): the small tile too, the 128-row partials then come from the replica kernel above.
+  float* replica_stats = nullptr;
+  if (tile == 2 && p.stats && M <= 4096 && M % 128 == 0 && ((long)p.Ho * p.Wo) % 128 == 0 && p.split_k == 1 && p.vec_epi &&
+      p.Cout % 4 == 0 && !p.out_bf16 && !(a->flags & KEEP_CONV_NO_SMALL_PARTIALS)) {
+    replica_stats = p.stats;
+    p.stats = nullptr;
+    tile = 1;
+  }
   if (tile == 2 && !p.stats && M <= 4096) tile = 1;
   const int big_tile = tile >= 2;
   const int steps = a->KH * a->KW * ((a->Cin + XBK - 1) / XBK);
@@ -1634,5 +1699,10 @@ int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int tile, hipStre
   }
 #undef KEEP_LAUNCH_GX
   KEEP_LAUNCH_CHECK("keep_conv2d(gather x3)");
+  if (replica_stats) {
+    p.stats = replica_stats;
+    hipLaunchKernelGGL(conv_x3_gather_stats_replica_kernel, dim3((unsigned)(M / 128), (unsigned)cdiv(a->Cout, 128)), dim3(256), 0, st, p);
+    KEEP_LAUNCH_CHECK("keep_conv2d(gather x3, statistics replica)");
+  }
   return KEEP_OK;
 }

@@ -1627,6 +1627,40 @@ def test_conv_x3_small_tiles_equal_the_streaming_kernel(n, h, wd, cin, cout, gn,
     assert torch.equal(got[0][2].cpu(), got[0][0].abs().flatten(1).max(1).values.cpu())
 
 
+@pytest.mark.parametrize("n,h,wd,cin,cout,down", [(1, 64, 64, 256, 256, True), (1, 32, 32, 256, 256, True), (1, 128, 128, 128, 128, True),
+                                                  (2, 64, 64, 128, 256, True), (3, 32, 32, 128, 128, True), (1, 32, 32, 256, 128, False)])
+def test_conv_x3_gather_small_tile_with_statistics_replica(n, h, wd, cin, cout, down):
+    """The encoder's stride-2 convolutions with few rows in flight: conv_x3_kernel's 64 x 64 tile + conv_x3_gather_stats_replica_kernel
+    give the output, the GroupNorm partials (the plan's 128-row partition) and max|out| of the 128 x 128 tile's fused epilogue
+    (KEEP_CONV_NO_SMALL_PARTIALS), bit for bit; a 1x1 GEMM-form launch with statistics takes the same route."""
+    x = rnd('gs_x', (n, cin, h, wd), 2.0) + 0.2
+    k = 3 if down else 1
+    w, b = rnd('gs_w', (cout, cin, k, k), 0.05), rnd('gs_b', (cout,))
+    xd, wp, bd = dev(nhwc(x)), pack(w), dev(b)
+    wx3, asc = x3w(wp)
+    kw = dict(mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, bounded=True, stats=True, split_k=1)
+    kw.update(dict(down=True) if down else dict(ksize=1, pad=0))
+    got = []
+    for fl in (0, L.CONV_NO_SMALL_PARTIALS):
+        ops.DEFAULT.flags = fl
+        ops.DEFAULT.amax_arena = None
+        y, st = ops.conv(xd, wp, bd, **kw)
+        got.append((y.clone(), st.part.clone(), None if st.amax is None else st.amax.clone(), st.P))
+    ops.DEFAULT.flags = 0
+    hw_o = got[0][0].shape[1] * got[0][0].shape[2]
+    P = got[0][3]
+    assert P == got[1][3] and P in (hw_o // 128, hw_o // 64), (P, hw_o)      # the plan's partition (reference batch of 16): 128 rows, 64 on the smallest maps
+    assert torch.isfinite(got[0][0]).all()
+    assert torch.equal(got[0][0], got[1][0]), 'outputs differ'
+    assert torch.equal(got[0][1], got[1][1]), 'GroupNorm partials differ'
+    assert (got[0][2] is None) == (got[1][2] is None) and (got[0][2] is None or torch.equal(got[0][2], got[1][2])), 'max|out| differs'
+    ref = F.conv2d(F.pad(x.double(), (0, 1, 0, 1)) if down else x.double(), w.double(), b.double(), stride=2 if down else 1)
+    assert (nchw(got[0][0]).cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max()
+    part = got[0][1].double()                                                # [N, P, C, 2]: sums / sums of squares per partial
+    yy = got[0][0].double().flatten(1, 2).view(n, P, hw_o // P, cout)
+    assert (part[..., 0] - yy.sum(2)).abs().max() <= 1e-3 and (part[..., 1] - (yy * yy).sum(2)).abs().max() <= 1e-3 * max(1.0, float((yy * yy).sum(2).max()))
+
+
 def test_layernorm_and_geglu_with_fused_range_maxima():
     """keep_layernorm_amax / keep_geglu_amax: outputs bit-identical to keep_layernorm / keep_geglu, amax[n] = max |out| over image n's
     rows (what keep_absmax returns for the output), with caller-zeroed slots and without; rows per image 1 .. 1024, ragged C."""

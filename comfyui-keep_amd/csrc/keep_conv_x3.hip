@@ -1641,6 +1641,9 @@ __global__ __launch_bounds__(256) void conv_x3_gather_stats_replica_kernel(ConvP
   }
 }
 
+#ifndef KEEP_GATHER_SMALL_ROWS
+#define KEEP_GATHER_SMALL_ROWS 4096      // rows in flight up to which a launch planned for the 128 x 128 tile runs the 64 x 64 tile (dev A/B: -D)
+#endif
 // tile: plan_conv's choice (1: 64x64 block tiles, 2: 128x128, 3: 128x128 as four 32-row waves with the LayerNorm epilogue) --
 // the launch never re-derives it
 int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int tile, hipStream_t st) {
@@ -1649,13 +1652,13 @@ int keep_conv2d_x3_gather(const keep_conv2d_args* a, ConvP& p, int tile, hipStre
   // tile when the real row count is small (one clip in flight: 4 x the blocks) -- the K order of a row's sum does not depend on the tile.
   // WITH statistics (the encoder's stride-2 convolutions): the small tile too, the 128-row partials then come from the replica kernel above.
   float* replica_stats = nullptr;
-  if (tile == 2 && p.stats && M <= 4096 && M % 128 == 0 && ((long)p.Ho * p.Wo) % 128 == 0 && p.split_k == 1 && p.vec_epi &&
+  if (tile == 2 && p.stats && M <= KEEP_GATHER_SMALL_ROWS && M % 128 == 0 && ((long)p.Ho * p.Wo) % 128 == 0 && p.split_k == 1 && p.vec_epi &&
       p.Cout % 4 == 0 && !p.out_bf16 && !(a->flags & KEEP_CONV_NO_SMALL_PARTIALS)) {
     replica_stats = p.stats;
     p.stats = nullptr;
     tile = 1;
   }
-  if (tile == 2 && !p.stats && M <= 4096) tile = 1;
+  if (tile == 2 && !p.stats && M <= KEEP_GATHER_SMALL_ROWS) tile = 1;
   const int big_tile = tile >= 2;
   const int steps = a->KH * a->KW * ((a->Cin + XBK - 1) / XBK);
   if (p.split_k > steps) p.split_k = steps;

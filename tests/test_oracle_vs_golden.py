@@ -302,6 +302,17 @@ def test_yolo_pre_and_post_processing_vs_reference_golden():
                 keep = FO._greedy_nms(rows[:, :4], rows[:, 4], np.float32(0.5)) if len(rows) else []
                 got = YF.faces_from_kept_rows(rows[keep] if keep else None, net_hw, frames.shape[1:3], 10)
                 assert np.array_equal(np.zeros((0, 15), np.int64) if got is None else got, want), (tag, name, n, 'host tail')
+    # edge cases of the product's host tail: no rows, only faces under min_face, clamps at the frame border, truncation toward zero
+    assert YF.faces_from_kept_rows(None, (160, 160), (100, 160), 10) is None
+    assert YF.faces_from_kept_rows(np.zeros((0, 16), np.float32), (160, 160), (100, 160), 10) is None
+    tiny = np.array([[50.0, 60.0, 58.0, 69.9, 0.99] + [55.0, 65.0] * 5 + [0.0]], np.float32)          # 9.9 px high after the 30 px of padding go
+    assert YF.faces_from_kept_rows(tiny, (160, 160), (100, 160), 10) is None
+    edge = np.array([[-5.0, 20.0, 170.0, 140.0, 0.99] + [-3.0, 200.0] * 5 + [0.0]], np.float32)
+    got = YF.faces_from_kept_rows(edge, (160, 160), (100, 160), 10)
+    assert got.dtype == np.int64 and got.tolist() == [[0, 0, 160, 100, 0] + [0, 100] * 5]
+    ref = FO.yolo_postprocess(np.concatenate((np.array([[82.5, 80.0, 175.0, 120.0, 0.99]], np.float32), edge[:, 5:15], np.array([[1.0]], np.float32)), 1),
+                              (160, 160), (100, 160), 0.7, 0.5)
+    assert np.array_equal(ref, got)
     # the resize restatement: identity, constant images, and a 2 x 2 -> 4 x 4 case by hand (coefficients 2048 * {.75, .25})
     img = np.arange(2 * 2 * 3, dtype=np.uint8).reshape(2, 2, 3) * 20
     up = FO.cv2_resize_linear_u8(img, 4, 4)

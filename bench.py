@@ -57,27 +57,81 @@ DTYPE = {'fp32': 'f32', 'bf16': 'bf16', 'x3': 'f16x3'}
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')
 
 
+FAKE = os.environ.get('KEEP_BENCH_FAKE_NET') == '1'     # tests/test_dist_gloo.py: the N-rank plumbing of this file on a machine without a GPU
+
+
+class _FakeBenchNet:
+    """KEEP_BENCH_FAKE_NET=1: stands in for KeepNet so that `bench.py --gpus N` can be driven over gloo on CPU -- rendezvous, the chunked
+    weight broadcast and its checksum, max-over-ranks timing, the per-rank gather, the one-video-per-GPU leg and the line's keys are the
+    real code; only the forward is a stand-in (and the line says so: "fake_engine": true, no roofline)."""
+    precision, x3_fallbacks, shard_across_ranks = 'x3', 0, True
+
+    def __init__(self):
+        self._index, self._blob = None, None
+
+    def load(self):
+        n = int(float(os.environ.get('KEEP_BENCH_FAKE_BLOB_MB', '3.5')) * (1 << 20)) // 4
+        self._index, self._blob = {'fake.weight': (0, (n,))}, torch.arange(n, dtype=torch.float32)
+
+    def packed_blob(self):
+        return self._blob
+
+    def adopt_packed(self, index, blob):
+        self._index, self._blob = index, blob
+
+    def set_precision(self, p):
+        self.precision = p
+        return self
+
+    def eval(self):
+        return self
+
+    def __call__(self, x):
+        time.sleep(0.002 * x.shape[0])
+        return 1.0 - x
+
+    def run_clips_u8(self, clips, max_b=None):
+        time.sleep(0.002 * len(clips))
+        return [255 - c for c in clips]
+
+
+def _sync():
+    if not FAKE:
+        torch.cuda.synchronize()
+
+
 def build_net(rank, world):
-    net = KeepNet(**DEFAULT_ARCH)
-    dev = torch.device('cuda', torch.cuda.current_device())
-    bcast_ms = None
+    net = _FakeBenchNet() if FAKE else KeepNet(**DEFAULT_ARCH)
+    bcast = None
     if rank == 0:
-        net.load_state_dict(synth.synth_state_dict(seed=0), strict=True)
-        net.to(dev)
+        if FAKE:
+            net.load()
+        else:
+            net.load_state_dict(synth.synth_state_dict(seed=0), strict=True)
+            net.to(torch.device('cuda', torch.cuda.current_device()))
         index, blob = net._index, net.packed_blob()
     else:
         index, blob = None, None
     if world > 1:
-        torch.cuda.synchronize()
+        _sync()
         torch.distributed.barrier()
         t0 = time.perf_counter()
         index, blob = kdist.broadcast_packed_weights(index, blob, src=0)
-        torch.cuda.synchronize()
+        _sync()
         torch.distributed.barrier()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
+        bcast = {"ms": (time.perf_counter() - t0) * 1e3}
         if rank != 0:
             net.adopt_packed(index, blob)
-    return net.eval(), bcast_ms
+        # the first real ncclBroadcast between GPUs is the driver's 8-GPU run: every rank reports an exact checksum of what it holds
+        # (int32 view, int64 sum) and rank 0 compares them -- a broadcast that moved wrong bytes shows up in the line, not in the pixels
+        flat = net.packed_blob().view(-1)
+        mine = flat.view(torch.int32).sum(dtype=torch.int64).reshape(1).to('cuda' if torch.distributed.get_backend() == 'nccl' else 'cpu')
+        sums = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(sums, mine)
+        bcast.update(kdist.LAST_BROADCAST)
+        bcast["verified"] = bool(all(int(t.item()) == int(sums[0].item()) for t in sums))
+        bcast["mb"] = flat.numel() * 4 / 1e6
+    return net.eval(), bcast
 
 
 def conv_roofline(net, x):
@@ -141,7 +195,38 @@ def conv_roofline(net, x):
         out["peak_note"] = ("dense fp16 MFMA peak 2500 TFLOP/s / 3: every fp32-grade product costs three fp16 MFMAs "
                             "(hi*hi + hi*lo + lo*hi); `achieved` counts algorithmic FLOPs once")
         out["mfma_frac"] = round(3.0 * tf / PEAK_16BIT_MFMA_TFLOPS, 4)
+        out.update(practical_peak_x3(tf))
     return out
+
+
+_PRACTICAL = {}
+
+
+def practical_peak_x3(achieved_tf):
+    """BESIDE the nominal peak (never instead of it): what the x3 product loop of the dominant kernel sustains on THIS box, in this
+    process, when everything but its MFMAs and LDS fragment reads is removed (tools/dev/x3_ceiling_probe.hip, variant 1, two blocks per CU,
+    random operands; built by __graft_entry__.build()).  profiles/r06_x3_ceiling_probe.txt holds the full table."""
+    if not _PRACTICAL:
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location('x3_ceiling', os.path.join(ROOT, 'tools', 'dev', 'x3_ceiling.py'))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            loop, bare = mod.practical_peak()
+            torch.cuda.synchronize()
+            _PRACTICAL.update(ok=True, loop=loop, bare=bare)
+        except Exception as e:      # no probe library on this box: say so, do not guess
+            _PRACTICAL.update(ok=False, why=f'{type(e).__name__}: {e}')
+    if not _PRACTICAL['ok']:
+        return {"practical_peak": None, "frac_of_practical": None, "practical_peak_note": "x3 ceiling probe unavailable (" + _PRACTICAL['why'] + ")"}
+    loop, bare = _PRACTICAL['loop'], _PRACTICAL['bare']
+    return {"practical_peak": round(loop['x3_tflops'], 1), "frac_of_practical": round(achieved_tf / loop['x3_tflops'], 4),
+            "practical_peak_note": ("measured in this run: the halo kernels' x3 product loop with its operands resident in LDS and nothing else (12 MFMAs + 8 "
+                                    "ds_read_b128 per tap and wave, random data, two blocks per CU) sustains %.0f TFLOP/s of raw MFMA rate at an in-kernel %.2f GHz = "
+                                    "%.0f x3-equivalent; a bare MFMA loop on random register operands %.0f raw at %.2f GHz.  `peak` / `frac` stay the nominal 2500 / 3"
+                                    % (loop['raw_tflops'], loop['clock_ghz'], loop['x3_tflops'], bare['raw_tflops'], bare['clock_ghz'])),
+            "bare_mfma_loop_tflops": round(bare['raw_tflops'], 1), "bare_mfma_loop_clock_ghz": round(bare['clock_ghz'], 3),
+            "x3_loop_clock_ghz": round(loop['clock_ghz'], 3)}
 
 
 def cpu_baseline(Tc):
@@ -466,40 +551,46 @@ def main():
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         sys.exit(subprocess.call(cmd, env=env))
 
-    rank, world, local = kdist.init_from_env()
+    rank, world, local = kdist.init_from_env('gloo' if FAKE else None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
-    net, bcast_ms = build_net(rank, world)
+    if not FAKE:
+        torch.cuda.set_device(local)
+    net, bcast = build_net(rank, world)
     net.set_precision(args.precision)
     B = args.clips
-    per_frame = {'bf16': 0.17e9, 'fp32': 0.36e9}.get(args.precision, 0.23e9)      # measured HBM per 512 x 512 frame in flight (KeepNet.clips_per_call)
-    free_b, _ = torch.cuda.mem_get_info()
-    if os.environ.get('KEEP_DIST_DEVICE') and world > 1:      # every rank on ONE device (1-GPU boxes): they share its HBM
-        free_b //= world
-    B = max(1, min(B, int(0.8 * free_b / (per_frame * T_CLIP))))
-    x = synth.synth_clip(T=T_CLIP, B=B, seed=1234 + rank, phase=0.37 * rank).cuda()
+    if FAKE:
+        x = torch.rand((B, T_CLIP, 3, 32, 32), generator=torch.Generator().manual_seed(1234 + rank))
+    else:
+        per_frame = {'bf16': 0.17e9, 'fp32': 0.36e9}.get(args.precision, 0.23e9)      # measured HBM per 512 x 512 frame in flight (KeepNet.clips_per_call)
+        free_b, _ = torch.cuda.mem_get_info()
+        if os.environ.get('KEEP_DIST_DEVICE') and world > 1:      # every rank on ONE device (1-GPU boxes): they share its HBM
+            free_b //= world
+        B = max(1, min(B, int(0.8 * free_b / (per_frame * T_CLIP))))
+        x = synth.synth_clip(T=T_CLIP, B=B, seed=1234 + rank, phase=0.37 * rank).cuda()
     B16 = min(B, 16)                  # the side legs (other policies, policy-vs-policy comparison, host-memory entry) stay at the 16 clips of rounds 1-4
     x16 = x[:B16].contiguous()
 
     def barrier():
-        torch.cuda.synchronize()
+        _sync()
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        _sync()
 
     def timed(xb, warmup, steps):
         for _ in range(warmup):
             net(xb)
         barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = (None, None) if FAKE else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         t0 = time.perf_counter()
-        e0.record()
+        if not FAKE:
+            e0.record()
         for _ in range(steps):
             o = net(xb)
-        e1.record()
+        if not FAKE:
+            e1.record()
         barrier()
         d = time.perf_counter() - t0
-        ev_ms = e0.elapsed_time(e1)
+        ev_ms = d * 1e3 if FAKE else e0.elapsed_time(e1)
         d_rank = d
         if world > 1:
             tmax = torch.tensor([d], dtype=torch.float64,
@@ -523,7 +614,8 @@ def main():
         # BASELINE configs[4]: one 300-crop video (15 clips x 20) per GPU through the processor's uint8 entry point, nothing
         # exchanged between ranks (shard_across_ranks off); value = all ranks' crops / slowest rank's wall time
         net.shard_across_ranks = False
-        u8 = [torch.randint(0, 256, (T_CLIP, 512, 512, 3), dtype=torch.uint8) for _ in range(15)]
+        side = 8 if FAKE else 512
+        u8 = [torch.randint(0, 256, (T_CLIP, side, side, 3), dtype=torch.uint8) for _ in range(15)]
         net.run_clips_u8(u8, max_b=15)
         barrier()
         t0 = time.perf_counter()
@@ -557,19 +649,26 @@ def main():
             # the reference pushes every interior frame through GMFlow's CNN encoder twice (KA:979-984); the engine runs it once
             # per frame (net.py:_gmflow_clip): ~33 GFLOP per frame of the reference count are not executed here
             "whole_net_tflops_executed": round(fps * (FLOP_PER_FRAME_T20 - GMFLOW_DUPLICATE_FLOP_PER_FRAME) / 1e12, 2),
-            "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
+            "peak_hbm_gb": None if FAKE else round(torch.cuda.max_memory_allocated() / 1e9, 1),
             "x3_range_fallbacks": net.x3_fallbacks,
-            "roofline": conv_roofline(net, x),
+            "roofline": None if FAKE else conv_roofline(net, x),
         }
-        # ... and the 5 of 9 taps the phase form of the Upsample convolutions does not multiply (roofline.skipped_gflop_per_step)
-        line["whole_net_tflops_executed"] = round(
-            line["whole_net_tflops_executed"] - line["roofline"]["skipped_gflop_per_step"] * 1e9 / (dt / args.steps) / 1e12, 2)
+        if FAKE:
+            line["fake_engine"] = True          # KEEP_BENCH_FAKE_NET=1: plumbing only, not a measurement
+        else:
+            # ... and the 5 of 9 taps the phase form of the Upsample convolutions does not multiply (roofline.skipped_gflop_per_step)
+            line["whole_net_tflops_executed"] = round(
+                line["whole_net_tflops_executed"] - line["roofline"]["skipped_gflop_per_step"] * 1e9 / (dt / args.steps) / 1e12, 2)
         if world > 1:
-            line["broadcast_ms"] = round(bcast_ms, 2)
-            line["broadcast_mb"] = round(net.packed_blob().numel() * 4 / 1e6, 1)
+            line["broadcast_ms"] = round(bcast["ms"], 2)
+            line["broadcast_mb"] = round(bcast["mb"], 1)
+            # what carried it: backend (`nccl` = RCCL over xGMI), the world size the backend saw, the library version, how many pieces
+            # (<= 256 MB each) the blob went out in, and whether every rank ended up with the same bytes (exact checksum per rank)
+            line["broadcast"] = dict(kdist.collective_library(), pieces=bcast.get("pieces"), largest_piece_mb=round(bcast.get("largest_piece_bytes", 0) / 1e6, 1),
+                                     verified_identical_on_all_ranks=bcast["verified"])
             line["frames_per_s_per_rank"] = per_rank
             line["config5_one_video_per_gpu"] = cfg5
-        extras = world == 1 and not args.no_extras
+        extras = world == 1 and not args.no_extras and not FAKE
         if extras:
             # ---- the other policies on the same input, each compared with the exact-f32 result
             out16, aux_main = net(x16, return_aux=True)
@@ -652,7 +751,7 @@ def main():
             # ---- the same two configurations through the product's own sequence entry point
             line["end_to_end_product"] = {"config3_300_frames_720p_1_face": product_leg(net, 300, 720, 1280, 1),
                                           "config4_300_frames_1080p_3_faces": product_leg(net, 300, 1080, 1920, 3)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not FAKE:
             line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_frames)
         print(json.dumps(line))
     if world > 1:

@@ -1624,6 +1624,45 @@ extern "C" int32_t keep_bgr_u8_to_comfy(const uint8_t* x, float* out, int64_t np
   return KEEP_OK;
 }
 
+// modules/utils.py:comfy_image_to_cv2 (reference utils.py:155-160) on the device: float32 RGB -> uint8 BGR, `(x * 255).astype(np.uint8)`:
+// ONE float32 multiply (numpy keeps float32 for a float32 array times a Python int), then C's truncating float -> integer conversion as
+// numpy performs it on x86-64: through a 32-bit integer (cvttps2dq) whose low byte is kept, so 256.0 wraps to 0 and -1.0 to 255; NaN,
+// +-inf and anything beyond the int32 range give the "integer indefinite" value 0x80000000, i.e. byte 0.  (v_cvt_i32_f32 SATURATES
+// instead: the range test below is what keeps the two equal outside [0, 1] as well.)  Four pixels (48 B in, 12 B out) per thread.
+__global__ __launch_bounds__(256) void comfy_to_bgr_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, long npix) {
+  auto cvt = [](float f) -> unsigned {
+    const float v = __fmul_rn(f, 255.0f);
+    return (fabsf(v) < 2147483648.0f) ? ((unsigned)(int)v & 255u) : 0u;      // (NaN fails the comparison)
+  };
+  const long nq = npix >> 2;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+    const float4* p = reinterpret_cast<const float4*>(x + q * 12);
+    const float4 a = p[0], b = p[1], c = p[2];           // r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
+    uint3 o;
+    o.x = cvt(a.z) | (cvt(a.y) << 8) | (cvt(a.x) << 16) | (cvt(b.y) << 24);          // B0 G0 R0 B1
+    o.y = cvt(b.x) | (cvt(a.w) << 8) | (cvt(c.x) << 16) | (cvt(b.w) << 24);          // G1 R1 B2 G2
+    o.z = cvt(b.z) | (cvt(c.w) << 8) | (cvt(c.z) << 16) | (cvt(c.y) << 24);          // R2 B3 G3 R3
+    unsigned* d = reinterpret_cast<unsigned*>(out + q * 12);
+    d[0] = o.x; d[1] = o.y; d[2] = o.z;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (npix & 3)) {      // the last one to three pixels
+    const long i = (nq << 2) + threadIdx.x;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) out[i * 3 + ch] = (uint8_t)cvt(x[i * 3 + (2 - ch)]);
+  }
+}
+
+extern "C" int32_t keep_comfy_to_bgr_u8(const float* x, uint8_t* out, int64_t npix, void* stream) {
+  KEEP_REQUIRE(x && out && npix > 0, "keep_comfy_to_bgr_u8: bad args");
+  KEEP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 3) == 0, "keep_comfy_to_bgr_u8: x must be 16-byte and out 4-byte aligned");
+  int blocks = cdiv(npix >> 2, 256);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(comfy_to_bgr_u8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)npix);
+  KEEP_LAUNCH_CHECK("keep_comfy_to_bgr_u8");
+  return KEEP_OK;
+}
+
 // keep_geglu + amax[n] = max |out| over image n (grid (bx, N): a block stays inside one image, one atomic per block)
 __global__ __launch_bounds__(256) void geglu_amax_kernel(const float* __restrict__ x, float* __restrict__ out, long per_img, int F,
                                                          unsigned* __restrict__ amax_bits) {

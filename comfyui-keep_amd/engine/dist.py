@@ -60,8 +60,42 @@ def broadcast_packed_weights(index, blob, src=0):
     if rank != src:
         blob = torch.empty(numel, dtype=torch.float32, device=dev)
     wire = blob if blob.device.type == dev.type else blob.to(dev)     # gloo moves host memory
-    dist.broadcast(wire, src=src)
+    # pieces of at most BCAST_CHUNK_MB (256 MB) of the one flat blob: the first multi-GPU run of a fresh RCCL communicator does not start
+    # with a single 633 MB call (registration / staging limits are per call), a failing piece names its byte range, and LAST_BROADCAST
+    # records what went over the wire for the bench line.  Views of one allocation: no copy, the same bytes as one call.
+    flat = wire.view(-1)
+    step = max(1, int(float(os.environ.get('KEEP_BCAST_CHUNK_MB', '256')) * (1 << 20)) // flat.element_size())
+    pieces = []
+    for a in range(0, flat.numel(), step):
+        b = min(flat.numel(), a + step)
+        try:
+            dist.broadcast(flat[a:b], src=src)
+        except Exception as e:
+            raise RuntimeError(f"weight broadcast failed on elements [{a}, {b}) of {flat.numel()} "
+                               f"(backend {dist.get_backend()}, world {dist.get_world_size()}, rank {rank}): {e}") from e
+        pieces.append(int((b - a) * flat.element_size()))
+    LAST_BROADCAST.clear()
+    LAST_BROADCAST.update(backend=str(dist.get_backend()), world=int(dist.get_world_size()), pieces=len(pieces), bytes=int(sum(pieces)),
+                          largest_piece_bytes=int(max(pieces)) if pieces else 0)
     return index, (blob if rank == src else wire.to(target))
+
+
+LAST_BROADCAST = {}      # what the last broadcast_packed_weights moved (backend, world, pieces, bytes): bench.py copies it into its line
+
+
+def collective_library():
+    """What actually carries the collectives of this process group, for the bench line: backend name, world size as the backend sees
+    it, and -- for `nccl` (= RCCL on ROCm) -- the library version torch reports (what NCCL_DEBUG=VERSION would print)."""
+    info = {"backend": None, "world": 1, "rccl_version": None}
+    if dist.is_available() and dist.is_initialized():
+        info["backend"], info["world"] = str(dist.get_backend()), int(dist.get_world_size())
+        if info["backend"] == 'nccl':
+            try:
+                v = torch.cuda.nccl.version()
+                info["rccl_version"] = '.'.join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+            except Exception as e:      # pragma: no cover
+                info["rccl_version"] = f"unavailable ({e})"
+    return info
 
 
 def gather_by_clip(local_results, n_clips, rank, world, to_all=False, shapes=None):

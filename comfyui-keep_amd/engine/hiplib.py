@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('KEEP_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libkeep_hip.so')   # (KEEP_HIP_LIB: dev A/B builds)
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 F32, BF16 = 0, 1
 MMA_F32, MMA_BF16, MMA_X3 = 0, 1, 2
@@ -89,6 +89,7 @@ _SIGNATURES = {
     'keep_tensor2img': [_vp, _vp, _i64, _vp],
     'keep_img2tensor': [_vp, _vp, _i64, _vp],
     'keep_bgr_u8_to_comfy': [_vp, _vp, _i64, _vp],
+    'keep_comfy_to_bgr_u8': [_vp, _vp, _i64, _vp],
     'keep_channel_argmax': [_vp, _vp, _i64, _i32, _i32, _vp],
     'keep_maxpool3s2': [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     'keep_dwconv3x3': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],

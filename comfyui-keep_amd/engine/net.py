@@ -231,7 +231,9 @@ class KeepNet:
             pass
         else:
             self.device = device
-            self.close_pool()              # the weights leave the GPU: the workers' copies go with them
+            # the worker pool (KEEP_AMD_GPUS) stays up: its workers hold THEIR copies of the same weights (weights_generation guards a
+            # stale one; load_state_dict / adopt_packed close it) -- KEEPModelPack.offload() runs after every node call, and closing the
+            # pool here cost every call a respawn of the workers (torch import, HIP init), a 633 MB broadcast and the x3 twins
             self._dev_blob, self._dev_blob16, self._dev_blobx3, self.w = None, None, None, None
             self.o.set_precision(self.o.mma)        # drop this net's references to the device blobs
             self._const = {}
@@ -701,9 +703,13 @@ class KeepNet:
                 res = self._forward_graphed(x, B, T, H, Wd)
             else:
                 res = self._forward(x, B, T, H, Wd, force_indices, return_aux, force_flows)
-            if _defer_check:
+            if _defer_check or self.precision != 'x3' or not CHECK_X3_RANGE:
                 return res
-            return self._checked(res, x, B, T, H, Wd, force_indices, return_aux, force_flows)
+            bits = self._status_bits()
+            if bits == 0:
+                return res
+            del res                                  # the x3 result goes back to the allocator before the f32 re-run
+            return self._checked(None, x, B, T, H, Wd, force_indices, return_aux, force_flows, bits=bits)
 
     def _status_bits(self):
         """This forward's status word (KEEP_STATUS_*): one 4-byte device -> host read."""
@@ -729,10 +735,14 @@ class KeepNet:
         self.precision = 'fp32'
         try:
             self._activate_precision()
-            if B > 16 and not return_aux and force_indices is None and force_flows is None:
-                # the exact-f32 policy holds 0.36 GB per frame against 0.22: a call sized for x3 (up to 48 clips) re-runs in parts
-                # (per-image plans: same bits as one call)
-                return torch.cat([self._forward(x[b0:b0 + 16].contiguous(), min(16, B - b0), T, H, Wd, None, False) for b0 in range(0, B, 16)], 0)
+            res = None                               # (callers drop their reference to the x3 result before calling: the re-run needs the room)
+            if not return_aux and force_indices is None and force_flows is None:
+                # the exact-f32 policy holds 0.36 GB per frame against 0.22: a call sized for x3 (by free HBM, up to 48 clips) re-runs in
+                # parts sized by what is free NOW under the f32 footprint (per-image plans: same bits as one call)
+                part = max(1, min(16, self.clips_per_call(T, H, Wd)))
+                if B > part:
+                    return torch.cat([self._forward(x[b0:b0 + part].contiguous(), min(part, B - b0), T, H, Wd, None, False)
+                                      for b0 in range(0, B, part)], 0)
             return self._forward(x, B, T, H, Wd, force_indices, return_aux, force_flows)
         finally:
             self.precision = 'x3'
@@ -1060,6 +1070,7 @@ class KeepNet:
                     L.call('keep_tensor2img', y, r8, len(grp) * T * H * Wd)
                     if sink is not None:
                         r8_host = r8.view(len(grp), T, H, Wd, 3)
+                        comp.synchronize()              # the sink reads the crops on ITS stream: the re-run (compute stream) must be complete
                     else:
                         r8_host = r8.view(len(grp), T, H, Wd, 3).cpu()
                 if sink is not None:                    # r8_host is the DEVICE tensor here (nothing was downloaded)

@@ -79,7 +79,8 @@ def main():
     conn = Client(('127.0.0.1', a.ctl_port), authkey=bytes.fromhex(os.environ['KEEP_POOL_AUTHKEY']))
     conn.send(a.rank)
     fake = os.environ.get('KEEP_POOL_FAKE_NET') == '1'
-    fail_at = os.environ.get('KEEP_POOL_TEST_FAIL', '')          # tests: '<rank>:<stage>' raises at that stage of that worker
+    # failure injection of the CPU tests ('<rank>:<stage>' raises at that stage of that worker): only with the stand-in engine
+    fail_at = os.environ.get('KEEP_POOL_TEST_FAIL', '') if fake else ''
     try:
         import numpy as np
         import torch

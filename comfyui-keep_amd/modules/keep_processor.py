@@ -129,6 +129,125 @@ class _DeviceFaces:
         return (self[i] for i in range(len(self._items)))
 
 
+_EMITTED = object()   # placeholder of a restored crop whose frame has been composited (streamed path)
+_PINNED_U8 = {}      # one cached pinned frame buffer per shape (hipHostMalloc of 0.8 GB costs ~0.1 s; frames never outlive the node call)
+
+
+class _ConvertedFrames:
+    """The node's IMAGE batch as uint8 BGR frames -- ``comfy_image_to_cv2`` (utils.py:155-160) for the whole sequence, on the device
+    (``keep_comfy_to_bgr_u8``: x * 255 in float32, truncating cast, RGB -> BGR) instead of three numpy passes per frame on one host
+    core: a worker thread uploads the float frames in chunks (pageable -> device), converts them and downloads the uint8 frames into
+    ONE pinned buffer; ``frames[i]`` / ``frames[a:b]`` wait only for the chunks they touch, so the detection pre-pass of the first
+    frames runs under the conversion of the rest.  Items are numpy views of the pinned buffer (what the helper and cv2 take)."""
+
+    def __init__(self, seq, device, chunk_bytes=128 << 20):
+        import threading
+        self.n, self.H, self.W = int(seq.shape[0]), int(seq.shape[1]), int(seq.shape[2])
+        self._seq, self._dev = seq, device
+        per = self.H * self.W * 3
+        self._chunk = max(1, min(self.n, chunk_bytes // (per * 4)))
+        self._nchunks = -(-self.n // self._chunk)
+        self._done = [threading.Event() for _ in range(self._nchunks)]
+        self._ready = threading.Event()          # the pinned buffer exists
+        self._err = None
+        self._arr = None
+        self._thread = threading.Thread(target=self._run, name='keep-comfy-convert', daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        try:
+            from ..engine import hiplib as L
+            shape = (self.n, self.H, self.W, 3)
+            buf = _PINNED_U8.get(shape)
+            if buf is None:
+                _PINNED_U8.clear()
+                try:
+                    buf = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+                    _PINNED_U8[shape] = buf
+                except RuntimeError:                                  # more than the host will pin
+                    buf = torch.empty(shape, dtype=torch.uint8)
+            self._buf, self._arr = buf, buf.numpy()
+            self._ready.set()
+            with torch.cuda.device(self._dev):
+                st = torch.cuda.Stream(device=self._dev)
+                pend = None
+                with torch.cuda.stream(st):
+                    for c in range(self._nchunks):
+                        a, b = c * self._chunk, min(self.n, (c + 1) * self._chunk)
+                        src = self._seq[a:b]
+                        if not src.is_contiguous():
+                            src = src.contiguous()
+                        d = src.to(self._dev, non_blocking=True)      # (a pageable source: the call returns when the chunk is staged)
+                        u = torch.empty((b - a, self.H, self.W, 3), dtype=torch.uint8, device=self._dev)
+                        L.call('keep_comfy_to_bgr_u8', d, u, (b - a) * self.H * self.W)
+                        buf[a:b].copy_(u, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        if pend is not None:                           # chunk c - 1 finished under this chunk's upload
+                            pend[1].synchronize()
+                            self._done[pend[0]].set()
+                        pend = (c, ev)
+                    pend[1].synchronize()
+                    self._done[pend[0]].set()
+        except BaseException as e:                                     # (out of memory, a lost device ...): the host converter, loudly
+            import logging
+            logging.getLogger('ComfyUI-KEEP').warning("device-side IMAGE conversion failed (%s); converting on the host", e)
+            try:
+                self._arr = np.stack([comfy_image_to_cv2(self._seq[i].unsqueeze(0)) for i in range(self.n)])
+            except BaseException as e2:                                # surfaced by the first access
+                self._err = e2
+            self._ready.set()
+            for d in self._done:
+                d.set()
+
+    def _wait(self, a, b):
+        self._ready.wait()
+        for c in range(a // self._chunk, min(self._nchunks, -(-b // self._chunk))):
+            self._done[c].wait()
+        if self._err is not None:
+            raise self._err
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            a, b, step = i.indices(self.n)
+            if step != 1:
+                return [self[j] for j in range(a, b, step)]
+            if b <= a:
+                return []
+            self._wait(a, b)
+            return [self._arr[j] for j in range(a, b)]
+        if i < 0:
+            i += self.n
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        self._wait(i, i + 1)
+        return self._arr[i]
+
+    def __iter__(self):
+        return (self[i] for i in range(self.n))
+
+
+def frames_from_comfy(seq, device):
+    """IMAGE batch [N,H,W,3] float32 (host or device) -> N uint8 BGR frames.  On the device when there is one and the library loads
+    (``_ConvertedFrames``); ``KEEP_AMD_DEVICE_CONVERT=0``, another dtype / layout, or no GPU: the per-frame host converter."""
+    dev = torch.device(device)
+    if (os.environ.get('KEEP_AMD_DEVICE_CONVERT', '1') != '0' and dev.type == 'cuda' and torch.cuda.is_available()
+            and isinstance(seq, torch.Tensor) and seq.dtype == torch.float32 and seq.dim() == 4 and seq.shape[-1] == 3
+            and seq.shape[0] > 0 and seq.shape[1] > 0 and seq.shape[2] > 0):
+        try:
+            from ..engine import hiplib as L
+            L.load()
+            if dev.index is None:
+                dev = torch.device('cuda', torch.cuda.current_device())
+            return _ConvertedFrames(seq, dev)
+        except Exception:
+            pass
+    return [comfy_image_to_cv2(seq[i].unsqueeze(0)) for i in range(seq.shape[0])]
+
+
 def split_clips(num_faces: int, max_clip_length: int):
     """[(start, end)] chunk boundaries of the flat crop list (keep_processor.py:263-264)."""
     return [(s, min(s + max_clip_length, num_faces)) for s in range(0, num_faces, max_clip_length)]
@@ -145,6 +264,8 @@ class KEEPFaceProcessor:
         # restored 512x512 faces of the last call, uint8 BGR (the reference discards them on the
         # aligned-sequence path; exposed so callers / tests can read what the net produced)
         self.last_restored_faces = []
+        # streamed sequence path: keep the restored crops (on the GPU) in ``last_restored_faces`` after the call -- off by default
+        self.keep_restored_faces = os.environ.get('KEEP_AMD_KEEP_RESTORED', '0') == '1'
         # reference quirk P2: `KEEP Image Sequence` with has_aligned=True restores every frame
         # and then returns the *input* frames.  Default: bug-compatible.  KEEP_AMD_RETURN_RESTORED_ALIGNED=1 (or setting
         # the attribute) returns the restored faces instead.
@@ -415,6 +536,7 @@ class KEEPFaceProcessor:
         if pool is not None and hasattr(pool, 'set_parser'):          # the workers parse what they restore
             pool.set_parser(engine)
         ready, classes = [None] * n_crops, [None] * n_crops
+        keep_restored = self.keep_restored_faces
         ps = getattr(self, '_paste_stream', None)
         if ps is None:
             ps = self._paste_stream = torch.cuda.Stream(device=dev)
@@ -469,6 +591,9 @@ class KEEPFaceProcessor:
                     cls = torch.stack([on_dev(classes[i]) for i in ids])
                     emit(t, paster.paste(bg, faces, list(helper.inverse_affine_matrices), cls, factor, draw_box))
                     pbar.update(1)
+                if not keep_restored:                                  # a long video must not hold every restored crop in HBM until the end
+                    for i in range(first[f0], first[f1]):
+                        ready[i], classes[i] = _EMITTED, None
             st['next'] = f1
 
         def sink(ids, crops_list, classes_list):
@@ -485,16 +610,22 @@ class KEEPFaceProcessor:
         if groups >= 2 and hasattr(net, 'clips_per_call'):
             cap = net.clips_per_call(max_clip_length, 512, 512)
             max_b = max(1, min(cap, -(-len(clips) // groups)))
+        import inspect
         try:
-            net.run_clips_u8(clips, max_b=max_b, sink=sink, parse=True)
-        except TypeError:                                              # a net whose run_clips_u8 takes no max_b / parse
-            net.run_clips_u8(clips, sink=sink)
+            params = inspect.signature(net.run_clips_u8).parameters
+        except (TypeError, ValueError):
+            params = {}
+        takes_all = any(p.kind == inspect.Parameter.VAR_KEYWORD for p in params.values())
+        kw = {k: v for k, v in (('max_b', max_b), ('parse', True)) if takes_all or k in params}    # decided by capability, not by catching
+        net.run_clips_u8(clips, sink=sink, **kw)                                                     # a TypeError from inside the forward
         advance()                                                      # frames without faces behind the last restored one
         ps.synchronize()
         if st['next'] != n_frames:
             raise RuntimeError(f"streamed paste-back: {n_frames - st['next']} frame(s) never became ready")
         pbar.update(n_frames)
-        self.last_restored_faces = _DeviceFaces(ready)
+        # the restored crops stay on the GPU only on request (tests / tools: ``keep_restored_faces``, KEEP_AMD_KEEP_RESTORED=1); by default
+        # each crop is released once its frame has been composited and nothing of the sequence outlives the call in HBM
+        self.last_restored_faces = _DeviceFaces(ready) if keep_restored else []
         return st['out']
 
     # ------------------------------------------------------------------ sequence
@@ -568,7 +699,8 @@ class KEEPFaceProcessor:
         n_frames = image_sequence_tensor.shape[0]
         if n_frames == 0:
             return image_sequence_tensor
-        frames_bgr = [comfy_image_to_cv2(image_sequence_tensor[i].unsqueeze(0)) for i in range(n_frames)]
+        # comfy_image_to_cv2 per frame (keep_processor.py:201,306 of the reference) -- on the device, chunked, under the detection pre-pass
+        frames_bgr = frames_from_comfy(image_sequence_tensor, self.device)
         out = self._process_frames(frames_bgr, final_upscale_factor, has_aligned_frames, only_center_face, draw_box,
                                    max_clip_length, as_u8=False)
         if out is None:

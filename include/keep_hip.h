@@ -31,7 +31,7 @@ extern "C" {
  * keep_nonfinite_flag.  v13: keep_conv2d_args.upsample accepts KEEP_UPSAMPLE_X2_PHASES (same layout; a v12 library refuses the
  * value, so the binding asks for 13).  v18: the two reserved words of keep_conv2d_args become `flags` / `plan_ref_images`, the one of
  * keep_attention_args `flags` (same layout and sizes; zero keeps the v17 behaviour) -- the library no longer reads ANY environment variable.  v19: keep_yolo_letterbox_u8, keep_yolo_select, keep_layernorm_amax, keep_geglu_amax, keep_retina_nms_ordered (additions only). */
-#define KEEP_ABI_VERSION 19
+#define KEEP_ABI_VERSION 20
 #define KEEP_OK 0
 #define KEEP_EINVAL (-1)
 #define KEEP_EUNSUP (-2)
@@ -383,6 +383,10 @@ int32_t keep_img2tensor(const uint8_t* x, float* out, int64_t npix, void* stream
 /* v18: modules/utils.py:cv2_to_comfy_image (reference utils.py:162-166) on the device: uint8 BGR [N,H,W,3] -> the ComfyUI IMAGE layout,
  * fp32 RGB in [0,1] = float32(u8) / 255 (one correctly rounded division, bit-equal to numpy's) */
 int32_t keep_bgr_u8_to_comfy(const uint8_t* x, float* out, int64_t npix, void* stream);
+/* v20: modules/utils.py:comfy_image_to_cv2 (reference utils.py:155-160) on the device: the ComfyUI IMAGE layout fp32 RGB [N,H,W,3] ->
+ * uint8 BGR, `(x * 255).astype(np.uint8)`: one float32 multiply, truncation towards zero through a 32-bit integer whose low byte is
+ * kept (numpy on x86-64: 256.0 -> 0, -1.0 -> 255; NaN / inf / beyond int32 -> 0).  x 16-byte aligned, out 4-byte aligned. */
+int32_t keep_comfy_to_bgr_u8(const float* x, uint8_t* out, int64_t npix, void* stream);
 
 
 /* ---- face parsing (wm_facelib/parsing/parsenet.py on keep_conv2d with KEEP_PAD_REFLECT, engine/parsenet.py) ----

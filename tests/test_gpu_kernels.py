@@ -1427,6 +1427,62 @@ def test_bgr_u8_to_comfy_equals_the_host_converter_on_every_value():
     assert torch.equal(out.cpu(), cv2_to_comfy_image(img)[0])
 
 
+def test_comfy_to_bgr_u8_equals_the_host_converter_on_every_boundary():
+    """keep_comfy_to_bgr_u8 == modules/utils.py:comfy_image_to_cv2 (reference utils.py:155-160: `(x * 255).astype(np.uint8)` + RGB2BGR):
+    every k / 255 and its two float32 neighbours (where the truncation flips), the values either side of every integer boundary k / 255
+    as float32 candidates x with x * 255 within 2 ulp of k, and -- outside [0, 1] -- what numpy does on x86-64 (wrap through int32; NaN,
+    inf and beyond-int32 -> 0).  Bit for bit, in all three channel positions, with a pixel count that is not a multiple of four."""
+    from comfyui_keep_amd.modules.utils import comfy_image_to_cv2
+    k = np.arange(257, dtype=np.float32)
+    base = (k / np.float32(255.0)).astype(np.float32)
+    cand = [base]
+    for _ in range(3):
+        cand.append(np.nextafter(cand[-1], np.float32(2.0)))
+    lo = base
+    for _ in range(3):
+        lo = np.nextafter(lo, np.float32(-1.0))
+        cand.append(lo)
+    odd = np.array([0.0, -0.0, 1.0, 1.0039216, 1.01, 2.0, -0.001, -0.5, -1.0, 3.5, 8.5e6, 1e9, 3e9, -3e9, np.inf, -np.inf, np.nan,
+                    1e-45, 0.9999999, 0.5, 0.49999997], np.float32)
+    v = np.concatenate(cand + [odd, np.random.default_rng(0).random(4099, dtype=np.float32) * 1.2 - 0.1])
+    v = v[: (v.size // 3) * 3]
+    assert (v.size // 3) % 4 != 0
+    for roll in range(3):
+        img = np.roll(v, roll).reshape(1, -1, 3)                                    # [H=1, W, 3]
+        with np.errstate(invalid='ignore'):
+            ref = comfy_image_to_cv2(torch.from_numpy(img))
+        out = torch.empty(img.shape, dtype=torch.uint8, device='cuda')
+        L.call('keep_comfy_to_bgr_u8', torch.from_numpy(img).cuda(), out, img.shape[1])
+        assert np.array_equal(out.cpu().numpy(), ref), roll
+
+
+def test_frames_from_comfy_device_path_equals_the_host_converter():
+    """modules/keep_processor.py:frames_from_comfy -- the node's IMAGE batch converted on the device by a worker thread in chunks (here 7
+    frames in chunks of 2 + 2 + 2 + 1, and a non-contiguous batch) -- equals the per-frame host converter; frames and slices wait only for
+    their chunks; KEEP_AMD_DEVICE_CONVERT=0 and a CPU device keep the host converter (plain list)."""
+    from comfyui_keep_amd.modules import keep_processor as KP
+    from comfyui_keep_amd.modules.utils import comfy_image_to_cv2
+    g = torch.Generator().manual_seed(3)
+    seq = torch.rand((7, 36, 50, 3), generator=g)
+    ref = [comfy_image_to_cv2(seq[i]) for i in range(7)]
+    fr = KP._ConvertedFrames(seq, torch.device('cuda', 0), chunk_bytes=2 * 36 * 50 * 3 * 4)
+    assert fr._nchunks == 4 and len(fr) == 7
+    assert np.array_equal(fr[6], ref[6]) and np.array_equal(fr[-7], ref[0])
+    assert all(np.array_equal(a, b) for a, b in zip(fr[1:6], ref[1:6])) and all(np.array_equal(a, b) for a, b in zip(fr, ref))
+    assert fr[0].dtype == np.uint8 and fr[0].flags['C_CONTIGUOUS']
+    wide = torch.rand((5, 36, 50, 6), generator=g)[..., ::2]                         # a strided view
+    assert not wide.is_contiguous()
+    got = KP.frames_from_comfy(wide, 'cuda')
+    assert isinstance(got, KP._ConvertedFrames) and all(np.array_equal(got[i], comfy_image_to_cv2(wide[i])) for i in range(5))
+    assert isinstance(KP.frames_from_comfy(seq, 'cpu'), list)
+    assert isinstance(KP.frames_from_comfy(seq.double(), 'cuda'), list)
+    os.environ['KEEP_AMD_DEVICE_CONVERT'] = '0'
+    try:
+        assert isinstance(KP.frames_from_comfy(seq, 'cuda'), list)
+    finally:
+        del os.environ['KEEP_AMD_DEVICE_CONVERT']
+
+
 @pytest.mark.parametrize("name,hw,K,N,act,bias,res,gn,ranged", [
     ('v / out_proj', 256, 512, 512, False, True, True, False, False),      # code transformer (KA:385-439): 512 -> 512 + residual
     ('linear1', 256, 512, 1024, True, True, False, False, False),          # 512 -> 1024 + GELU

@@ -27,8 +27,14 @@ pytestmark = pytest.mark.gpu
 #   wide regime (round 3's weights + clip, flows of hundreds of pixels: the out-of-range edge case): 8.3e-3 ... 1.7e-2  -> 2.5e-2
 # The flip rule is NOT this constant: a token may differ from the reference only if its margin is below twice the top-1 logit
 # error MEASURED in the same run (`per_frame_top1_logit_err` is printed by every run).
-LOGIT_ERR_BOUND = 8e-3
+# Round 6: the bound is PER GOLDEN, twice the largest value ever measured on it (any box, either policy) -- a single 8e-3 for the whole
+# regime admitted flips up to margin 1.6e-2 on the goldens that never came near it.
+LOGIT_ERR_BOUND = 8e-3            # (the physical regime's ceiling: no golden of it may exceed this)
 LOGIT_ERR_BOUND_WIDE = 2.5e-2
+LOGIT_ERR_BOUNDS = {'keep_forward_T3.npz': 2.8e-3,          # measured 1.4e-3
+                    'keep_forward_T20.npz': 6.6e-3,         # measured 3.3e-3 / 3.0e-3 (x3 / fp32)
+                    'keep_forward_asian_T2.npz': 8e-3,      # measured 6.2e-3 (frames of +-3.8: 1.3 x -- at the regime's ceiling)
+                    'keep_forward_T3_wide.npz': 2.5e-2}     # measured 8.3e-3 ... 1.7e-2
 OPS = np.load(os.path.join(GOLDEN, 'ops.npz'))
 
 
@@ -193,7 +199,8 @@ def _full_forward_check(net, gold_name, T, wide=False):
     <= 3e-4 of the output scale), and all-frames / all-pixels free running against the oracle with its flows injected (tests
     below).  (The reference goldens hold a 32 x 32 strided digest + per-channel statistics per frame, not every pixel.)
     wide: round 3's regime (flows of hundreds of pixels) -- the out-of-range edge case, with its own logit bound."""
-    bound = LOGIT_ERR_BOUND_WIDE if wide else LOGIT_ERR_BOUND
+    bound = LOGIT_ERR_BOUNDS.get(gold_name, LOGIT_ERR_BOUND_WIDE if wide else LOGIT_ERR_BOUND)
+    assert bound <= (LOGIT_ERR_BOUND_WIDE if wide else LOGIT_ERR_BOUND)
     g = np.load(os.path.join(GOLDEN, gold_name))
     x = synth.synth_clip(T=T, B=1, seed=1234, pattern='waves' if wide else 'texture').cuda()
     out, aux = net(x, need_upscale=False, return_aux=True)
@@ -306,7 +313,53 @@ def test_full_forward_T3_wide_flow_regime_vs_reference_golden(gpu_net):
 def test_full_forward_T20_vs_reference_golden(gpu_net):
     """The metric's own clip length: 19 recurrent steps of prev_out -> warp -> hq_encoder -> Kalman -> indices
     (keep_arch.py:1062-1127) against the imported reference (tests/golden/keep_forward_T20.npz)."""
-    _full_forward_check(gpu_net, 'keep_forward_T20.npz', 20)
+    out = _full_forward_check(gpu_net, 'keep_forward_T20.npz', 20)
+    # round 6: EVERY pixel of the 128x128 centre crop of frames 0-3 against the REFERENCE itself at the metric's own clip length
+    # (keep_forward_T20_pixels.npz, oracle/make_golden_r6.py), free running: the frames in front of the first token whose reference
+    # margin (7.5e-4, frame 4) lies below the logit error -- _full_forward_check has just asserted that no index differs before it
+    g = np.load(os.path.join(GOLDEN, 'keep_forward_T20_pixels.npz'))
+    a, b, c, d = (int(v) for v in g['crop'])
+    frames = [int(v) for v in g['frames']]
+    err = np.abs(out[0][frames][:, :, a:b, c:d].cpu().numpy() - g['out_crop']).reshape(len(frames), -1).max(1)
+    print(f'T20 every pixel of the centre crop of frames {frames} vs the reference [{gpu_net.precision}]:', err)
+    assert float(err[0]) <= 5e-5 and float(err.max()) <= 2e-4, err
+
+
+def test_x3_vs_exact_f32_first_flips_are_explained_by_the_logit_difference(synth_weights):
+    """What bench.py prints as `vs_exact_f32_policy`, asserted: the x3 policy against the exact-f32 policy on the same clips, free
+    running.  Both are fp32-grade arithmetics of one graph; their code indices may part only where the exact-f32 run's own top-1 /
+    top-2 margin is below twice the top-1 logit difference MEASURED between the two runs up to that frame (the flip rule of
+    `_full_forward_check`, with the exact policy in the reference's place), frame 0 (no flow, no recurrence) must agree on every
+    token above margin 1e-3, and the frames in front of a clip's first flip must be within 1e-3."""
+    from comfyui_keep_amd.engine.net import KeepNet
+    net = KeepNet(**DEFAULT_ARCH)
+    net.load_state_dict(synth_weights, strict=True)
+    net.to('cuda').eval()
+    B, T = 4, 20
+    x = torch.cat([synth.synth_clip(T=T, B=1, seed=1234 + 7 * b, pattern='texture') for b in range(B)]).cuda()
+    net.set_precision('fp32')
+    ref, raux = net(x, return_aux=True)
+    ref, rmargin, ridx, rtop = ref.cpu(), raux['margins'].cpu(), raux['indices'].cpu(), raux['logit_top1'].cpu()
+    net.set_precision('x3')
+    out, aux = net(x, return_aux=True)
+    agree = aux['indices'].cpu() == ridx                              # [B,T,256]
+    dl = (aux['logit_top1'].cpu() - rtop).abs()
+    rows = []
+    for b in range(B):
+        first = next((t for t in range(T) if not bool(agree[b, t].all())), T)
+        upto = min(first + 1, T)
+        measured = float(dl[b, :upto][agree[b, :upto]].max())
+        flips = rmargin[b, first][~agree[b, first]].tolist() if first < T else []
+        before = float((out[b, :first].cpu() - ref[b, :first]).abs().max()) if first > 0 else 0.0
+        rows.append((first, round(measured, 6), [round(m, 6) for m in flips], round(before, 7)))
+        assert bool(agree[b, 0][rmargin[b, 0] > 1e-3].all()), rows
+        assert first >= 1 and measured <= LOGIT_ERR_BOUNDS['keep_forward_T20.npz'], rows
+        for t in range(upto):
+            assert bool(agree[b, t][rmargin[b, t] > max(1e-3, 2.0 * measured)].all()), (b, t, rows)
+        assert all(m < 2.0 * measured for m in flips), rows
+        assert before <= 1e-3, rows
+    print('x3 vs exact f32, per clip (first frame with a flip, measured top-1 logit difference, margins of the first flips, '
+          'max-abs pixel difference before it):', rows)
 
 
 def test_full_forward_T20_vs_oracle_drift_report(gpu_net, synth_weights):

@@ -184,6 +184,7 @@ def test_streamed_sequence_equals_the_per_frame_path(gpu_net, monkeypatch):
     import synth_facehelper as SF
     H, W, faces, n = 360, 480, 2, 10
     proc, helper = SF.make_processor(gpu_net, (H, W), faces)
+    proc.keep_restored_faces = True          # (off by default: a crop is released once its frame has been composited)
     g = torch.Generator().manual_seed(5)
     frames = torch.rand((n, H, W, 3), generator=g)
 

@@ -190,6 +190,15 @@ def test_full_forward_T20_vs_golden(synth_weights):
     err = np.abs(_digest(out[0])[:first] - g['out_grid'][:first]).max()
     print('oracle vs reference, T=20: first frame with a differing index', first, '; max-abs digest diff before it', err)
     assert err <= 1e-3, err
+    # round 6: every pixel of the 128x128 centre crop of frames 0-3 of the same reference run (keep_forward_T20_pixels.npz,
+    # oracle/make_golden_r6.py)
+    gp = np.load(os.path.join(GOLDEN, 'keep_forward_T20_pixels.npz'))
+    a, b, c, d = (int(v) for v in gp['crop'])
+    frames = [int(v) for v in gp['frames']]
+    assert first > max(frames)
+    perr = np.abs(out[0][frames][:, :, a:b, c:d].numpy() - gp['out_crop']).reshape(len(frames), -1).max(1)
+    print('oracle vs reference, T=20, every pixel of the centre crop of frames', frames, ':', perr)
+    assert perr.max() <= 3e-4, perr
 
 
 def test_converters_oracle_and_host_converters_vs_reference_golden():

@@ -643,36 +643,57 @@ class KEEPFaceProcessor:
         use_batch = hasattr(det, 'detect_batch') and getattr(helper, 'det_model', 'retinaface') != 'dlib' and len(frames_bgr) > 0
         chunk = max(1, int(getattr(getattr(det, 'engine', None), 'max_frames', 32))) if use_batch else 1
         bar = tqdm(total=len(frames_bgr), desc="Detecting face landmarks")
-        for s in range(0, len(frames_bgr), chunk):
-            part = frames_bgr[s:s + chunk]
-            states, batched = None, None
-            if use_batch:
-                states, batched = self._detect_batched(det, part, resize=640)
-            for j, frame in enumerate(part):
-                helper.clean_all()
-                if states is not None:
-                    helper.input_img, helper.is_gray = states[j]       # what read_image(frame) left behind (:172-184)
-                else:
-                    helper.read_image(frame)
-                if batched is None:
-                    helper.get_face_landmarks_5(only_center_face=only_center_face, resize=640, eye_dist_threshold=5)
-                else:
-                    helper.face_detector = _ReplayDetector(batched[j])
-                    try:
+        starts = list(range(0, len(frames_bgr), chunk))
+        # Round 6: the detector's forward of chunk k (GPU, one worker thread: the launches and the D2H waits release the GIL) runs under the
+        # HOST preparation of chunk k + 1 (read_image + the INTER_AREA resize of every frame: a third of the pre-pass) -- the same calls
+        # on the same data in the same order per frame, only interleaved; KEEP_AMD_DETECT_OVERLAP=0: one after the other
+        pool = None
+        if use_batch and len(starts) > 1 and os.environ.get('KEEP_AMD_DETECT_OVERLAP', '1') != '0':
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='keep-detect')
+        try:
+            prepared = self._prep_detect_chunk(frames_bgr[starts[0]:starts[0] + chunk], 640) if use_batch else None
+            for k, s in enumerate(starts):
+                part = frames_bgr[s:s + chunk]
+                states, batched = None, None
+                if use_batch:
+                    states, batch = prepared
+                    fut = None
+                    if batch is not None:
+                        fut = pool.submit(det.detect_batch, batch, 0.97) if pool is not None else None
+                        if fut is None:
+                            batched = det.detect_batch(batch, 0.97)
+                    if k + 1 < len(starts):                                # host work of the next chunk, under this chunk's forward
+                        prepared = self._prep_detect_chunk(frames_bgr[starts[k + 1]:starts[k + 1] + chunk], 640)
+                    if fut is not None:
+                        batched = fut.result()
+                for j, frame in enumerate(part):
+                    helper.clean_all()
+                    if states is not None:
+                        helper.input_img, helper.is_gray = states[j]       # what read_image(frame) left behind (:172-184)
+                    else:
+                        helper.read_image(frame)
+                    if batched is None:
                         helper.get_face_landmarks_5(only_center_face=only_center_face, resize=640, eye_dist_threshold=5)
-                    finally:
-                        helper.face_detector = det
-                raw.append(list(helper.all_landmarks_5))
-                bar.update(1)
+                    else:
+                        helper.face_detector = _ReplayDetector(batched[j])
+                        try:
+                            helper.get_face_landmarks_5(only_center_face=only_center_face, resize=640, eye_dist_threshold=5)
+                        finally:
+                            helper.face_detector = det
+                    raw.append(list(helper.all_landmarks_5))
+                    bar.update(1)
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
         bar.close()
         return raw
 
-    def _detect_batched(self, det, frames_bgr, resize):
-        """One chunk of frames: the helper state ``read_image`` leaves behind per frame (input image, grey flag) and the detector
-        inputs ``get_face_landmarks_5`` would build from it (face_restoration_helper.py:206-216: frames whose short side exceeds
-        ``resize`` are scaled down with INTER_AREA), stacked and run through ``det.detect_batch`` with the helper's 0.97
-        confidence threshold (:221).  Detections are None when the frames differ in size or are not uint8 (16-bit sources
-        become float64 in ``read_image``: the per-frame path converts them the way the reference does)."""
+    def _prep_detect_chunk(self, frames_bgr, resize):
+        """One chunk of frames, host side only: the helper state ``read_image`` leaves behind per frame (input image, grey flag) and the
+        detector inputs ``get_face_landmarks_5`` would build from it (face_restoration_helper.py:206-216: frames whose short side exceeds
+        ``resize`` are scaled down with INTER_AREA), stacked -> (states, batch).  ``batch`` is None when the frames differ in size or are
+        not uint8 (16-bit sources become float64 in ``read_image``: the per-frame path converts them the way the reference does)."""
         helper = self.face_helper
         states, imgs = [], []
         for frame in frames_bgr:
@@ -689,8 +710,12 @@ class KEEPFaceProcessor:
             imgs.append(img if isinstance(img, torch.Tensor) else np.ascontiguousarray(img))
         if any(tuple(im.shape) != tuple(imgs[0].shape) or im.dtype not in (np.uint8, torch.uint8) for im in imgs):
             return states, None
-        batch = torch.stack(imgs) if isinstance(imgs[0], torch.Tensor) else np.stack(imgs)
-        return states, det.detect_batch(batch, 0.97)
+        return states, (torch.stack(imgs) if isinstance(imgs[0], torch.Tensor) else np.stack(imgs))
+
+    def _detect_batched(self, det, frames_bgr, resize):
+        """``_prep_detect_chunk`` + the detector's batched forward with the helper's 0.97 confidence threshold (:221): (states, detections)."""
+        states, batch = self._prep_detect_chunk(frames_bgr, resize)
+        return states, (None if batch is None else det.detect_batch(batch, 0.97))
 
     @torch.no_grad()
     def process_image_sequence(self, image_sequence_tensor: torch.Tensor, final_upscale_factor: float,

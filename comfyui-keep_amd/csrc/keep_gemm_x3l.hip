@@ -22,6 +22,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define GL_G 4                      // k-steps (of 16 channels) per register group: 64 channels
 #define GL_EP 36                    // floats per parked row: 32 + 4 pad
+// Round 6: operands reach the fragment layout through LDS.  A fragment-layout load (lane = row, 32 bytes) touches 32 cache lines per
+// instruction: 65 cycles of the CU's texture-address path instead of 16 -- ~4 of the 5.9 us of a warm launch (profiles/r05_gemm_forms.txt).
+// A wave now loads its 32 rows x 64 channels of A (and the 32 rows x 4 chunks of pre-split B) with 16-byte pieces CONSECUTIVE across lanes
+// (16 lanes = one 256-byte row run: 8 lines per instruction), parks them in its private LDS rows at a 272-byte pitch (68 floats: the eight
+// rows a ds_read_b128 phase touches fall on disjoint banks) and reads the MFMA fragments back: same values in the same registers, same
+// MFMA order -- same bits.  KEEP_GL_DIRECT=1 (dev builds) keeps the direct fragment loads.
+#define GL_ROWB (GL_G * 64 + 16)    // bytes per staged row
 // rows per image the family takes: the 16 x 16 token maps (code transformer, AttnBlock).  The 32 x 32 maps (CFA: 135 launches per clip)
 // were measured too: -0.5 ms per clip with one clip in flight, +1.8 ms per 16-clip step (64 x 64 tiles with slice totals against the
 // 128 x 128 tile of the sequential sum) -- left on conv_x3_kernel.
@@ -31,7 +38,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int NW, int TM, bool PLAIN>
 __global__ __launch_bounds__(NW * 64) void gemm_x3l_kernel(ConvP p, int m_fast) {
   constexpr int BM = TM * 32, NT = NW * 64;
-  __shared__ __attribute__((aligned(16))) float part[NW * BM * GL_EP];
+  constexpr int STG_W = (TM + 1) * 32 * GL_ROWB;            // staging bytes per wave: TM x 32 rows of A + 32 rows of B
+  constexpr int LDS_B = NW * STG_W > NW * BM * GL_EP * 4 ? NW * STG_W : NW * BM * GL_EP * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_B];
+  float* part = reinterpret_cast<float*>(lds_raw);          // the parked partial tiles reuse the staging rows (one barrier in between)
   __shared__ __attribute__((aligned(16))) float pro_s[PLAIN ? 4 : 2 * 2048];      // GroupNorm (scale | shift) of the tile's image
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -52,27 +62,27 @@ __global__ __launch_bounds__(NW * 64) void gemm_x3l_kernel(ConvP p, int m_fast) 
   };
   const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.in + m0 * p.in_ld, ((rows_here - 1) * p.in_ld + K) * 4);
   const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.wx3 + (long)n0 * K * 2, 32L * K * 4);
-  const int a_voff = (l31 * p.in_ld + lhi * 8) * 4;      // + i * 32 rows; channel offset in the scalar operand
-  const int b_voff = l31 * K * 4 + lhi * 16;             // weight row = K/16 chunks of [hi16 | lo16] = 64 B
+  // piece j of a group: rows 4 j + (lane >> 4), bytes (lane & 15) * 16 of the row's 256-byte run of the group
+  const int r4 = lane >> 4, c16 = (lane & 15) * 16;
+  const int a_voff = r4 * p.in_ld * 4 + c16;             // + j * 4 rows (+ i * 32 rows); the group's channel offset in the scalar operand
+  const int b_voff = r4 * K * 4 + c16;                   // weight row = K/16 chunks of [hi16 | lo16] = 64 B: a group is 256 B of it
+  unsigned char* stg_a = lds_raw + wave * STG_W;
+  unsigned char* stg_b = stg_a + TM * 32 * GL_ROWB;
+  const int st_off = r4 * GL_ROWB + c16;                 // where this lane parks piece j (+ j * 4 rows)
 
   struct Grp {
-    u32x4 a[TM][GL_G][2];
-    u32x4 b[GL_G][2];
+    u32x4 a[TM][8];
+    u32x4 b[8];
   };
   auto fetch = [&](int g, Grp& R) {
     const int kc = k0 + g * 16 * GL_G;                   // first channel of the group (wave-uniform)
 #pragma unroll
-    for (int ks = 0; ks < GL_G; ++ks) {
-      R.b[ks][0] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff, (kc + ks * 16) * 4, 0);
-      R.b[ks][1] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff + 32, (kc + ks * 16) * 4, 0);
-    }
+    for (int j = 0; j < 8; ++j) R.b[j] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff + j * 4 * K * 4, kc * 4, 0);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int ks = 0; ks < GL_G; ++ks) {
-        R.a[i][ks][0] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff + i * 32 * p.in_ld * 4, (kc + ks * 16) * 4, 0);
-        R.a[i][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff + i * 32 * p.in_ld * 4 + 16, (kc + ks * 16) * 4, 0);
-      }
+      for (int j = 0; j < 8; ++j)
+        R.a[i][j] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff + (i * 32 + j * 4) * p.in_ld * 4, kc * 4, 0);
   };
 
   Grp R0, R1;
@@ -96,10 +106,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_x3l_kernel(ConvP p, int m_fast) 
 
   auto compute = [&](int g, Grp& R) {
     const int kc = k0 + g * 16 * GL_G + lhi * 8;
+    // park the group (this wave's rows only: LDS serves a wave's requests in order, no barrier), then read it back in the fragment layout
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(stg_b + st_off + j * 4 * GL_ROWB) = R.b[j];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(stg_a + st_off + (i * 32 + j * 4) * GL_ROWB) = R.a[i][j];
 #pragma unroll
     for (int ks = 0; ks < GL_G; ++ks) {
-      const f16x8 bh = __builtin_bit_cast(f16x8, R.b[ks][0]);
-      const f16x8 bl = __builtin_bit_cast(f16x8, R.b[ks][1]);
+      const f16x8 bh = *reinterpret_cast<const f16x8*>(stg_b + l31 * GL_ROWB + ks * 64 + lhi * 16);
+      const f16x8 bl = *reinterpret_cast<const f16x8*>(stg_b + l31 * GL_ROWB + ks * 64 + 32 + lhi * 16);
       float sc[8], sh[8];
       if (!PLAIN) {
         const float4 s0 = *reinterpret_cast<const float4*>(&pro_s[kc + ks * 16]);
@@ -112,10 +129,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_x3l_kernel(ConvP p, int m_fast) 
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         float v[8];
-        v[0] = __uint_as_float(R.a[i][ks][0].x); v[1] = __uint_as_float(R.a[i][ks][0].y);
-        v[2] = __uint_as_float(R.a[i][ks][0].z); v[3] = __uint_as_float(R.a[i][ks][0].w);
-        v[4] = __uint_as_float(R.a[i][ks][1].x); v[5] = __uint_as_float(R.a[i][ks][1].y);
-        v[6] = __uint_as_float(R.a[i][ks][1].z); v[7] = __uint_as_float(R.a[i][ks][1].w);
+        {
+          const float4 v0 = *reinterpret_cast<const float4*>(stg_a + (i * 32 + l31) * GL_ROWB + ks * 64 + lhi * 32);
+          const float4 v1 = *reinterpret_cast<const float4*>(stg_a + (i * 32 + l31) * GL_ROWB + ks * 64 + lhi * 32 + 16);
+          v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+        }
         if (!PLAIN) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -148,7 +166,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_x3l_kernel(ConvP p, int m_fast) 
     }
   }
 
-  // park the slice's partial tile: part[wave][row][col]
+  // park the slice's partial tile: part[wave][row][col] -- over the staging rows, once every wave is past its last fragment read
+  __syncthreads();
   float* mine = part + wave * BM * GL_EP;
 #pragma unroll
   for (int i = 0; i < TM; ++i)

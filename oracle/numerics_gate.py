@@ -12,6 +12,7 @@ tests/golden/ under the assertions tests/test_gpu_net.py::_full_forward_check ap
                   follows inside the frame): the x3 product a.w = a_hi.w_hi + a_hi.w_lo + a_lo.w_hi with the two LOW terms on MX-fp8 operands
                   (OCP MX: 32-element blocks along the reduction axis sharing one power-of-two scale, e4m3 elements) -- on gfx950 those two
                   MFMAs would run at twice the fp16 rate (2 instead of 3 units per product)
+  mxfp8_lo_all    the same for EVERY convolution of the two encoders, the generator and the CFT blocks (the index chain included)
 
     python oracle/numerics_gate.py [variant ...] [--t20]      # T = 3 always; --t20 adds the metric's own clip length (~2 min per variant)
 
@@ -109,6 +110,9 @@ def make_conv(variant, counter):
             counter[0] += 1
             return winograd_conv3x3(x, w, b)
         if variant == 'mxfp8_lo_18_22' and w.shape[-1] == 3 and w.shape[1] % 32 == 0 and any(p.startswith(f'generator.blocks.{j}.') for j in (18, 19, 20, 21, 22)):
+            counter[0] += 1
+            return x3_conv_mxfp8_low_terms(x, w, b, stride, padding)
+        if variant == 'mxfp8_lo_all' and w.shape[1] % 32 == 0:        # every VQGAN-stack / CFT convolution (3x3 and 1x1) of both encoders and the generator
             counter[0] += 1
             return x3_conv_mxfp8_low_terms(x, w, b, stride, padding)
         return base(x, W, p, stride, padding)

@@ -1,6 +1,5 @@
 cd /root/repo
-python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "small_tile or partials or replica" 2>&1 | tail -4
-python tools/dev/flag_ab.py 1 spec=0 nospec=16384 2>&1 | grep -v Warning | tail -8
-python tools/dev/flag_ab.py 2 spec=0 nospec=16384 2>&1 | grep -v Warning | tail -5
-python tools/dev/product_leg.py config3 2>&1 | grep "product_leg" | cut -c1-250
-python tools/dev/product_leg.py config3 2>&1 | grep "process_image_sequence" | sed 's/.*process_image_sequence/pis/' | cut -c1-200
+python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "gemm_x3" 2>&1 | tail -4
+python tools/dev/lib_ab.py --b 1 --rounds 3 new=default old=comfyui-keep_amd/csrc/ab/lib_oldgemm.so 2>&1 | grep -v Warning | tail -8
+python tools/dev/gemm_lat_bench.py 2>&1 | grep -v Warning | head -30
+KEEP_HIP_LIB=comfyui-keep_amd/csrc/ab/lib_oldgemm.so python tools/dev/gemm_lat_bench.py 2>&1 | grep -v Warning | head -30

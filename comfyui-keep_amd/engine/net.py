@@ -39,6 +39,9 @@ GRAPH_MAX_CLIPS = int(os.environ.get('KEEP_AMD_GRAPH_MAX_CLIPS', '2'))
 # two-stream order of the forward (GMFlow + Kalman gains on a second stream under the frame recurrence) for calls of at most this
 # many clips (0 = never); the first chunk of pairs / the following chunks (pairs per GMFlow launch group)
 STREAM_OVERLAP_MAX_CLIPS = int(os.environ.get('KEEP_AMD_OVERLAP_MAX_CLIPS', '2'))
+# CFT: the encoder half of encode_enc's first convolution and shortcut once per clip for all frames, the decoder half in the frame loop (A/B: 0
+# = the reference's order: one convolution over cat[enc, dec] per frame)
+CFT_SPLIT = os.environ.get('KEEP_CFT_SPLIT', '1') != '0'
 CFA_FREE_RANGES = os.environ.get('KEEP_CFA_FREE_RANGES', '1') != '0'   # x3: CFA range scales from producers' fused maxima instead of probes (A/B: 0)
 # the CFA block's LayerNorm / GEGLU maxima fused into their kernels up to this many token rows per launch (few clips in flight: the probe launch is
 # the cost); above it the probes stay -- thousands of blocks behind one atomic word per image cost more than the probe (+4 ms per 16-clip step,
@@ -325,7 +328,7 @@ class KeepNet:
         y = self.o.linear(o, w[f'{p}.proj_out.weight'], w[f'{p}.proj_out.bias'], residual=x.view(N * HW, C), bounded=True, n_img=N)
         return y.view(N, H, Wd, C)
 
-    def _vq_stack(self, x, prefix, blocks, taps=(), hook=None):
+    def _vq_stack(self, x, prefix, blocks, taps=(), hook=None, tap_stats=None):
         """Encoder.forward / Generator.forward (VQ:288-292, 339-343) over NHWC maps.
         ``hook(j, x, st) -> (x, st)`` runs after block j (generator CFT/CFA taps, KA:1104-1121).  ``st`` travels with x:
         the per-channel (sum, sumsq) partials its producing convolution reduced in the epilogue, or None."""
@@ -352,6 +355,8 @@ class KeepNet:
                 pending = self._gn(x, p, st)
             if i in taps:
                 feats[str(x.shape[2])] = x
+                if tap_stats is not None:                # (what the producing convolution reduced about the tap: GroupNorm partials, max|x|)
+                    tap_stats[str(x.shape[2])] = st
             if hook is not None and kind != 'norm':
                 x, st = hook(i, x, st)
         return x, feats
@@ -395,11 +400,40 @@ class KeepNet:
             (None if margin is None else margin.view(B, Ltok))
 
     # ------------------------------------------------------------------ CFT / CFA
-    def _cft(self, enc, dec, p):
-        """KA:465-472: dec + cond*(dec*scale(e) + shift(e)), e = ResBlock(cat[enc, dec])."""
+    def _cft_splittable(self, p, C):
+        w = self.w
+        return (CFT_SPLIT and f'{p}.encode_enc.conv1.weight_enc' in w and w[f'{p}.encode_enc.conv1.weight_enc'].shape[-1] == C
+                and self.o.mma != L.MMA_BF16)
+
+    def _cft_enc_part(self, enc, p, st=None):
+        """The encoder half of ``encode_enc`` (VQ:170-181 over cat[enc, dec], KA:466): GroupNorm(32 groups over 2C channels) never mixes the
+        two halves -- groups 0-15 are GroupNorm(16 groups) of enc with norm1's first C weights -- and conv1 / the 1x1 shortcut are sums over
+        input channels, so   conv1(swish(GN(cat)))  = conv1[:, :C](swish(GN16(enc))) + conv1[:, C:](swish(GN16(dec))) + bias   and
+        conv_out(cat) = conv_out[:, :C](enc) + conv_out[:, C:](dec) + bias.   enc [N,h,w,C] (all frames of the clips at once) ->
+        (A1, S1): the two encoder-half sums without bias, added as residuals by ``_cft`` in the frame loop."""
+        w, q = self.w, f'{p}.encode_enc'
+        C = enc.shape[-1]
+        g1 = ops.norm_affine(enc, w[f'{q}.norm1.weight'][:C], w[f'{q}.norm1.bias'][:C], 16, 1e-6, stats=st)
+        a1 = self.o.conv(enc, w[f'{q}.conv1.weight_enc'], None, pro=g1, pro_act=L.PRO_SWISH)
+        s1 = self.o.linear(enc, w[f'{q}.conv_out.weight_enc'], None, n_img=enc.shape[0], x_amax=None if st is None else st.amax)
+        return a1, s1
+
+    def _cft(self, enc, dec, p, pre=None, dec_st=None):
+        """KA:465-472: dec + cond*(dec*scale(e) + shift(e)), e = ResBlock(cat[enc, dec]).  ``pre``: ``_cft_enc_part(enc)`` of this frame
+        (computed per clip by the forward); ``dec_st``: the statistics the producer of ``dec`` reduced."""
         w = self.w
         C = dec.shape[-1]
-        e, est = self._resblock(ops.concat2(enc, dec), f'{p}.encode_enc')
+        if self._cft_splittable(p, C):
+            q = f'{p}.encode_enc'
+            a1, s1 = pre if pre is not None else self._cft_enc_part(enc, p)
+            g1 = ops.norm_affine(dec, w[f'{q}.norm1.weight'][C:], w[f'{q}.norm1.bias'][C:], 16, 1e-6, stats=dec_st)
+            h, hst = self.o.conv(dec, w[f'{q}.conv1.weight_dec'], w[f'{q}.conv1.bias'], pro=g1, pro_act=L.PRO_SWISH, residual=a1, stats=True)
+            sc = self.o.linear(dec, w[f'{q}.conv_out.weight_dec'], w[f'{q}.conv_out.bias'], residual=s1, n_img=dec.shape[0],
+                               x_amax=None if dec_st is None else dec_st.amax)
+            e, est = self.o.conv(h, w[f'{q}.conv2.weight'], w[f'{q}.conv2.bias'], pro=self._gn(h, f'{q}.norm2', hst), pro_act=L.PRO_SWISH,
+                                 residual=sc, stats=True)
+        else:
+            e, est = self._resblock(ops.concat2(enc, dec), f'{p}.encode_enc')
         ss, sst = self.o.conv(e, w[f'{p}.ss0.weight'], w[f'{p}.ss0.bias'], act=L.ACT_LRELU02, stats=True,
                               x_amax=None if est is None else est.amax)                          # [.., 2C]
         ss_amax = None if sst is None else sst.amax             # max over all 2C channels bounds either half
@@ -823,8 +857,12 @@ class KeepNet:
         # K2: LQ encoder over all B*T frames, stash CFT taps
         xn = ops.nchw_to_nhwc(x.view(B * T, 3, H, Wd))
         taps = [FUSE_ENCODER_BLOCK[s] for s in cfg['cft_list']]
+        tap_st = {}
         with _Range('K2 lq_encoder'):
-            z, feats = self._vq_stack(xn, 'encoder', encoder_blocks(cfg), taps)
+            z, feats = self._vq_stack(xn, 'encoder', encoder_blocks(cfg), taps, tap_stats=tap_st)
+            # the encoder half of every CFT block's first convolution + shortcut: all B*T frames in one launch each (they read the LQ taps only)
+            cft_pre = {k: tuple(t.view(B, T, *t.shape[1:]) for t in self._cft_enc_part(v, f'cft.{k}', tap_st.get(k)))
+                       for k, v in feats.items() if k in cfg['cft_list'] and self._cft_splittable(f'cft.{k}', v.shape[-1])}
         enc_feat = {k: v.view(B, T, *v.shape[1:]) for k, v in feats.items()}
         zc = z.view(B, T, *z.shape[1:])
         # K3: Kalman gains over the whole clip.  They only enter frames i >= 1 (KA:1067-1070), so a T = 1 "clip" (the
@@ -882,7 +920,8 @@ class KeepNet:
             def hook(j, y, yst, i=i):                                    # K7 taps (KA:1104-1121)
                 if j in cft_at:
                     s = cft_at[j]
-                    y, yst = self._cft(self._frame(enc_feat[s], i), y, f'cft.{s}')
+                    pre = None if s not in cft_pre else tuple(self._frame(t, i) for t in cft_pre[s])
+                    y, yst = self._cft(self._frame(enc_feat[s], i), y, f'cft.{s}', pre, yst)
                 if j in cfa_at:
                     s = cfa_at[j]
                     y_amax = None if yst is None else yst.amax                 # (frame 0: the producing convolution's fused max|out|)

@@ -94,6 +94,17 @@ def logical_tensors(sd, cfg=None):
                 # layer runs on the 16-channel-chunk MFMA kernels instead of the generic gather kernel
                 t = torch.nn.functional.pad(t, (0, 16 - t.shape[3] % 16))
         out[name] = t.contiguous()
+    # CFT (KA:465-472): encode_enc is a ResBlock over cat[enc_feat, dec_feat].  Its first convolution and its 1x1 shortcut are linear in
+    # their input channels and the GroupNorm in front (32 groups over 2C channels) never mixes the two halves, so the encoder half of both
+    # -- which depends on the LQ frame only -- is evaluated once per clip for all frames (engine/net.py:_cft_enc_part) and the frame
+    # recurrence runs the decoder half: the [.., :C] / [.., C:] input-channel slices as tensors of their own (derived, like `_s2d`)
+    for sz in cfg['cft_list']:
+        p = f'cft.{sz}.encode_enc'
+        w1, wo = out.get(f'{p}.conv1.weight'), out.get(f'{p}.conv_out.weight')
+        if w1 is not None and wo is not None and w1.shape[-1] % 2 == 0 and w1.shape[-1] == wo.shape[-1] and (w1.shape[-1] // 2) % 32 == 0:
+            C = w1.shape[-1] // 2
+            out[f'{p}.conv1.weight_enc'], out[f'{p}.conv1.weight_dec'] = w1[..., :C].contiguous(), w1[..., C:].contiguous()
+            out[f'{p}.conv_out.weight_enc'], out[f'{p}.conv_out.weight_dec'] = wo[..., :C].contiguous(), wo[..., C:].contiguous()
     k7 = 'flownet.model.backbone.conv1.weight'
     if k7 in out and tuple(out[k7].shape[1:]) == (7, 7, 3):
         out[k7 + '_s2d'] = s2d_weights_7x7(out[k7])

@@ -76,6 +76,33 @@ def test_cft_cfa_vs_golden(gpu_net):
     close(nchw(y), OPS['cfa'], 3e-4, 'cfa')
 
 
+def test_cft_encoder_half_once_per_clip_equals_the_whole_block(gpu_net):
+    """Round 6: encode_enc's first convolution and 1x1 shortcut over cat[enc, dec] (KA:466, VQ:170-181) as encoder half (once per clip, all
+    frames: `_cft_enc_part`) + decoder half (frame loop): the GroupNorm over 2C channels never mixes the halves and both operators are sums
+    over input channels.  Against the one-convolution form (KEEP_CFT_SPLIT=0) to fp32 re-association; the precomputed halves handed in
+    equal the on-the-fly ones bit for bit; statistics from a producer (dec_st) equal the probed ones to rounding."""
+    from comfyui_keep_amd.engine import net as net_mod
+    net = gpu_net
+    g = torch.Generator().manual_seed(11)
+    for key, C, hw in (('32', 256, 32), ('16', 512, 16)):
+        enc = (torch.randn((2, hw, hw, C), generator=g) * 1.5).cuda()
+        dec = (torch.randn((2, hw, hw, C), generator=g) * 0.7 + 0.2).cuda()
+        y, st = net._cft(enc, dec, f'cft.{key}')
+        pre = net._cft_enc_part(enc, f'cft.{key}')
+        y2, _ = net._cft(enc, dec, f'cft.{key}', pre)
+        assert torch.equal(y, y2)
+        old = net_mod.CFT_SPLIT
+        try:
+            net_mod.CFT_SPLIT = False
+            ref, _ = net._cft(enc, dec, f'cft.{key}')
+        finally:
+            net_mod.CFT_SPLIT = old
+        scale = float(ref.abs().max())
+        err = float((y - ref).abs().max())
+        print(f'cft.{key} [{net.precision}] split vs one convolution: {err:.3e} of scale {scale:.3g}')
+        assert torch.isfinite(y).all() and err <= 3e-6 * max(1.0, scale)
+
+
 def test_cfa_range_scales_from_producer_maxima(gpu_net):
     """x3 policy: CFA takes five of its nine range scales from maxima its producers already hold (`curr_amax`: the producing
     convolution's fused max|out|; the q / kv projections' fused maxima; |attention output| <= max|v|) instead of probing -- with inputs of

@@ -282,7 +282,16 @@ def test_packed_blob_layouts(synth_weights):
     n_in = sum(t.numel() for t in synth_weights.values())
     # ... and GMFlow's 7x7 stride-2 first convolution a derived [64,4,4,16] twin for the space-to-depth form (keep_rgb_s2d)
     assert lt['flownet.model.backbone.conv1.weight_s2d'].shape == (64, 4, 4, 16)
-    assert sum(t.numel() for t in lt.values()) == n_in + 256 * 9 * 14 + 64 * 4 * 4 * 16
+    # ... and (round 6) every CFT block's encode_enc first convolution and 1x1 shortcut once more as their encoder / decoder input-channel
+    # halves (engine/net.py:_cft_enc_part): the same numbers, sliced
+    for sz, C in (('16', 512), ('32', 256), ('64', 256)):
+        q = f'cft.{sz}.encode_enc'
+        full, sc = lt[f'{q}.conv1.weight'], lt[f'{q}.conv_out.weight']
+        assert full.shape == (C, 3, 3, 2 * C) and sc.shape == (C, 2 * C)
+        assert torch.equal(torch.cat([lt[f'{q}.conv1.weight_enc'], lt[f'{q}.conv1.weight_dec']], -1), full)
+        assert torch.equal(torch.cat([lt[f'{q}.conv_out.weight_enc'], lt[f'{q}.conv_out.weight_dec']], -1), sc)
+    halves = sum(C * 9 * 2 * C + C * 2 * C for C in (512, 256, 256))
+    assert sum(t.numel() for t in lt.values()) == n_in + 256 * 9 * 14 + 64 * 4 * 4 * 16 + halves
 
 
 def test_face_tracking_restatement():

@@ -1,5 +1,5 @@
 cd /root/repo
-python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "gemm_x3" 2>&1 | tail -4
-python tools/dev/lib_ab.py --b 1 --rounds 3 new=default old=comfyui-keep_amd/csrc/ab/lib_oldgemm.so 2>&1 | grep -v Warning | tail -8
-python tools/dev/gemm_lat_bench.py 2>&1 | grep -v Warning | head -30
-KEEP_HIP_LIB=comfyui-keep_amd/csrc/ab/lib_oldgemm.so python tools/dev/gemm_lat_bench.py 2>&1 | grep -v Warning | head -30
+python -m pytest tests/test_gpu_net.py -x -q -m gpu -s -k "cft or T3_vs_reference or T20_vs_reference or batched_clips or asian" 2>&1 | grep -v "^$" | cut -c1-400 | tail -25
+python tools/dev/env_ab.py --b 1 split:KEEP_CFT_SPLIT=1 whole:KEEP_CFT_SPLIT=0 2>&1 | grep -v Warning | tail -6
+python tools/dev/env_ab.py --b 16 split:KEEP_CFT_SPLIT=1 whole:KEEP_CFT_SPLIT=0 2>&1 | grep -v Warning | tail -6
+python tools/dev/x3_ceiling.py > gpurun_out/r06_x3_ceiling_probe.txt 2>&1; cat gpurun_out/r06_x3_ceiling_probe.txt

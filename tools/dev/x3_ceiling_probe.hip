@@ -9,6 +9,10 @@
 //              fp32 -> 2 x fp16 conversion, no HBM / L2 traffic, no epilogue, random data
 //   variant 2  variant 1 + the conversion's arithmetic in the MFMA shadows (per gap two scalar-f32 VALU on private registers: the
 //              affine + split of the streaming kernel without its memory side)
+//   variant 3  the MX-fp8 lever priced (oracle/numerics_gate.py says the numerics pass): per four 16-channel K steps and tap the a_hi.b_hi term
+//              stays 4 x 4 fp16 MFMAs from LDS operands (as in variant 1, without the lo fragment reads), the two LOW terms become
+//              2 x 4 `v_mfma_scale_f32_32x32x64_f8f6f4` (e4m3 operands of K = 64, unit block scales) on register-resident random fp8
+//              operands: 16 + 8 MFMA issues per 4 K steps instead of 48.  x3-equivalent = fp32-grade products per second x 2.
 //
 // Every block records s_memtime (shader cycles) and s_memrealtime (100 MHz) around its loop: clock = cycles / ticks.  Built as a shared
 // object (extern "C" x3_probe_run) that bench.py loads for `roofline.practical_peak`; `tools/dev/x3_ceiling.py` prints the table that
@@ -19,6 +23,7 @@
 #include <stdio.h>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
@@ -57,12 +62,46 @@ __global__ __launch_bounds__(256, 2) void x3_probe_kernel(float* __restrict__ ou
       bl[j][e] = rnd_half(seed ^ (lane * 64 + 48 + j * 8 + e)) * (_Float16)0.0009765625f;
     }
   }
+  v8i qa[2], qb[2];      // variant 3: random fp8 (e4m3) operand bytes, K = 64 per lane pair
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      qa[j][e] = (int)(hash32(seed * 3u + lane * 32 + j * 8 + e) & 0x77777777u);      // exponents below the NaN / inf patterns
+      qb[j][e] = (int)(hash32(seed * 5u + lane * 32 + 16 + j * 8 + e) & 0x77777777u);
+    }
   float va = 1.0f + lane * 1e-3f, vb = 0.5f;
   unsigned long long c0 = 0, t0 = 0;
   if (threadIdx.x == 0) {
     c0 = __builtin_amdgcn_s_memtime();
     t0 = __builtin_amdgcn_s_memrealtime();
   }
+  if (VARIANT == 3) {
+    // one iteration = one tap over FOUR 16-channel K steps: 4 x 4 fp16 MFMAs (a_hi . b_hi) + 2 x 4 fp8 MFMAs of K = 64 (the two low terms)
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int arow = wave * 64 + row + (tap % 3) + 34 * (tap / 3) + ((it + ks) & 3);
+          const int brow = tap * 64 + row;
+          const unsigned char* pa = lds + arow * PITCH + kh * 16;
+          const unsigned char* pb = lds + (A_ROWS + brow) * PITCH + kh * 16 + (ks & 1) * 32;
+          ah[0] = *reinterpret_cast<const h8*>(pa);
+          ah[1] = *reinterpret_cast<const h8*>(pa + 32 * PITCH);
+          bh[0] = *reinterpret_cast<const h8*>(pb);
+          bh[1] = *reinterpret_cast<const h8*>(pb + 32 * PITCH);
+#pragma unroll
+          for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a >> 1], bh[a & 1], acc[a], 0, 0, 0);
+        }
+#pragma unroll
+        for (int term = 0; term < 2; ++term)
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+            acc[a] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa[(a >> 1) ^ term], qb[(a & 1) ^ term], acc[a], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      }
+    }
+  } else
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -127,7 +166,8 @@ extern "C" int x3_probe_run(int variant, int blocks_per_cu, int iters, double* r
     switch (variant) {
       case 0: hipLaunchKernelGGL(x3_probe_kernel<0>, dim3(blocks), dim3(256), 0, 0, out, clk, n, 12345u); break;
       case 1: hipLaunchKernelGGL(x3_probe_kernel<1>, dim3(blocks), dim3(256), 0, 0, out, clk, n, 12345u); break;
-      default: hipLaunchKernelGGL(x3_probe_kernel<2>, dim3(blocks), dim3(256), 0, 0, out, clk, n, 12345u); break;
+      case 2: hipLaunchKernelGGL(x3_probe_kernel<2>, dim3(blocks), dim3(256), 0, 0, out, clk, n, 12345u); break;
+      default: hipLaunchKernelGGL(x3_probe_kernel<3>, dim3(blocks), dim3(256), 0, 0, out, clk, n, 12345u); break;
     }
   };
   launch(iters / 8 + 1);      // warm-up (clocks, caches)
@@ -147,7 +187,9 @@ extern "C" int x3_probe_run(int variant, int blocks_per_cu, int iters, double* r
     ticks += (double)h[b * 2 + 1];
   }
   free(h);
-  const double mfma_per_wave = (double)iters * 9 * 12;
+  // variant 3: an iteration covers FOUR K steps per tap -- 16 fp16 MFMAs + 8 fp8 MFMAs of four times the K: `raw` counts what x3 would have
+  // issued for the same products (48 fp16 MFMAs), so that raw / 3 stays "fp32-grade products per second x 2" across variants
+  const double mfma_per_wave = (double)iters * 9 * (variant == 3 ? 48 : 12);
   const double waves = (double)blocks * 4;
   const double flops = waves * mfma_per_wave * 2.0 * 32 * 32 * 16;
   res[0] = ms;

@@ -54,7 +54,7 @@ FLOP_PER_FRAME_T20 = 1038.5e9         # SURVEY.md 8d (reference graph, 2 FLOP/MA
 GMFLOW_DUPLICATE_FLOP_PER_FRAME = 33.0e9   # backbone passes of interior frames the reference repeats: 18 of 38 per T=20 clip
 PEAK = {'fp32': PEAK_F32_MFMA_TFLOPS, 'bf16': PEAK_16BIT_MFMA_TFLOPS, 'x3': PEAK_16BIT_MFMA_TFLOPS / 3.0}
 DTYPE = {'fp32': 'f32', 'bf16': 'bf16', 'x3': 'f16x3'}
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r06_pmc_traffic.json')
 
 
 FAKE = os.environ.get('KEEP_BENCH_FAKE_NET') == '1'     # tests/test_dist_gloo.py: the N-rank plumbing of this file on a machine without a GPU

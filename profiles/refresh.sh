@@ -1,30 +1,26 @@
 #!/bin/bash
-# Round 5 (the bench's default workload is 48 clips per call since the second half of the round: files *_b48*; the 16-clip files stay for continuity).
-# Copy the summaries tools/profile_step.sh wrote under gpurun_out/ (on the GPU box, merged back by gpurun) into the
-# tracked profiles/ directory.  Each source file is the unedited output of the command quoted in its header.
-#   on the GPU box:   bash tools/profile_step.sh x3 16 r5p_x3_b16 ; KEEP_AMD_GRAPH=0 KEEP_AMD_OVERLAP_MAX_CLIPS=0 PMC_COUNTERS= bash tools/profile_step.sh x3 1 r5p_x3_b1 ;
-#                     python bench.py > gpurun_out/r5p_bench.json ; python tools/dev/conv_census.py 16 conv > gpurun_out/r5p_census_b16.txt
-#   here:             bash profiles/refresh.sh
+# Round 6: every r06_* file below comes from ONE gpurun call = one box (bench line, kernel tables, PMC traffic, census, per-shape PMC rows):
+#   on the GPU box (tools/dev/run1.sh of that call):
+#     bash tools/profile_step.sh x3 48 r6p_x3_b48 ; cp gpurun_out/r6p_x3_b48/x3_b48_pmc.json profiles/r06_pmc_traffic.json   (bench.py reads it: roofline.traffic)
+#     python bench.py > gpurun_out/r6p_bench.json
+#     KEEP_AMD_GRAPH=0 KEEP_AMD_OVERLAP_MAX_CLIPS=0 PMC_COUNTERS= bash tools/profile_step.sh x3 1 r6p_x3_b1
+#     python tools/dev/conv_census.py 48 conv_x3 > gpurun_out/r6p_census_b48.txt ; ... 48 halo > r6p_census_halo_b48.txt ; ... 1 '' > r6p_census_b1.txt
+#     bash tools/dev/pmc_shapes.sh r6p_pmc_shapes > gpurun_out/r6p_pmc_shapes.txt
+#   here:  bash profiles/refresh.sh
+# Each source file is the unedited output of the command quoted in its header.  (Rounds 1-5: git log -- profiles/refresh.sh.)
 set -e
 cd "$(dirname "$0")/.."
 G=gpurun_out
 hdr() { echo "# rocprofv3 --kernel-trace --stats -- python tools/run_step.py $1 $2 2   ($1 policy, $2 clip(s) x T=20 per pass, 2 passes; pass 1 includes first-touch allocation and the x3 weight split; $3)"; }
-[ -f $G/r5p_x3_b16/x3_b16_kernel_stats.txt ] && { hdr x3 16 "round-5 kernels"; cat $G/r5p_x3_b16/x3_b16_kernel_stats.txt; } > profiles/r05_x3_b16_kernel_stats.txt
-[ -f $G/r5p_x3_b1/x3_b1_kernel_stats.txt ] && { hdr x3 1 "KEEP_AMD_GRAPH=0 KEEP_AMD_OVERLAP_MAX_CLIPS=0: eager launches on one stream, so every kernel is a trace record"; cat $G/r5p_x3_b1/x3_b1_kernel_stats.txt; } > profiles/r05_x3_b1_kernel_stats.txt
-if [ -f $G/r5p_x3_b16/x3_b16_pmc.json ]; then
-  cp $G/r5p_x3_b16/x3_b16_pmc.json profiles/r05_pmc_traffic_b16.json
-  { echo "# rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace --output-format csv -- python tools/run_step.py x3 16 1"; echo "# KiB per launch as reported; FETCH_SIZE is doubled on gfx950 in r05_pmc_traffic.json (MI355X_MICROARCH.md, HBM section)"; cat $G/r5p_x3_b16/x3_b16_pmc.txt; } > profiles/r05_pmc_step_x3_b16.txt
+[ -f $G/r6p_x3_b48/x3_b48_kernel_stats.txt ] && { hdr x3 48 "the bench's default workload; same box and call as profiles/r06_bench_default.json"; cat $G/r6p_x3_b48/x3_b48_kernel_stats.txt; } > profiles/r06_x3_b48_kernel_stats.txt
+[ -f $G/r6p_x3_b1/x3_b1_kernel_stats.txt ] && { hdr x3 1 "KEEP_AMD_GRAPH=0 KEEP_AMD_OVERLAP_MAX_CLIPS=0: eager launches on one stream, so every kernel is a trace record; same box and call as the bench line"; cat $G/r6p_x3_b1/x3_b1_kernel_stats.txt; } > profiles/r06_x3_b1_kernel_stats.txt
+if [ -f $G/r6p_x3_b48/x3_b48_pmc.json ]; then
+  cp $G/r6p_x3_b48/x3_b48_pmc.json profiles/r06_pmc_traffic.json
+  { echo "# rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace --output-format csv -- python tools/run_step.py x3 48 1   (same box and call as the bench line)"; echo "# KiB per launch as reported; FETCH_SIZE is doubled on gfx950 in r06_pmc_traffic.json (MI355X_MICROARCH.md, HBM section)"; cat $G/r6p_x3_b48/x3_b48_pmc.txt; } > profiles/r06_pmc_step_x3_b48.txt
 fi
-[ -f $G/r5p_bench.json ] && grep '^{' $G/r5p_bench.json | tail -1 > profiles/r05_bench_default.json
-[ -f $G/r5p_x3_b48/x3_b48_kernel_stats.txt ] && { hdr x3 48 "the bench's default workload"; cat $G/r5p_x3_b48/x3_b48_kernel_stats.txt; } > profiles/r05_x3_b48_kernel_stats.txt
-if [ -f $G/r5p_x3_b48/x3_b48_pmc.json ]; then
-  cp $G/r5p_x3_b48/x3_b48_pmc.json profiles/r05_pmc_traffic.json
-  { echo "# rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace --output-format csv -- python tools/run_step.py x3 48 1"; echo "# KiB per launch as reported; FETCH_SIZE is doubled on gfx950 in r05_pmc_traffic.json (MI355X_MICROARCH.md, HBM section)"; cat $G/r5p_x3_b48/x3_b48_pmc.txt; } > profiles/r05_pmc_step_x3_b48.txt
-fi
-[ -f $G/r5p_census_b48.txt ] && grep -v "^/opt" $G/r5p_census_b48.txt > profiles/r05_conv_census_x3_b48.txt
-[ -f $G/r5p_census_halo_b48.txt ] && grep -v "^/opt" $G/r5p_census_halo_b48.txt > profiles/r05_conv_census_halo_x3_b48.txt
-[ -f $G/r5p_census_b16.txt ] && grep -v "^/opt" $G/r5p_census_b16.txt > profiles/r05_conv_census_x3_b16.txt
-[ -f $G/r5p_census_halo_b16.txt ] && grep -v "^/opt" $G/r5p_census_halo_b16.txt > profiles/r05_conv_census_halo_x3_b16.txt
-[ -f $G/r5p_census_b1.txt ] && { echo "# kernel names are the PLAN family's (keep_conv_plan): at one clip the launcher of the halo family hands maps of <= 64 / 128 items of the 256-pixel kernels to"; echo "# conv3x3_x3q_kernel (un-split) / conv3x3_x3p_kernel (split-K partials) -- the bit-equal 64-pixel forms of DESIGN 5.6; the times are what ran (r05_x3_b1_kernel_stats.txt names them)"; grep -v "^/opt" $G/r5p_census_b1.txt; } > profiles/r05_conv_census_x3_b1.txt
-[ -f $G/r5p_gemm_forms.txt ] && { echo "# python tools/dev/gemm_lat_bench.py: us per launch (hipGraph replay of 40 launches) of the token GEMMs by form and images per launch --"; echo "# seq: one sequential sum (KEEP_CONV_NO_GEMM_LAT); waves: gemm_x3l_kernel at every row count; tiles: conv_x3_kernel with canonical slices at every row count"; grep -v "^/opt" $G/r5p_gemm_forms.txt; } > profiles/r05_gemm_forms.txt
-ls -la profiles/r05_* 2>/dev/null
+[ -f $G/r6p_bench.json ] && grep '^{' $G/r6p_bench.json | tail -1 > profiles/r06_bench_default.json
+[ -f $G/r6p_census_b48.txt ] && grep -v "^/opt" $G/r6p_census_b48.txt > profiles/r06_conv_census_x3_b48.txt
+[ -f $G/r6p_census_halo_b48.txt ] && grep -v "^/opt" $G/r6p_census_halo_b48.txt > profiles/r06_conv_census_halo_x3_b48.txt
+[ -f $G/r6p_census_b1.txt ] && { echo "# kernel names are the PLAN family's (keep_conv_plan): at one clip the launcher of the halo family hands maps of <= 64 / 128 items of the 256-pixel kernels to"; echo "# conv3x3_x3q_kernel (un-split) / conv3x3_x3p_kernel (split-K partials) -- the bit-equal 64-pixel forms of DESIGN 5.6; the times are what ran (r06_x3_b1_kernel_stats.txt names them)"; grep -v "^/opt" $G/r6p_census_b1.txt; } > profiles/r06_conv_census_x3_b1.txt
+[ -f $G/r6p_pmc_shapes.txt ] && { echo "# bash tools/dev/pmc_shapes.sh: per-shape PMC rows of the dominant kernel (conv3x3_halo_x3s_kernel, GroupNorm-swish prologue + residual + statistics) at the bench's 48 images per launch,"; echo "# one rocprofv3 --pmc pass per counter set and layer (tools/bench_conv.py c64_512_n48 / c128_256_n48, 6 launches each); same box and call as the bench line.  Launches under a PMC pass"; echo "# run at a lower clock (1.32 GHz effective here against 1.7-1.8 without counters): the traffic and the busy FRACTION are the evidence, not the time."; grep -v "^/opt" $G/r6p_pmc_shapes.txt; } > profiles/r06_pmc_conv_shapes.txt
+ls -la profiles/r06_* 2>/dev/null

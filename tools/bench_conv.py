@@ -25,6 +25,10 @@ LAYERS = {  # name: (N, H, W, Cin, Cout, ksize, upsample)
     'up128_512': (4, 256, 256, 128, 128, 3, True),
     'c256_64': (4, 64, 64, 256, 256, 3, False),
     'c512_16': (4, 16, 16, 512, 512, 3, False),
+    'c64_512_n48': (48, 512, 512, 64, 64, 3, False),        # the frame loop's launches at the bench's 48 clips per call
+    'c128_256_n48': (48, 256, 256, 128, 128, 3, False),
+    'c256_64_n1': (1, 64, 64, 256, 256, 3, False),          # one clip in flight: the 64-pixel-block kernels (conv3x3_x3q_kernel)
+    'c256_32_n1': (1, 32, 32, 256, 256, 3, False),
     'lin128': (1, 622592, 1, 128, 128, 1, False),
     'lin256_1024': (1, 622592, 1, 256, 1024, 1, False),
     't512_1024': (1, 4096, 1, 512, 1024, 1, False),
@@ -42,7 +46,7 @@ LAYERS = {  # name: (N, H, W, Cin, Cout, ksize, upsample)
 }
 
 
-def run(name, mma, in_bf16, iters=20):
+def run(name, mma, in_bf16, iters=int(os.environ.get('ITERS', '20'))):
     N, H, W, Cin, Cout, k, up = LAYERS[name]
     x = torch.randn(N, H, W, Cin, device='cuda')
     w = torch.randn(Cout, k, k, Cin, device='cuda') * 0.05
@@ -97,7 +101,8 @@ if __name__ == '__main__':
         sys.exit(0)
     if os.environ.get('X3'):      # split fp16: plain input, and with the fused GroupNorm affine + swish prologue
         for n in names:
-            run(n, L.MMA_X3, False)
+            if not os.environ.get('PRO_ONLY'):
+                run(n, L.MMA_X3, False)
             if LAYERS[n][5] == 3:
                 run(n, L.MMA_X3, True)
         sys.exit(0)

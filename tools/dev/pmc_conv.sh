@@ -6,13 +6,13 @@ mkdir -p "$OUT"
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 i=0
-for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_INSTS_SALU" "GRBM_GUI_ACTIVE SQ_WAVES"; do
+for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_INSTS_SALU" "GRBM_GUI_ACTIVE SQ_WAVES" ${PMC_EXTRA:+"$PMC_EXTRA"}; do
   i=$((i+1))
   X3=1 timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/p$i" -o p$i -- python "$REPO/tools/bench_conv.py" "$@" > "$OUT/p$i.log" 2>&1 || echo "pass $i failed: $SET"
 done
 cd "$REPO"
 python - "$OUT" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, os, sys, collections
 out = sys.argv[1]
 csv.field_size_limit(1 << 30)
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
@@ -20,7 +20,7 @@ dur = collections.defaultdict(list)          # (kernel, grid) -> launch duration
 for f in glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'][:70]
-        if 'halo_x3' not in k:
+        if os.environ.get('PMC_FILTER', 'halo_x3') not in k:
             continue
         a = acc[k][r['Counter_Name']]
         a[0] += float(r['Counter_Value']); a[1] += 1

@@ -491,8 +491,8 @@ def product_leg(net, n_frames, H, W, faces):
     assert tuple(outf.shape) == (n_frames, H, W, 3) and outf.dtype == torch.float32
     rec["process_image_sequence"] = {"value": round(n_frames / df, 2), "unit": "video frames/s", "seconds": round(df, 3),
                                      "what": "the node's call: float32 RGB IMAGE tensor in host memory -> float32 IMAGE tensor in host "
-                                             "memory (adds the reference's comfy_image_to_cv2 per frame on the host and 4x the "
-                                             "download bytes)"}
+                                             "memory (round 6: comfy_image_to_cv2 for the whole batch on the device -- keep_comfy_to_bgr_u8, in chunks "
+                                             "under the detection pre-pass; 4x the bytes of the uint8 entry point each way)"}
     return rec
 
 

@@ -592,6 +592,80 @@ def test_batched_detection_prepass_equals_the_per_frame_loop():
     assert all(np.array_equal(a[0], b[0]) for a, b in zip(out['loop'], out['batch']))
 
 
+def test_detection_prepass_overlaps_chunks_without_changing_results(monkeypatch):
+    """Round 6: with several chunks of detector frames the forward of chunk k runs on a worker thread under the host preparation of
+    chunk k + 1 (KEEP_AMD_DETECT_OVERLAP, default on).  Same landmarks as the one-after-the-other order and as the per-frame loop, every
+    chunk prepared exactly once and in order, the detector called once per chunk from ONE worker thread; an exception inside the
+    detector's forward surfaces in the caller."""
+    import threading
+    import types
+    log = []
+
+    class Det:
+        def __init__(self, fail_at=None):
+            self.engine = types.SimpleNamespace(max_frames=4)         # chunks of four frames
+            self.threads, self.fail_at, self.n = set(), fail_at, 0
+
+        def detect_batch(self, frames, thr=0.8):
+            self.threads.add(threading.get_ident())
+            log.append(('forward', int(frames[0, 0, 0, 0])))
+            self.n += 1
+            if self.fail_at == self.n:
+                raise RuntimeError('detector down')
+            return [np.array([[float(f[0, 0, 0]), 1, float(f[0, 0, 0]) + 50, 60, 0.99] + list(np.arange(10, dtype=np.float32) + float(f[0, 0, 0]))], np.float32)
+                    for f in frames]
+
+    class Helper:
+        det_model = 'retinaface_resnet50'
+
+        def __init__(self, det):
+            self.face_detector = det
+
+        def clean_all(self):
+            self.all_landmarks_5, self.input_img = [], None
+
+        def read_image(self, img):
+            self.input_img = img
+            log.append(('read', int(img[0, 0, 0])))
+
+        def get_face_landmarks_5(self, only_center_face=False, resize=640, eye_dist_threshold=None):
+            b = self.face_detector.detect_faces(self.input_img, 0.97)
+            self.all_landmarks_5 = [b[i, 5:].reshape(5, 2) for i in range(b.shape[0])]
+            return len(self.all_landmarks_5)
+
+    frames = [np.full((32, 40, 3), i, np.uint8) for i in range(10)]
+    outs = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('KEEP_AMD_DETECT_OVERLAP', mode)
+        del log[:]
+        det = Det()
+        proc = KEEPFaceProcessor(KEEPModelPack(_RecordingNet(), Helper(det), None, None, 'KEEP'))
+        outs[mode] = proc._detect_all(frames, True)
+        assert [v for k, v in log if k == 'read'] == list(range(10))               # every frame prepared once, in order
+        assert [v for k, v in log if k == 'forward'] == [0, 4, 8]                  # one forward per chunk, in order
+        assert len(det.threads) == 1 and (threading.get_ident() in det.threads) == (mode == '0')
+        if mode == '1':      # chunk 1 was prepared (reads 4..7) before chunk 0's forward was collected: the read of frame 4 precedes nothing that needs chunk 0's result
+            assert log.index(('read', 4)) < log.index(('forward', 4))
+    assert all(np.array_equal(a[0], b[0]) for a, b in zip(outs['1'], outs['0'])) and len(outs['1']) == 10
+    assert all(float(outs['1'][i][0][0, 0]) == float(i) for i in range(10))
+    monkeypatch.setenv('KEEP_AMD_DETECT_OVERLAP', '1')
+    proc = KEEPFaceProcessor(KEEPModelPack(_RecordingNet(), Helper(Det(fail_at=2)), None, None, 'KEEP'))
+    with pytest.raises(RuntimeError, match='detector down'):
+        proc._detect_all(frames, True)
+
+
+def test_frames_from_comfy_host_fallbacks():
+    """modules/keep_processor.py:frames_from_comfy without a GPU: a CPU device (and, on any device, inputs the device kernel does not take)
+    yield the per-frame host converter's frames as a plain list -- the reference's `comfy_image_to_cv2` per frame."""
+    from comfyui_keep_amd.modules import keep_processor as KPm
+    from comfyui_keep_amd.modules.utils import comfy_image_to_cv2
+    seq = torch.rand((3, 8, 10, 3), generator=torch.Generator().manual_seed(0))
+    got = KPm.frames_from_comfy(seq, 'cpu')
+    assert isinstance(got, list) and len(got) == 3
+    assert all(np.array_equal(g, comfy_image_to_cv2(seq[i])) and g.dtype == np.uint8 and g.shape == (8, 10, 3) for i, g in enumerate(got))
+    assert isinstance(KPm.frames_from_comfy(seq.double(), 'cuda'), list)          # not float32: the host converter, whatever the device
+
+
 def test_device_crop_warp_hook_keeps_the_helper_contract(monkeypatch):
     """8f-2 host logic: with the GPU cv path on, ``_align_warp`` fits the similarity on the host (cv2.estimateAffinePartial2D) and
     crops on the device, filling ``affine_matrices`` / ``cropped_faces`` exactly like ``align_warp_face``; pad_blur or the cv path

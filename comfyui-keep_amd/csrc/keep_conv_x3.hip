@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3_kernel(ConvP p, int ti
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         s4[q] += e[q];
-        ss4[q] += e[q] * e[q];
+        ss4[q] = __builtin_fmaf(e[q], e[q], ss4[q]);      // (explicit: the general epilogue's loop form left SOME of these uncontracted -- the replica kernel of keep_conv_x3s.hip reproduces one fused form)
         amx = fmaxf(amx, fabsf(e[q]));
       }
     }
@@ -1449,6 +1449,7 @@ bool keep_conv_x3_gather_is_gemm(const keep_conv2d_args* a) {
 
 bool keep_conv_x3p_ok(const keep_conv2d_args* a, const ConvP& p, int split_k);
 bool keep_conv_x3q_ok(const keep_conv2d_args* a, const ConvP& p, int split_k);
+bool keep_conv_x3p_full_ok(const keep_conv2d_args* a, const ConvP& p, int split_k);
 int keep_conv2d_x3_small_full(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 int keep_conv2d_x3_partials(const keep_conv2d_args* a, ConvP& p, hipStream_t st);
 bool keep_conv_x3_stream_ok(const keep_conv2d_args* a, const ConvP& p, int split_k);
@@ -1471,6 +1472,7 @@ int keep_conv2d_x3_halo(const keep_conv2d_args* a, ConvP& p, hipStream_t st) {
   if (keep_conv_x3p_ok(a, p, p.split_k)) return keep_conv2d_x3_partials(a, p, st);                        // keep_conv_x3p.hip (few images: 64-pixel tiles, same partials)
   if (keep_conv_x3_stream_ok(a, p, p.split_k) && keep_conv_x3q_ok(a, p, p.split_k)) return keep_conv2d_x3_small_full(a, p, st);      // few items: 64-pixel blocks, the streaming kernel's values
   if (keep_conv_x3_stream_ok(a, p, p.split_k)) return keep_conv2d_x3_stream(a, p, x3_num_cu(), st);      // keep_conv_x3s.hip
+  if (keep_conv_x3p_full_ok(a, p, p.split_k)) return keep_conv2d_x3_partials(a, p, st);                  // few items, this kernel's epilogue (aux tensor / 16-wide maps): 64-pixel blocks, same values
   const bool wide = (a->Ho % 8 == 0 && a->Wo % 32 == 0);
   const int tw = wide ? 32 : 16, th = 256 / tw;
   const int tiles_x = a->Wo / tw, tiles_y = a->Ho / th, ncb = (a->Cout + 63) / 64;

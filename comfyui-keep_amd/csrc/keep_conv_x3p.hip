@@ -233,10 +233,56 @@ __global__ __launch_bounds__(256) void conv3x3_x3p_kernel(ConvP p, int tiles_x, 
       }
     }
   }
-#undef XP_BARRIER
-  // the partial of this (tile, cout block, z): ws[z][m][co], scaled like the halo kernel's split-K epilogue (v * asc)
   const float asc = p.acc_scale * in_inv;
   const int hw_o = p.Ho * p.Wo;
+  if (p.split_k == 1) {
+    // Round 6 -- un-split plans the streaming kernel does not take (an aux tensor: CFT's shift convolution, KA:470-472; 16-wide maps), few
+    // items: the WHOLE convolution from these blocks, conv3x3_halo_x3_kernel's epilogue arithmetic (e = fma(acc, scale, bias); activation;
+    // residual, or res + aux_w (res aux + e)) on rows of 32 channels, per-image max|out|; its GroupNorm partials come from
+    // conv_stats_replica_kernel (8 x 32 tiles: the launcher admits statistics only there).  Same operand arithmetic and MFMA order as the
+    // partials above: bit-equal to the 256-pixel kernel (tests/test_gpu_kernels.py).
+    XP_BARRIER()                                                          // every wave is past its last fragment read: the halo stages become the row staging
+    float* et = reinterpret_cast<float*>(hs_raw) + wave * 32 * 36;      // 4 waves x 4608 B <= 3 stages x 8640 B
+#pragma unroll
+    for (int r = 0; r < 16; ++r) et[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 36 + l31] = acc[r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const int c4 = (lane & 7) * 4, co4 = n0 + chf * 32 + c4;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + co4);
+    float amx = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rr = it * 8 + (lane >> 3);
+      const long m = (long)n * hw_o + (oy0 + 2 * ph + (rr >> 4)) * p.Wo + ox0 + (rr & 15);
+      const float4 v = *reinterpret_cast<const float4*>(et + rr * 36 + c4);
+      float e[4] = {__builtin_fmaf(v.x, asc, bias4.x), __builtin_fmaf(v.y, asc, bias4.y), __builtin_fmaf(v.z, asc, bias4.z),
+                    __builtin_fmaf(v.w, asc, bias4.w)};
+      if (p.epi_act != KEEP_ACT_NONE) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = p.fast ? act_apply_fast(e[q], p.epi_act) : act_apply(e[q], p.epi_act);
+      }
+      if (p.res) {
+        const float4 r4 = *reinterpret_cast<const float4*>(p.res + m * p.res_ld + co4);
+        const float rr4[4] = {r4.x, r4.y, r4.z, r4.w};
+        if (p.aux) {
+          const float4 a4 = *reinterpret_cast<const float4*>(p.aux + m * (long)p.Cout + co4);
+          const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) e[q] = rr4[q] + p.aux_w * (rr4[q] * aa[q] + e[q]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) e[q] += rr4[q];
+        }
+      }
+      *reinterpret_cast<float4*>(p.out + m * p.out_ld + co4) = make_float4(e[0], e[1], e[2], e[3]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) amx = fmaxf(amx, fabsf(e[q]));
+    }
+    if (p.out_amax) wave_amax_commit(p.out_amax + n, amx);
+    return;
+  }
+#undef XP_BARRIER
+  // the partial of this (tile, cout block, z): ws[z][m][co], scaled like the halo kernel's split-K epilogue (v * asc)
   const int co = n0 + chf * 32 + l31;
   if (co < p.Cout) {
 #pragma unroll
@@ -279,6 +325,7 @@ __global__ __launch_bounds__(256) void conv3x3_x3q_kernel(ConvP p, int tiles_x, 
   float in_s = 1.f, in_inv = 1.f;
   if (p.in_amax) x3_range_scale(p.in_amax[n], in_s, in_inv);
   const float rs = (PRO == KEEP_PRO_NONE && p.in_amax) ? in_s : 1.f;
+  const int Hv = p.upsample ? 2 * p.H : p.H, Wv = p.upsample ? 2 * p.W : p.W;      // nearest x2 (VQ:149-150) folded into the halo addresses like the streaming kernel's
   int h_voff[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -287,7 +334,10 @@ __global__ __launch_bounds__(256) void conv3x3_x3q_kernel(ConvP p, int tiles_x, 
     if (hp < XP_HPIX) {
       const int hy = hp / XP_HW, hx = hp - hy * XP_HW;
       const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) h_voff[k] = ((iy * p.W + ix) * p.in_ld + g * 4) * 4;
+      if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
+        const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+        h_voff[k] = ((sy * p.W + sx) * p.in_ld + g * 4) * 4;
+      }
     }
   }
   auto make_rsrc = [&](const void* ptr, int bytes) {
@@ -454,6 +504,10 @@ __global__ __launch_bounds__(256) void conv3x3_x3q_kernel(ConvP p, int tiles_x, 
     const float4 v = *reinterpret_cast<const float4*>(et + rr * 36 + c4);
     float e[4] = {__builtin_fmaf(v.x, asc, bias4.x), __builtin_fmaf(v.y, asc, bias4.y), __builtin_fmaf(v.z, asc, bias4.z),
                   __builtin_fmaf(v.w, asc, bias4.w)};
+    if (p.epi_act != KEEP_ACT_NONE) {      // (uniform; before the residual, the streaming kernel's order and forms)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e[q] = p.fast ? act_apply_fast(e[q], p.epi_act) : act_apply(e[q], p.epi_act);
+    }
     if (p.res) {
       const float4 r4 = *reinterpret_cast<const float4*>(p.res + m * p.res_ld + co);
       e[0] += r4.x; e[1] += r4.y; e[2] += r4.z; e[3] += r4.w;
@@ -470,6 +524,18 @@ bool keep_conv_x3p_ok(const keep_conv2d_args* a, const ConvP& p, int split_k) {
   const long items_old = (long)a->N * ((a->Ho * a->Wo) / 256) * ((a->Cout + 63) / 64) * split_k;
   return split_k > 1 && !a->upsample && a->pad_mode == KEEP_PAD_ZERO && a->Ho % 4 == 0 && a->Wo % 16 == 0 && (a->Ho * a->Wo) % 256 == 0 &&
          a->Cout % 64 == 0 && a->Cin % 16 == 0 && items_old <= 128 && a->workspace &&
+         (a->pro_act == KEEP_PRO_NONE || (a->pro_act == KEEP_PRO_SWISH && p.fast)) && !(a->flags & KEEP_CONV_NO_SMALL_PARTIALS);
+}
+
+void keep_conv_stats_replica(const ConvP& p, int n_img, hipStream_t st);      // keep_conv_x3s.hip
+
+// Un-split plans conv3x3_halo_x3_kernel would run (keep_conv2d_x3_halo has already offered them to the streaming kernel's family) with few
+// items: the same 64-pixel blocks with the full epilogue.  Statistics only on 8 x 32-tile maps (the replica kernel's partition).
+bool keep_conv_x3p_full_ok(const keep_conv2d_args* a, const ConvP& p, int split_k) {
+  const long items_old = (long)a->N * ((a->Ho * a->Wo) / 256) * ((a->Cout + 63) / 64);
+  return split_k == 1 && !a->upsample && a->pad_mode == KEEP_PAD_ZERO && a->Ho % 4 == 0 && a->Wo % 16 == 0 && (a->Ho * a->Wo) % 256 == 0 &&
+         a->Cout % 64 == 0 && a->Cin % 16 == 0 && a->Cin >= 32 && items_old <= 64 && (!a->aux || a->residual) && a->out_ld % 4 == 0 &&
+         (!a->residual || a->res_ld % 4 == 0) && (!p.stats || (a->Ho % 8 == 0 && a->Wo % 32 == 0 && a->out_ld == a->Cout)) &&
          (a->pro_act == KEEP_PRO_NONE || (a->pro_act == KEEP_PRO_SWISH && p.fast)) && !(a->flags & KEEP_CONV_NO_SMALL_PARTIALS);
 }
 
@@ -492,17 +558,18 @@ int keep_conv2d_x3_partials(const keep_conv2d_args* a, ConvP& p, hipStream_t st)
   else KEEP_LAUNCH_XP(KEEP_PRO_NONE, false)
 #undef KEEP_LAUNCH_XP
   KEEP_LAUNCH_CHECK("keep_conv2d(halo x3, small-tile partials)");
+  if (p.split_k == 1 && p.stats) keep_conv_stats_replica(p, a->N, st);      // (the full-epilogue form: keep_conv_x3p_full_ok)
   return KEEP_OK;
 }
-
-void keep_conv_stats_replica(const ConvP& p, int n_img, hipStream_t st);      // keep_conv_x3s.hip
 
 // Un-split plans on wide maps (what conv3x3_halo_x3s_kernel takes) with few items: the 64-pixel blocks, same values.
 bool keep_conv_x3q_ok(const keep_conv2d_args* a, const ConvP& p, int split_k) {
   const long items_s = (long)a->N * (a->Ho / 8) * (a->Wo / 32) * ((a->Cout + 63) / 64);
   const bool aff = a->pro_scale != nullptr;
-  return split_k == 1 && !a->upsample && a->pad_mode == KEEP_PAD_ZERO && a->Ho % 8 == 0 && a->Wo % 32 == 0 && a->Cout % 64 == 0 &&
-         a->Cin % 16 == 0 && a->Cin >= 32 && items_s <= 64 && !a->aux && a->epi_act == KEEP_ACT_NONE &&
+  // round 6: an epilogue activation (CFT's scale.0|shift.0 + LeakyReLU, KA:468-469) and the 9-tap nearest-x2 form (the 16 -> 32 Upsample) too:
+  // one uniform branch / two shifts in the halo addresses, the streaming kernel's own
+  return split_k == 1 && a->upsample != KEEP_UPSAMPLE_X2_PHASES && a->pad_mode == KEEP_PAD_ZERO && a->Ho % 8 == 0 && a->Wo % 32 == 0 && a->Cout % 64 == 0 &&
+         a->Cin % 16 == 0 && a->Cin >= 32 && items_s <= 64 && !a->aux &&
          ((a->pro_act == KEEP_PRO_SWISH && aff && p.fast) || a->pro_act == KEEP_PRO_NONE) && (!p.stats || a->out_ld == a->Cout) &&
          !(a->flags & (KEEP_CONV_NO_SMALL_PARTIALS | KEEP_CONV_NO_STREAM));
 }

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_x3s_kernel(ConvP p, int t
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           s4[q] += e[q];
-          ss4[q] += e[q] * e[q];
+          ss4[q] = __builtin_fmaf(e[q], e[q], ss4[q]);
           amx = fmaxf(amx, fabsf(e[q]));
         }
       }
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void conv_stats_replica_kernel(ConvP p, int ti
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         s4[q] += e[q];
-        ss4[q] += e[q] * e[q];
+        ss4[q] = __builtin_fmaf(e[q], e[q], ss4[q]);
       }
     }
   }

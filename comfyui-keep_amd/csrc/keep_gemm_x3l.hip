@@ -32,7 +32,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // rows per image the family takes: the 16 x 16 token maps (code transformer, AttnBlock).  The 32 x 32 maps (CFA: 135 launches per clip)
 // were measured too: -0.5 ms per clip with one clip in flight, +1.8 ms per 16-clip step (64 x 64 tiles with slice totals against the
 // 128 x 128 tile of the sequential sum) -- left on conv_x3_kernel.
+#ifndef GL_MAX_HW
 #define GL_MAX_HW 256
+#endif
 #define GL_MAX_TILES 512            // launches of more 32 x 32 output tiles run on conv_x3_kernel with canonical slices (same bits)
 
 template <int NW, int TM, bool PLAIN>

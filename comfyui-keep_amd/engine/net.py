@@ -434,7 +434,8 @@ class KeepNet:
                                  residual=sc, stats=True)
         else:
             e, est = self._resblock(ops.concat2(enc, dec), f'{p}.encode_enc')
-        ss, sst = self.o.conv(e, w[f'{p}.ss0.weight'], w[f'{p}.ss0.bias'], act=L.ACT_LRELU02, stats=True,
+        # (only the fused max|out| of ss is used -- its GroupNorm partials never were: 'amax' lets the 16 x 16 stage take the 64-pixel blocks)
+        ss, sst = self.o.conv(e, w[f'{p}.ss0.weight'], w[f'{p}.ss0.bias'], act=L.ACT_LRELU02, stats='amax',
                               x_amax=None if est is None else est.amax)                          # [.., 2C]
         ss_amax = None if sst is None else sst.amax             # max over all 2C channels bounds either half
         scale = self.o.conv(ss, w[f'{p}.scale.2.weight'], w[f'{p}.scale.2.bias'], cin=C, in_off=0, x_amax=ss_amax)

@@ -1647,40 +1647,102 @@ def test_conv_x3_small_tile_partials_are_the_256_pixel_kernels(n, h, wd, cin, co
     assert bool(((nchw(outs[0]).double().cpu() - ref).abs() <= 3e-6 * scale).all())
 
 
-@pytest.mark.parametrize("n,h,wd,cin,cout,gn,res,ranged", [
-    (1, 32, 32, 256, 256, True, True, False),       # ResBlock convolutions of the 32 x 32 stage (16 chunks)
-    (1, 64, 64, 256, 256, True, True, False),       # 64 x 64 stage: 64 items of the streaming kernel -> 1024 small blocks
-    (1, 32, 32, 512, 256, True, False, False),      # 32 chunks
-    (1, 64, 64, 128, 256, True, True, False),       # 8 chunks
-    (2, 32, 32, 256, 512, False, False, True),      # no prologue, probed range scale per image
-    (1, 64, 64, 144, 256, False, True, False),      # 9 chunks: the loop form of the ring
-    (1, 32, 64, 64, 64, True, False, False)])       # 4 chunks, a non-square map
-def test_conv_x3_small_tiles_equal_the_streaming_kernel(n, h, wd, cin, cout, gn, res, ranged):
+@pytest.mark.parametrize("n,h,wd,cin,cout,gn,res,ranged,act,up", [
+    (1, 32, 32, 256, 256, True, True, False, False, False),       # ResBlock convolutions of the 32 x 32 stage (16 chunks)
+    (1, 64, 64, 256, 256, True, True, False, False, False),       # 64 x 64 stage: 64 items of the streaming kernel -> 1024 small blocks
+    (1, 32, 32, 512, 256, True, False, False, False, False),      # 32 chunks
+    (1, 64, 64, 128, 256, True, True, False, False, False),       # 8 chunks
+    (2, 32, 32, 256, 512, False, False, True, False, False),      # no prologue, probed range scale per image
+    (1, 64, 64, 144, 256, False, True, False, False, False),      # 9 chunks: the loop form of the ring
+    (1, 32, 64, 64, 64, True, False, False, False, False),        # 4 chunks, a non-square map
+    (1, 32, 32, 256, 512, False, False, True, True, False),       # round 6: CFT scale.0|shift.0 + LeakyReLU(0.2) (KA:468-469), probed input
+    (1, 64, 64, 256, 512, False, False, True, True, False),
+    (1, 16, 16, 512, 512, False, False, True, False, True),       # round 6: the 16 -> 32 Upsample in its 9-tap form (nearest x2 in the halo addresses)
+    (2, 16, 32, 128, 64, False, True, True, True, True)])         # both, two images, a non-square source
+def test_conv_x3_small_tiles_equal_the_streaming_kernel(n, h, wd, cin, cout, gn, res, ranged, act, up):
     """conv3x3_x3q_kernel + conv_stats_replica_kernel (un-split plans on wide maps, few items): output, GroupNorm partials and max|out|
-    BIT-EQUAL to conv3x3_halo_x3s_kernel's (KEEP_CONV_NO_SMALL_PARTIALS) -- its conversion arithmetic, product order and epilogue order."""
+    BIT-EQUAL to conv3x3_halo_x3s_kernel's (KEEP_CONV_NO_SMALL_PARTIALS) -- its conversion arithmetic, product order and epilogue order
+    (round 6: with an epilogue activation and with the nearest-x2 source addressing too)."""
     x = rnd('sq_x', (n, cin, h, wd), 2.0) + 0.3
     if ranged:
         x = x * torch.tensor([1.0, 900.0][:n]).view(-1, 1, 1, 1)
     w, b = rnd('sq_w', (cout, cin, 3, 3), 0.05), rnd('sq_b', (cout,))
-    r = rnd('sq_r', (n, cout, h, wd)) if res else None
+    r = rnd('sq_r', (n, cout, (2 * h if up else h), (2 * wd if up else wd))) if res else None
     xd, wp, bd = dev(nhwc(x)), pack(w), dev(b)
     wx3, asc = x3w(wp)
     pro = None
     if gn:
         pro = ops.norm_affine(xd, dev(rnd('sq_g', (cin,)) * 0.2 + 1), dev(rnd('sq_bt', (cin,)) * 0.2), 16, 1e-6)
     kw = dict(mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, pro=pro, pro_act=L.PRO_SWISH if gn else L.PRO_NONE,
-              residual=None if r is None else dev(nhwc(r)), bounded=not ranged, stats=True, split_k=1)
+              residual=None if r is None else dev(nhwc(r)), bounded=not ranged, stats=True, split_k=1,
+              act=L.ACT_LRELU02 if act else L.ACT_NONE, upsample=bool(up))
+    old_up2 = ops.UP2_PHASES
+    ops.UP2_PHASES = False          # (the 9-tap form is what the net runs at 16 -> 32: 16-wide source tiles)
     got = []
     for fl in (0, L.CONV_NO_SMALL_PARTIALS):
         ops.DEFAULT.flags = fl
         ops.DEFAULT.amax_arena = None          # fresh (zeroed by the library) max|out| slots per call
         y, st = ops.conv(xd, wp, bd, **kw)
         got.append((y.clone(), st.part.clone(), st.amax.clone()))
+    ops.UP2_PHASES = old_up2
     assert torch.isfinite(got[0][0]).all()
     assert torch.equal(got[0][0], got[1][0]), 'outputs differ'
     assert torch.equal(got[0][1], got[1][1]), 'GroupNorm partials differ'
     assert torch.equal(got[0][2], got[1][2]), 'max|out| differs'
     assert torch.equal(got[0][2].cpu(), got[0][0].abs().flatten(1).max(1).values.cpu())
+    if act or up:      # ... and the value itself against float64 (the bound of the kernel family: 3e-6 of sum |x| |w|)
+        xe = nchw(xd).double().cpu()
+        if up:
+            xe = F.interpolate(xe, scale_factor=2.0, mode='nearest')
+        ref = F.conv2d(xe, w.double(), b.double(), padding=1)
+        if act:
+            ref = F.leaky_relu(ref, 0.2)
+        if r is not None:
+            ref = ref + r.double()
+        scale = F.conv2d(xe.abs(), w.double().abs(), padding=1).flatten(1).max(1).values.view(n, 1, 1, 1)
+        assert bool(((nchw(got[0][0]).double().cpu() - ref).abs() <= 3e-6 * scale).all())
+
+
+@pytest.mark.parametrize("n,h,wd,cin,cout,act,aux,res,stats,slice_in", [
+    (1, 32, 32, 256, 256, False, True, True, True, True),        # CFT shift convolution (KA:470-472): channel slice in, residual + aux, statistics
+    (1, 64, 64, 256, 256, False, True, True, True, True),
+    (1, 16, 16, 512, 1024, True, False, False, 'amax', False),   # CFT scale.0|shift.0 + LeakyReLU at 16 x 16: 16-wide tiles, only max|out|
+    (2, 16, 16, 512, 512, False, False, True, 'amax', False),    # a plain 16-wide convolution with a residual, two images
+    (1, 32, 32, 128, 64, True, True, True, True, False)])        # activation AND aux
+def test_conv_x3_small_tiles_full_epilogue_equal_the_stage_barrier_kernel(n, h, wd, cin, cout, act, aux, res, stats, slice_in):
+    """Round 6: un-split plans the streaming kernel does not take (aux tensor, 16-wide maps) with few items -- conv3x3_x3p_kernel's blocks with
+    the full epilogue (+ conv_stats_replica_kernel) -- BIT-EQUAL to conv3x3_halo_x3_kernel (KEEP_CONV_NO_SMALL_PARTIALS): output, GroupNorm
+    partials, max|out|; and the value against float64."""
+    ld = 2 * cin if slice_in else cin
+    xfull = rnd('sf_x', (n, ld, h, wd), 2.0) + 0.3
+    w, b = rnd('sf_w', (cout, cin, 3, 3), 0.05), rnd('sf_b', (cout,))
+    r = rnd('sf_r', (n, cout, h, wd)) if res else None
+    a_t = rnd('sf_a', (n, cout, h, wd)) if aux else None
+    xd, wp, bd = dev(nhwc(xfull)), pack(w), dev(b)
+    wx3, asc = x3w(wp)
+    kw = dict(mma=L.MMA_X3, wx3=wx3, x3_acc_scale=asc, residual=None if r is None else dev(nhwc(r)), aux=None if a_t is None else dev(nhwc(a_t)),
+              aux_w=0.75, act=L.ACT_LRELU02 if act else L.ACT_NONE, stats=stats, split_k=1)
+    if slice_in:
+        kw.update(cin=cin, in_off=cin)
+    got = []
+    for fl in (0, L.CONV_NO_SMALL_PARTIALS):
+        ops.DEFAULT.flags = fl
+        ops.DEFAULT.amax_arena = None
+        y, st = ops.conv(xd, wp, bd, **kw)
+        got.append((y.clone(), None if st.part is None else st.part.clone(), st.amax.clone()))
+    ops.DEFAULT.flags = 0
+    assert torch.isfinite(got[0][0]).all()
+    assert torch.equal(got[0][0], got[1][0]), 'outputs differ'
+    assert (got[0][1] is None) == (got[1][1] is None) and (got[0][1] is None or torch.equal(got[0][1], got[1][1])), 'GroupNorm partials differ'
+    assert torch.equal(got[0][2], got[1][2]), 'max|out| differs'
+    xe = xfull[:, cin:] if slice_in else xfull
+    ref = F.conv2d(xe.double(), w.double(), b.double(), padding=1)
+    if act:
+        ref = F.leaky_relu(ref, 0.2)
+    if r is not None:
+        ref = (r.double() + 0.75 * (r.double() * a_t.double() + ref)) if aux else ref + r.double()
+    scale = F.conv2d(xe.double().abs(), w.double().abs(), padding=1).flatten(1).max(1).values.view(n, 1, 1, 1)
+    assert bool(((nchw(got[0][0]).double().cpu() - ref).abs() <= 4e-6 * scale * (1.75 if aux else 1.0)).all())
 
 
 @pytest.mark.parametrize("n,h,wd,cin,cout,down", [(1, 64, 64, 256, 256, True), (1, 32, 32, 256, 256, True), (1, 128, 128, 128, 128, True),

@@ -1,3 +1,5 @@
 cd /root/repo
-(cd /tmp && rocprofv3 --list-avail 2>/dev/null | grep -o "\b\(TA\|TCP\|TCC\|TD\|SQ\)_[A-Za-z0-9_]*" | sort -u > /root/repo/gpurun_out/r6i_counters.txt); wc -l gpurun_out/r6i_counters.txt; grep -i "TA_.*BUSY\|TCP_.*STALL\|TCP_.*LATENCY\|SQ_WAIT_INST\|SQ_INST_CYCLES\|TA_.*CYCLES" gpurun_out/r6i_counters.txt | head -40
-PMC_FILTER=x3q PMC_EXTRA="TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum" bash tools/dev/pmc_conv.sh r6i_pmc_x3q c256_64_n1 c256_32_n1 2>&1 | grep -v "^/opt" | tail -70
+python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "small_tile or partials or replica or halo" 2>&1 | tail -6
+python -m pytest tests/test_gpu_net.py -x -q -m gpu -k "cft or T3_vs_reference or batched_clips or config3 or hipgraph or two_stream" 2>&1 | tail -4
+python tools/dev/lib_ab.py --b 1 --rounds 2 new=default old=comfyui-keep_amd/csrc/ab/lib_old.so 2>&1 | grep -v Warning | tail -5
+python tools/dev/lib_ab.py --b 16 --rounds 2 new=default old=comfyui-keep_amd/csrc/ab/lib_old.so 2>&1 | grep -v Warning | tail -5

@@ -5,7 +5,7 @@
 #     python bench.py > gpurun_out/r6p_bench.json
 #     KEEP_AMD_GRAPH=0 KEEP_AMD_OVERLAP_MAX_CLIPS=0 PMC_COUNTERS= bash tools/profile_step.sh x3 1 r6p_x3_b1
 #     python tools/dev/conv_census.py 48 conv_x3 > gpurun_out/r6p_census_b48.txt ; ... 48 halo > r6p_census_halo_b48.txt ; ... 1 '' > r6p_census_b1.txt
-#     bash tools/dev/pmc_shapes.sh r6p_pmc_shapes > gpurun_out/r6p_pmc_shapes.txt
+#     bash tools/dev/pmc_shapes.sh r6p_pmc_shapes > gpurun_out/r6p_pmc_shapes.txt ; python tools/dev/x3_ceiling.py > gpurun_out/r6p_ceiling.txt
 #   here:  bash profiles/refresh.sh
 # Each source file is the unedited output of the command quoted in its header.  (Rounds 1-5: git log -- profiles/refresh.sh.)
 set -e
@@ -23,4 +23,5 @@ fi
 [ -f $G/r6p_census_halo_b48.txt ] && grep -v "^/opt" $G/r6p_census_halo_b48.txt > profiles/r06_conv_census_halo_x3_b48.txt
 [ -f $G/r6p_census_b1.txt ] && { echo "# kernel names are the PLAN family's (keep_conv_plan): at one clip the launcher of the halo family hands maps of <= 64 / 128 items of the 256-pixel kernels to"; echo "# conv3x3_x3q_kernel (un-split) / conv3x3_x3p_kernel (split-K partials) -- the bit-equal 64-pixel forms of DESIGN 5.6; the times are what ran (r06_x3_b1_kernel_stats.txt names them)"; grep -v "^/opt" $G/r6p_census_b1.txt; } > profiles/r06_conv_census_x3_b1.txt
 [ -f $G/r6p_pmc_shapes.txt ] && { echo "# bash tools/dev/pmc_shapes.sh: per-shape PMC rows of the dominant kernel (conv3x3_halo_x3s_kernel, GroupNorm-swish prologue + residual + statistics) at the bench's 48 images per launch,"; echo "# one rocprofv3 --pmc pass per counter set and layer (tools/bench_conv.py c64_512_n48 / c128_256_n48, 6 launches each); same box and call as the bench line.  Launches under a PMC pass"; echo "# run at a lower clock (1.32 GHz effective here against 1.7-1.8 without counters): the traffic and the busy FRACTION are the evidence, not the time."; grep -v "^/opt" $G/r6p_pmc_shapes.txt; } > profiles/r06_pmc_conv_shapes.txt
+[ -s $G/r6p_ceiling.txt ] && grep -v "^/opt" $G/r6p_ceiling.txt > profiles/r06_x3_ceiling_probe.txt      # python tools/dev/x3_ceiling.py, same box and call
 ls -la profiles/r06_* 2>/dev/null

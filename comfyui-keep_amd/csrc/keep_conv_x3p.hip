@@ -23,9 +23,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define XPP 40                         // fp16 per halo row: 16 hi + 16 lo + 8 pad (80 B), as in keep_conv_x3.hip
 #define XP_HW 18                       // halo width of a 16-column tile
 #define XP_HPIX (6 * XP_HW)            // 4 + 2 rows
-#define XP_HBYTES (XP_HPIX * XPP * 2)  // 8640
+#define XP_HBYTES (128 * XPP * 2)      // 10240: 128 rows per stage, rows 108 .. 127 parked but never read (every thread converts two pieces: one basic block)
 #define XP_WBYTES (9 * 64 * 64)        // 36864: 9 taps x 64 couts x 64 B
 
+#ifndef XQ_SCHED
+#define XQ_SCHED 1      // round 6: conversion of chunk c + 1 scheduled into the MFMA chain of chunk c (0: the compiler's own order)
+#endif
 #define XP_ST 3                        // operand stages in LDS: the loads of chunk c + 2 are issued before the MFMAs of chunk c
 // NCH > 0: the block's chunk count, known at compile time -- the ring is straight-line code and the compiler's wait counts are exact (inside
 // a loop it orders every LDS read of a stage behind vmcnt(0): the DMA that filled the stage came through the back edge); 0: any count.
@@ -196,6 +199,109 @@ __global__ __launch_bounds__(256) void conv3x3_x3p_kernel(ConvP p, int tiles_x, 
       }
   };
 
+  // Round 6: a wave's 27 MFMAs per chunk are ONE dependent chain (~32 cycles each); `fused(bc, bn)` issues them with the conversion + LDS writes of
+  // the chunk in stage bn cut into 25 steps, one per MFMA gap (the expressions of `stage`, a padded piece selected to zero instead of branched
+  // around; every gap pinned by a sched_barrier), and the next tap's fragments requested under the current tap's MFMAs.
+  auto fused = [&](int bc, int bn) __attribute__((always_inline)) {
+    const _Float16* Ws = reinterpret_cast<const _Float16*>(XP_WS(bc));
+    const _Float16* Hs = reinterpret_cast<const _Float16*>(hs_raw + bc * XP_HBYTES);
+    _Float16* Hn = reinterpret_cast<_Float16*>(hs_raw + bn * XP_HBYTES);
+    unsigned char* wn = XP_WS(bn);
+    const float4 sc4 = sc4s[bn], sh4 = sh4s[bn];
+    const f32x2 sc01 = {sc4.x, sc4.y}, sc23 = {sc4.z, sc4.w}, sh01 = {sh4.x, sh4.y}, sh23 = {sh4.z, sh4.w};
+    const f32x2 nsc01 = sc01 * -1.4426950408889634f, nsc23 = sc23 * -1.4426950408889634f;
+    const f32x2 nsh01 = sh01 * -1.4426950408889634f, nsh23 = sh23 * -1.4426950408889634f;
+    f32x2 v01[2], v23[2], y01[2], y23[2], d01[2], d23[2];
+    f16x2 h01[2], h23[2];
+    auto step = [&](int i) __attribute__((always_inline)) {
+      if (i < 16) {
+        const int k = i >> 3, j = i & 7;
+        if (j == 0) {
+          v01[k] = f32x2{hregs[bn][k].x, hregs[bn][k].y};
+          v23[k] = f32x2{hregs[bn][k].z, hregs[bn][k].w};
+          if (has_pro) {
+            y01[k] = v01[k] * sc01 + sh01;
+            y23[k] = v23[k] * sc23 + sh23;
+          }
+        } else if (j == 1) {
+          if (PRO == KEEP_PRO_SWISH) {
+            d01[k] = v01[k] * nsc01 + nsh01;
+            d23[k] = v23[k] * nsc23 + nsh23;
+          }
+        } else if (j == 2) {
+          if (PRO == KEEP_PRO_SWISH) {
+            d01[k] = f32x2{__builtin_amdgcn_exp2f(d01[k].x), __builtin_amdgcn_exp2f(d01[k].y)};
+            d23[k] = f32x2{__builtin_amdgcn_exp2f(d23[k].x), __builtin_amdgcn_exp2f(d23[k].y)};
+          }
+        } else if (j == 3) {
+          if (PRO == KEEP_PRO_SWISH) {
+            d01[k] += 1.0f;
+            d23[k] += 1.0f;
+          }
+        } else if (j == 4) {
+          if (PRO == KEEP_PRO_SWISH) {
+            d01[k] = f32x2{__builtin_amdgcn_rcpf(d01[k].x), __builtin_amdgcn_rcpf(d01[k].y)};
+            d23[k] = f32x2{__builtin_amdgcn_rcpf(d23[k].x), __builtin_amdgcn_rcpf(d23[k].y)};
+          }
+        } else if (j == 5) {
+          if (PRO == KEEP_PRO_SWISH) {
+            v01[k] = y01[k] * d01[k];
+            v23[k] = y23[k] * d23[k];
+          } else if (has_pro) {
+            v01[k] = y01[k];
+            v23[k] = y23[k];
+          }
+          if (PRO == KEEP_PRO_NONE && p.in_amax) {
+            v01[k] *= in_s;
+            v23[k] *= in_s;
+          }
+        } else if (j == 6) {
+          h01[k] = __builtin_convertvector(v01[k], f16x2);
+          h23[k] = __builtin_convertvector(v23[k], f16x2);
+        } else {
+          const f16x2 l01 = __builtin_convertvector(v01[k] - __builtin_convertvector(h01[k], f32x2), f16x2);
+          const f16x2 l23 = __builtin_convertvector(v23[k] - __builtin_convertvector(h23[k], f32x2), f16x2);
+          const bool pad = has_pro && h_voff[k] < 0;      // zero padding applies to the normalised + activated tensor
+          const f16x4 zero = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+          const f16x4 hi = {h01[k].x, h01[k].y, h23[k].x, h23[k].y}, lo = {l01.x, l01.y, l23.x, l23.y};
+          _Float16* dst = &Hn[((tid >> 2) + k * 64) * XPP + g * 4];
+          *reinterpret_cast<f16x4*>(dst) = pad ? zero : hi;
+          *reinterpret_cast<f16x4*>(dst + 16) = pad ? zero : lo;
+        }
+      } else if (i < 25) {
+        const int t = i - 16;
+        const int q = __builtin_amdgcn_readfirstlane(wave) * 9 + t;
+        *reinterpret_cast<u32x4*>(wn + q * 1024 + lane * 16) = wregs[bn][t];
+      }
+    };
+    const _Float16* src0 = &Hs[a_base];
+    f16x8 ah = *reinterpret_cast<const f16x8*>(src0), al = *reinterpret_cast<const f16x8*>(src0 + 16);
+    f16x8 bh = *reinterpret_cast<const f16x8*>(&Ws[b_base + (chf * 32) * 32]), bl = *reinterpret_cast<const f16x8*>(&Ws[(b_base + (chf * 32) * 32) ^ 16]);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      f16x8 nah = ah, nal = al, nbh = bh, nbl = bl;
+      if (t < 8) {
+        const int kh = (t + 1) / 3, kw = (t + 1) % 3;
+        const _Float16* src = &Hs[a_base + (kh * XP_HW + kw) * XPP];
+        nah = *reinterpret_cast<const f16x8*>(src);
+        nal = *reinterpret_cast<const f16x8*>(src + 16);
+        const int o = b_base + ((t + 1) * 64 + chf * 32) * 32;
+        nbh = *reinterpret_cast<const f16x8*>(&Ws[o]);
+        nbl = *reinterpret_cast<const f16x8*>(&Ws[o ^ 16]);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);      // conv3x3_halo_x3_kernel's term order
+      step(3 * t);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+      step(3 * t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+      step(3 * t + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      ah = nah; al = nal; bh = nbh; bl = nbl;
+    }
+  };
+
 // (a __syncthreads() carries vmcnt(0): it would wait for the loads of chunk c + 2 as well; LDS writes are complete at lgkmcnt(0))
 #define XP_BARRIER()                  \
   __builtin_amdgcn_s_waitcnt(0xc07f); \
@@ -210,10 +316,15 @@ __global__ __launch_bounds__(256) void conv3x3_x3p_kernel(ConvP p, int tiles_x, 
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {      // chunk ch_begin + c lives in stage c % XP_ST
         if (c + 2 < NCH) fetch(ch_begin + c + 2, (c + 2) % XP_ST);
-        mma(c % XP_ST);
-        if (c + 1 < NCH) {
-          stage((c + 1) % XP_ST);
+        if (XQ_SCHED && c + 1 < NCH) {
+          fused(c % XP_ST, (c + 1) % XP_ST);
           XP_BARRIER()
+        } else {
+          mma(c % XP_ST);
+          if (c + 1 < NCH) {
+            stage((c + 1) % XP_ST);
+            XP_BARRIER()
+          }
         }
       }
     } else {
@@ -310,7 +421,13 @@ __global__ __launch_bounds__(256) void conv3x3_x3q_kernel(ConvP p, int tiles_x, 
   __shared__ __attribute__((aligned(1024))) unsigned char ws0[XP_WBYTES];
   __shared__ __attribute__((aligned(1024))) unsigned char ws1[XP_WBYTES];
   __shared__ __attribute__((aligned(1024))) unsigned char ws2[XP_WBYTES];
-  __shared__ __attribute__((aligned(16))) unsigned char hs_raw[XP_ST * XP_HBYTES];
+  // one LDS object per halo stage as well (round 6): the conversion of chunk c + 1 is scheduled INTO the MFMA sequence of chunk c (below), which
+  // needs the compiler to know that its ds_writes and the fragment reads of chunk c touch different memory
+  // (128 rows, not 108: every thread converts and parks two pieces -- rows 108 .. 127 are never read -- so that the conversion is one basic block)
+  __shared__ __attribute__((aligned(16))) unsigned char hs0[128 * XPP * 2];
+  __shared__ __attribute__((aligned(16))) unsigned char hs1[128 * XPP * 2];
+  __shared__ __attribute__((aligned(16))) unsigned char hs2[128 * XPP * 2];
+#define XP_HS(i) ((i) == 0 ? hs0 : ((i) == 1 ? hs1 : hs2))
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int ph = wave >> 1, chf = wave & 1;
@@ -391,12 +508,12 @@ __global__ __launch_bounds__(256) void conv3x3_x3q_kernel(ConvP p, int tiles_x, 
         *reinterpret_cast<u32x4*>(wbase + q * 1024 + lane * 16) = wregs[buf][t];
       }
     }
-    _Float16* Hs = reinterpret_cast<_Float16*>(hs_raw + buf * XP_HBYTES);
+    _Float16* Hs = reinterpret_cast<_Float16*>(XP_HS(buf));
     const float csc[4] = {sc4s[buf].x, sc4s[buf].y, sc4s[buf].z, sc4s[buf].w}, csh[4] = {sh4s[buf].x, sh4s[buf].y, sh4s[buf].z, sh4s[buf].w};
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int hp = (tid >> 2) + k * 64;
-      if (hp < XP_HPIX) {
+      {      // (no `hp < XP_HPIX` test: rows beyond the halo hold zeros nobody reads)
         const float hv[4] = {hregs[buf][k].x, hregs[buf][k].y, hregs[buf][k].z, hregs[buf][k].w};
         const float padf = (AFF && h_voff[k] < 0) ? 1e30f : 0.f;
         float cv[4], cw[4];
@@ -432,7 +549,7 @@ __global__ __launch_bounds__(256) void conv3x3_x3q_kernel(ConvP p, int tiles_x, 
   const int b_base = l31 * 32 + ((lhi ^ ((l31 >> 2) & 3)) * 8);
   auto mma = [&](int buf) {
     const _Float16* Ws = reinterpret_cast<const _Float16*>(XP_WS(buf));
-    const _Float16* Hs = reinterpret_cast<const _Float16*>(hs_raw + buf * XP_HBYTES);
+    const _Float16* Hs = reinterpret_cast<const _Float16*>(XP_HS(buf));
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -450,6 +567,102 @@ __global__ __launch_bounds__(256) void conv3x3_x3q_kernel(ConvP p, int tiles_x, 
         }
       }
   };
+  // Round 6: the 27 MFMAs of a chunk form ONE dependent chain (a wave owns one 32 x 32 accumulator): ~32 cycles each in which the wave can issue
+  // whatever does not depend on them (up to five single-issue instructions per MFMA ride for free).  `fused(bc, bn)` issues the chunk
+  // in stage bc and, one step per MFMA gap, the conversion + LDS writes of the chunk in stage bn (the expressions of `stage`, cut into 25 steps of
+  // <= 4 VALU / 4 transcendentals / one or two LDS writes; every gap is pinned by a sched_barrier) -- the staging no longer queues behind the chain.
+  auto fused = [&](int bc, int bn) __attribute__((always_inline)) {
+    const _Float16* Ws = reinterpret_cast<const _Float16*>(XP_WS(bc));
+    const _Float16* Hs = reinterpret_cast<const _Float16*>(XP_HS(bc));
+    _Float16* Hn = reinterpret_cast<_Float16*>(XP_HS(bn));
+    unsigned char* wn = XP_WS(bn);
+    const float csc[4] = {sc4s[bn].x, sc4s[bn].y, sc4s[bn].z, sc4s[bn].w}, csh[4] = {sh4s[bn].x, sh4s[bn].y, sh4s[bn].z, sh4s[bn].w};
+    float cv[2][4], cw[2][4], lo4[2][4];
+    f16x2 h01[2], h23[2];
+    auto step = [&](int i) __attribute__((always_inline)) {
+      if (i < 16) {
+        const int k = i >> 3, j = i & 7;
+        const float hv[4] = {hregs[bn][k].x, hregs[bn][k].y, hregs[bn][k].z, hregs[bn][k].w};
+        const float padf = (AFF && h_voff[k] < 0) ? 1e30f : 0.f;
+        if (j == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cv[k][q] = AFF ? __builtin_fmaf(hv[q], csc[q], csh[q]) : hv[q] * rs;
+        } else if (j == 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (PRO == KEEP_PRO_SWISH) cw[k][q] = __builtin_fmaf(cv[k][q], -1.4426950408889634f, padf);
+            else if (AFF) {
+              cv[k][q] *= rs;
+              cv[k][q] = padf != 0.f ? 0.f : cv[k][q];
+            }
+          }
+        } else if (j == 2) {
+          if (PRO == KEEP_PRO_SWISH) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cw[k][q] = __builtin_amdgcn_exp2f(cw[k][q]);
+          }
+        } else if (j == 3) {
+          if (PRO == KEEP_PRO_SWISH) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cw[k][q] += 1.0f;
+          }
+        } else if (j == 4) {
+          if (PRO == KEEP_PRO_SWISH) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cw[k][q] = __builtin_amdgcn_rcpf(cw[k][q]);
+          }
+        } else if (j == 5) {
+          if (PRO == KEEP_PRO_SWISH) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cv[k][q] *= cw[k][q];
+          }
+        } else if (j == 6) {
+          h01[k] = __builtin_convertvector(f32x2{cv[k][0], cv[k][1]}, f16x2);
+          h23[k] = __builtin_convertvector(f32x2{cv[k][2], cv[k][3]}, f16x2);
+          lo4[k][0] = __builtin_fmaf((float)h01[k].x, -1.0f, cv[k][0]);
+          lo4[k][1] = __builtin_fmaf((float)h01[k].y, -1.0f, cv[k][1]);
+        } else {
+          lo4[k][2] = __builtin_fmaf((float)h23[k].x, -1.0f, cv[k][2]);
+          lo4[k][3] = __builtin_fmaf((float)h23[k].y, -1.0f, cv[k][3]);
+          const f16x2 q01 = __builtin_convertvector(f32x2{lo4[k][0], lo4[k][1]}, f16x2), q23 = __builtin_convertvector(f32x2{lo4[k][2], lo4[k][3]}, f16x2);
+          const f16x4 hi = {h01[k].x, h01[k].y, h23[k].x, h23[k].y}, lo = {q01.x, q01.y, q23.x, q23.y};
+          _Float16* dst = &Hn[((tid >> 2) + k * 64) * XPP + g * 4];
+          *reinterpret_cast<f16x4*>(dst) = hi;
+          *reinterpret_cast<f16x4*>(dst + 16) = lo;
+        }
+      } else if (i < 25) {
+        const int t = i - 16;
+        const int q = __builtin_amdgcn_readfirstlane(wave) * 9 + t;
+        *reinterpret_cast<u32x4*>(wn + q * 1024 + lane * 16) = wregs[bn][t];
+      }
+    };
+    const _Float16* src0 = &Hs[a_base];
+    f16x8 ah = *reinterpret_cast<const f16x8*>(src0), al = *reinterpret_cast<const f16x8*>(src0 + 16);
+    f16x8 bh = *reinterpret_cast<const f16x8*>(&Ws[b_base + (chf * 32) * 32]), bl = *reinterpret_cast<const f16x8*>(&Ws[(b_base + (chf * 32) * 32) ^ 16]);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      f16x8 nah = ah, nal = al, nbh = bh, nbl = bl;
+      if (t < 8) {      // the next tap's fragments, requested under this tap's MFMAs
+        const int kh = (t + 1) / 3, kw = (t + 1) % 3;
+        const _Float16* src = &Hs[a_base + (kh * XP_HW + kw) * XPP];
+        nah = *reinterpret_cast<const f16x8*>(src);
+        nal = *reinterpret_cast<const f16x8*>(src + 16);
+        const int o = b_base + ((t + 1) * 64 + chf * 32) * 32;
+        nbh = *reinterpret_cast<const f16x8*>(&Ws[o]);
+        nbl = *reinterpret_cast<const f16x8*>(&Ws[o ^ 16]);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);      // the streaming kernel's term order
+      step(3 * t);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+      step(3 * t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+      step(3 * t + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      ah = nah; al = nal; bh = nbh; bl = nbl;
+    }
+  };
 #define XP_BARRIER()                  \
   __builtin_amdgcn_s_waitcnt(0xc07f); \
   __builtin_amdgcn_s_barrier();
@@ -463,10 +676,15 @@ __global__ __launch_bounds__(256) void conv3x3_x3q_kernel(ConvP p, int tiles_x, 
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         if (c + 2 < NCH && XQ_ABL != 3) fetch(c + 2, (c + 2) % XP_ST);
-        mma(c % XP_ST);
-        if (c + 1 < NCH) {
-          if (XQ_ABL != 1) stage((c + 1) % XP_ST);
+        if (XQ_SCHED && XQ_ABL == 0 && c + 1 < NCH) {
+          fused(c % XP_ST, (c + 1) % XP_ST);
           XP_BARRIER()
+        } else {
+          mma(c % XP_ST);
+          if (c + 1 < NCH) {
+            if (XQ_ABL != 1) stage((c + 1) % XP_ST);
+            XP_BARRIER()
+          }
         }
       }
     } else {
@@ -487,7 +705,7 @@ __global__ __launch_bounds__(256) void conv3x3_x3q_kernel(ConvP p, int tiles_x, 
   // ---- epilogue: the wave parks its 32 x 32 tile (over halo stage 0 + 1: every wave is past its last fragment read) and writes rows of 32 channels
   XP_BARRIER()
 #undef XP_BARRIER
-  float* et = reinterpret_cast<float*>(hs_raw) + wave * 32 * 36;      // 4 waves x 4608 B <= 2 stages x 8640 B
+  float* et = reinterpret_cast<float*>(ws0) + wave * 32 * 36;         // 4 waves x 4608 B of weight stage 0 (every wave is past its last fragment read)
 #pragma unroll
   for (int r = 0; r < 16; ++r) et[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 36 + l31] = acc[r];
   __builtin_amdgcn_s_waitcnt(0xc07f);

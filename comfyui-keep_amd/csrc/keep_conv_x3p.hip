@@ -405,6 +405,9 @@ __global__ __launch_bounds__(256) void conv3x3_x3p_kernel(ConvP p, int tiles_x, 
   }
 }
 
+#ifndef XQ_DIST
+#define XQ_DIST 2      // chunks between a chunk's loads and its conversion (3: the register ring holds three chunks in flight)
+#endif
 #ifndef XQ_ABL
 #define XQ_ABL 0      // dev: 1 no staging after the first chunk, 2 no MFMAs, 3 no operand fetch after the prologue, 4 no fragment reads
 #endif
@@ -670,12 +673,13 @@ __global__ __launch_bounds__(256) void conv3x3_x3q_kernel(ConvP p, int tiles_x, 
     const bool two = NCH > 0 ? NCH > 1 : nch > 1;
     fetch(0, 0);
     if (two) fetch(1, 1);
+    if (XQ_DIST == 3 && NCH > 2) fetch(2, 2);
     stage(0);
     XP_BARRIER()
     if (NCH > 0) {
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        if (c + 2 < NCH && XQ_ABL != 3) fetch(c + 2, (c + 2) % XP_ST);
+        if (c + XQ_DIST < NCH && XQ_ABL != 3) fetch(c + XQ_DIST, (c + XQ_DIST) % XP_ST);
         if (XQ_SCHED && XQ_ABL == 0 && c + 1 < NCH) {
           fused(c % XP_ST, (c + 1) % XP_ST);
           XP_BARRIER()
@@ -781,13 +785,16 @@ int keep_conv2d_x3_partials(const keep_conv2d_args* a, ConvP& p, hipStream_t st)
 }
 
 // Un-split plans on wide maps (what conv3x3_halo_x3s_kernel takes) with few items: the 64-pixel blocks, same values.
+#ifndef XQ_MAX_ITEMS
+#define XQ_MAX_ITEMS 64      // items of the 256-pixel streaming kernel up to which the 64-pixel blocks take the map
+#endif
 bool keep_conv_x3q_ok(const keep_conv2d_args* a, const ConvP& p, int split_k) {
   const long items_s = (long)a->N * (a->Ho / 8) * (a->Wo / 32) * ((a->Cout + 63) / 64);
   const bool aff = a->pro_scale != nullptr;
   // round 6: an epilogue activation (CFT's scale.0|shift.0 + LeakyReLU, KA:468-469) and the 9-tap nearest-x2 form (the 16 -> 32 Upsample) too:
   // one uniform branch / two shifts in the halo addresses, the streaming kernel's own
   return split_k == 1 && a->upsample != KEEP_UPSAMPLE_X2_PHASES && a->pad_mode == KEEP_PAD_ZERO && a->Ho % 8 == 0 && a->Wo % 32 == 0 && a->Cout % 64 == 0 &&
-         a->Cin % 16 == 0 && a->Cin >= 32 && items_s <= 64 && !a->aux &&
+         a->Cin % 16 == 0 && a->Cin >= 32 && items_s <= XQ_MAX_ITEMS && !a->aux &&
          ((a->pro_act == KEEP_PRO_SWISH && aff && p.fast) || a->pro_act == KEEP_PRO_NONE) && (!p.stats || a->out_ld == a->Cout) &&
          !(a->flags & (KEEP_CONV_NO_SMALL_PARTIALS | KEEP_CONV_NO_STREAM));
 }

@@ -1807,3 +1807,30 @@ def test_layernorm_and_geglu_with_fused_range_maxima():
         assert torch.equal(y2, ref) and torch.equal(am2, am)
     with pytest.raises(L.KeepHipError):
         L.call('keep_layernorm_amax', x, g, b, None, y2, 10, 128, 1e-5, 3, am2, 0)
+
+
+@pytest.mark.parametrize('hw,cin,cout,swish', [(32, 64, 64, True), (48, 64, 64, False), (64, 128, 128, True)])
+def test_winograd_x3_microkernel_vs_fp64(hw, cin, cout, swish):
+    """tools/dev/winograd_probe.hip (evidence for DESIGN 5.7, NOT product): the Winograd F(2x2, 3x3) x3 microkernel -- GroupNorm affine (+ swish) prologue, bias
+    epilogue, persistent blocks, ragged tile counts per block -- against an fp64 convolution of the same activated input: fp32-grade like the product's x3 kernels."""
+    import sys
+    dev = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'dev')
+    if not os.path.exists(os.path.join(dev, 'libwinograd_probe.so')):
+        pytest.skip('tools/dev/libwinograd_probe.so not built (python __graft_entry__.py)')
+    sys.path.insert(0, dev)
+    import winograd_probe as WP
+    lib = WP.load('')
+    torch.manual_seed(hw + cin)
+    N = 3
+    w = (torch.randn(cout, 3, 3, cin) * 0.05).cuda()
+    bias = (torch.randn(cout) * 0.1).cuda()
+    scale, shift = (torch.rand(N, cin) + 0.5).cuda(), (torch.randn(N, cin) * 0.2).cuda()
+    x = torch.randn(N, hw, hw, cin, device='cuda')
+    u, inv = WP.pack_weights(w)
+    y = WP.run(lib, x, u, bias, scale, shift, inv, swish=swish)
+    a = x.double() * scale.double()[:, None, None, :] + shift.double()[:, None, None, :]
+    if swish:
+        a = a * torch.sigmoid(a)
+    ref = F.conv2d(a.permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), bias.double(), padding=1).permute(0, 2, 3, 1)
+    err = (y.double() - ref).abs().max().item()
+    assert torch.isfinite(y).all() and err <= 4e-6 * max(1.0, ref.abs().max().item()), err

@@ -1,2 +1,3 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "winograd" 2>&1 | tail -4
+timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -6
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2

@@ -27,6 +27,8 @@ LAYERS = {  # name: (N, H, W, Cin, Cout, ksize, upsample)
     'c512_16': (4, 16, 16, 512, 512, 3, False),
     'c64_512_n48': (48, 512, 512, 64, 64, 3, False),        # the frame loop's launches at the bench's 48 clips per call
     'c128_256_n48': (48, 256, 256, 128, 128, 3, False),
+    'c64_512_n1': (1, 512, 512, 64, 64, 3, False),          # one clip in flight: the streaming kernel on ONE image
+    'c128_256_n1': (1, 256, 256, 128, 128, 3, False),
     'c256_64_n1': (1, 64, 64, 256, 256, 3, False),          # one clip in flight: the 64-pixel-block kernels (conv3x3_x3q_kernel)
     'c256_32_n1': (1, 32, 32, 256, 256, 3, False),
     'lin128': (1, 622592, 1, 128, 128, 1, False),
